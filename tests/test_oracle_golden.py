@@ -1,0 +1,83 @@
+"""Pin the CPU oracle (oracle/nmf_oracle.py) against golden vectors captured from the reference.
+
+Tolerances (the reference's own fp32-vs-fp64 self-consistency budget):
+  one update step from identical state : rel-Frobenius <= 1e-5 (fp32), 1e-12 (fp64)
+  fits of <= 100 iterations            : rel-Frobenius <= 1e-4 on W, H; |recon_err diff| <= 1e-5
+The oracle uses the same numpy calls as the reference, so on the same BLAS it is usually
+bit-identical; the tolerance only absorbs numpy 1.26 (fixture generator) vs numpy 2.x here.
+"""
+import numpy as np
+import pytest
+
+from oracle import nmf_oracle as orc
+from tests._golden import case_names, load_case, rel_fro
+
+CASES = case_names()
+
+
+def test_fixture_inventory():
+    assert len(CASES) >= 50
+    assert any(c.startswith("swim_4x1_fro") for c in CASES)  # BASELINE config 1
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_partition_matches_reference(name):
+    """determine_block_params / compute_local_dim index math (utils.py:15-46, 97-115)."""
+    meta, A, W0, H0, z = load_case(name)
+    p_r, p_c = meta["grid"]
+    for r in range(p_r * p_c):
+        r0, r1, c0, c1 = orc.data_block(r, p_r, p_c, meta["m"], meta["n"])
+        assert [r0, r1, c0, c1] == list(z["r%d_A_range" % r])
+        (w0, w1), (h0, h1) = orc.factor_ranges(r, p_r, p_c, meta["m"], meta["n"])
+        assert [w0, w1] == list(z["r%d_W_range" % r])
+        assert [h0, h1] == list(z["r%d_H_range" % r])
+
+
+def test_reference_file_split_known_answer():
+    """tests/test_dist_file_split.py:25-30 of the reference: wtsi 96x21 on a (2,1) grid."""
+    assert orc.data_block(0, 2, 1, 96, 21) == (0, 48, 0, 21)
+    assert orc.data_block(1, 2, 1, 96, 21) == (48, 96, 0, 21)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_single_update_step(name):
+    meta, A, W0, H0, z = load_case(name)
+    p_r, p_c = meta["grid"]
+    g = orc.SimGrid(A, W0, H0, p_r, p_c, norm=meta["norm"], W_update=meta["W_update"])
+    assert float(g.eps) == float(z["r0_eps"])
+    g.update()
+    tol = 1e-5 if meta["dtype"] == "float32" else 1e-12
+    for r in range(p_r * p_c):
+        assert g.W[r].dtype == np.dtype(meta["dtype"])
+        assert rel_fro(g.W[r], z["r%d_step1_W" % r]) <= tol
+        assert rel_fro(g.H[r], z["r%d_step1_H" % r]) <= tol
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fit(name):
+    meta, A, W0, H0, z = load_case(name)
+    p_r, p_c = meta["grid"]
+    f32 = meta["dtype"] == "float32"
+    for itr in meta["itrs"]:
+        g = orc.SimGrid(A, W0, H0, p_r, p_c, norm=meta["norm"], W_update=meta["W_update"])
+        W, H, err = g.fit(itr)
+        tol = (1e-4 if f32 else 1e-10)
+        for r in range(p_r * p_c):
+            assert rel_fro(W[r], z["r%d_fit%d_W" % (r, itr)]) <= tol, (itr, r)
+            assert rel_fro(H[r], z["r%d_fit%d_H" % (r, itr)]) <= tol, (itr, r)
+        assert abs(err - float(z["r0_fit%d_err" % itr])) <= (1e-5 if f32 else 1e-12)
+
+
+@pytest.mark.parametrize("norm,thr", [("fro", 1e-3), ("kl", 1e-3)])
+@pytest.mark.parametrize("grid", [(1, 2), (2, 1)])
+def test_reference_convergence_thresholds(norm, thr, grid):
+    """The only thing the reference's own tests pin on this path
+    (tests/test_dist_nmf_1d.py:14-46): rel_error < 1e-3 after 2000 MU iterations on the
+    exact rank-2 24x12 problem, float64, random init."""
+    np.random.seed(100)
+    m, k, n = 24, 2, 12
+    A = np.random.rand(m, k) @ np.random.rand(k, n)
+    W0, H0 = np.random.rand(m, k), np.random.rand(k, n)
+    g = orc.SimGrid(A, W0, H0, grid[0], grid[1], norm=norm)
+    _, _, err = g.fit(2000)
+    assert err < thr
