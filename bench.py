@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- MU iterations/sec of the MI355X update engine on BASELINE.json's headline workload.
+
+Workload (config.workload): synthetic dense fp32 X = 262144 x 8192, k = 64, MU / Frobenius, 1D row grid
+p_r = N, p_c = 1 (BASELINE config 3).  The global X is fixed, so N GPUs each hold m/N rows: strong scaling.
+A "step" is one full MU iteration exactly as PyNMF.fit runs it (W update, H update with the new W, the
+allreduce of [W^T A | W^T W] when N > 1, and the clamp on every 10th step), X already resident in HBM.
+
+  python bench.py                      # N=1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     : the dominant kernel (fused A H^T + W update, one launch), algorithmic flops / HIP-event time
+  kernels      : the same measurement for every kernel class of the step
+  cpu_baseline : the numpy oracle (port of the reference's path) timed on the host, bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=262144)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--norm", default="fro")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, reps=5, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in evs:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return sum(ts) / len(ts), ts[0]
+
+
+def cpu_baseline(n, k, m_full):
+    """The oracle's single-rank MU/FRO step (same numpy calls as dist_nmf.py:716-751) on a row slab, 1 BLAS thread
+    (the reference forces OMP_NUM_THREADS=1 per rank, main.py:3)."""
+    import numpy as np
+    from oracle import nmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    m_s = 8192
+    rs = np.random.RandomState(0)
+    A = rs.rand(m_s, n).astype(np.float32)
+    W = rs.rand(m_s, k).astype(np.float32)
+    H = rs.rand(k, n).astype(np.float32)
+    eps = np.finfo(np.float32).eps
+
+    def run(iters):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            orc.fro_mu_step_local(A, W, H, eps)
+        return (time.perf_counter() - t0) / iters
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            run(1)
+            t = run(6)
+    else:
+        run(1)
+        t = run(6)
+    t_full = t * (m_full / m_s)
+    return {"value": 1.0 / t_full, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": "oracle fro_mu_step_local on a %dx%d row slab (1/%d of X), k=%d, 1 BLAS thread, 6 timed steps; "
+                      "%.3f s/step on the slab, scaled by rows to the full X" % (m_s, n, m_full // m_s, k, t),
+            "slab_seconds_per_step": t,
+            "gflops": (4.0 * m_s * n * k + 4.0 * (m_s + n) * k * k) / t / 1e9}
+
+
+def main():
+    a = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks" % a.gpus)
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    from pydnmfk_amd.utils import determine_block_params, parse
+
+    m, n, k = a.m, a.n, a.k
+    comms = MPI_comm(None, world, 1)
+    p = parse()
+    p.comm1, p.comm, p.p_r, p.p_c, p.k, p.m, p.n = comms.comm, comms, world, 1, k, m, n
+    p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    p.norm, p.method, p.W_update, p.eps = a.norm, "mu", True, 1.1920929e-07
+    m_l = determine_block_params(rank, (world, 1), (m, n)).determine_block_shape_asymm()[0]
+
+    # synthetic data, generated on device: X ~ U[0,1), W0 per rank, H0 from rank 0
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    A = torch.rand(m_l, n, device=dev, generator=g)
+    g.manual_seed(4321 + rank)
+    W = torch.rand(m_l, k, device=dev, generator=g)
+    g.manual_seed(99)
+    H = torch.rand(k, n, device=dev, generator=g)
+    if world > 1:
+        dist.broadcast(H, src=0)
+
+    def step(i):
+        nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(W).all() and torch.isfinite(H).all()
+
+    out = None
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        flops_iter = 4.0 * m * n * k + 4.0 * (m + n) * k * k      # SURVEY 8d, whole job
+        out = {
+            "metric": "mu_iterations_per_sec", "value": a.steps / elapsed, "unit": "iter/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)" % (
+                a.norm.upper(), m, n, k, world), "m": m, "n": n, "k": k, "rows_per_gpu": m_l,
+                "parallelism": "row-sharded X, allreduce[W^T A | W^T W]" if world > 1 else "single GPU"},
+            "step_tflops_per_gpu": flops_iter / world / (ms * 1e-3) / 1e12,
+            "step_mfma_frac": flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
+        }
+
+    if not a.no_kernel_timing and a.norm == "fro":
+        # per-kernel HIP-event timings on this rank's slab (same launches as inside the step)
+        G = ops.gram_hht(H, new_gram(k, dev))
+        Wt = W.clone()
+        AtW = torch.empty(k, n, device=dev)
+        kern = {}
+        t_avg, t_min = event_time_ms(lambda: ops.aht_update_w(A, H, G, Wt, p.eps))
+        fl = 2.0 * m_l * n * k + 2.0 * m_l * k * k
+        kern["nt_kernel<fused A.H^T + W update>"] = {"ms": t_avg, "ms_min": t_min, "tflops": fl / t_avg / 1e9,
+                                                    "frac_mfma": fl / t_avg / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                                                    "algorithmic_gbs": (4.0 * m_l * n + 8.0 * m_l * k) / t_avg / 1e6}
+        t_avg2, t_min2 = event_time_ms(lambda: ops.wta(A, W, AtW))
+        fl2 = 2.0 * m_l * n * k
+        kern["tn_kernel<W^T.A> + reduce_partials"] = {"ms": t_avg2, "ms_min": t_min2, "tflops": fl2 / t_avg2 / 1e9,
+                                                     "frac_mfma": fl2 / t_avg2 / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                                                     "algorithmic_gbs": (4.0 * m_l * n + 4.0 * m_l * k) / t_avg2 / 1e6}
+        t3, t3m = event_time_ms(lambda: ops.sqnorm(A))
+        kern["sqnorm_kernel (||A||^2, eltwise/norm class)"] = {"ms": t3, "ms_min": t3m,
+                                                              "algorithmic_gbs": 4.0 * m_l * n / t3 / 1e6,
+                                                              "frac_hbm": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS}
+        G2 = ops.gram_wtw(W, new_gram(k, dev))
+        Ht = H.clone()
+        t4, t4m = event_time_ms(lambda: ops.mu_update_h(Ht, AtW, G2, p.eps, False))
+        kern["tn_kernel<H update>"] = {"ms": t4, "ms_min": t4m, "algorithmic_gbs": 12.0 * n * k / t4 / 1e6}
+        t5, _ = event_time_ms(lambda: ops.gram_wtw(W, G2))
+        t6, _ = event_time_ms(lambda: ops.gram_hht(H, G))
+        kern["gram_wtw"] = {"ms": t5}
+        kern["gram_hht"] = {"ms": t6}
+        if rank == 0:
+            out["roofline"] = {"kernel": "nt_kernel<KT=%d,FUSED_W> (dnmf_aht_update_w)" % (max(1, (k + 31) // 32)),
+                               "bound": "mfma", "achieved": fl / t_avg / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": fl / t_avg / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "flops_per_launch": fl, "ms_per_launch": t_avg}
+            out["roofline_hbm"] = {"kernel": "sqnorm_kernel", "bound": "hbm", "achieved": 4.0 * m_l * n / t3 / 1e6,
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS,
+                                   "traffic": None}
+            out["kernels"] = kern
+
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, k, m)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+/*
+ * dnmf.h -- C ABI of libdnmf_hip.so: the MI355X (gfx950) multiplicative-update engine
+ * that replaces the numpy hot path of lanl/pyDNMFk.
+ *
+ * The reference has no FFI layer: its hot path is reached by plain Python calls
+ * (pyDNMFk/dist_nmf.py, pyDNMFk/pyDNMF.py).  Each entry point below names the reference
+ * lines it replaces.  Calling convention:
+ *   - every matrix is dense row-major fp32 in DEVICE memory, given as pointer + leading
+ *     dimension (elements); the caller owns every buffer, nothing is retained;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     stream-ordered, no entry point synchronises the device or allocates memory;
+ *   - `ws` is caller-provided device scratch of at least dnmf_ws_bytes(m, n, k) bytes;
+ *   - return value: 0 on success, negative DNMF_E* on error (dnmf_last_error() has text);
+ *   - k <= DNMF_MAX_K.  Internally k is padded to KP = 32/64/128; "gram" buffers G are
+ *     always KP x KP, ld = KP, zero padded (dnmf_kp(k) returns KP).
+ * Collectives are NOT in this library: the p_r x p_c grid exchanges (allreduce /
+ * allgather / reduce_scatter over RCCL) are issued by the host between these calls,
+ * exactly where the reference calls mpi4py (dist_nmf.py:681,707,114,163,169,195,202).
+ */
+#ifndef DNMF_H
+#define DNMF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNMF_MAX_K 128
+#define DNMF_OK 0
+#define DNMF_EINVAL (-1)   /* bad shape / null pointer / k too large */
+#define DNMF_EWS (-2)      /* workspace too small */
+#define DNMF_EHIP (-3)     /* HIP launch error */
+
+const char* dnmf_last_error(void);
+int dnmf_version(void);
+/* padded rank used for internal k x k buffers (32, 64 or 128); <0 if k unsupported */
+int dnmf_kp(int k);
+/* scratch bytes sufficient for ANY entry point below on an m x n block with rank k */
+size_t dnmf_ws_bytes(long m, long n, int k);
+
+/* ---- Gram matrices (dist_nmf.py:679 `np.matmul(A.T, A)` in global_gram; :113 in 2D) ---- */
+/* G[KP x KP] = H H^T for H [k x n] (called as global_gram(H.T), dist_nmf.py:729,241) */
+int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, size_t ws_bytes, void* stream);
+/* G[KP x KP] = W^T W for W [m x k] (global_gram(W), dist_nmf.py:748,222) */
+int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- The two big contractions (dist_nmf.py:705 `np.matmul(A, B)` in global_mm; :166,:198 in 2D) ---- */
+/* AH[m x k] = A[m x n] H[k x n]^T        (global_mm(A_ij, H_j.T), dist_nmf.py:730; AH_glob :198) */
+int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh,
+             float* AH, long ldah, void* stream);
+/* AtW[k x n] = W[m x k]^T A[m x n]       (global_mm(W_i.T, A_ij), dist_nmf.py:749; ATW_glob :166) */
+int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw,
+             float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Multiplicative updates (element-wise multiply/divide with the small k x k product) ---- */
+/* W *= AH / (W G + eps), G = H H^T       (dist_nmf.py:731-732, :244-245) */
+int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G,
+                     float eps, void* stream);
+/* H *= AtW / (H^T G + eps)^T, G = W^T W  (dist_nmf.py:750-751, :224-225); clamp!=0 also applies
+ * H = max(H, eps) afterwards (pyDNMF.py:156,171) */
+int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G,
+                     float eps, int clamp, void* stream);
+/* Fused W phase for p_c == 1 (no exchange between the GEMM and the update):
+ * W *= (A H^T) / (W G + eps) in one pass over A  (dist_nmf.py:716-732) */
+int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, int k, long ldh,
+                      const float* G, float* W, long ldw, float eps, void* stream);
+
+/* ---- One whole local MU/Frobenius step on one rank (dist_nmf.py:755-771 with p_r = p_c = 1),
+ * W first then H with the new W; clamp!=0 applies pyDNMF.py:155-157 after the step. ---- */
+int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
+                     int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- KL pieces (dist_nmf.py:776-869; 2D :294-343).  U = A / (W H + eps) is never materialised. ---- */
+/* UHT[m x k] = (A / (W H + eps)) H^T     (glob_UX(axis=0), dist_nmf.py:806,810; UHT_glob :337-338) */
+int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                int k, float eps, float* UHT, long ldo, void* stream);
+/* WTU[k x n] = W^T (A / (W H + eps))     (glob_UX(axis=1), dist_nmf.py:806,808; WTU_glob :311-312) */
+int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                int k, float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream);
+/* x[k] = row sums of H [k x n]           (sum_along_axis(H, axis=1), dist_nmf.py:793-795) */
+int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream);
+/* x[k] = column sums of W [m x k]        (sum_along_axis(W, axis=0), dist_nmf.py:793; pyDNMF.py:187) */
+int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, size_t ws_bytes, void* stream);
+/* W[i][j] *= S[i][j] / (x[j] + eps)      (dist_nmf.py:828-830) */
+int dnmf_kl_update_w(float* W, long m, int k, long ldw, const float* S, long lds_, const float* x, float eps,
+                     void* stream);
+/* H[j][c] *= S[j][c] / (x[j] + eps); clamp as above (dist_nmf.py:847-849) */
+int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* S, long lds_, const float* x, float eps,
+                     int clamp, void* stream);
+/* One whole local MU/KL step on one rank (dist_nmf.py:851-869 with p_r = p_c = 1) */
+int dnmf_mu_kl_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
+                    int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- PyNMF.fit helpers (pyDNMF.py:155-157, 185-194, 205-218) ---- */
+/* X = max(X, eps) over a rows x cols matrix */
+int dnmf_clamp_min(float* X, long rows, long cols, long ldx, float eps, void* stream);
+/* W[i][j] /= (s[j] + eps) (pyDNMF.py:192) */
+int dnmf_scale_cols_div(float* W, long m, int k, long ldw, const float* s, float eps, void* stream);
+/* H[j][c] *= s[j] (pyDNMF.py:193) */
+int dnmf_scale_rows_mul(float* H, int k, long n, long ldh, const float* s, void* stream);
+/* *out (double, device) = sum A^2  (np.linalg.norm(A)**2, pyDNMF.py:208,215) */
+int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* stream);
+/* *out (double, device) = sum (A - W H)^2 without materialising the residual (pyDNMF.py:207,215) */
+int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNMF_H */

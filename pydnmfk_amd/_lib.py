@@ -1,0 +1,74 @@
+"""ctypes binding of libdnmf_hip.so (C ABI declared in include/dnmf.h).
+
+There is NO CPU fallback: if the library is missing the import of this module fails
+loudly, and every compute entry point requires CUDA(HIP) device pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnmf_hip.so")
+
+c_float_p = ctypes.c_void_p
+c_long, c_int, c_float, c_size_t, c_void_p = ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/dnmf.h one to one
+SIGNATURES = {
+    "dnmf_last_error": [],
+    "dnmf_version": [],
+    "dnmf_kp": [c_int],
+    "dnmf_ws_bytes": [c_long, c_long, c_int],
+    "dnmf_gram_hht": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
+    "dnmf_gram_wtw": [c_void_p, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
+    "dnmf_aht": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p],
+    "dnmf_wta": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_size_t,
+                 c_void_p],
+    "dnmf_mu_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],
+    "dnmf_mu_update_h": [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_float, c_int, c_void_p],
+    "dnmf_aht_update_w": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_void_p, c_long,
+                          c_float, c_void_p],
+    "dnmf_mu_fro_step": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int,
+                         c_int, c_void_p, c_size_t, c_void_p],
+    "dnmf_kl_uht": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
+                    c_long, c_void_p],
+    "dnmf_kl_wtu": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
+                    c_long, c_void_p, c_size_t, c_void_p],
+    "dnmf_rowsum": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
+    "dnmf_colsum": [c_void_p, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
+    "dnmf_kl_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],
+    "dnmf_kl_update_h": [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_float, c_int, c_void_p],
+    "dnmf_mu_kl_step": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int,
+                        c_int, c_void_p, c_size_t, c_void_p],
+    "dnmf_clamp_min": [c_void_p, c_long, c_long, c_long, c_float, c_void_p],
+    "dnmf_scale_cols_div": [c_void_p, c_long, c_int, c_long, c_void_p, c_float, c_void_p],
+    "dnmf_scale_rows_mul": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
+    "dnmf_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p],
+    "dnmf_resid_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
+                          c_void_p],
+}
+_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pydnmfk_amd: %s not found. Build it with `python -m pydnmfk_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted from include/dnmf.h
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, c_int)
+    return lib
+
+
+lib = load()
+
+
+class DnmfError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise DnmfError("libdnmf_hip: %s (code %d)" % (lib.dnmf_last_error().decode(), rc))

@@ -1,0 +1,1163 @@
+// dnmf.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for the distributed-NMF multiplicative-update path.
+//
+// Written for gfx950 only: 64-wide wavefronts, fp32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 = an
+// fmaf chain), 160 KiB LDS per CU, 8 XCDs.  See DESIGN.md for the data layout and per-kernel rooflines and
+// include/dnmf.h for the reference lines each entry point replaces.
+//
+// Two GEMM forms carry the whole path (k = NMF rank, padded to KP = 32*KT):
+//   NT form  C[i][j] = sum_c X[i][c] * Y[j][c]   contraction index contiguous in both operands
+//            -> A H^T (K2), H H^T (K1), W (H H^T) (K3).  X is streamed through LDS (the MFMA operand
+//               layout puts the 32 rows of a tile across lanes, so a transpose is unavoidable).
+//   TN form  C[j][c] = sum_i X[i][j] * Y[i][c]   contraction index is the row of both operands
+//            -> W^T A (K6), W^T W (K5), (W^T W) H (K7).  Operands go global -> VGPR directly in MFMA
+//               layout with 16-byte coalesced loads; no LDS, no barriers.
+// MFMA 32x32x2 f32 operand maps (lane l, li = l & 31, h = l >> 5):
+//   A-operand: A[i = li][kk = h]   B-operand: B[kk = h][j = li]
+//   C/D: col = li, row = (reg & 3) + 8 * (reg >> 2) + 4 * h   (reg in [0,16))
+// The contraction order inside a tile and the output row/column order inside a tile are permuted freely
+// (sums are order-agnostic up to fp32 rounding; outputs are written to their true addresses).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "dnmf.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------- errors
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DNMF_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return DNMF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+
+// C/D row of accumulator register `reg` for lane-half h
+__device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ----------------------------------------------------------------------------------------------- loads
+// V contiguous floats starting at column `col` of a row; zero outside [0, ncols).
+// FAST: col % V == 0, ncols % 4 == 0, row pointer 16-B aligned, so a vector is wholly in or out.
+template <int V, bool FAST>
+__device__ __forceinline__ void load_vec(float (&d)[V], const float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) {
+            if constexpr (V == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(row + col);
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            } else if constexpr (V == 2) {
+                f32x2 v = *reinterpret_cast<const f32x2*>(row + col);
+                d[0] = v[0]; d[1] = v[1];
+            } else {
+                d[0] = row[col];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (ok && col + e < ncols) ? row[col + e] : 0.f;
+    }
+}
+
+template <int V, bool FAST>
+__device__ __forceinline__ void store_vec(const float (&d)[V], float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) {
+            if constexpr (V == 4) {
+                f32x4 v = {d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<f32x4*>(row + col) = v;
+            } else if constexpr (V == 2) {
+                f32x2 v = {d[0], d[1]};
+                *reinterpret_cast<f32x2*>(row + col) = v;
+            } else {
+                row[col] = d[0];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            if (ok && col + e < ncols) row[col + e] = d[e];
+    }
+}
+
+// =============================================================================================== NT form
+constexpr int BK = 32;  // contraction tile (floats): 128-B LDS rows
+
+// LDS tile = rows x 32 floats; the eight 16-B chunks of a row are XOR-swizzled with (row >> 1) & 7 so that
+// a ds_read_b128 by lanes (row = li, chunk = 2s + h) is bank-conflict free (rows of one 16-lane group map
+// to distinct 16-B slots of the 256-B bank row).
+__device__ __forceinline__ int lds_idx(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+enum { NT_STORE = 0, NT_FUSED_W = 1, NT_UPDATE_W = 2 };
+
+struct NtArgs {
+    const float* X; long ldx; long nrows; long ncols;  // streamed operand; contraction over ncols
+    const float* Y; long ldy; int yrows;               // small operand [yrows x ncols]
+    long cols_per_split;                               // contraction range per blockIdx.y (multiple of BK)
+    float* out; long ldo; long split_stride; int store_all;
+    float* W; long ldw; const float* G; const float* AH; long ldah; float eps; int k;
+};
+
+template <int R, bool FAST>
+__device__ __forceinline__ void stage_load(f32x4 (&v)[R / 32], const float* __restrict__ X, long ldx, long nrows,
+                                           long cend, long row0, long c0, int tid) {
+    const int ch = tid & 7;
+    const long c = c0 + ch * 4;
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+        const long r = row0 + it * 32 + (tid >> 3);
+        float d[4];
+        load_vec<4, FAST>(d, X + r * ldx, c, cend, r < nrows);
+        v[it] = f32x4{d[0], d[1], d[2], d[3]};
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[R / 32], int tid) {
+    const int ch = tid & 7;
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+        const int r = it * 32 + (tid >> 3);
+        *reinterpret_cast<f32x4*>(&tile[lds_idx(r, ch)]) = v[it];
+    }
+}
+
+// acc[mt][jt] += X[row0 + wave*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T
+template <int KT, int MT, bool FAST>
+__device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
+                                            long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
+                                            long cend, float* smem) {
+    constexpr int BM = 128 * MT, KP = 32 * KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    constexpr int STAGE = (BM + KP) * BK;  // floats per pipeline stage: [X tile | Y tile]
+    f32x4 xv[BM / 32], yv[KP / 32];
+    const long nk = (cend - cbeg + BK - 1) / BK;
+    if (nk <= 0) return;
+    stage_load<BM, FAST>(xv, X, ldx, nrows, cend, row0, cbeg, tid);
+    stage_load<KP, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg, tid);
+    stage_store<BM>(smem, xv, tid);
+    stage_store<KP>(smem + BM * BK, yv, tid);
+    __syncthreads();
+    for (long kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            stage_load<BM, FAST>(xv, X, ldx, nrows, cend, row0, cbeg + (kt + 1) * BK, tid);
+            stage_load<KP, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg + (kt + 1) * BK, tid);
+        }
+        const float* xc = smem + cur * STAGE;
+        const float* yc = xc + BM * BK;
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 a[MT], b[KT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(wave * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+                b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
+        }
+        if (more) {
+            stage_store<BM>(smem + (cur ^ 1) * STAGE, xv, tid);
+            stage_store<KP>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KT, int MT, bool FAST, int MODE>
+__global__ __launch_bounds__(256) void nt_kernel(NtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = 128 * MT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * BM;
+
+    f32x16 acc[MT][KT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
+
+    if constexpr (MODE == NT_STORE || MODE == NT_FUSED_W) {
+        const long cbeg = (long)blockIdx.y * p.cols_per_split;
+        long cend = cbeg + p.cols_per_split;
+        if (cend > p.ncols) cend = p.ncols;
+        nt_mainloop<KT, MT, FAST>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+    }
+
+    if constexpr (MODE == NT_STORE) {
+        float* out = p.out + (long)blockIdx.y * p.split_stride;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = row0 + wave * 32 * MT + mt * 32 + crow(r, h);
+                    const int col = jt * 32 + li;
+                    if (p.store_all || (row < p.nrows && col < p.yrows)) out[row * p.ldo + col] = acc[mt][jt][r];
+                }
+    } else {
+        // second product: acc2 = W[rows] . G  (G = H H^T is symmetric, so G[j][jj] serves as Y[j][c = jj])
+        f32x16 acc2[MT][KT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][jt][r] = 0.f;
+        nt_mainloop<KT, MT, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = row0 + wave * 32 * MT + mt * 32 + crow(r, h);
+                    const int col = jt * 32 + li;
+                    if (row < p.nrows && col < p.k) {
+                        float ah;
+                        if constexpr (MODE == NT_FUSED_W) ah = acc[mt][jt][r];
+                        else ah = p.AH[row * p.ldah + col];
+                        const float w = p.W[row * p.ldw + col];
+                        const float q = ah / (acc2[mt][jt][r] + p.eps);   // dist_nmf.py:731-732
+                        p.W[row * p.ldw + col] = w * q;
+                    }
+                }
+    }
+}
+
+// =============================================================================================== TN form
+enum { TN_PARTIAL = 0, TN_UPDATE_H = 1 };
+
+struct TnArgs {
+    const float* X; long ldx; int xcols;     // [nrows x xcols]  -> output rows j
+    const float* Y; long ldy; long ycols;    // [nrows x ycols]  -> output cols c
+    long nrows; long rows_per_chunk; int nchunks; int ncolblk;
+    float* P; long chunk_stride; long ldp;   // TN_PARTIAL: P[chunk][KP][ldp]
+    float* H; long ldh; const float* S; long lds_; float eps; int clamp; int k; long n;  // TN_UPDATE_H
+};
+
+template <int KT, int NT, bool FAST, int U>
+__device__ __forceinline__ void tn_load(float (&a)[U][KT], float (&b)[U][NT], const float* __restrict__ X, long ldx,
+                                        int xcols, const float* __restrict__ Y, long ldy, long ycols, long col0,
+                                        long r, long rend, int li, int h) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long row = r + 2 * u + h;
+        const bool ok = row < rend;
+        load_vec<KT, FAST>(a[u], X + row * ldx, (long)KT * li, xcols, ok);
+        load_vec<NT, FAST>(b[u], Y + row * ldy, col0 + (long)NT * li, ycols, ok);
+    }
+}
+
+template <int KT, int NT, int U>
+__device__ __forceinline__ void tn_comp(f32x16 (&acc)[KT][NT], const float (&a)[U][KT], const float (&b)[U][NT]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a[u][ke], b[u][ne], acc[ke][ne]);
+}
+
+// acc[ke][ne] (reg, lane) = C[j = KT*crow(reg,h) + ke][c = col0 + NT*li + ne], contraction over rows [rbeg, rend)
+template <int KT, int NT, bool FAST>
+__device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* __restrict__ X, long ldx, int xcols,
+                                            const float* __restrict__ Y, long ldy, long ycols, long col0, long rbeg,
+                                            long rend, int li, int h) {
+    constexpr int U = 4;  // row pairs per register batch
+    float a0[U][KT], b0[U][NT], a1[U][KT], b1[U][NT];
+    tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, rbeg, rend, li, h);
+    for (long r = rbeg; r < rend; r += 4 * U) {
+        tn_load<KT, NT, FAST, U>(a1, b1, X, ldx, xcols, Y, ldy, ycols, col0, r + 2 * U, rend, li, h);
+        tn_comp<KT, NT, U>(acc, a0, b0);
+        tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r + 4 * U, rend, li, h);
+        tn_comp<KT, NT, U>(acc, a1, b1);
+    }
+}
+
+template <int KT, int NT, bool FAST, int MODE>
+__global__ __launch_bounds__(256) void tn_kernel(TnArgs p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const long gw = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long chunk = gw / p.ncolblk;
+    const long colblk = gw % p.ncolblk;
+    if (chunk >= p.nchunks) return;
+    const long col0 = colblk * 32 * NT;
+    const long rbeg = chunk * p.rows_per_chunk;
+    long rend = rbeg + p.rows_per_chunk;
+    if (rend > p.nrows) rend = p.nrows;
+
+    f32x16 acc[KT][NT];
+#pragma unroll
+    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ke][ne][r] = 0.f;
+
+    tn_mainloop<KT, NT, FAST>(acc, p.X, p.ldx, p.xcols, p.Y, p.ldy, p.ycols, col0, rbeg, rend, li, h);
+
+    if constexpr (MODE == TN_PARTIAL) {
+        float* Pc = p.P + chunk * p.chunk_stride;
+#pragma unroll
+        for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = KT * crow(r, h) + ke;
+                float d[NT];
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) d[ne] = acc[ke][ne][r];
+                store_vec<NT, true>(d, Pc + (long)j * p.ldp, col0 + (long)NT * li, p.ldp, true);
+            }
+    } else {
+        // H[j][c] *= S[j][c] / (acc + eps)   with acc = sum_jj G[jj][j] H[jj][c]   (dist_nmf.py:750-751)
+#pragma unroll
+        for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = KT * crow(r, h) + ke;
+                const bool ok = j < p.k;
+                const long c = col0 + (long)NT * li;
+                float hv[NT], sv[NT];
+                load_vec<NT, FAST>(hv, p.H + (long)j * p.ldh, c, p.n, ok);
+                load_vec<NT, FAST>(sv, p.S + (long)j * p.lds_, c, p.n, ok);
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) {
+                    const float q = sv[ne] / (acc[ke][ne][r] + p.eps);
+                    float v = hv[ne] * q;
+                    if (p.clamp) v = fmaxf(v, p.eps);
+                    hv[ne] = v;
+                }
+                store_vec<NT, FAST>(hv, p.H + (long)j * p.ldh, c, p.n, ok);
+            }
+    }
+}
+
+// out[j][c] = sum_s P[s][j][c], j < rows, c < cols (fixed order -> deterministic); everything else of the
+// rows_out x ldo output that lies inside [rows_out x cols_out] is written as 0 (zero padding of gram buffers).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, long stride, long ldp,
+                                                              int nsplit, float* __restrict__ out, long ldo,
+                                                              int rows, long cols, int rows_out, long cols_out) {
+    const long c4 = cdiv(cols_out, 4);
+    const long total = (long)rows_out * c4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = idx / c4;
+        const long c = (idx % c4) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (j < rows && c < cols) {
+            const float* src = P + (long)j * ldp + c;
+            for (int k = 0; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(src + k * stride);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < cols_out) out[(long)j * ldo + c + e] = (j < rows && c + e < cols) ? s[e] : 0.f;
+    }
+}
+
+// =============================================================================================== small kernels
+__global__ __launch_bounds__(256) void clamp_kernel(float* X, long rows, long cols, long ldx, float eps) {
+    const long total = rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cols, c = idx % cols;
+        float* p = X + r * ldx + c;
+        *p = fmaxf(*p, eps);
+    }
+}
+
+// W[i][j] = W[i][j] / (s[j] + eps)   |   H[j][c] = H[j][c] * s[j]
+template <int OP>
+__global__ __launch_bounds__(256) void scale_kernel(float* X, long rows, long cols, long ldx, const float* s, float eps) {
+    const long total = rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cols, c = idx % cols;
+        float* p = X + r * ldx + c;
+        if (OP == 0) *p = *p / (s[c] + eps);
+        else *p = *p * s[r];
+    }
+}
+
+// KL eltwise: X[r][c] *= S[r][c] / (x[BYROW ? r : c] + eps)   (dist_nmf.py:828-830, 847-849)
+template <bool BYROW>
+__global__ __launch_bounds__(256) void kl_update_kernel(float* X, long rows, long cols, long ldx, const float* S,
+                                                        long lds_, const float* x, float eps, int clamp) {
+    const long total = rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cols, c = idx % cols;
+        const float q = S[r * lds_ + c] / (x[BYROW ? r : c] + eps);
+        float v = X[r * ldx + c] * q;
+        if (clamp) v = fmaxf(v, eps);
+        X[r * ldx + c] = v;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_atomic_sum(double v, double* out) {
+    __shared__ double red[16];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        atomicAdd(out, s);
+    }
+}
+
+// sum of squares of an m x n matrix; fp32 products, fp64 accumulation
+template <bool FAST>
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ A, long m, long n, long lda, double* out) {
+    double acc = 0.0;
+    if constexpr (FAST) {
+        const long n4 = n / 4, total = m * n4;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const long r = idx / n4, c = (idx % n4) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(A + r * lda + c);
+            acc += (double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        }
+    } else {
+        const long total = m * n;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const float v = A[(idx / n) * lda + idx % n];
+            acc += (double)(v * v);
+        }
+    }
+    block_atomic_sum(acc, out);
+}
+
+// x[j] = sum_c H[j][c]  -- one workgroup per row
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ H, long n, long ldh, float* x) {
+    const float* row = H + (long)blockIdx.x * ldh;
+    double acc = 0.0;
+    for (long c = threadIdx.x; c < n; c += blockDim.x) acc += (double)row[c];
+    __shared__ double red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) x[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// stage 1 of x[j] = sum_i W[i][j]: partial[blk][j] over a slab of rows (coalesced along j)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ W, long m, int k, long ldw,
+                                                             long rows_per_blk, float* partial, int kp) {
+    __shared__ float red[256];
+    const int j = threadIdx.x % kp, g = threadIdx.x / kp, ng = 256 / kp;
+    const long r0 = (long)blockIdx.x * rows_per_blk;
+    long r1 = r0 + rows_per_blk;
+    if (r1 > m) r1 = m;
+    float acc = 0.f;
+    if (j < k)
+        for (long r = r0 + g; r < r1; r += ng) acc += W[r * ldw + j];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0) {
+        for (int q = 1; q < ng; ++q) acc += red[q * kp + j];
+        partial[(long)blockIdx.x * kp + j] = acc;
+    }
+}
+
+__global__ void colsum_final_kernel(const float* partial, int nblk, int kp, int k, float* x) {
+    const int j = threadIdx.x;
+    if (j >= k) return;
+    double acc = 0.0;
+    for (int b = 0; b < nblk; ++b) acc += (double)partial[(long)b * kp + j];
+    x[j] = (float)acc;
+}
+
+// =============================================================================================== NN-small-k form
+// S[i][c] = sum_j W[i][j] H[j][c] computed tile-wise in accumulators, never stored:
+//   acc[mt][ne] (reg, lane) = S[i = row0 + mt*32 + crow(reg,h)] ... wait: here the MFMA M index is the A-row i,
+//   so C/D rows are i and C/D columns (lanes) are the data columns c = col0 + 4*li + ne.
+// Used for the residual norm (pyDNMF.py:205-218) and the KL H-side product W^T U (dist_nmf.py:806-808).
+enum { NN_RESID = 0, NN_KL_WTU = 1 };
+
+struct NnArgs {
+    const float* A; long lda; long m; long n;
+    const float* W; long ldw; const float* H; long ldh; int k;
+    float eps; double* out;                          // NN_RESID
+    float* P; long chunk_stride; long ldp;           // NN_KL_WTU partials [rowblk][KP][ldp]
+    long nrowblk; int ncolblk;
+};
+
+// S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
+template <int KT, int NT, bool FAST>
+__device__ __forceinline__ void nn_tile(f32x16 (&acc)[NT], const float* __restrict__ W, long ldw, long m, int k,
+                                        const float* __restrict__ H, long ldh, long n, long row0, long col0, int li,
+                                        int h) {
+#pragma unroll
+    for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+    const long wrow = row0 + li;
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) {  // 8 contraction indices per step: jj = 8s + 4h + e
+        float a[4];
+        load_vec<4, FAST>(a, W + wrow * ldw, 8 * s + 4 * h, k, wrow < m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = 8 * s + 4 * h + e;
+            float b[NT];
+            load_vec<NT, FAST>(b, H + (long)jj * ldh, col0 + NT * li, n, jj < k);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
+        }
+    }
+}
+
+template <int KT, bool FAST>
+__global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double total = 0.0;
+    if (gw < p.nrowblk * p.ncolblk) {
+        const long rowblk = gw / p.ncolblk, colblk = gw % p.ncolblk;
+        const long row0 = rowblk * 32, col0 = colblk * 128;
+        f32x16 acc[4];
+        nn_tile<KT, 4, FAST>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + crow(r, h);
+            float a[4];
+            load_vec<4, FAST>(a, p.A + row * p.lda, col0 + 4 * li, p.n, row < p.m);
+#pragma unroll
+            for (int ne = 0; ne < 4; ++ne) {
+                // rows >= m and cols >= n have a = 0 and acc = 0 (zero-filled operands) -> contribute 0
+                const float d = a[ne] - acc[ne][r];
+                part += d * d;
+            }
+        }
+        total = (double)part;
+    }
+    block_atomic_sum(total, p.out);
+}
+
+// KL H-side: P[rowblk-chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)
+// One wave owns a 128-column block and a chunk of 32-row blocks; per row block it forms S (NN tile), turns it
+// into U in place (same C/D registers) and feeds U as the B operand of W^T U: the contraction index i is the
+// C/D row index, i.e. it lives in registers, which is exactly the B-operand layout (row pairs (rho, rho+4)).
+template <int KT, int NT, bool FAST>
+__global__ __launch_bounds__(256) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nchunks = cdiv(p.nrowblk, rowblks_per_chunk);
+    if (gw >= nchunks * p.ncolblk) return;
+    const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;
+    const long col0 = colblk * 32 * NT;
+    f32x16 out[KT][NT];
+#pragma unroll
+    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ke][ne][r] = 0.f;
+    long rb1 = (chunk + 1) * rowblks_per_chunk;
+    if (rb1 > p.nrowblk) rb1 = p.nrowblk;
+    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb) {
+        const long row0 = rb * 32;
+        f32x16 acc[NT];
+        nn_tile<KT, NT, FAST>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + crow(r, h);
+            float a[NT];
+            load_vec<NT, FAST>(a, p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = a[ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+        }
+        // out[ke][ne] += sum_i W[i][KT*li' + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + crow(r, h);
+            float w[KT];
+            load_vec<KT, FAST>(w, p.W + row * p.ldw, (long)KT * li, p.k, row < p.m);
+#pragma unroll
+            for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) out[ke][ne] = MFMA32(w[ke], acc[ne][r], out[ke][ne]);
+        }
+    }
+    float* Pc = p.P + chunk * p.chunk_stride;
+#pragma unroll
+    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = KT * crow(r, h) + ke;
+            float d[NT];
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) d[ne] = out[ke][ne][r];
+            store_vec<NT, true>(d, Pc + (long)j * p.ldp, col0 + (long)NT * li, p.ldp, true);
+        }
+}
+
+// KL W-side: UHT[i][j] = sum_c (A[i][c] / (S[i][c] + eps)) * H[j][c]
+// The contraction index c must end up in registers, so S is formed TRANSPOSED: S^T[c][i] with the MFMA M index = c
+// (A-operand lane (c, h) holds H[jj][c]: coalesced) and N index = i (B-operand lane (i, h) holds W[i][jj]).
+// C/D then has lane = row i of A and registers = columns c; A is read in that layout (16-B pieces of 32
+// different rows per instruction; KL is MFMA-bound by a wide margin), U^T replaces S^T in place and is
+// the B operand of (U H^T)^T[j][i] = sum_c H[j][c] U^T[c][i].
+template <int KT, bool FAST>
+__global__ __launch_bounds__(256) void kl_uht_kernel(NnArgs p, float* __restrict__ UHT, long ldo) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per 32-row block, all columns
+    if (gw >= p.nrowblk) return;
+    const long row0 = gw * 32;
+    const long arow = row0 + li;
+    const bool rok = arow < p.m;
+    f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[jt][r] = 0.f;
+    // this lane's W row as B operand of S^T: W[arow][jj], jj = 8s + 4h + e  (kept in registers for all column blocks)
+    float wreg[4 * KT][4];
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) load_vec<4, FAST>(wreg[s], p.W + arow * p.ldw, 8 * s + 4 * h, p.k, rok);
+
+    for (long c0 = 0; c0 < p.n; c0 += 32) {
+        f32x16 st;  // S^T tile: rows c (c0 + crow), lanes i
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = 8 * s + 4 * h + e;
+                const long c = c0 + li;
+                const float hv = (jj < p.k && c < p.n) ? p.H[(long)jj * p.ldh + c] : 0.f;
+                st = MFMA32(hv, wreg[s][e], st);
+            }
+        // U^T[c][i] = A[i][c] / (S^T + eps): lane i needs A[arow][c0 + 8g + 4h + (0..3)] for register group g
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float a[4];
+            load_vec<4, FAST>(a, p.A + arow * p.lda, c0 + 8 * g + 4 * h, p.n, rok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[4 * g + e] = a[e] / (st[4 * g + e] + p.eps);
+        }
+        // out[jt] += H[jt*32 + .][c] * U^T[c][i]: contraction c = c0 + crow(r, h); A-operand lane (j, h) holds H[j][c]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) {
+                const int j = jt * 32 + li;
+                float hh[4];
+                load_vec<4, FAST>(hh, p.H + (long)j * p.ldh, c0 + 8 * g + 4 * h, p.n, j < p.k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[jt] = MFMA32(hh[e], st[4 * g + e], out[jt]);
+            }
+        }
+    }
+    // out[jt] (reg, lane): j = jt*32 + crow(reg, h), i = arow -> UHT[i][j]; registers 4g..4g+3 are 4 consecutive j
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float d[4] = {out[jt][4 * g], out[jt][4 * g + 1], out[jt][4 * g + 2], out[jt][4 * g + 3]};
+            store_vec<4, FAST>(d, UHT + arow * ldo, jt * 32 + 8 * g + 4 * h, p.k, rok);
+        }
+}
+
+// =============================================================================================== host side
+int kt_of(int k) {
+    if (k < 1 || k > DNMF_MAX_K) return -1;
+    return k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+}
+
+hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int KT, int MT, bool FAST, int MODE>
+int launch_nt_inst(const NtArgs& a, long nrowtiles, int nsplit, hipStream_t st) {
+    constexpr size_t lds = 2ul * (128 * MT + 32 * KT) * BK * sizeof(float);
+    static bool once = false;
+    if (!once) { allow_lds(nt_kernel<KT, MT, FAST, MODE>, lds); once = true; }
+    hipLaunchKernelGGL((nt_kernel<KT, MT, FAST, MODE>), dim3((unsigned)nrowtiles, (unsigned)nsplit), dim3(256), lds, st, a);
+    return check_launch("nt_kernel");
+}
+
+template <int MODE>
+int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
+#define NT_CASE(KT_, MT_)                                                                      \
+    if (kt == KT_) {                                                                           \
+        const long tiles = cdiv(a.nrows, 128 * MT_);                                           \
+        return fast ? launch_nt_inst<KT_, MT_, true, MODE>(a, tiles, nsplit, st)               \
+                    : launch_nt_inst<KT_, MT_, false, MODE>(a, tiles, nsplit, st);             \
+    }
+    NT_CASE(1, 2)
+    NT_CASE(2, 1)
+    NT_CASE(4, 1)
+#undef NT_CASE
+    return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
+}
+
+inline int nt_rows_per_tile(int kt) { return kt == 1 ? 256 : 128; }
+inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
+
+template <int MODE>
+int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
+    const long waves = (long)a.nchunks * a.ncolblk;
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+#define TN_CASE(KT_, NT_)                                                                      \
+    if (kt == KT_) {                                                                           \
+        if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, MODE>), grid, block, 0, st, a);    \
+        return check_launch("tn_kernel");                                                      \
+    }
+    TN_CASE(1, 4)
+    TN_CASE(2, 4)
+    TN_CASE(4, 2)
+#undef TN_CASE
+    return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
+}
+
+int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out, long ldo, int rows, long cols,
+                  int rows_out, long cols_out, hipStream_t st) {
+    const long total = (long)rows_out * cdiv(cols_out, 4);
+    const unsigned grid = (unsigned)std::min<long>(cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, P, stride, ldp, nsplit, out, ldo, rows,
+                       cols, rows_out, cols_out);
+    return check_launch("reduce_partials");
+}
+
+// ---- chunking heuristics (shared by the ws-size query and the launches)
+struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
+
+TnPlan plan_tn(long nrows, long ycols, int kt, int nt) {
+    TnPlan p;
+    p.ncolblk = (int)cdiv(ycols, 32 * nt);
+    const long target_waves = 4096;
+    long nchunks = std::max<long>(1, target_waves / p.ncolblk);
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, 256)));
+    p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
+    p.nchunks = (int)cdiv(nrows, p.rows_per_chunk);
+    p.ldp = (long)p.ncolblk * 32 * nt;
+    p.chunk_stride = p.ldp * 32 * kt;
+    return p;
+}
+
+struct SplitPlan { int nsplit; long cols_per_split; };
+
+SplitPlan plan_gram_nt(long n) {
+    SplitPlan s;
+    s.cols_per_split = 256;
+    if (n > 256 * 512) s.cols_per_split = round_up(cdiv(n, 512), BK);
+    s.nsplit = (int)std::max<long>(1, cdiv(n, s.cols_per_split));
+    return s;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct WsLayout {
+    size_t g_off, s_off, x_off, part_off, total;  // G [KP*KP] | S = AtW / AH / UHT / WTU | x [KP] | partials
+};
+
+size_t partial_bytes(long m, long n, int k) {
+    const int kt = kt_of(k), kp = 32 * kt;
+    size_t b = 0;
+    {   // wta / kl_wtu: A [m x n]
+        TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
+        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float));
+        TnPlan q = plan_tn(m, n, kt, tn_nt(kt));  // kl_wtu: same column sets as wta
+        b = std::max(b, (size_t)cdiv(cdiv(m, 32), std::max<long>(1, q.rows_per_chunk / 32)) * q.ldp * kp * sizeof(float));
+    }
+    {   // gram W^T W: Y = W [m x k]
+        TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt);
+        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float));
+    }
+    {   // gram H H^T
+        SplitPlan s = plan_gram_nt(n);
+        b = std::max(b, (size_t)s.nsplit * nt_rows_per_tile(kt) * kp * sizeof(float));
+    }
+    b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
+    return b;
+}
+
+WsLayout ws_layout(long m, long n, int k) {
+    const int kp = 32 * kt_of(k);
+    WsLayout w;
+    w.g_off = 0;
+    w.s_off = align256((size_t)kp * kp * sizeof(float));
+    const size_t s_elems = std::max((size_t)k * round_up(n, 4), (size_t)m * round_up(k, 4));
+    w.x_off = w.s_off + align256(s_elems * sizeof(float));
+    w.part_off = w.x_off + align256((size_t)kp * sizeof(float));
+    w.total = w.part_off + align256(partial_bytes(m, n, k));
+    return w;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+const char* dnmf_last_error(void) { return g_err; }
+int dnmf_version(void) { return 100; }
+int dnmf_kp(int k) { const int kt = kt_of(k); return kt < 0 ? -1 : 32 * kt; }
+
+size_t dnmf_ws_bytes(long m, long n, int k) {
+    if (kt_of(k) < 0 || m < 1 || n < 1) return 0;
+    return ws_layout(m, n, k).total;
+}
+
+#define REQUIRE(cond, ...) \
+    do { if (!(cond)) return fail(DNMF_EINVAL, __VA_ARGS__); } while (0)
+
+int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && H && G && ws && n >= 1 && ldh >= n, "gram_hht: bad arguments (k=%d n=%ld)", k, n);
+    const int kp = 32 * kt;
+    const SplitPlan sp = plan_gram_nt(n);
+    const long tile_rows = nt_rows_per_tile(kt);
+    const size_t need = (size_t)sp.nsplit * tile_rows * kp * sizeof(float);
+    if (ws_bytes < need) return fail(DNMF_EWS, "gram_hht: workspace %zu < %zu", ws_bytes, need);
+    NtArgs a{};
+    a.X = H; a.ldx = ldh; a.nrows = k; a.ncols = n;
+    a.Y = H; a.ldy = ldh; a.yrows = k;
+    a.cols_per_split = sp.cols_per_split;
+    a.out = (float*)ws; a.ldo = kp; a.split_stride = tile_rows * kp; a.store_all = 1;
+    const bool fast = aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
+    int rc = launch_nt<NT_STORE>(kt, fast, a, sp.nsplit, S(stream));
+    if (rc) return rc;
+    return launch_reduce((const float*)ws, tile_rows * kp, kp, sp.nsplit, G, kp, k, k, kp, kp, S(stream));
+}
+
+int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && G && ws && m >= 1 && ldw >= k, "gram_wtw: bad arguments (k=%d m=%ld)", k, m);
+    const int kp = 32 * kt;
+    // TN form with X = Y = W; NT column sets per wave (KT = 4 uses 2 column blocks of 64 to bound registers)
+    const int nt = kt == 4 ? 2 : kt;
+    TnPlan p = plan_tn(m, kp, kt, nt);
+    const size_t need = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    if (ws_bytes < need) return fail(DNMF_EWS, "gram_wtw: workspace %zu < %zu", ws_bytes, need);
+    TnArgs a{};
+    a.X = W; a.ldx = ldw; a.xcols = k; a.Y = W; a.ldy = ldw; a.ycols = k;
+    a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
+    a.P = (float*)ws; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
+    const bool fast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    const long waves = (long)a.nchunks * a.ncolblk;
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+    hipStream_t st = S(stream);
+#define GRAM_CASE(KT_, NT_)                                                                          \
+    if (kt == KT_) {                                                                                 \
+        if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, TN_PARTIAL>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, TN_PARTIAL>), grid, block, 0, st, a);    \
+    }
+    GRAM_CASE(1, 1) GRAM_CASE(2, 2) GRAM_CASE(4, 2)
+#undef GRAM_CASE
+    int rc = check_launch("gram_wtw");
+    if (rc) return rc;
+    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, G, kp, k, k, kp, kp, st);
+}
+
+int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
+             void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldh >= n && ldah >= k, "aht: bad arguments");
+    NtArgs a{};
+    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
+    a.Y = H; a.ldy = ldh; a.yrows = k;
+    a.cols_per_split = round_up(n, BK);
+    a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
+    const bool fast = aligned16(A) && aligned16(H) && lda % 4 == 0 && ldh % 4 == 0 && n % 4 == 0;
+    return launch_nt<NT_STORE>(kt, fast, a, 1, S(stream));
+}
+
+int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
+                      float* W, long ldw, float eps, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && lda >= n && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
+    NtArgs a{};
+    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
+    a.Y = H; a.ldy = ldh; a.yrows = k;
+    a.cols_per_split = round_up(n, BK);
+    a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
+    const bool fast = aligned16(A) && aligned16(H) && aligned16(W) && lda % 4 == 0 && ldh % 4 == 0 && n % 4 == 0 &&
+                      ldw % 4 == 0 && k % 4 == 0;
+    return launch_nt<NT_FUSED_W>(kt, fast, a, 1, S(stream));
+}
+
+int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                     void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && AH && G && m >= 1 && ldw >= k && ldah >= k, "mu_update_w: bad arguments");
+    NtArgs a{};
+    a.nrows = m;
+    a.W = W; a.ldw = ldw; a.G = G; a.AH = AH; a.ldah = ldah; a.eps = eps; a.k = k;
+    const bool fast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    return launch_nt<NT_UPDATE_W>(kt, fast, a, 1, S(stream));
+}
+
+int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+             void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldatw >= n, "wta: bad arguments");
+    const int nt = tn_nt(kt);
+    TnPlan p = plan_tn(m, n, kt, nt);
+    const size_t need = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    if (ws_bytes < need) return fail(DNMF_EWS, "wta: workspace %zu < %zu", ws_bytes, need);
+    TnArgs a{};
+    a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
+    a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
+    a.P = (float*)ws; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
+    const bool fast = aligned16(A) && aligned16(W) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0;
+    int rc = launch_tn<TN_PARTIAL>(kt, fast, a, S(stream));
+    if (rc) return rc;
+    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, S(stream));
+}
+
+int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
+                     int clamp, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
+    const int kp = 32 * kt, nt = tn_nt(kt);
+    TnArgs a{};
+    a.X = G; a.ldx = kp; a.xcols = kp; a.Y = H; a.ldy = ldh; a.ycols = n;
+    a.nrows = k; a.rows_per_chunk = round_up(k, 16); a.nchunks = 1; a.ncolblk = (int)cdiv(n, 32 * nt);
+    a.H = H; a.ldh = ldh; a.S = AtW; a.lds_ = ldatw; a.eps = eps; a.clamp = clamp; a.k = k; a.n = n;
+    const bool fast = aligned16(H) && aligned16(AtW) && ldh % 4 == 0 && ldatw % 4 == 0 && n % 4 == 0;
+    return launch_tn<TN_UPDATE_H>(kt, fast, a, S(stream));
+}
+
+int dnmf_clamp_min(float* X, long rows, long cols, long ldx, float eps, void* stream) {
+    REQUIRE(X && rows >= 1 && cols >= 1 && ldx >= cols, "clamp_min: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(rows * cols, 256), 8192);
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, S(stream), X, rows, cols, ldx, eps);
+    return check_launch("clamp");
+}
+
+int dnmf_scale_cols_div(float* W, long m, int k, long ldw, const float* s, float eps, void* stream) {
+    REQUIRE(W && s && m >= 1 && k >= 1 && ldw >= k, "scale_cols_div: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m * k, 256), 8192);
+    hipLaunchKernelGGL(scale_kernel<0>, dim3(grid), dim3(256), 0, S(stream), W, m, (long)k, ldw, s, eps);
+    return check_launch("scale_cols_div");
+}
+
+int dnmf_scale_rows_mul(float* H, int k, long n, long ldh, const float* s, void* stream) {
+    REQUIRE(H && s && n >= 1 && k >= 1 && ldh >= n, "scale_rows_mul: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv((long)k * n, 256), 8192);
+    hipLaunchKernelGGL(scale_kernel<1>, dim3(grid), dim3(256), 0, S(stream), H, (long)k, n, ldh, s, 0.f);
+    return check_launch("scale_rows_mul");
+}
+
+int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* stream) {
+    REQUIRE(A && out && m >= 1 && n >= 1 && lda >= n, "sqnorm: bad arguments");
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "sqnorm: memset failed");
+    const bool fast = aligned16(A) && lda % 4 == 0 && n % 4 == 0;
+    const long work = fast ? m * (n / 4) : m * n;
+    const unsigned grid = (unsigned)std::min<long>(cdiv(work, 256), 2048);
+    if (fast) hipLaunchKernelGGL(sqnorm_kernel<true>, dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    else hipLaunchKernelGGL(sqnorm_kernel<false>, dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    return check_launch("sqnorm");
+}
+
+static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, float eps) {
+    NnArgs a{};
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
+    a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
+    return a;
+}
+
+static bool nn_fast(const float* A, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k) {
+    return aligned16(A) && aligned16(W) && aligned16(H) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0 &&
+           ldh % 4 == 0;
+}
+
+int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, double* out, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, 0.f);
+    a.out = out;
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
+    const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
+#define RS_CASE(KT_)                                                                   \
+    if (kt == KT_) {                                                                   \
+        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((resid_kernel<KT_, false>), grid, block, 0, st, a);    \
+    }
+    RS_CASE(1) RS_CASE(2) RS_CASE(4)
+#undef RS_CASE
+    return check_launch("resid_sqnorm");
+}
+
+int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                float eps, float* UHT, long ldo, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(UHT) && ldo % 4 == 0;
+    const dim3 grid((unsigned)cdiv(a.nrowblk, 4)), block(256);
+    hipStream_t st = S(stream);
+#define UH_CASE(KT_)                                                                              \
+    if (kt == KT_) {                                                                              \
+        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, 0, st, a, UHT, ldo); \
+        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, 0, st, a, UHT, ldo);    \
+    }
+    UH_CASE(1) UH_CASE(2) UH_CASE(4)
+#undef UH_CASE
+    return check_launch("kl_uht");
+}
+
+int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
+    const int kp = 32 * kt;
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    const int nt = tn_nt(kt);
+    TnPlan p = plan_tn(m, n, kt, nt);
+    a.ncolblk = p.ncolblk;
+    const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
+    const long nchunks = cdiv(a.nrowblk, rowblks_per_chunk);
+    a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
+    const size_t need = (size_t)nchunks * a.chunk_stride * sizeof(float);
+    if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
+    const dim3 grid((unsigned)cdiv(nchunks * a.ncolblk, 4)), block(256);
+    hipStream_t st = S(stream);
+#define WU_CASE(KT_, NT_)                                                                                       \
+    if (kt == KT_) {                                                                                            \
+        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, 0, st, a, rowblks_per_chunk); \
+        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, 0, st, a, rowblks_per_chunk);    \
+    }
+    WU_CASE(1, 4) WU_CASE(2, 4) WU_CASE(4, 2)
+#undef WU_CASE
+    int rc = check_launch("kl_wtu");
+    if (rc) return rc;
+    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k, n, k, n, st);
+}
+
+int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {
+    REQUIRE(H && x && k >= 1 && n >= 1 && ldh >= n, "rowsum: bad arguments");
+    hipLaunchKernelGGL(rowsum_kernel, dim3(k), dim3(256), 0, S(stream), H, n, ldh, x);
+    return check_launch("rowsum");
+}
+
+int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && x && ws && m >= 1 && ldw >= k, "colsum: bad arguments");
+    const int kp = 32 * kt;
+    const long rows_per_blk = 1024;
+    const int nblk = (int)cdiv(m, rows_per_blk);
+    if (ws_bytes < (size_t)nblk * kp * sizeof(float)) return fail(DNMF_EWS, "colsum: workspace too small");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, S(stream), W, m, k, ldw, rows_per_blk, (float*)ws, kp);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(kp), 0, S(stream), (const float*)ws, nblk, kp, k, x);
+    return check_launch("colsum");
+}
+
+int dnmf_kl_update_w(float* W, long m, int k, long ldw, const float* Sm, long lds_, const float* x, float eps,
+                     void* stream) {
+    REQUIRE(W && Sm && x && m >= 1 && k >= 1 && ldw >= k && lds_ >= k, "kl_update_w: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m * k, 256), 8192);
+    hipLaunchKernelGGL(kl_update_kernel<false>, dim3(grid), dim3(256), 0, S(stream), W, m, (long)k, ldw, Sm, lds_, x, eps, 0);
+    return check_launch("kl_update_w");
+}
+
+int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* Sm, long lds_, const float* x, float eps,
+                     int clamp, void* stream) {
+    REQUIRE(H && Sm && x && n >= 1 && k >= 1 && ldh >= n && lds_ >= n, "kl_update_h: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv((long)k * n, 256), 8192);
+    hipLaunchKernelGGL(kl_update_kernel<true>, dim3(grid), dim3(256), 0, S(stream), H, (long)k, n, ldh, Sm, lds_, x, eps, clamp);
+    return check_launch("kl_update_h");
+}
+
+int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+                     float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_fro_step: bad arguments");
+    const WsLayout L = ws_layout(m, n, k);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_fro_step: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    float* G = (float*)(base + L.g_off);
+    float* Sb = (float*)(base + L.s_off);
+    void* part = base + L.part_off;
+    const size_t part_bytes = L.total - L.part_off;
+    int rc;
+    if (w_update) {                                                                   // dist_nmf.py:716-732
+        if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
+        if ((rc = dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
+    }
+    const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
+    if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_wta(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
+    if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
+    return DNMF_OK;
+}
+
+int dnmf_mu_kl_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                    int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_kl_step: bad arguments");
+    const WsLayout L = ws_layout(m, n, k);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_kl_step: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    float* Sb = (float*)(base + L.s_off);
+    float* x = (float*)(base + L.x_off);
+    void* part = base + L.part_off;
+    const size_t part_bytes = L.total - L.part_off;
+    int rc;
+    if (w_update) {                                                                   // dist_nmf.py:813-830
+        const long ldu = round_up(k, 4);
+        if ((rc = dnmf_rowsum(H, k, n, ldh, x, stream))) return rc;
+        if ((rc = dnmf_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldu, stream))) return rc;
+        if ((rc = dnmf_kl_update_w(W, m, k, ldw, Sb, ldu, x, eps, stream))) return rc;
+    }
+    const long ldo = round_up(n, 4);                                                  // dist_nmf.py:832-849
+    if ((rc = dnmf_colsum(W, m, k, ldw, x, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_kl_wtu(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldo, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_kl_update_h(H, k, n, ldh, Sb, ldo, x, eps, clamp, stream))) return rc;
+    if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+"""Cartesian p_r x p_c process grid over torch.distributed (RCCL on GPUs, gloo in CPU tests).
+
+Mirrors reference pyDNMFk/dist_comm.py:16-56 (`MPI_comm`) and the slice of the mpi4py
+communicator API the MU path uses.  One process per GPU; rank r sits at grid
+coordinates (i, j) = divmod(r, p_c) (row-major, `Create_cart(..., reorder=False)`,
+dist_comm.py:22).  Naming follows the reference:
+  cart_1d_row()    = Sub([True, False])  -> the p_r ranks that share grid column j
+  cart_1d_column() = Sub([False, True])  -> the p_c ranks that share grid row i
+The reference's barrier after every collective (dist_nmf.py:115,139,164,...) is dropped:
+collectives here are stream-ordered.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
+
+
+class TorchComm:
+    """Communicator handle: a torch.distributed process group with an mpi4py-shaped surface."""
+
+    def __init__(self, group=None, ranks=None):
+        self.group = group
+        if _dist_on():
+            self.world_rank = dist.get_rank()
+            self.ranks = list(ranks) if ranks is not None else list(range(dist.get_world_size()))
+            self.rank = self.ranks.index(self.world_rank)
+            self.size = len(self.ranks)
+            self.device = (torch.device("cuda", torch.cuda.current_device())
+                           if dist.get_backend() == "nccl" else torch.device("cpu"))
+        else:
+            self.world_rank, self.ranks, self.rank, self.size = 0, [0], 0, 1
+            self.device = torch.device("cpu")
+
+    # ---- mpi4py-shaped surface
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)
+
+    Barrier = barrier
+
+    def Free(self):
+        pass
+
+    def _to_tensor(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.clone(), "t"
+        if isinstance(x, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(x)).to(self.device), "n"
+        if isinstance(x, (int, np.integer)):
+            return torch.tensor([int(x)], dtype=torch.int64, device=self.device), "i"
+        return torch.tensor([float(x)], dtype=torch.float64, device=self.device), "f"
+
+    @staticmethod
+    def _from_tensor(t, kind, like):
+        if kind == "t":
+            return t
+        if kind == "n":
+            return t.cpu().numpy().astype(like.dtype, copy=False)
+        return int(t.item()) if kind == "i" else float(t.item())
+
+    def allreduce(self, x, op=None):
+        """SUM allreduce returning a new object (mpi4py lowercase semantics)."""
+        if self.size == 1:
+            return x
+        t, kind = self._to_tensor(x)
+        dist.all_reduce(t, group=self.group)
+        return self._from_tensor(t, kind, x)
+
+    def bcast(self, x, root=0):
+        if self.size == 1:
+            return x
+        if isinstance(x, torch.Tensor):
+            t = x.clone()
+            dist.broadcast(t, src=self.ranks[root], group=self.group)
+            return t
+        box = [x]
+        dist.broadcast_object_list(box, src=self.ranks[root], group=self.group)
+        return box[0]
+
+    def allgather(self, x):
+        if self.size == 1:
+            return [x]
+        if isinstance(x, torch.Tensor):
+            shapes = [None] * self.size
+            dist.all_gather_object(shapes, tuple(x.shape), group=self.group)
+            return self.allgather_blocks(x, shapes)
+        out = [None] * self.size
+        dist.all_gather_object(out, x, group=self.group)
+        return out
+
+    # ---- in-place device collectives used by the update choreography
+    def allreduce_(self, t):
+        if self.size > 1:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def allgather_blocks(self, x, shapes):
+        """All-gather row-major blocks whose per-rank shapes are known (ragged allowed: padded to the largest)."""
+        if self.size == 1:
+            return [x]
+        numels = [int(np.prod(s)) for s in shapes]
+        mx = max(numels)
+        send = x.reshape(-1)
+        if send.numel() < mx:
+            send = torch.cat([send, send.new_zeros(mx - send.numel())])
+        recv = send.new_empty(self.size * mx)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+        return [recv[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)]
+
+    def reduce_scatter_rows(self, full, counts):
+        """SUM reduce-scatter of a (sum(counts) x c) row-major buffer by row blocks (MPI Reduce_scatter)."""
+        if self.size == 1:
+            return full
+        c = full.shape[1]
+        if len(set(counts)) == 1:
+            out = full.new_empty(counts[0], c)
+            dist.reduce_scatter_tensor(out, full.contiguous(), group=self.group)
+            return out
+        t = full.clone()  # ragged blocks: allreduce + slice (same sums, more traffic)
+        dist.all_reduce(t, group=self.group)
+        off = sum(counts[: self.rank])
+        return t[off: off + counts[self.rank]].contiguous()
+
+    def Reduce_scatter(self, sendbuf, recvbuf, op=None):
+        counts = [None] * self.size
+        if self.size == 1:
+            recvbuf.copy_(sendbuf.view_as(recvbuf))
+            return
+        dist.all_gather_object(counts, int(recvbuf.shape[0]), group=self.group)
+        recvbuf.copy_(self.reduce_scatter_rows(sendbuf, counts))
+
+
+def COMM_WORLD():
+    """The world communicator (every rank of the torch.distributed job, or a single process)."""
+    return TorchComm(None)
+
+
+class MPI_comm:
+    """Reference dist_comm.py:16-56.  `comm` may be None (world) or a TorchComm."""
+
+    def __init__(self, comm, p_r, p_c):
+        self.comm = comm if comm is not None else COMM_WORLD()
+        self.rank = self.comm.Get_rank()
+        self.size = self.comm.Get_size()
+        self.p_r, self.p_c = int(p_r), int(p_c)
+        if self.p_r * self.p_c != self.size:
+            raise ValueError("grid %dx%d needs %d ranks, communicator has %d" % (p_r, p_c, p_r * p_c, self.size))
+        self.coord2d = list(divmod(self.rank, self.p_c))       # Create_cart(reorder=False).Get_coords
+        self._row = self._col = None
+
+    def _make(self, groups):
+        mine = None
+        for ranks in groups:                                   # new_group is collective over the world
+            world = [self.comm.ranks[r] for r in ranks]
+            g = dist.new_group(world) if (self.size > 1 and len(world) > 1) else None
+            if self.rank in ranks:
+                if self.size == 1:
+                    mine = TorchComm(None)
+                elif len(world) == 1:
+                    mine = _SelfComm(world[0])
+                else:
+                    mine = TorchComm(g, world)
+        return mine
+
+    def cart_1d_row(self):
+        """Ranks with the same grid column j (size p_r, ordered by i) -- dist_comm.py:25-37."""
+        if self._row is None:
+            self._row = self._make([[i * self.p_c + j for i in range(self.p_r)] for j in range(self.p_c)])
+        self.cartesian1d_row = self._row
+        return self._row
+
+    def cart_1d_column(self):
+        """Ranks with the same grid row i (size p_c, ordered by j) -- dist_comm.py:39-51."""
+        if self._col is None:
+            self._col = self._make([[i * self.p_c + j for j in range(self.p_c)] for i in range(self.p_r)])
+        self.cartesian1d_column = self._col
+        return self._col
+
+    def Free(self):
+        """dist_comm.py:53-56 (the reference re-creates and frees the sub-communicators; groups are cached here)."""
+        pass
+
+
+class _SelfComm(TorchComm):
+    """A size-1 sub-communicator inside a larger job (e.g. the column group of a p_c = 1 grid)."""
+
+    def __init__(self, world_rank):
+        self.group, self.world_rank, self.ranks, self.rank, self.size = None, world_rank, [world_rank], 0, 1
+        self.device = torch.device("cpu")

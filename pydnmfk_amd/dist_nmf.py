@@ -1,0 +1,238 @@
+"""One multiplicative-update step on a 1D or 2D process grid -- the MI355X update engine.
+
+Drop-in for reference pyDNMFk/dist_nmf.py: `nmf_algorithms_1D(A_ij, W_i, H_j, params).update()`
+(:618,:634-660) and `nmf_algorithms_2D(A_ij, W_ij, H_ij, params).update()` (:51,:66-92), MU method
+for the Frobenius and KL objectives.  Arrays are torch float32 tensors on the GPU; W and H are
+updated IN PLACE and returned, A_ij is never written (same ownership as the reference).
+
+All arithmetic runs in libdnmf_hip.so through `ops` (pydnmfk_amd.engine.HipOps by default).  This
+module only sequences kernels and the grid exchanges, placed exactly where the reference calls
+mpi4py (allreduce / allgather / Reduce_scatter), minus its barriers.  There is no CPU path: `ops`
+exists as a parameter so the choreography can be exercised by tests with a checker back end.
+
+HALS and BCD (dist_nmf.py:411-579, :873-1047) are not part of this engine yet.
+"""
+import torch
+
+_cache = {}
+
+
+def _buf(key, numel, like):
+    """Persistent scratch tensors: a fresh nmf_algorithms_* object is built every iteration
+    (pyDNMF.py:154,169), so buffers live in a module cache keyed by shape/device."""
+    key = (like.device,) + key
+    t = _cache.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.zeros(numel, dtype=torch.float32, device=like.device)
+        _cache[key] = t
+    return t
+
+
+def _default_ops():
+    from .engine import HIP_OPS
+    return HIP_OPS
+
+
+def _kp(k):
+    if k < 1 or k > 128:
+        raise ValueError("rank k=%d unsupported (1 <= k <= 128)" % k)
+    return 32 if k <= 32 else (64 if k <= 64 else 128)
+
+
+def _pad64(x):
+    return (x + 63) // 64 * 64
+
+
+class _Base:
+    def _dispatch(self, clamp):
+        norm, method = self.norm.upper(), self.method.upper()
+        if norm == 'FRO':
+            if method == 'MU':
+                self.Fro_MU_update(self.W_update, clamp)
+            elif method in ('HALS', 'BCD'):
+                raise NotImplementedError("method '%s' is not part of the MI355X MU engine (MU only)" % self.method)
+            else:
+                raise Exception('Not a valid method: Choose (mu/hals/bcd)')    # dist_nmf.py:84,652
+        elif norm == 'KL':
+            if method == 'MU':
+                self.KL_MU_update(self.W_update, clamp)
+            else:
+                raise Exception('Not a valid method: Choose (mu)')             # dist_nmf.py:89,657
+        else:
+            raise Exception('Not a valid norm: Choose (fro/kl)')               # dist_nmf.py:91,659
+
+
+class nmf_algorithms_1D(_Base):
+    """1D grids: p_c == 1 (A and W row-sharded, H replicated) or p_r == 1 (A and H column-sharded,
+    W replicated).  Reference dist_nmf.py:582-869."""
+
+    def __init__(self, A_ij, W_i, H_j, params=None, ops=None):
+        self.m, self.n, self.p_r, self.p_c, self.k = params.m, params.n, params.p_r, params.p_c, params.k
+        self.params = params
+        self.comm1 = params.comm1
+        self.norm, self.method = params.norm, params.method
+        self.A_ij, self.W_i, self.H_j = A_ij, W_i, H_j
+        self.eps = float(params.eps)
+        self.p = self.p_r * self.p_c
+        self.W_update = params.W_update
+        self.rank = self.comm1.rank
+        self.local_W_m = self.W_i.shape[0]
+        self.local_H_n = self.H_j.shape[1]
+        self.ops = ops if ops is not None else _default_ops()
+
+    def update(self, clamp=False):
+        """One step; `clamp=True` additionally applies H = max(H, eps), W = max(W, eps) after it
+        (what PyNMF.fit does when i % 10 == 0, pyDNMF.py:170-172)."""
+        self._dispatch(clamp)
+        return self.W_i, self.H_j
+
+    # ---- Frobenius (dist_nmf.py:716-771)
+    def Fro_MU_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_i, self.H_j, self.eps, self.k
+        if self.p == 1 and hasattr(ops, "mu_fro_step"):
+            ops.mu_fro_step(A, W, H, eps, W_update, clamp)         # whole local step, one library call
+            return
+        kp = _kp(k)
+        m_l, n_l = A.shape
+        if W_update:                                               # Fro_MU_update_W :716-732
+            if self.p_c == 1:                                      # no exchange: fused single pass over A
+                G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+                ops.gram_hht(H, G)
+                ops.aht_update_w(A, H, G, W, eps)
+            else:                                                  # allreduce [A H^T | H H^T] (:681,:707)
+                off = _pad64(m_l * k)
+                buf = _buf(("ahg", m_l, k), off + kp * kp, A)
+                AH, G = buf[: m_l * k].view(m_l, k), buf[off: off + kp * kp].view(kp, kp)
+                ops.gram_hht(H, G)
+                ops.aht(A, H, AH)
+                self.comm1.allreduce_(buf[: off + kp * kp])
+                ops.mu_update_w(W, AH, G, eps)
+        off = _pad64(k * n_l)                                      # Fro_MU_update_H :736-751
+        buf = _buf(("atwg", k, n_l), off + kp * kp, A)
+        AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
+        ops.gram_wtw(W, G)
+        ops.wta(A, W, AtW)
+        if self.p_r != 1:                                          # allreduce [W^T A | W^T W] (:681,:707)
+            self.comm1.allreduce_(buf[: off + kp * kp])
+        ops.mu_update_h(H, AtW, G, eps, clamp)
+        if clamp:
+            ops.clamp_min(W, eps)
+
+    # ---- KL (dist_nmf.py:776-869)
+    def KL_MU_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_i, self.H_j, self.eps, self.k
+        if self.p == 1 and hasattr(ops, "mu_kl_step"):
+            ops.mu_kl_step(A, W, H, eps, W_update, clamp)
+            return
+        m_l, n_l = A.shape
+        if W_update:                                               # KL_MU_update_W :813-830
+            off = _pad64(m_l * k)
+            buf = _buf(("uhx", m_l, k), off + 128, A)
+            UHT, x2 = buf[: m_l * k].view(m_l, k), buf[off: off + k]
+            ops.rowsum(H, x2)                                      # :827
+            ops.kl_uht(A, W, H, eps, UHT)                          # :806,:810
+            if self.p_c != 1:
+                self.comm1.allreduce_(buf[: off + k])              # :797,:707
+            ops.kl_update_w(W, UHT, x2, eps)
+        off = _pad64(k * n_l)                                      # KL_MU_update_H :832-849
+        buf = _buf(("wux", k, n_l), off + 128, A)
+        WTU, x1 = buf[: k * n_l].view(k, n_l), buf[off: off + k]
+        ops.colsum(W, x1)                                          # :846
+        ops.kl_wtu(A, W, H, eps, WTU)                              # :806,:808
+        if self.p_r != 1:
+            self.comm1.allreduce_(buf[: off + k])
+        ops.kl_update_h(H, WTU, x1, eps, clamp)
+        if clamp:
+            ops.clamp_min(W, eps)
+
+
+class nmf_algorithms_2D(_Base):
+    """2D grid (p_r > 1 and p_c > 1).  Reference dist_nmf.py:7-407.  `row_comm` is the size-p_r
+    group sharing grid column j, `col_comm` the size-p_c group sharing grid row i (dist_comm.py:34,48)."""
+
+    def __init__(self, A_ij, W_ij, H_ij, params=None, ops=None):
+        self.params = params
+        self.m, self.n, self.p_r, self.p_c, self.k = params.m, params.n, params.p_r, params.p_c, params.k
+        self.comm1 = params.comm1
+        self.cartesian1d_row, self.cartesian1d_column, self.comm = params.row_comm, params.col_comm, params.comm
+        self.A_ij, self.W_ij, self.H_ij = A_ij, W_ij, H_ij
+        self.eps = float(params.eps)
+        self.p = self.p_r * self.p_c
+        self.W_update = params.W_update
+        self.norm, self.method = params.norm, params.method
+        self.rank = self.comm1.rank
+        self.local_W_m = self.W_ij.shape[0]
+        self.local_H_n = self.H_ij.shape[1]
+        self.ops = ops if ops is not None else _default_ops()
+        # per-member slice sizes inside the sub-communicators (utils.py:99-103), needed for ragged grids
+        from .utils import determine_block_params
+        m_l, n_l = A_ij.shape
+        self.w_counts = [determine_block_params(q, (self.p_c, 1), (m_l, self.k)).determine_block_shape_asymm()[0]
+                         for q in range(self.p_c)]
+        self.h_counts = [determine_block_params(q, (1, self.p_r), (self.k, n_l)).determine_block_shape_asymm()[1]
+                         for q in range(self.p_r)]
+
+    def update(self, clamp=False):
+        self._dispatch(clamp)
+        return self.W_ij, self.H_ij
+
+    # ---- gathers (dist_nmf.py:163-165, :195-197, :268-291)
+    def gather_W(self):
+        blocks = self.cartesian1d_column.allgather_blocks(self.W_ij, [(c, self.k) for c in self.w_counts])
+        return torch.cat(blocks, dim=0) if len(blocks) > 1 else blocks[0]          # vstack -> W_i [m_l x k]
+
+    def gather_H(self):
+        blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
+        return torch.cat(blocks, dim=1).contiguous() if len(blocks) > 1 else blocks[0]  # hstack -> H_j [k x n_l]
+
+    def _scatter_to_W(self, V):
+        """Reduce_scatter over the column group of an (m_l x k) buffer -> (m_w x k)  (:202, :340)."""
+        return self.cartesian1d_column.reduce_scatter_rows(V, self.w_counts)
+
+    def _scatter_to_H(self, Y):
+        """Reduce_scatter over the row group of Y^T (n_l x k) -> (n_h x k) -> transpose (:169-171, :314-316)."""
+        ks = self.cartesian1d_row.reduce_scatter_rows(Y.t().contiguous(), self.h_counts)
+        return ks.t().contiguous()
+
+    # ---- Frobenius (dist_nmf.py:207-263)
+    def Fro_MU_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
+        kp = _kp(k)
+        m_l, n_l = A.shape
+        G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+        if W_update:                                               # Fro_MU_update_W :227-245
+            ops.gram_hht(H, G)
+            self.comm1.allreduce_(G)                               # global_gram :114
+            H_j = self.gather_H()                                  # AH_glob :195-197
+            V = ops.aht(A, H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))   # :198
+            AH = self._scatter_to_W(V)                             # :202
+            ops.mu_update_w(W, AH, G, eps)                         # :244-245
+        ops.gram_wtw(W, G)                                         # Fro_MU_update_H :207-225
+        self.comm1.allreduce_(G)
+        W_i = self.gather_W()                                      # ATW_glob :163-165
+        Y = ops.wta(A, W_i, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))       # :166
+        AtW = self._scatter_to_H(Y)                                # :169-171
+        ops.mu_update_h(H, AtW, G, eps, clamp)                     # :224-225
+        if clamp:
+            ops.clamp_min(W, eps)
+
+    # ---- KL (dist_nmf.py:351-407)
+    def KL_MU_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
+        m_l, n_l = A.shape
+        x = _buf(("x", 128), 128, A)[:k]
+        if W_update:                                               # KL_MU_update_W :351-369
+            ops.rowsum(H, x)
+            self.comm1.allreduce_(x)                               # sum_axis :346-349
+            W_i, H_j = self.gather_W(), self.gather_H()            # gather_W_H :367
+            UHT = ops.kl_uht(A, W_i, H_j, eps, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))  # :337-338
+            sk = self._scatter_to_W(UHT)                           # :340
+            ops.kl_update_w(W, sk, x, eps)                         # :369
+        ops.colsum(W, x)                                           # KL_MU_update_H :371-389
+        self.comm1.allreduce_(x)
+        W_i, H_j = self.gather_W(), self.gather_H()                # :387
+        WTU = ops.kl_wtu(A, W_i, H_j, eps, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))      # :311-312
+        ks = self._scatter_to_H(WTU)                               # :314-316
+        ops.kl_update_h(H, ks, x, eps, clamp)                      # :389
+        if clamp:
+            ops.clamp_min(W, eps)

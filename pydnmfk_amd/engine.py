@@ -1,0 +1,211 @@
+"""Typed wrappers over the C ABI operating on torch CUDA(HIP) tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic operation
+of the hot path runs in libdnmf_hip.so.  All tensors must be float32, on a CUDA device and
+row-major with unit inner stride; anything else raises (no silent host fallback).
+"""
+import torch
+
+from ._lib import check, lib
+
+_ws_cache = {}
+
+
+def _req(t, name, ndim=2):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor on a CUDA device, got %s (no CPU fallback)" % (name, type(t)))
+    if not t.is_cuda:
+        raise TypeError("%s: tensor is on %s; the MU engine only runs on the GPU (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s: dtype %s unsupported; the engine computes in float32" % (name, t.dtype))
+    if t.dim() != ndim or (t.numel() and t.stride(-1) != 1):
+        raise ValueError("%s: must be %d-D row-major with unit inner stride" % (name, ndim))
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def kp(k):
+    v = lib.dnmf_kp(int(k))
+    if v < 0:
+        raise ValueError("rank k=%d unsupported (1 <= k <= 128)" % k)
+    return v
+
+
+def workspace(m, n, k, device):
+    """Scratch buffer large enough for any entry point on an m x n block (cached per device/shape)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(m), int(n), int(k))
+    ws = _ws_cache.get(key)
+    if ws is None:
+        nbytes = lib.dnmf_ws_bytes(int(m), int(n), int(k))
+        if nbytes == 0:
+            raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def new_gram(k, device):
+    return torch.zeros(kp(k), kp(k), dtype=torch.float32, device=device)
+
+
+class HipOps:
+    """The operator set the update choreography (dist_nmf.py) is written against."""
+
+    name = "hip"
+
+    # ---- grams
+    def gram_hht(self, H, out):
+        _req(H, "H"); _req(out, "G")
+        k, n = H.shape
+        ws = workspace(k, n, k, H.device)
+        check(lib.dnmf_gram_hht(H.data_ptr(), k, n, _ld(H), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def gram_wtw(self, W, out):
+        _req(W, "W"); _req(out, "G")
+        m, k = W.shape
+        ws = workspace(m, k, k, W.device)
+        check(lib.dnmf_gram_wtw(W.data_ptr(), m, k, _ld(W), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    # ---- big contractions
+    def aht(self, A, H, out):
+        _req(A, "A"); _req(H, "H"); _req(out, "AH")
+        m, n = A.shape
+        k = H.shape[0]
+        check(lib.dnmf_aht(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), _stream()))
+        return out
+
+    def wta(self, A, W, out):
+        _req(A, "A"); _req(W, "W"); _req(out, "AtW")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
+        check(lib.dnmf_wta(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
+                           ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    # ---- updates
+    def mu_update_w(self, W, AH, G, eps):
+        _req(W, "W"); _req(AH, "AH"); _req(G, "G")
+        m, k = W.shape
+        check(lib.dnmf_mu_update_w(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), float(eps),
+                                   _stream()))
+
+    def mu_update_h(self, H, AtW, G, eps, clamp=False):
+        _req(H, "H"); _req(AtW, "AtW"); _req(G, "G")
+        k, n = H.shape
+        check(lib.dnmf_mu_update_h(H.data_ptr(), k, n, _ld(H), AtW.data_ptr(), _ld(AtW), G.data_ptr(), float(eps),
+                                   int(bool(clamp)), _stream()))
+
+    def aht_update_w(self, A, H, G, W, eps):
+        _req(A, "A"); _req(H, "H"); _req(G, "G"); _req(W, "W")
+        m, n = A.shape
+        k = H.shape[0]
+        check(lib.dnmf_aht_update_w(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
+                                    _ld(W), float(eps), _stream()))
+
+    def mu_fro_step(self, A, W, H, eps, w_update=True, clamp=False):
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
+        check(lib.dnmf_mu_fro_step(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+                                   float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
+                                   _stream()))
+
+    # ---- KL
+    def kl_uht(self, A, W, H, eps, out):
+        _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "UHT")
+        m, n = A.shape
+        k = W.shape[1]
+        check(lib.dnmf_kl_uht(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                              out.data_ptr(), _ld(out), _stream()))
+        return out
+
+    def kl_wtu(self, A, W, H, eps, out):
+        _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "WTU")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
+        check(lib.dnmf_kl_wtu(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                              out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def rowsum(self, H, out):
+        _req(H, "H"); _req(out, "x", 1)
+        k, n = H.shape
+        check(lib.dnmf_rowsum(H.data_ptr(), k, n, _ld(H), out.data_ptr(), _stream()))
+        return out
+
+    def colsum(self, W, out):
+        _req(W, "W"); _req(out, "x", 1)
+        m, k = W.shape
+        ws = workspace(m, k, k, W.device)
+        check(lib.dnmf_colsum(W.data_ptr(), m, k, _ld(W), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def kl_update_w(self, W, S, x, eps):
+        _req(W, "W"); _req(S, "S"); _req(x, "x", 1)
+        m, k = W.shape
+        check(lib.dnmf_kl_update_w(W.data_ptr(), m, k, _ld(W), S.data_ptr(), _ld(S), x.data_ptr(), float(eps),
+                                   _stream()))
+
+    def kl_update_h(self, H, S, x, eps, clamp=False):
+        _req(H, "H"); _req(S, "S"); _req(x, "x", 1)
+        k, n = H.shape
+        check(lib.dnmf_kl_update_h(H.data_ptr(), k, n, _ld(H), S.data_ptr(), _ld(S), x.data_ptr(), float(eps),
+                                   int(bool(clamp)), _stream()))
+
+    def mu_kl_step(self, A, W, H, eps, w_update=True, clamp=False):
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
+        check(lib.dnmf_mu_kl_step(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+                                  float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
+                                  _stream()))
+
+    # ---- fit helpers
+    def clamp_min(self, X, eps):
+        _req(X, "X")
+        check(lib.dnmf_clamp_min(X.data_ptr(), X.shape[0], X.shape[1], _ld(X), float(eps), _stream()))
+
+    def scale_cols_div(self, W, s, eps):
+        _req(W, "W"); _req(s, "s", 1)
+        check(lib.dnmf_scale_cols_div(W.data_ptr(), W.shape[0], W.shape[1], _ld(W), s.data_ptr(), float(eps),
+                                      _stream()))
+
+    def scale_rows_mul(self, H, s):
+        _req(H, "H"); _req(s, "s", 1)
+        check(lib.dnmf_scale_rows_mul(H.data_ptr(), H.shape[0], H.shape[1], _ld(H), s.data_ptr(), _stream()))
+
+    def sqnorm(self, A):
+        _req(A, "A")
+        out = torch.empty(1, dtype=torch.float64, device=A.device)
+        check(lib.dnmf_sqnorm(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), out.data_ptr(), _stream()))
+        return out
+
+    def resid_sqnorm(self, A, W, H):
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        out = torch.empty(1, dtype=torch.float64, device=A.device)
+        check(lib.dnmf_resid_sqnorm(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), W.data_ptr(), _ld(W), H.data_ptr(),
+                                    _ld(H), W.shape[1], out.data_ptr(), _stream()))
+        return out
+
+    # ---- allocation helpers used by the choreography
+    def empty(self, shape, like):
+        return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+    def zeros(self, shape, like):
+        return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+HIP_OPS = HipOps()

@@ -1,0 +1,174 @@
+"""Single-k distributed NMF driver on MI355X -- drop-in for reference pyDNMFk/pyDNMF.py (`PyNMF`).
+
+    W, H, recon_err = PyNMF(A_ij, factors=None, save_factors=False, params=args).fit()
+
+Same `params` attribute bag, same loop semantics (pyDNMF.py:138-182): `itr` update steps, clamp to
+eps when i % 10 == 0 (after that step's update), and on the last step column-normalise W
+(:185-194) and evaluate the Frobenius relative error (:205-218).  A_ij / factors may be numpy arrays
+(copied to the current GPU; numpy arrays come back) or torch CUDA tensors (torch tensors come back).
+Everything numeric runs in libdnmf_hip.so; there is no CPU path.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * compute dtype is float32 (the engine's only dtype); float64 input raises;
+  * method must be 'mu' (HALS/BCD not in the engine yet); init='nnsvd' is not provided;
+  * `prune=True` is accepted only when the block has no all-zero row/column (then it is a no-op).
+"""
+import numpy as np
+import torch
+
+from .dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
+from .utils import data_operations, var_init
+
+
+def _to_device(x, device):
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x))
+    if t.dtype == torch.float64:
+        raise TypeError("PyNMF: float64 input; the MI355X engine computes in float32 -- cast with .astype('float32')")
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class PyNMF:
+    """Reference pyDNMF.py:6-239 (the MU path of it)."""
+
+    def __init__(self, A_ij, factors=None, save_factors=False, params=None, ops=None):
+        self._numpy_io = not isinstance(A_ij, torch.Tensor)
+        self.ops = ops
+        if ops is None:
+            if isinstance(A_ij, torch.Tensor) and not A_ij.is_cuda:
+                raise TypeError("PyNMF: A_ij is a CPU tensor; pass a CUDA tensor or a numpy array (no CPU fallback)")
+            if not torch.cuda.is_available():
+                raise RuntimeError("PyNMF: no GPU visible; the MI355X engine has no CPU fallback")
+            device = A_ij.device if isinstance(A_ij, torch.Tensor) else torch.device("cuda", torch.cuda.current_device())
+        else:
+            device = A_ij.device if isinstance(A_ij, torch.Tensor) else torch.device("cpu")
+        self.device = device
+        self.A_ij = _to_device(A_ij, device)
+        self.params = params
+        self.m_loc, self.n_loc = self.A_ij.shape
+        self.init = self.params.init if getattr(self.params, "init", None) else 'rand'
+        if "grid" in vars(self.params) and self.params.grid:
+            self.p_r, self.p_c, self.k = self.params.grid[0], self.params.grid[1], self.params.k
+            self.params.p_r, self.params.p_c = self.p_r, self.p_c
+        else:
+            self.p_r, self.p_c, self.k = self.params.p_r, self.params.p_c, self.params.k
+        self.comm1 = self.params.comm1
+        self.cart_1d_row, self.cart_1d_column, self.comm = self.params.row_comm, self.params.col_comm, self.params.comm
+        self.verbose = self.params.verbose if getattr(self.params, "verbose", False) else False
+        self.rank = self.comm1.rank
+        self.eps = float(np.finfo(np.float32).eps)                  # pyDNMF.py:68 for float32 data
+        self.params.eps = self.eps
+        self.norm = var_init(self.params, 'norm', default='kl')     # :70
+        self.method = var_init(self.params, 'method', default='mu')
+        self.prune = var_init(self.params, 'prune', default=True)
+        self.save_factors = save_factors
+        self.params.itr = var_init(self.params, 'itr', default=5000)
+        self.itr = self.params.itr
+        try:
+            self.W_update = self.params.W_update
+        except AttributeError:
+            self.params.W_update = True
+            self.W_update = True
+        self.p = self.p_r * self.p_c
+        self.topo = '2d' if (self.p_r != 1 and self.p_c != 1) else '1d'   # :83-87
+        self.params.topo = self.topo
+        self.data_op = data_operations(self.A_ij, self.params)      # :88 -> params.m, n, m_loc, n_loc, ...
+        self.params = self.data_op.params
+        if factors is not None:                                     # :90-96 (copied on entry)
+            W0, H0 = _to_device(factors[0], device).clone(), _to_device(factors[1], device).clone()
+        else:
+            W0, H0 = self.init_factors()
+        if self.topo == '1d':
+            self.W_i, self.H_j = W0, H0
+        else:
+            self.W_ij, self.H_ij = W0, H0
+        if self.prune:
+            nz = self.A_ij != 0
+            if bool((nz.sum(1) == 0).any()) or bool((nz.sum(0) == 0).any()):
+                raise NotImplementedError("PyNMF: zero rows/columns present; pruning (utils.py:117-217) is not part "
+                                          "of the MI355X engine -- remove them or pass params.prune=False")
+
+    def init_factors(self):
+        """pyDNMF.py:107-135, init='rand': uniform [0,1) from the process-global numpy RNG (so seeding numpy
+        reproduces the reference's draw order), cast to float32; the replicated factor is broadcast from rank 0."""
+        if self.init != 'rand':
+            raise NotImplementedError("init='%s': only 'rand' (or factors=...) is provided by the MI355X engine" % self.init)
+        f32 = np.float32
+        if self.topo == '2d':
+            W = np.random.rand(self.params.m_loc, self.k).astype(f32)
+            H = np.random.rand(self.k, self.params.n_loc).astype(f32)
+        elif self.p_c == 1:
+            W = np.random.rand(self.m_loc, self.k).astype(f32)
+            H = np.random.rand(self.k, self.n_loc).astype(f32) if self.rank == 0 else None
+            H = self.comm1.bcast(H, root=0)
+        else:
+            H = np.random.rand(self.k, self.n_loc).astype(f32)
+            W = np.random.rand(self.m_loc, self.k).astype(f32) if self.rank == 0 else None
+            W = self.comm1.bcast(W, root=0)
+        return _to_device(W, self.device), _to_device(H, self.device)
+
+    def _ops(self):
+        if self.ops is None:
+            from .engine import HIP_OPS
+            self.ops = HIP_OPS
+        return self.ops
+
+    def _out(self, t):
+        return t.cpu().numpy() if self._numpy_io else t
+
+    def fit(self):
+        """pyDNMF.py:138-182.  Returns (W, H, recon_err)."""
+        if self.method.lower() != 'mu':
+            raise NotImplementedError("method '%s' is not part of the MI355X MU engine (MU only)" % self.method)
+        ops = self._ops()
+        for i in range(self.itr):
+            clamp = (i % 10 == 0)                                   # :155 / :170, fused into the step
+            if self.topo == '2d':
+                self.W_ij, self.H_ij = nmf_algorithms_2D(self.A_ij, self.W_ij, self.H_ij, params=self.params,
+                                                         ops=ops).update(clamp=clamp)
+            else:
+                self.W_i, self.H_j = nmf_algorithms_1D(self.A_ij, self.W_i, self.H_j, params=self.params,
+                                                       ops=ops).update(clamp=clamp)
+            if i == self.itr - 1:
+                if self.topo == '2d':
+                    self.W_ij, self.H_ij = self.normalize_features(self.W_ij, self.H_ij)
+                else:
+                    self.W_i, self.H_j = self.normalize_features(self.W_i, self.H_j)
+                self.relative_err()
+                if self.verbose is True and self.rank == 0:
+                    print('relative error is:', self.recon_err)
+                W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
+                if self.save_factors:
+                    from .data_io import data_write
+                    data_write(self.params).save_factors([W.cpu().numpy(), H.cpu().numpy()])
+                return self._out(W), self._out(H), self.recon_err
+
+    def normalize_features(self, Wall, Hall):
+        """pyDNMF.py:185-194: s = column sums of W (allreduced iff 2D or p_r != 1); W /= s + eps; H *= s^T."""
+        ops = self._ops()
+        s = ops.colsum(Wall, ops.zeros((self.k,), Wall))
+        if self.topo == '2d' or self.p_r != 1:
+            self.comm1.allreduce_(s)
+        ops.scale_cols_div(Wall, s, self.eps)
+        ops.scale_rows_mul(Hall, s)
+        return Wall, Hall
+
+    def cart_2d_collect_factors(self):
+        """pyDNMF.py:197-202."""
+        alg = nmf_algorithms_2D(self.A_ij, self.W_ij, self.H_ij, params=self.params, ops=self._ops())
+        self.H_j = alg.gather_H()
+        self.W_i = alg.gather_W()
+
+    def relative_err(self):
+        """pyDNMF.py:205-218: ||A - W H||_F / ||A||_F; squared norms are summed over ranks, then sqrt."""
+        ops = self._ops()
+        if self.topo == '2d':
+            self.cart_2d_collect_factors()
+        sq = torch.cat([ops.resid_sqnorm(self.A_ij, self.W_i, self.H_j), ops.sqnorm(self.A_ij)])
+        self.comm1.allreduce_(sq)
+        num, den = (float(v) for v in sq.cpu())
+        self.glob_norm_err, self.glob_norm_A = float(np.sqrt(num)), float(np.sqrt(den))
+        self.recon_err = self.glob_norm_err / self.glob_norm_A
+        return self.recon_err

@@ -1,0 +1,92 @@
+"""Partition math, the `args` attribute bag and dimension bookkeeping.
+
+Mirrors the hot-path parts of reference pyDNMFk/utils.py: `determine_block_params` (:15-46),
+`data_operations.compute_global_dim/compute_local_dim` (:73-115), `var_init` (:473-477),
+`parse` (:480-483).  Pruning, checkpoints and the MLP helpers are out of scope.
+"""
+import numpy as np
+
+
+class parse:
+    """Empty attribute bag populated by assignment (utils.py:480-483)."""
+
+    def __init__(self):
+        pass
+
+
+def var_init(clas, var, default):
+    """Return clas.<var>, first setting it to `default` if absent (utils.py:473-477)."""
+    if not hasattr(clas, var):
+        setattr(clas, var, default)
+    return getattr(clas, var)
+
+
+class determine_block_params:
+    """Block index ranges of a `shape` array on a `pgrid` grid for one rank (utils.py:15-46)."""
+
+    def __init__(self, comm, pgrid, shape):
+        self.rank = comm if isinstance(comm, (int, np.integer)) else comm.rank
+        self.pgrid = tuple(int(p) for p in pgrid)
+        self.rank = self.rank if int(np.prod(self.pgrid)) > 1 else 0
+        self.shape = tuple(int(s) for s in shape)
+
+    def determine_block_index_range_asymm(self):
+        """(start_inds, end_inds), end inclusive; the first n % p blocks hold one extra item (utils.py:36-41)."""
+        chunk_ind = np.unravel_index(self.rank, self.pgrid)
+        start = [int(i) * (n // k) + min(int(i), n % k) for n, k, i in zip(self.shape, self.pgrid, chunk_ind)]
+        end = [(int(i) + 1) * (n // k) + min(int(i) + 1, n % k) - 1 for n, k, i in zip(self.shape, self.pgrid, chunk_ind)]
+        return start, end
+
+    def determine_block_shape_asymm(self):
+        s, e = self.determine_block_index_range_asymm()
+        return [j - i + 1 for i, j in zip(s, e)]
+
+
+class data_operations:
+    """Global/local dimension bookkeeping for a rank's block (utils.py:49-115).  Writes
+    params.m, params.n, params.m_loc, params.n_loc, params.W_start/W_end/H_start/H_end."""
+
+    def __init__(self, data, params):
+        self.ten = data
+        self.params = params
+        self.comm1 = params.comm1
+        self.cart_1d_row = params.row_comm
+        self.cart_1d_column = params.col_comm
+        self.rank = self.comm1.rank
+        self.p_r, self.p_c = params.p_r, params.p_c
+        self.topo = params.topo
+        self.k = params.k
+        self.compute_global_dim()
+        self.compute_local_dim()
+        self.m, self.n = params.m, params.n
+
+    def compute_global_dim(self):
+        """utils.py:73-93: global m, n from the local block shapes via integer allreduces."""
+        loc_m, loc_n = int(self.ten.shape[0]), int(self.ten.shape[1])
+        p = self.params
+        if self.p_r != 1 and self.p_c == 1:
+            p.n = loc_n
+            p.m = self.comm1.allreduce(loc_m)
+        elif self.p_c != 1 and self.p_r == 1:
+            p.n = self.comm1.allreduce(loc_n)
+            p.m = loc_m
+        else:
+            p.m = self.comm1.allreduce(loc_m if self.rank % self.p_c == 0 else 0)
+            p.n = self.comm1.allreduce(loc_n if self.rank // self.p_c == 0 else 0)
+
+    def compute_local_dim(self):
+        """utils.py:97-115: factor slice sizes and offsets."""
+        p = self.params
+        if self.topo == "2d":
+            bm = determine_block_params(self.cart_1d_column, (self.p_c, 1), (self.ten.shape[0], self.k))
+            bn = determine_block_params(self.cart_1d_row, (1, self.p_r), (self.k, self.ten.shape[1]))
+        else:
+            bm = determine_block_params(self.comm1, (self.p_r, 1), (p.m, self.k))
+            bn = determine_block_params(self.comm1, (1, self.p_c), (self.k, p.n))
+        m_loc = bm.determine_block_shape_asymm()[0]
+        n_loc = bn.determine_block_shape_asymm()[1]
+        w = bm.determine_block_index_range_asymm()
+        h = bn.determine_block_index_range_asymm()
+        p.m_loc, p.n_loc = m_loc, n_loc
+        p.W_start, p.W_end = w[0][0], w[1][0] + 1
+        p.H_start, p.H_end = h[0][1], h[1][1] + 1

@@ -1,0 +1,37 @@
+"""The C-ABI library loads and exports every symbol include/dnmf.h declares; argument validation
+works without touching a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "dnmf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dnmf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from pydnmfk_amd import _lib
+    names = _declared()
+    assert len(names) >= 24
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "symbol %s declared in include/dnmf.h but not exported" % n
+        assert n in _lib.SIGNATURES, "symbol %s has no ctypes signature in pydnmfk_amd/_lib.py" % n
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_argument_validation_without_gpu():
+    from pydnmfk_amd._lib import lib
+    assert lib.dnmf_version() >= 100
+    assert [lib.dnmf_kp(k) for k in (1, 4, 32, 33, 64, 65, 128)] == [32, 32, 32, 64, 64, 128, 128]
+    assert lib.dnmf_kp(0) < 0 and lib.dnmf_kp(129) < 0
+    assert lib.dnmf_ws_bytes(0, 10, 4) == 0
+    assert lib.dnmf_ws_bytes(262144, 8192, 64) > 64 * 8192 * 4
+    # null pointers / bad rank are rejected before any HIP call
+    assert lib.dnmf_aht(None, 8, 8, 8, None, 4, 8, None, 4, None) == -1
+    assert b"aht" in lib.dnmf_last_error()
+    assert lib.dnmf_mu_fro_step(None, 8, 8, 8, None, 4, None, 8, 200, 1e-7, 1, 0, None, 0, None) == -1

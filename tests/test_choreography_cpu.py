@@ -1,0 +1,148 @@
+"""Host logic on CPU: the PyNMF / nmf_algorithms_* / MPI_comm choreography (kernel order, packed
+allreduces, allgather / reduce_scatter on sub-groups, ragged blocks) run under gloo with world sizes
+1..4 against the golden vectors captured from the reference.  Arithmetic here comes from the checker
+double in tests/_ops_double.py -- these tests say nothing about the HIP kernels (those are `-m gpu`).
+"""
+import os
+import socket
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests._golden import load_case, rel_fro
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_case_rank(rank, world, port, name, q):
+    try:
+        import torch.distributed as dist
+        from oracle import nmf_oracle as orc
+        from pydnmfk_amd.dist_comm import MPI_comm
+        from pydnmfk_amd.pyDNMF import PyNMF
+        from pydnmfk_amd.utils import determine_block_params, parse
+        from tests._ops_double import OracleOps
+
+        torch.set_num_threads(1)
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        meta, A, W0, H0, z = load_case(name)
+        p_r, p_c = meta["grid"]
+        comms = MPI_comm(None, p_r, p_c)
+        out = {}
+        for itr in meta["itrs"]:
+            args = parse()
+            args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
+            args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+            args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+            args.norm, args.method, args.W_update = meta["norm"], "mu", meta["W_update"]
+            s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+            assert [s[0], e[0] + 1, s[1], e[1] + 1] == list(z["r%d_A_range" % rank])
+            A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1]
+            (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, meta["m"], meta["n"])
+            W, H, err = PyNMF(A_ij, factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=OracleOps()).fit()
+            assert (args.m, args.n) == (meta["m"], meta["n"])
+            assert [args.m_loc, args.n_loc] == list(z["r%d_m_loc_n_loc" % rank])
+            out[itr] = (rel_fro(W, z["r%d_fit%d_W" % (rank, itr)]), rel_fro(H, z["r%d_fit%d_H" % (rank, itr)]),
+                        abs(err - float(z["r0_fit%d_err" % itr])))
+        q.put((rank, out, None))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def _run(name):
+    meta = load_case(name)[0]
+    world = meta["grid"][0] * meta["grid"][1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_case_rank, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, err in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+        for itr, (dw, dh, de) in out.items():
+            assert dw <= 1e-4 and dh <= 1e-4 and de <= 1e-5, (name, rank, itr, dw, dh, de)
+
+
+CASES = [
+    "t24x12_1x1_fro_float32", "t24x12_1x1_kl_float32",
+    "t24x12_2x1_fro_float32", "t24x12_1x2_fro_float32", "t24x12_2x1_kl_float32", "t24x12_1x2_kl_float32",
+    "t24x12_2x2_fro_float32", "t24x12_2x2_kl_float32",
+    "r25x13_3x1_fro_float32", "r25x13_1x3_kl_float32", "r25x13_2x2_fro_float32", "r25x13_2x2_kl_float32",
+    "swim_4x1_fro_float32", "swim_2x2_kl_float32", "t24x12_2x1_kl_float32_noW",
+    "lr200x136k64_2x2_fro_float32", "lr150x140k128_2x1_kl_float32",
+]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_choreography_matches_reference(name):
+    _run(name)
+
+
+def test_invalid_method_and_norm_raise():
+    """Error behaviour of update() (dist_nmf.py:84-91, 652-659)."""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
+    from pydnmfk_amd.utils import parse
+    from tests._ops_double import OracleOps
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.p_r, args.p_c, args.k, args.m, args.n = comms.comm, 1, 1, 2, 4, 3
+    args.eps, args.W_update = 1e-7, True
+    A, W, H = torch.rand(4, 3), torch.rand(4, 2), torch.rand(2, 3)
+    for norm, method, msg in (("fro", "xx", "Not a valid method"), ("kl", "hals", "Not a valid method"),
+                              ("l1", "mu", "Not a valid norm")):
+        args.norm, args.method = norm, method
+        with pytest.raises(Exception, match=msg):
+            nmf_algorithms_1D(A, W, H, params=args, ops=OracleOps()).update()
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Without an injected checker back end, CPU input must fail loudly (no silent host path)."""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMF import PyNMF
+    from pydnmfk_amd.utils import parse
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, 2
+    args.row_comm, args.col_comm, args.init, args.itr = comms.cart_1d_row(), comms.cart_1d_column(), "rand", 1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PyNMF(np.random.rand(8, 6).astype(np.float32), params=args)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        PyNMF(torch.rand(8, 6), params=args)
+
+
+def test_save_factors_layout(tmp_path):
+    """data_io.py:175-196 layout: 1x1 grid writes W_factors/W_0.npy and H_factors/H_0.npy."""
+    from pydnmfk_amd.data_io import data_write
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.utils import parse
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.p_r, args.p_c = comms.comm, 1, 1
+    args.results_paths = str(tmp_path) + "/"
+    W, H = np.random.rand(5, 2).astype(np.float32), np.random.rand(2, 4).astype(np.float32)
+    data_write(args).save_factors([W, H])
+    assert np.array_equal(np.load(tmp_path / "W_factors" / "W_0.npy"), W)
+    assert np.array_equal(np.load(tmp_path / "H_factors" / "H_0.npy"), H)
+    data_write(args).save_factors([W, H], reg=True)
+    assert (tmp_path / "W_reg_factors" / "W_0.npy").exists()

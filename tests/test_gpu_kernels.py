@@ -1,0 +1,183 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point against numpy (the same calls the reference
+makes, cited per test) on seeded inputs, including ragged / unaligned shapes that force the generic
+(non-vectorised) path and k that is not a multiple of the 32-wide MFMA tile.
+
+Tolerance (fp32): rel-Frobenius <= 2e-6 per GEMM-like op vs a float64 numpy evaluation of the same
+formula (fp32 MFMA is an exact fmaf chain; the difference is summation order), <= 1e-5 per fused update.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float32).eps)
+# (m, n, k): tile-aligned, ragged, tiny, k on both sides of the KP boundaries, unaligned leading dims
+SHAPES = [(512, 384, 64), (300, 260, 32), (257, 131, 33), (130, 72, 128), (24, 12, 2), (1024, 256, 4),
+          (97, 53, 7), (640, 200, 96), (2048, 1024, 64), (33, 515, 65)]
+
+
+def _rel(x, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(np.asarray(x, dtype=np.float64) - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from pydnmfk_amd.engine import HIP_OPS
+    return HIP_OPS
+
+
+def _mk(m, n, k, seed=0):
+    rs = np.random.RandomState(seed + m + 7 * n + 13 * k)
+    A = rs.rand(m, n).astype(np.float32)
+    A[rs.rand(m, n) < 0.2] = 0.0          # exact zeros, as in swim.mat
+    W = rs.rand(m, k).astype(np.float32)
+    H = rs.rand(k, n).astype(np.float32)
+    return A, W, H
+
+
+def _d(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_grams(ops, m, n, k):
+    """np.matmul(A.T, A) in global_gram (dist_nmf.py:679): H H^T and W^T W, zero-padded to KP x KP."""
+    from pydnmfk_amd.engine import new_gram
+    _, W, H = _mk(m, n, k)
+    G = new_gram(k, torch.device("cuda"))
+    G.fill_(7.0)
+    g = ops.gram_hht(_d(H), G).cpu().numpy()
+    assert _rel(g[:k, :k], H.astype(np.float64) @ H.T.astype(np.float64)) < 2e-6
+    assert not g[k:].any() and not g[:, k:].any()
+    assert np.array_equal(g, g.T)
+    G.fill_(7.0)
+    g = ops.gram_wtw(_d(W), G).cpu().numpy()
+    assert _rel(g[:k, :k], W.T.astype(np.float64) @ W.astype(np.float64)) < 2e-6
+    assert not g[k:].any() and not g[:, k:].any()
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_aht_and_wta(ops, m, n, k):
+    """np.matmul(A, H.T) and np.matmul(W.T, A) in global_mm (dist_nmf.py:705)."""
+    A, W, H = _mk(m, n, k)
+    dA = _d(A)
+    AH = ops.aht(dA, _d(H), torch.full((m, k), 7.0, device="cuda")).cpu().numpy()
+    assert _rel(AH, A.astype(np.float64) @ H.T.astype(np.float64)) < 2e-6
+    AtW = ops.wta(dA, _d(W), torch.full((k, n), 7.0, device="cuda")).cpu().numpy()
+    assert _rel(AtW, W.T.astype(np.float64) @ A.astype(np.float64)) < 2e-6
+
+
+def test_strided_views(ops):
+    """Leading dimensions larger than the logical width (sub-blocks of bigger buffers)."""
+    m, n, k = 200, 136, 64
+    A, W, H = _mk(m, n, k)
+    bigA = torch.zeros(m, n + 8, device="cuda"); bigA[:, :n] = _d(A)
+    bigH = torch.zeros(k, n + 12, device="cuda"); bigH[:, :n] = _d(H)
+    bigW = torch.zeros(m, k + 4, device="cuda"); bigW[:, :k] = _d(W)
+    AH = ops.aht(bigA[:, :n], bigH[:, :n], torch.empty(m, k, device="cuda")).cpu().numpy()
+    assert _rel(AH, A.astype(np.float64) @ H.T.astype(np.float64)) < 2e-6
+    AtW = ops.wta(bigA[:, :n], bigW[:, :k], torch.empty(k, n, device="cuda")).cpu().numpy()
+    assert _rel(AtW, W.T.astype(np.float64) @ A.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_mu_updates(ops, m, n, k):
+    """W *= AH / (W HHT + eps) (dist_nmf.py:731-732); H *= AtW / (H^T WTW + eps)^T (:750-751); fused W phase."""
+    from pydnmfk_amd.engine import new_gram
+    A, W, H = _mk(m, n, k)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    dev = torch.device("cuda")
+    G = ops.gram_hht(_d(H), new_gram(k, dev))
+    AH = (A64 @ H64.T).astype(np.float32)
+    Wd = _d(W)
+    ops.mu_update_w(Wd, _d(AH), G, EPS)
+    W_ref = W64 * (AH.astype(np.float64) / (W64 @ (H64 @ H64.T) + EPS))
+    assert _rel(Wd.cpu().numpy(), W_ref) < 1e-5
+    Wf = _d(W)
+    ops.aht_update_w(_d(A), _d(H), G, Wf, EPS)
+    assert _rel(Wf.cpu().numpy(), W_ref) < 1e-5
+    G2 = ops.gram_wtw(_d(W), new_gram(k, dev))
+    AtW = (W64.T @ A64).astype(np.float32)
+    for clamp in (False, True):
+        Hd = _d(H)
+        ops.mu_update_h(Hd, _d(AtW), G2, EPS, clamp)
+        H_ref = H64 * (AtW.astype(np.float64) / (H64.T @ (W64.T @ W64) + EPS).T)
+        if clamp:
+            H_ref = np.maximum(H_ref, EPS)
+        assert _rel(Hd.cpu().numpy(), H_ref) < 1e-5
+        if clamp:
+            assert float(Hd.min()) >= EPS
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_kl_pieces(ops, m, n, k):
+    """U = A/(WH+eps); U H^T; W^T U (dist_nmf.py:806-810); row/column sums (:793-795); eltwise (:828-830, :847-849)."""
+    A, W, H = _mk(m, n, k)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    U = A64 / (W64 @ H64 + EPS)
+    uht = ops.kl_uht(_d(A), _d(W), _d(H), EPS, torch.full((m, k), 7.0, device="cuda")).cpu().numpy()
+    assert _rel(uht, U @ H64.T) < 5e-6
+    wtu = ops.kl_wtu(_d(A), _d(W), _d(H), EPS, torch.full((k, n), 7.0, device="cuda")).cpu().numpy()
+    assert _rel(wtu, W64.T @ U) < 5e-6
+    x2 = ops.rowsum(_d(H), torch.empty(k, device="cuda")).cpu().numpy()
+    assert _rel(x2, H64.sum(1)) < 1e-6
+    x1 = ops.colsum(_d(W), torch.empty(k, device="cuda")).cpu().numpy()
+    assert _rel(x1, W64.sum(0)) < 1e-6
+    Wd = _d(W)
+    ops.kl_update_w(Wd, _d(uht), _d(x2), EPS)
+    assert _rel(Wd.cpu().numpy(), W64 * (uht / (x2[None, :].astype(np.float64) + EPS))) < 1e-6
+    Hd = _d(H)
+    ops.kl_update_h(Hd, _d(wtu), _d(x1), EPS, False)
+    assert _rel(Hd.cpu().numpy(), H64 * (wtu / (x1[:, None].astype(np.float64) + EPS))) < 1e-6
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_norms_and_fit_helpers(ops, m, n, k):
+    """np.linalg.norm(A)**2 and np.linalg.norm(A - W@H)**2 (pyDNMF.py:207-217); clamp (:155-157); normalise (:185-194)."""
+    A, W, H = _mk(m, n, k)
+    W *= 0.1
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    assert abs(float(ops.sqnorm(_d(A))) / float((A64 ** 2).sum()) - 1) < 1e-6
+    assert abs(float(ops.resid_sqnorm(_d(A), _d(W), _d(H))) / float(((A64 - W64 @ H64) ** 2).sum()) - 1) < 5e-6
+    X = _d(A - 0.5)
+    ops.clamp_min(X, EPS)
+    assert np.array_equal(X.cpu().numpy(), np.maximum(A - 0.5, np.float32(EPS)))
+    s = ops.colsum(_d(W), torch.empty(k, device="cuda"))
+    Wd, Hd = _d(W), _d(H)
+    ops.scale_cols_div(Wd, s, EPS)
+    ops.scale_rows_mul(Hd, s)
+    sn = s.cpu().numpy()
+    assert _rel(Wd.cpu().numpy(), W / (sn[None, :] + np.float32(EPS))) < 1e-6
+    assert _rel(Hd.cpu().numpy(), H * sn[:, None]) < 1e-6
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+@pytest.mark.parametrize("norm", ["fro", "kl"])
+def test_whole_step_matches_oracle(ops, m, n, k, norm):
+    """dnmf_mu_{fro,kl}_step vs the oracle's single-rank step (dist_nmf.py:755-771 / :851-869), with and
+    without the W update (regression mode) and with the fit loop's clamp."""
+    from oracle import nmf_oracle as orc
+    A, W, H = _mk(m, n, k)
+    for w_update, clamp in ((True, False), (False, False), (True, True)):
+        Wd, Hd = _d(W), _d(H)
+        (ops.mu_fro_step if norm == "fro" else ops.mu_kl_step)(_d(A), Wd, Hd, EPS, w_update, clamp)
+        Wr, Hr = W.copy(), H.copy()
+        step = orc.fro_mu_step_local if norm == "fro" else orc.kl_mu_step_local
+        step(A, Wr, Hr, np.float32(EPS), W_update=w_update)
+        if clamp:
+            Wr, Hr = np.maximum(Wr, np.float32(EPS)), np.maximum(Hr, np.float32(EPS))
+        assert _rel(Wd.cpu().numpy(), Wr) < 1e-5, (w_update, clamp)
+        assert _rel(Hd.cpu().numpy(), Hr) < 1e-5, (w_update, clamp)
+
+
+def test_errors_are_loud(ops):
+    from pydnmfk_amd._lib import DnmfError
+    with pytest.raises(TypeError):
+        ops.aht(torch.rand(4, 4), torch.rand(2, 4), torch.empty(4, 2))           # CPU tensors
+    with pytest.raises(TypeError):
+        ops.sqnorm(torch.rand(4, 4, device="cuda", dtype=torch.float64))        # float64
+    with pytest.raises((ValueError, DnmfError)):
+        ops.gram_wtw(torch.rand(300, 200, device="cuda"), torch.empty(128, 128, device="cuda"))  # k > 128

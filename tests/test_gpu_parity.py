@@ -1,0 +1,123 @@
+"""End-to-end parity on the GPU through the reference's own entry point, PyNMF(...).fit():
+  * against the golden vectors captured from the reference (single-rank cases; multi-rank grids are
+    covered by the gloo choreography tests + per-kernel GPU tests, a GPU box has one device);
+  * against the oracle on seeded problems too big for fixtures;
+  * at BASELINE config-2 size (65536 x 4096, k=32) through size-independent properties.
+
+Tolerances (north_star "within a stated fp32 tolerance"):
+  one update step from identical state: rel-Frobenius <= 1e-5
+  fits of <= 100 iterations: rel-Frobenius <= 1e-4 on W and H, |recon_err difference| <= 1e-5
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from tests._golden import case_names, load_case, rel_fro  # noqa: E402
+
+SINGLE = [c for c in case_names() if "_1x1_" in c and c.endswith(("float32", "float32_noW"))]
+
+
+def _args(k, itr, norm, W_update=True):
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.utils import parse
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, k
+    args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+    args.norm, args.method, args.W_update = norm, "mu", W_update
+    return args
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_fit_matches_reference_golden(name):
+    from pydnmfk_amd.pyDNMF import PyNMF
+    meta, A, W0, H0, z = load_case(name)
+    for itr in meta["itrs"]:
+        W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"])).fit()
+        assert isinstance(W, np.ndarray) and W.dtype == np.float32       # numpy in -> numpy out
+        assert rel_fro(W, z["r0_fit%d_W" % itr]) <= 1e-4, itr
+        assert rel_fro(H, z["r0_fit%d_H" % itr]) <= 1e-4, itr
+        assert abs(err - float(z["r0_fit%d_err" % itr])) <= 1e-5, itr
+
+
+@pytest.mark.parametrize("name", SINGLE)
+def test_single_update_matches_reference_golden(name):
+    """One bare nmf_algorithms_1D.update() from identical state (no clamp, no normalisation)."""
+    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
+    meta, A, W0, H0, z = load_case(name)
+    args = _args(meta["k"], 1, meta["norm"], meta["W_update"])
+    args.m, args.n, args.eps = meta["m"], meta["n"], float(np.finfo(np.float32).eps)
+    W, H = torch.from_numpy(W0).cuda(), torch.from_numpy(H0).cuda()
+    W1, H1 = nmf_algorithms_1D(torch.from_numpy(A).cuda(), W, H, params=args).update()
+    assert W1 is W and H1 is H                                           # in place, same objects returned
+    assert rel_fro(W.cpu().numpy(), z["r0_step1_W"]) <= 1e-5
+    assert rel_fro(H.cpu().numpy(), z["r0_step1_H"]) <= 1e-5
+
+
+@pytest.mark.parametrize("m,n,k,norm,itr", [(4096, 1024, 64, "fro", 20), (3000, 1500, 32, "fro", 20),
+                                            (2048, 768, 128, "fro", 12), (2048, 1024, 64, "kl", 12),
+                                            (1100, 900, 16, "kl", 12)])
+def test_fit_matches_oracle_seeded(m, n, k, norm, itr):
+    """Low-rank-plus-noise X (SURVEY 8d parity generator, RandomState(100) as in tests/test_dist_nmf_1d.py:14)."""
+    from oracle import nmf_oracle as orc
+    from pydnmfk_amd.pyDNMF import PyNMF
+    rs = np.random.RandomState(100)
+    A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.01 * rs.randn(m, n)).astype(np.float32)
+    W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+    W, H, err = PyNMF(torch.from_numpy(A).cuda(), factors=[W0, H0], params=_args(k, itr, norm)).fit()
+    assert isinstance(W, torch.Tensor) and W.is_cuda                     # torch in -> torch out
+    Wr, Hr, err_r = orc.fit_single(A, W0, H0, itr, norm=norm)
+    assert rel_fro(W.cpu().numpy(), Wr) <= 1e-4
+    assert rel_fro(H.cpu().numpy(), Hr) <= 1e-4
+    assert abs(err - err_r) <= 1e-5
+
+
+def test_reference_convergence_threshold():
+    """The reference's own assertion (tests/test_dist_nmf_1d.py:46): rel_error < 1e-3 on the exact rank-2
+    24x12 problem after 2000 MU iterations from a random init (here in float32 on the GPU)."""
+    from pydnmfk_amd.pyDNMF import PyNMF
+    np.random.seed(100)
+    m, k, n = 24, 2, 12
+    A = (np.random.rand(m, k) @ np.random.rand(k, n)).astype(np.float32)
+    for norm in ("fro", "kl"):
+        np.random.seed(5)
+        _, _, err = PyNMF(A, factors=None, params=_args(k, 2000, norm)).fit()
+        assert err < 1e-3, norm
+
+
+def test_config2_size_properties():
+    """BASELINE config 2 (65536 x 4096, k=32, MU/FRO, 1 GPU) -- too big for the CPU oracle in seconds, so
+    checked through properties: non-negativity, monotone decrease of the Frobenius objective (the MU
+    guarantee), unit column sums of W after normalisation, and a 'checksum of checksums' tying the
+    contraction kernels to the residual kernel:
+        ||A - WH||^2 = ||A||^2 - 2 <W^T A, H> + <W^T W, H H^T>."""
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    from pydnmfk_amd.pyDNMF import PyNMF
+    m, n, k = 65536, 4096, 32
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    A = torch.rand(m, n, device="cuda", generator=g)
+    W0 = torch.rand(m, k, device="cuda", generator=g)
+    H0 = torch.rand(k, n, device="cuda", generator=g)
+    errs = []
+    for itr in (1, 3, 6):
+        W, H, err = PyNMF(A, factors=[W0, H0], params=_args(k, itr, "fro")).fit()
+        errs.append(err)
+        assert float(W.min()) >= 0 and float(H.min()) >= 0
+        assert torch.isfinite(W).all() and torch.isfinite(H).all()
+    assert errs[0] > errs[1] > errs[2]
+    assert abs(float(W.sum(0).max()) - 1) < 1e-4 and abs(float(W.sum(0).min()) - 1) < 1e-4
+    dev = A.device
+    AtW = ops.wta(A, W, torch.empty(k, n, device=dev)).double()
+    WtW = ops.gram_wtw(W, new_gram(k, dev))[:k, :k].double()
+    HHt = ops.gram_hht(H, new_gram(k, dev))[:k, :k].double()
+    a2 = float(ops.sqnorm(A))
+    direct = float(ops.resid_sqnorm(A, W, H))
+    identity = a2 - 2 * float((AtW * H.double()).sum()) + float((WtW * HHt).sum())
+    assert abs(direct - identity) / a2 < 1e-6
+    # A H^T against W^T A through <A H^T, W> = <W^T A, H>
+    AH = ops.aht(A, H, torch.empty(m, k, device=dev)).double()
+    lhs, rhs = float((AH * W.double()).sum()), float((AtW * H.double()).sum())
+    assert abs(lhs - rhs) / abs(rhs) < 1e-6
