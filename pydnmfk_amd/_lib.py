@@ -6,6 +6,10 @@ loudly, and every compute entry point requires CUDA(HIP) device pointers.
 import ctypes
 import os
 
+# torch bundles its own libamdhip64; it MUST be loaded first so that libdnmf_hip.so binds to the same HIP
+# runtime instance (two runtimes in one process = "no ROCm-capable device" + foreign device pointers).
+import torch  # noqa: F401  isort:skip
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdnmf_hip.so")
 

@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "dnmf.h"
@@ -44,6 +45,9 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// hipGetLastError is sticky per thread and shared with the host framework: clear before each launch sequence
+inline void clear_hip_error() { (void)hipGetLastError(); }
 
 int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -368,24 +372,38 @@ __global__ __launch_bounds__(256) void tn_kernel(TnArgs p) {
     }
 }
 
-// out[j][c] = sum_s P[s][j][c], j < rows, c < cols (fixed order -> deterministic); everything else of the
-// rows_out x ldo output that lies inside [rows_out x cols_out] is written as 0 (zero padding of gram buffers).
+// out[y][j][c] = sum_{s in slice y} P[s][j][c], j < rows, c < cols.  256 threads = 64 consecutive float4 outputs x 4
+// split lanes; lane g sums splits g, g+4, ... of its slice in order, the four lane sums are combined in fixed order
+// through LDS -> bitwise deterministic.  Everything else inside [rows_out x cols_out] is written as 0 (zero padding
+// of the gram buffers).  gridDim.y > 1 = first stage of a two-stage reduction (out = scratch, y_stride apart).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, long stride, long ldp,
-                                                              int nsplit, float* __restrict__ out, long ldo,
-                                                              int rows, long cols, int rows_out, long cols_out) {
+                                                              int nsplit, int splits_per_y, float* __restrict__ out,
+                                                              long ldo, long y_stride, int rows, long cols,
+                                                              int rows_out, long cols_out) {
+    __shared__ f32x4 red[256];
     const long c4 = cdiv(cols_out, 4);
     const long total = (long)rows_out * c4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int j = idx / c4;
-        const long c = (idx % c4) * 4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (j < rows && c < cols) {
-            const float* src = P + (long)j * ldp + c;
-            for (int k = 0; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(src + k * stride);
-        }
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + o;
+    const int s0 = blockIdx.y * splits_per_y;
+    const int s1 = min(nsplit, s0 + splits_per_y);
+    const int j = idx / c4;
+    const long c = (idx % c4) * 4;
+    const bool live = idx < total && j < rows && c < cols;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float* src = P + (long)j * ldp + c;
+#pragma unroll 4
+        for (int k = s0 + g; k < s1; k += 4) s += *reinterpret_cast<const f32x4*>(src + k * stride);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        s = ((red[o] + red[64 + o]) + red[128 + o]) + red[192 + o];
+        float* dst = out + (long)blockIdx.y * y_stride + (long)j * ldo;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (c + e < cols_out) out[(long)j * ldo + c + e] = (j < rows && c + e < cols) ? s[e] : 0.f;
+            if (c + e < cols_out) dst[c + e] = (live && c + e < cols) ? s[e] : 0.f;
     }
 }
 
@@ -704,7 +722,10 @@ int kt_of(int k) {
     return k <= 32 ? 1 : (k <= 64 ? 2 : 4);
 }
 
-hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+hipStream_t S(void* s) {
+    clear_hip_error();
+    return reinterpret_cast<hipStream_t>(s);
+}
 
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
@@ -728,7 +749,9 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
         return fast ? launch_nt_inst<KT_, MT_, true, MODE>(a, tiles, nsplit, st)               \
                     : launch_nt_inst<KT_, MT_, false, MODE>(a, tiles, nsplit, st);             \
     }
+    static const bool mt2 = getenv("DNMF_NT_MT2") != nullptr;  // experiment switch: 256-row tiles for k <= 64
     NT_CASE(1, 2)
+    if (mt2 && MODE != NT_STORE) { NT_CASE(2, 2) }
     NT_CASE(2, 1)
     NT_CASE(4, 1)
 #undef NT_CASE
@@ -755,12 +778,30 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }
 
+// two-stage when there are many partials per output (gram of a tall W): slices of 32 splits, then one more pass
+constexpr int REDUCE_SLICE = 32;
+inline int reduce_slices(int nsplit) { return nsplit > 2 * REDUCE_SLICE ? (int)cdiv(nsplit, REDUCE_SLICE) : 1; }
+inline size_t reduce_scratch_bytes(int nsplit, int rows_out, long cols_out) {
+    const int y = reduce_slices(nsplit);
+    return y > 1 ? (size_t)y * rows_out * round_up(cols_out, 4) * sizeof(float) : 0;
+}
+
+// `scratch` must hold reduce_scratch_bytes(nsplit, rows_out, cols_out)
 int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out, long ldo, int rows, long cols,
-                  int rows_out, long cols_out, hipStream_t st) {
+                  int rows_out, long cols_out, float* scratch, hipStream_t st) {
     const long total = (long)rows_out * cdiv(cols_out, 4);
-    const unsigned grid = (unsigned)std::min<long>(cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, P, stride, ldp, nsplit, out, ldo, rows,
-                       cols, rows_out, cols_out);
+    const unsigned gx = (unsigned)cdiv(total, 64);
+    const int ny = reduce_slices(nsplit);
+    if (ny == 1) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
+                           0L, rows, cols, rows_out, cols_out);
+    } else {
+        const long ld2 = round_up(cols_out, 4), ys = (long)rows_out * ld2;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, ny), dim3(256), 0, st, P, stride, ldp, nsplit, REDUCE_SLICE,
+                           scratch, ld2, ys, rows, cols, rows_out, cols_out);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, ys, ld2, ny, ny, out,
+                           ldo, 0L, rows_out, cols_out, rows_out, cols_out);
+    }
     return check_launch("reduce_partials");
 }
 
@@ -801,17 +842,17 @@ size_t partial_bytes(long m, long n, int k) {
     size_t b = 0;
     {   // wta / kl_wtu: A [m x n]
         TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
-        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float));
-        TnPlan q = plan_tn(m, n, kt, tn_nt(kt));  // kl_wtu: same column sets as wta
-        b = std::max(b, (size_t)cdiv(cdiv(m, 32), std::max<long>(1, q.rows_per_chunk / 32)) * q.ldp * kp * sizeof(float));
+        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, k, n));
+        const long klc = cdiv(cdiv(m, 32), std::max<long>(1, p.rows_per_chunk / 32));  // kl_wtu: same column sets as wta
+        b = std::max(b, (size_t)klc * p.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)klc, k, n));
     }
     {   // gram W^T W: Y = W [m x k]
         TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt);
-        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float));
+        b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, kp, kp));
     }
     {   // gram H H^T
         SplitPlan s = plan_gram_nt(n);
-        b = std::max(b, (size_t)s.nsplit * nt_rows_per_tile(kt) * kp * sizeof(float));
+        b = std::max(b, (size_t)s.nsplit * nt_rows_per_tile(kt) * kp * sizeof(float) + reduce_scratch_bytes(s.nsplit, kp, kp));
     }
     b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
     return b;
@@ -852,7 +893,8 @@ int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, s
     const int kp = 32 * kt;
     const SplitPlan sp = plan_gram_nt(n);
     const long tile_rows = nt_rows_per_tile(kt);
-    const size_t need = (size_t)sp.nsplit * tile_rows * kp * sizeof(float);
+    const size_t pbytes = (size_t)sp.nsplit * tile_rows * kp * sizeof(float);
+    const size_t need = pbytes + reduce_scratch_bytes(sp.nsplit, kp, kp);
     if (ws_bytes < need) return fail(DNMF_EWS, "gram_hht: workspace %zu < %zu", ws_bytes, need);
     NtArgs a{};
     a.X = H; a.ldx = ldh; a.nrows = k; a.ncols = n;
@@ -862,7 +904,8 @@ int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, s
     const bool fast = aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
     int rc = launch_nt<NT_STORE>(kt, fast, a, sp.nsplit, S(stream));
     if (rc) return rc;
-    return launch_reduce((const float*)ws, tile_rows * kp, kp, sp.nsplit, G, kp, k, k, kp, kp, S(stream));
+    return launch_reduce((const float*)ws, tile_rows * kp, kp, sp.nsplit, G, kp, k, k, kp, kp,
+                         (float*)((char*)ws + pbytes), S(stream));
 }
 
 int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, size_t ws_bytes, void* stream) {
@@ -872,7 +915,8 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
     // TN form with X = Y = W; NT column sets per wave (KT = 4 uses 2 column blocks of 64 to bound registers)
     const int nt = kt == 4 ? 2 : kt;
     TnPlan p = plan_tn(m, kp, kt, nt);
-    const size_t need = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    const size_t need = pbytes + reduce_scratch_bytes(p.nchunks, kp, kp);
     if (ws_bytes < need) return fail(DNMF_EWS, "gram_wtw: workspace %zu < %zu", ws_bytes, need);
     TnArgs a{};
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = W; a.ldy = ldw; a.ycols = k;
@@ -891,7 +935,8 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
 #undef GRAM_CASE
     int rc = check_launch("gram_wtw");
     if (rc) return rc;
-    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, G, kp, k, k, kp, kp, st);
+    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, G, kp, k, k, kp, kp,
+                         (float*)((char*)ws + pbytes), st);
 }
 
 int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
@@ -938,7 +983,8 @@ int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, lo
     REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldatw >= n, "wta: bad arguments");
     const int nt = tn_nt(kt);
     TnPlan p = plan_tn(m, n, kt, nt);
-    const size_t need = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
+    const size_t need = pbytes + reduce_scratch_bytes(p.nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "wta: workspace %zu < %zu", ws_bytes, need);
     TnArgs a{};
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
@@ -947,7 +993,8 @@ int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, lo
     const bool fast = aligned16(A) && aligned16(W) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0;
     int rc = launch_tn<TN_PARTIAL>(kt, fast, a, S(stream));
     if (rc) return rc;
-    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, S(stream));
+    return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n,
+                         (float*)((char*)ws + pbytes), S(stream));
 }
 
 int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
@@ -1059,7 +1106,8 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
     const long nchunks = cdiv(a.nrowblk, rowblks_per_chunk);
     a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
-    const size_t need = (size_t)nchunks * a.chunk_stride * sizeof(float);
+    const size_t pbytes = (size_t)nchunks * a.chunk_stride * sizeof(float);
+    const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
     const dim3 grid((unsigned)cdiv(nchunks * a.ncolblk, 4)), block(256);
@@ -1073,7 +1121,8 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
 #undef WU_CASE
     int rc = check_launch("kl_wtu");
     if (rc) return rc;
-    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k, n, k, n, st);
+    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k, n, k, n,
+                         (float*)((char*)ws + pbytes), st);
 }
 
 int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {

@@ -17,7 +17,7 @@ def load_case(name):
     meta = json.loads(str(z["meta"]))
     d = np.load(os.path.join(GOLDEN, "data_%s.npz" % meta["dataset"]))
     dt = np.dtype(meta["dtype"])
-    A = d["A"].astype(dt)
+    A = np.ascontiguousarray(d["A"].astype(dt))  # swim.mat is Fortran-ordered
     W0 = d["W0"].astype(dt)
     H0 = d["H0"].astype(dt)
     return meta, A, W0, H0, z
