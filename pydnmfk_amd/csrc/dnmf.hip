@@ -127,52 +127,71 @@ struct NtArgs {
     float* W; long ldw; const float* G; const float* AH; long ldah; float eps; int k;
 };
 
-template <int R, bool FAST>
-__device__ __forceinline__ void stage_load(f32x4 (&v)[R / 32], const float* __restrict__ X, long ldx, long nrows,
-                                           long cend, long row0, long c0, int tid) {
+// Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
+// `interior` (block-uniform): the whole tile is in bounds -> plain loads with no exec-masked branches.
+template <int R, int T, bool FAST>
+__device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const float* __restrict__ X, long ldx,
+                                           long nrows, long cend, long row0, long c0, int tid, bool interior) {
+    constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
     const int ch = tid & 7;
     const long c = c0 + ch * 4;
+    if (FAST && interior) {
 #pragma unroll
-    for (int it = 0; it < R / 32; ++it) {
-        const long r = row0 + it * 32 + (tid >> 3);
-        float d[4];
-        load_vec<4, FAST>(d, X + r * ldx, c, cend, r < nrows);
-        v[it] = f32x4{d[0], d[1], d[2], d[3]};
+        for (int it = 0; it < NP; ++it) {
+            const int rl = it * RP + (tid >> 3);
+            if (R % RP == 0 || rl < R) v[it] = *reinterpret_cast<const f32x4*>(X + (row0 + rl) * ldx + c);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int rl = it * RP + (tid >> 3);
+            const long r = row0 + rl;
+            float d[4];
+            load_vec<4, FAST>(d, X + r * ldx, c, cend, r < nrows && (R % RP == 0 || rl < R));
+            v[it] = f32x4{d[0], d[1], d[2], d[3]};
+        }
     }
 }
 
-template <int R>
-__device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[R / 32], int tid) {
+template <int R, int T>
+__device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], int tid) {
+    constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
     const int ch = tid & 7;
 #pragma unroll
-    for (int it = 0; it < R / 32; ++it) {
-        const int r = it * 32 + (tid >> 3);
-        *reinterpret_cast<f32x4*>(&tile[lds_idx(r, ch)]) = v[it];
+    for (int it = 0; it < NP; ++it) {
+        const int r = it * RP + (tid >> 3);
+        if (R % RP == 0 || r < R) *reinterpret_cast<f32x4*>(&tile[lds_idx(r, ch)]) = v[it];
     }
 }
 
-// acc[mt][jt] += X[row0 + wave*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T
-template <int KT, int MT, bool FAST>
+// acc[mt][jt] += X[row0 + wave*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T      (NW waves per workgroup)
+template <int KT, int MT, int NW, bool FAST>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
-    constexpr int BM = 128 * MT, KP = 32 * KT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK;  // floats per pipeline stage: [X tile | Y tile]
-    f32x4 xv[BM / 32], yv[KP / 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    f32x4 xv[(BM + T / 8 - 1) / (T / 8)], yv[(KP + T / 8 - 1) / (T / 8)];
     const long nk = (cend - cbeg + BK - 1) / BK;
     if (nk <= 0) return;
-    stage_load<BM, FAST>(xv, X, ldx, nrows, cend, row0, cbeg, tid);
-    stage_load<KP, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg, tid);
-    stage_store<BM>(smem, xv, tid);
-    stage_store<KP>(smem + BM * BK, yv, tid);
+    const bool rows_in = row0 + BM <= nrows, yrows_in = yrows >= KP;
+    {
+        const bool cin = cbeg + BK <= cend;
+        stage_load<BM, T, FAST>(xv, X, ldx, nrows, cend, row0, cbeg, tid, rows_in && cin);
+        stage_load<KP, T, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg, tid, yrows_in && cin);
+    }
+    stage_store<BM, T>(smem, xv, tid);
+    stage_store<KP, T>(smem + BM * BK, yv, tid);
     __syncthreads();
     for (long kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            stage_load<BM, FAST>(xv, X, ldx, nrows, cend, row0, cbeg + (kt + 1) * BK, tid);
-            stage_load<KP, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg + (kt + 1) * BK, tid);
+            const long c0 = cbeg + (kt + 1) * BK;
+            const bool cin = c0 + BK <= cend;
+            stage_load<BM, T, FAST>(xv, X, ldx, nrows, cend, row0, c0, tid, rows_in && cin);
+            stage_load<KP, T, FAST>(yv, Y, ldy, yrows, cend, 0, c0, tid, yrows_in && cin);
         }
         const float* xc = smem + cur * STAGE;
         const float* yc = xc + BM * BK;
@@ -193,17 +212,17 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* 
                     for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
         }
         if (more) {
-            stage_store<BM>(smem + (cur ^ 1) * STAGE, xv, tid);
-            stage_store<KP>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
+            stage_store<BM, T>(smem + (cur ^ 1) * STAGE, xv, tid);
+            stage_store<KP, T>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
         }
         __syncthreads();
     }
 }
 
-template <int KT, int MT, bool FAST, int MODE>
-__global__ __launch_bounds__(256) void nt_kernel(NtArgs p) {
+template <int KT, int MT, int NW, bool FAST, int MODE>
+__global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BM = 128 * MT;
+    constexpr int BM = 32 * MT * NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
     const long row0 = (long)blockIdx.x * BM;
 
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(256) void nt_kernel(NtArgs p) {
         const long cbeg = (long)blockIdx.y * p.cols_per_split;
         long cend = cbeg + p.cols_per_split;
         if (cend > p.ncols) cend = p.ncols;
-        nt_mainloop<KT, MT, FAST>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        nt_mainloop<KT, MT, NW, FAST>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
     }
 
     if constexpr (MODE == NT_STORE) {
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(256) void nt_kernel(NtArgs p) {
             for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][jt][r] = 0.f;
-        nt_mainloop<KT, MT, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        nt_mainloop<KT, MT, NW, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -298,6 +317,36 @@ __device__ __forceinline__ void tn_comp(f32x16 (&acc)[KT][NT], const float (&a)[
             for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a[u][ke], b[u][ne], acc[ke][ne]);
 }
 
+// unconditional vector load of V floats (address must be valid)
+template <int V>
+__device__ __forceinline__ void load_vec_raw(float (&d)[V], const float* __restrict__ p) {
+    if constexpr (V == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else if constexpr (V == 2) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        d[0] = v[0]; d[1] = v[1];
+    } else {
+        d[0] = p[0];
+    }
+}
+
+// one register batch = U row pairs, loaded with NO control flow: the row index is clamped to `rlast` (a valid row) and
+// the column offsets xc / yc are pre-clamped to valid columns, so hipcc can count outstanding loads (vmcnt(N))
+// instead of draining with vmcnt(0) around exec-masked branches.
+template <int KT, int NT, int U>
+__device__ __forceinline__ void tn_load_raw(float (&a)[U][KT], float (&b)[U][NT], const float* __restrict__ X, long ldx,
+                                            const float* __restrict__ Y, long ldy, long xc, long yc, long r, long rlast,
+                                            int h) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long row = r + 2 * u + h;
+        row = row < rlast ? row : rlast;
+        load_vec_raw<KT>(a[u], X + row * ldx + xc);
+        load_vec_raw<NT>(b[u], Y + row * ldy + yc);
+    }
+}
+
 // acc[ke][ne] (reg, lane) = C[j = KT*crow(reg,h) + ke][c = col0 + NT*li + ne], contraction over rows [rbeg, rend)
 template <int KT, int NT, bool FAST>
 __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* __restrict__ X, long ldx, int xcols,
@@ -305,17 +354,47 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
                                             long rend, int li, int h) {
     constexpr int U = 4;  // row pairs per register batch
     float a0[U][KT], b0[U][NT], a1[U][KT], b1[U][NT];
-    tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, rbeg, rend, li, h);
-    for (long r = rbeg; r < rend; r += 4 * U) {
-        tn_load<KT, NT, FAST, U>(a1, b1, X, ldx, xcols, Y, ldy, ycols, col0, r + 2 * U, rend, li, h);
+    long r = rbeg;
+    if constexpr (FAST) {
+        // Full batches, software pipelined one batch ahead.  Lanes whose output row j >= xcols or output column
+        // c >= ycols read a clamped (valid) column instead: an MFMA output row/column depends only on the matching
+        // A-operand / B-operand lane, so those lanes only pollute outputs that are never stored.
+        const long nb = (rend - rbeg) / (2 * U);
+        if (nb > 0) {
+            long xc = (long)KT * li, yc = col0 + (long)NT * li;
+            xc = xc < xcols ? xc : xcols - KT;
+            yc = yc < ycols ? yc : ycols - NT;
+            const long rlast = rbeg + nb * 2 * U - 1;
+            tn_load_raw<KT, NT, U>(a0, b0, X, ldx, Y, ldy, xc, yc, r, rlast, h);
+            long b = 0;
+            for (; b + 2 <= nb; b += 2) {
+                // sched_barrier pins the issue order (prefetch batch, then the MFMAs of the previous one); without it
+                // hipcc sinks the loads next to their first use and drains them with vmcnt(0) four times per batch
+                tn_load_raw<KT, NT, U>(a1, b1, X, ldx, Y, ldy, xc, yc, r + 2 * U, rlast, h);
+                __builtin_amdgcn_sched_barrier(0);
+                tn_comp<KT, NT, U>(acc, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                tn_load_raw<KT, NT, U>(a0, b0, X, ldx, Y, ldy, xc, yc, r + 4 * U, rlast, h);  // clamped past the end
+                __builtin_amdgcn_sched_barrier(0);
+                tn_comp<KT, NT, U>(acc, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                r += 4 * U;
+            }
+            if (b < nb) {
+                tn_comp<KT, NT, U>(acc, a0, b0);
+                r += 2 * U;
+            }
+        }
+    }
+    // ragged tail (and the whole loop of the generic path): predicated loads, zero fill
+    for (; r < rend; r += 2 * U) {
+        tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r, rend, li, h);
         tn_comp<KT, NT, U>(acc, a0, b0);
-        tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r + 4 * U, rend, li, h);
-        tn_comp<KT, NT, U>(acc, a1, b1);
     }
 }
 
 template <int KT, int NT, bool FAST, int MODE>
-__global__ __launch_bounds__(256) void tn_kernel(TnArgs p) {
+__global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const long gw = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long chunk = gw / p.ncolblk;
@@ -732,28 +811,40 @@ void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int KT, int MT, bool FAST, int MODE>
-int launch_nt_inst(const NtArgs& a, long nrowtiles, int nsplit, hipStream_t st) {
-    constexpr size_t lds = 2ul * (128 * MT + 32 * KT) * BK * sizeof(float);
+template <int KT, int MT, int NW, bool FAST, int MODE>
+int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
+    constexpr int BM = 32 * MT * NW;
+    constexpr size_t lds = 2ul * (BM + 32 * KT) * BK * sizeof(float);
     static bool once = false;
-    if (!once) { allow_lds(nt_kernel<KT, MT, FAST, MODE>, lds); once = true; }
-    hipLaunchKernelGGL((nt_kernel<KT, MT, FAST, MODE>), dim3((unsigned)nrowtiles, (unsigned)nsplit), dim3(256), lds, st, a);
+    if (!once) { allow_lds(nt_kernel<KT, MT, NW, FAST, MODE>, lds); once = true; }
+    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, FAST, MODE>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
+                       dim3(64 * NW), lds, st, a);
     return check_launch("nt_kernel");
+}
+
+// Tile configuration per padded rank.  cfg = 0 is the default; other values are experiment switches
+// (env DNMF_NT_CFG) kept so A/B runs can be made from one binary.
+//   KT=1 (k<=32): 256-row tile, 4 waves x 64 rows      KT=4 (k<=128): 128-row tile, 4 waves x 32 rows
+//   KT=2 (k<=64): cfg 0 = 256-row tile, 8 waves x 32 rows; cfg 1 = 128 rows / 4 waves; cfg 2 = 256 rows / 4 waves x 64
+inline int nt_cfg() {
+    static const int cfg = getenv("DNMF_NT_CFG") ? atoi(getenv("DNMF_NT_CFG")) : 0;
+    return cfg;
 }
 
 template <int MODE>
 int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
-#define NT_CASE(KT_, MT_)                                                                      \
-    if (kt == KT_) {                                                                           \
-        const long tiles = cdiv(a.nrows, 128 * MT_);                                           \
-        return fast ? launch_nt_inst<KT_, MT_, true, MODE>(a, tiles, nsplit, st)               \
-                    : launch_nt_inst<KT_, MT_, false, MODE>(a, tiles, nsplit, st);             \
+#define NT_CASE(KT_, MT_, NW_)                                                                    \
+    return fast ? launch_nt_inst<KT_, MT_, NW_, true, MODE>(a, nsplit, st)                         \
+                : launch_nt_inst<KT_, MT_, NW_, false, MODE>(a, nsplit, st);
+    if (kt == 1) { NT_CASE(1, 2, 4) }
+    if (kt == 2) {
+        if (MODE == NT_STORE && a.store_all) { NT_CASE(2, 1, 4) }   // gram split tiles: 128-row partial layout
+        const int cfg = nt_cfg();
+        if (cfg == 1) { NT_CASE(2, 1, 4) }
+        if (cfg == 2) { NT_CASE(2, 2, 4) }
+        NT_CASE(2, 1, 8)
     }
-    static const bool mt2 = getenv("DNMF_NT_MT2") != nullptr;  // experiment switch: 256-row tiles for k <= 64
-    NT_CASE(1, 2)
-    if (mt2 && MODE != NT_STORE) { NT_CASE(2, 2) }
-    NT_CASE(2, 1)
-    NT_CASE(4, 1)
+    if (kt == 4) { NT_CASE(4, 1, 4) }
 #undef NT_CASE
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }
