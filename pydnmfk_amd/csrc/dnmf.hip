@@ -331,23 +331,16 @@ __device__ __forceinline__ void load_vec_raw(float (&d)[V], const float* __restr
     }
 }
 
-// one register batch = U row pairs, loaded with NO control flow: the row index is clamped to `rlast` (a valid row) and
-// the column offsets xc / yc are pre-clamped to valid columns, so hipcc can count outstanding loads (vmcnt(N))
-// instead of draining with vmcnt(0) around exec-masked branches.
-template <int KT, int NT, int U>
-__device__ __forceinline__ void tn_load_raw(float (&a)[U][KT], float (&b)[U][NT], const float* __restrict__ X, long ldx,
-                                            const float* __restrict__ Y, long ldy, long xc, long yc, long r, long rlast,
-                                            int h) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        long row = r + 2 * u + h;
-        row = row < rlast ? row : rlast;
-        load_vec_raw<KT>(a[u], X + row * ldx + xc);
-        load_vec_raw<NT>(b[u], Y + row * ldy + yc);
-    }
-}
-
 // acc[ke][ne] (reg, lane) = C[j = KT*crow(reg,h) + ke][c = col0 + NT*li + ne], contraction over rows [rbeg, rend)
+//
+// FAST path = software pipeline over full batches of U row pairs, one batch ahead, with the two loads of the NEXT
+// batch's row pair u issued right before the KT*NT MFMAs of THIS batch's row pair u (issue order pinned with
+// sched_barrier).  Measured on MI355X (262144 x 8192, k = 64; tools/kbench.py): this interleave 2.34 ms; the same loads
+// as one block of 8 ahead of the 32 MFMAs 3.5 ms (waves stall issuing VMEM while the matrix pipe idles: MFMA busy 51 %
+// vs 88 %); exec-masked predicated loads (hipcc then drains with vmcnt(0)) 2.58 ms.  Loads are branch-free: the
+// batch base is a wave-uniform pointer, the per-lane part (2u + h) * ld + column a loop-invariant 32-bit offset.
+// Lanes whose output row j >= xcols or output column c >= ycols read a clamped (valid) column instead: an MFMA output
+// row / column depends only on the matching A- / B-operand lane, so they only pollute outputs that are never stored.
 template <int KT, int NT, bool FAST>
 __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* __restrict__ X, long ldx, int xcols,
                                             const float* __restrict__ Y, long ldy, long ycols, long col0, long rbeg,
@@ -356,28 +349,55 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
     float a0[U][KT], b0[U][NT], a1[U][KT], b1[U][NT];
     long r = rbeg;
     if constexpr (FAST) {
-        // Full batches, software pipelined one batch ahead.  Lanes whose output row j >= xcols or output column
-        // c >= ycols read a clamped (valid) column instead: an MFMA output row/column depends only on the matching
-        // A-operand / B-operand lane, so those lanes only pollute outputs that are never stored.
         const long nb = (rend - rbeg) / (2 * U);
-        if (nb > 0) {
+        if (nb > 0 && 8 * ldx < 0x7fffffffL && 8 * ldy < 0x7fffffffL) {
             long xc = (long)KT * li, yc = col0 + (long)NT * li;
             xc = xc < xcols ? xc : xcols - KT;
             yc = yc < ycols ? yc : ycols - NT;
-            const long rlast = rbeg + nb * 2 * U - 1;
-            tn_load_raw<KT, NT, U>(a0, b0, X, ldx, Y, ldy, xc, yc, r, rlast, h);
+            int xo[U], yo[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xo[u] = (int)((2 * u + h) * ldx + xc);
+                yo[u] = (int)((2 * u + h) * ldy + yc);
+            }
+            const long rlastb = rbeg + (nb - 1) * 2 * U;   // first row of the last full batch
+            {
+                const float* X0 = X + r * ldx; const float* Y0 = Y + r * ldy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    load_vec_raw<KT>(a0[u], X0 + xo[u]);
+                    load_vec_raw<NT>(b0[u], Y0 + yo[u]);
+                }
+            }
             long b = 0;
             for (; b + 2 <= nb; b += 2) {
-                // sched_barrier pins the issue order (prefetch batch, then the MFMAs of the previous one); without it
-                // hipcc sinks the loads next to their first use and drains them with vmcnt(0) four times per batch
-                tn_load_raw<KT, NT, U>(a1, b1, X, ldx, Y, ldy, xc, yc, r + 2 * U, rlast, h);
-                __builtin_amdgcn_sched_barrier(0);
-                tn_comp<KT, NT, U>(acc, a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                tn_load_raw<KT, NT, U>(a0, b0, X, ldx, Y, ldy, xc, yc, r + 4 * U, rlast, h);  // clamped past the end
-                __builtin_amdgcn_sched_barrier(0);
-                tn_comp<KT, NT, U>(acc, a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
+                const long r1 = r + 2 * U;
+                long r2 = r + 4 * U;
+                r2 = r2 < rlastb ? r2 : rlastb;              // prefetch past the end re-reads the last batch (unused)
+                const float* X1 = X + r1 * ldx; const float* Y1 = Y + r1 * ldy;
+                const float* X2 = X + r2 * ldx; const float* Y2 = Y + r2 * ldy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    load_vec_raw<KT>(a1[u], X1 + xo[u]);
+                    load_vec_raw<NT>(b1[u], Y1 + yo[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a0[u][ke], b0[u][ne], acc[ke][ne]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    load_vec_raw<KT>(a0[u], X2 + xo[u]);
+                    load_vec_raw<NT>(b0[u], Y2 + yo[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a1[u][ke], b1[u][ne], acc[ke][ne]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 r += 4 * U;
             }
             if (b < nb) {
@@ -386,7 +406,7 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
             }
         }
     }
-    // ragged tail (and the whole loop of the generic path): predicated loads, zero fill
+    // ragged tail of the FAST path and the whole generic path: predicated loads, zero fill
     for (; r < rend; r += 2 * U) {
         tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r, rend, li, h);
         tn_comp<KT, NT, U>(acc, a0, b0);
@@ -396,7 +416,9 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
 template <int KT, int NT, bool FAST, int MODE>
 __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const long gw = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // wave-uniform quantities kept provably scalar (readfirstlane) so row bases live in SGPRs
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * (blockDim.x >> 6) + wid;
     const long chunk = gw / p.ncolblk;
     const long colblk = gw % p.ncolblk;
     if (chunk >= p.nchunks) return;
@@ -825,7 +847,7 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
 // Tile configuration per padded rank.  cfg = 0 is the default; other values are experiment switches
 // (env DNMF_NT_CFG) kept so A/B runs can be made from one binary.
 //   KT=1 (k<=32): 256-row tile, 4 waves x 64 rows      KT=4 (k<=128): 128-row tile, 4 waves x 32 rows
-//   KT=2 (k<=64): cfg 0 = 256-row tile, 8 waves x 32 rows; cfg 1 = 128 rows / 4 waves; cfg 2 = 256 rows / 4 waves x 64
+//   KT=2 (k<=64): cfg 0 = 128-row tile, 4 waves x 32 rows; cfg 1 = 256 rows / 8 waves x 32; cfg 2 = 256 rows / 4 waves x 64
 inline int nt_cfg() {
     static const int cfg = getenv("DNMF_NT_CFG") ? atoi(getenv("DNMF_NT_CFG")) : 0;
     return cfg;
@@ -840,9 +862,9 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
     if (kt == 2) {
         if (MODE == NT_STORE && a.store_all) { NT_CASE(2, 1, 4) }   // gram split tiles: 128-row partial layout
         const int cfg = nt_cfg();
-        if (cfg == 1) { NT_CASE(2, 1, 4) }
+        if (cfg == 1) { NT_CASE(2, 1, 8) }
         if (cfg == 2) { NT_CASE(2, 2, 4) }
-        NT_CASE(2, 1, 8)
+        NT_CASE(2, 1, 4)
     }
     if (kt == 4) { NT_CASE(4, 1, 4) }
 #undef NT_CASE
@@ -902,7 +924,7 @@ struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long ch
 TnPlan plan_tn(long nrows, long ycols, int kt, int nt) {
     TnPlan p;
     p.ncolblk = (int)cdiv(ycols, 32 * nt);
-    const long target_waves = 4096;
+    static const long target_waves = getenv("DNMF_TN_WAVES") ? atol(getenv("DNMF_TN_WAVES")) : 2048;  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
     long nchunks = std::max<long>(1, target_waves / p.ncolblk);
     nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, 256)));
     p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
@@ -1046,7 +1068,7 @@ int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, lo
 int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
                       float* W, long ldw, float eps, void* stream) {
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && lda >= n && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
+    REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
     a.Y = H; a.ldy = ldh; a.yrows = k;
@@ -1071,7 +1093,7 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
 int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
              void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldatw >= n, "wta: bad arguments");
+    REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldw >= k && ldatw >= n, "wta: bad arguments");
     const int nt = tn_nt(kt);
     TnPlan p = plan_tn(m, n, kt, nt);
     const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);

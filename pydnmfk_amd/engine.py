@@ -24,6 +24,7 @@ def _req(t, name, ndim=2):
 
 
 def _ld(t):
+    # stride(0) == 0 (a row broadcast with .expand) is passed through: every row aliases the same memory
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
 
 
