@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--norm", default="fro")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -93,6 +94,22 @@ def cpu_baseline(n, k, m_full):
             "gflops": (4.0 * m_s * n * k + 4.0 * (m_s + n) * k * k) / t / 1e9}
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the fused NT kernel from the committed PMC pass (profiles/*_pmc.json; collected by
+    tools/collect_profiles.sh in separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, c in d.items():
+            if name.startswith("nt_kernel<2,") and name.rstrip().endswith(", 1>") and "hbm_bytes" in c:
+                best = {"bytes": c["hbm_bytes"], "source": os.path.basename(f)}
+    return best
+
+
 def main():
     a = parse_args()
     import torch
@@ -105,11 +122,18 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks" % a.gpus)
         a.gpus = world
+    ndev = torch.cuda.device_count()
+    if world > ndev and a.backend == "nccl":
+        sys.exit("bench.py: %d ranks but %d GPUs" % (world, ndev))
+    local = local % max(1, ndev)            # gloo debugging runs may stack ranks on one device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -133,7 +157,7 @@ def main():
     g.manual_seed(99)
     H = torch.rand(k, n, device=dev, generator=g)
     if world > 1:
-        dist.broadcast(H, src=0)
+        H = comms.comm.bcast(H, root=0)
 
     def step(i):
         nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
@@ -225,6 +249,10 @@ def main():
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                "flops_per_launch": fl_nt, "ms_per_launch": t["aht_update_w"]}
+            tr = pmc_traffic_bytes() if (m, n, k, world) == (262144, 8192, 64, 1) else None
+            if tr is not None:
+                out["roofline"]["traffic"] = tr["bytes"]
+                out["roofline"]["traffic_note"] = "HBM bytes per launch, PMC pass %s (FETCH_SIZE x2 + WRITE_SIZE)" % tr["source"]
             out["roofline_hbm"] = {"kernel": "sqnorm_kernel", "bound": "hbm", "achieved": 4.0 * m_l * n / t3 / 1e6,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS,
                                    "traffic": None}

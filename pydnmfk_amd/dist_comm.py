@@ -28,11 +28,13 @@ class TorchComm:
             self.ranks = list(ranks) if ranks is not None else list(range(dist.get_world_size()))
             self.rank = self.ranks.index(self.world_rank)
             self.size = len(self.ranks)
+            self.backend = dist.get_backend()
             self.device = (torch.device("cuda", torch.cuda.current_device())
-                           if dist.get_backend() == "nccl" else torch.device("cpu"))
+                           if self.backend == "nccl" else torch.device("cpu"))
         else:
             self.world_rank, self.ranks, self.rank, self.size = 0, [0], 0, 1
             self.device = torch.device("cpu")
+            self.backend = None
 
     # ---- mpi4py-shaped surface
     def Get_rank(self):
@@ -72,13 +74,17 @@ class TorchComm:
         if self.size == 1:
             return x
         t, kind = self._to_tensor(x)
-        dist.all_reduce(t, group=self.group)
+        self.allreduce_(t)
         return self._from_tensor(t, kind, x)
 
     def bcast(self, x, root=0):
         if self.size == 1:
             return x
         if isinstance(x, torch.Tensor):
+            if self._host_staged(x):
+                c = x.cpu()
+                dist.broadcast(c, src=self.ranks[root], group=self.group)
+                return c.to(x.device)
             t = x.clone()
             dist.broadcast(t, src=self.ranks[root], group=self.group)
             return t
@@ -98,9 +104,18 @@ class TorchComm:
         return out
 
     # ---- in-place device collectives used by the update choreography
+    def _host_staged(self, t):
+        """gloo transport (tests / debugging) moves bytes through host memory; RCCL works on device buffers."""
+        return self.backend == "gloo" and t.is_cuda
+
     def allreduce_(self, t):
         if self.size > 1:
-            dist.all_reduce(t, group=self.group)
+            if self._host_staged(t):
+                c = t.cpu()
+                dist.all_reduce(c, group=self.group)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, group=self.group)
         return t
 
     def allgather_blocks(self, x, shapes):
@@ -112,8 +127,14 @@ class TorchComm:
         send = x.reshape(-1)
         if send.numel() < mx:
             send = torch.cat([send, send.new_zeros(mx - send.numel())])
-        recv = send.new_empty(self.size * mx)
-        dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+        if self._host_staged(send):
+            c = send.contiguous().cpu()
+            rc = c.new_empty(self.size * mx)
+            dist.all_gather_into_tensor(rc, c, group=self.group)
+            recv = rc.to(send.device)
+        else:
+            recv = send.new_empty(self.size * mx)
+            dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
         return [recv[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)]
 
     def reduce_scatter_rows(self, full, counts):
@@ -121,12 +142,12 @@ class TorchComm:
         if self.size == 1:
             return full
         c = full.shape[1]
-        if len(set(counts)) == 1:
+        if len(set(counts)) == 1 and not self._host_staged(full) and self.backend != "gloo":
             out = full.new_empty(counts[0], c)
             dist.reduce_scatter_tensor(out, full.contiguous(), group=self.group)
             return out
-        t = full.clone()  # ragged blocks: allreduce + slice (same sums, more traffic)
-        dist.all_reduce(t, group=self.group)
+        t = full.clone()  # ragged blocks (or gloo, which has no reduce_scatter): allreduce + slice, same sums
+        self.allreduce_(t)
         off = sum(counts[: self.rank])
         return t[off: off + counts[self.rank]].contiguous()
 

@@ -3,82 +3,14 @@ allreduces, allgather / reduce_scatter on sub-groups, ragged blocks) run under g
 1..4 against the golden vectors captured from the reference.  Arithmetic here comes from the checker
 double in tests/_ops_double.py -- these tests say nothing about the HIP kernels (those are `-m gpu`).
 """
-import os
-import socket
-import traceback
-
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
-
-from tests._golden import load_case, rel_fro
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def _run_case_rank(rank, world, port, name, q):
-    try:
-        import torch.distributed as dist
-        from oracle import nmf_oracle as orc
-        from pydnmfk_amd.dist_comm import MPI_comm
-        from pydnmfk_amd.pyDNMF import PyNMF
-        from pydnmfk_amd.utils import determine_block_params, parse
-        from tests._ops_double import OracleOps
-
-        torch.set_num_threads(1)
-        if world > 1:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        meta, A, W0, H0, z = load_case(name)
-        p_r, p_c = meta["grid"]
-        comms = MPI_comm(None, p_r, p_c)
-        out = {}
-        for itr in meta["itrs"]:
-            args = parse()
-            args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
-            args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-            args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
-            args.norm, args.method, args.W_update = meta["norm"], "mu", meta["W_update"]
-            s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
-            assert [s[0], e[0] + 1, s[1], e[1] + 1] == list(z["r%d_A_range" % rank])
-            A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1]
-            (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, meta["m"], meta["n"])
-            W, H, err = PyNMF(A_ij, factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=OracleOps()).fit()
-            assert (args.m, args.n) == (meta["m"], meta["n"])
-            assert [args.m_loc, args.n_loc] == list(z["r%d_m_loc_n_loc" % rank])
-            out[itr] = (rel_fro(W, z["r%d_fit%d_W" % (rank, itr)]), rel_fro(H, z["r%d_fit%d_H" % (rank, itr)]),
-                        abs(err - float(z["r0_fit%d_err" % itr])))
-        q.put((rank, out, None))
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-    except Exception:  # noqa: BLE001
-        q.put((rank, None, traceback.format_exc()))
 
 
 def _run(name):
-    meta = load_case(name)[0]
-    world = meta["grid"][0] * meta["grid"][1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_run_case_rank, args=(r, world, port, name, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, out, err in res:
-        assert err is None, "rank %d failed:\n%s" % (rank, err)
-        for itr, (dw, dh, de) in out.items():
-            assert dw <= 1e-4 and dh <= 1e-4 and de <= 1e-5, (name, rank, itr, dw, dh, de)
+    from tests._mp import run_case
+    run_case(name, use_hip=False)
 
 
 CASES = [

@@ -1,0 +1,19 @@
+"""Multi-rank product path on the GPU: the real HIP kernels driven by the p_r x p_c choreography with 2-4
+processes, all on cuda:0 (a GPU box has one device), exchanging through gloo (host-staged) instead of RCCL.
+Checks W, H per rank and recon_err against the golden vectors captured from the reference on the same grids.
+What this does not cover is the RCCL transport itself (the 8-GPU runs are the driver's)."""
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_float32", "r25x13_3x1_fro_float32",
+         "r25x13_2x2_kl_float32", "swim_4x1_fro_float32", "swim_1x4_fro_float32", "swim_2x2_kl_float32",
+         "lr200x136k64_2x2_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
+         "lr136x100k32_2x2_kl_float32"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_multirank_hip_matches_reference(name):
+    from tests._mp import run_case
+    run_case(name, use_hip=True, timeout=400)
