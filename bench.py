@@ -33,9 +33,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--m", type=int, default=262144)
-    ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--rows", dest="m", type=int, default=262144)
+    ap.add_argument("--cols", dest="n", type=int, default=8192)
+    ap.add_argument("--rank", dest="k", type=int, default=64)
     ap.add_argument("--norm", default="fro")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

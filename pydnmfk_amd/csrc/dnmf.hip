@@ -164,66 +164,143 @@ __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T
     }
 }
 
-// acc[mt][jt] += X[row0 + wave*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T      (NW waves per workgroup)
-template <int KT, int MT, int NW, bool FAST>
+// acc[mt][jt] += X[row0 + rg*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T
+// NW waves per workgroup = (NW / KS) row groups x KS contraction slices: with KS = 2 the two waves that share a row
+// group each take half of every k-tile's fragment groups and the partial accumulators are summed through LDS at the
+// end (result in the slice-0 waves).  KS = 2 doubles the waves per SIMD when the shard has too few row tiles to fill
+// the chip (m_l = 32768 at 8 GPUs = 256 tiles = one 4-wave workgroup per CU).
+// PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
+// in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
+// with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
+template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
-    constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
-    constexpr int STAGE = (BM + KP) * BK;  // floats per pipeline stage: [X tile | Y tile]
+    constexpr int NRG = NW / KS;             // row groups (waves along M)
+    constexpr int BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
+    constexpr int STAGE = (BM + KP) * BK;    // floats per pipeline stage: [X tile | Y tile]
+    constexpr int NS = BK / 8;               // fragment groups per k-tile
+    static_assert(NS % KS == 0, "contraction slices must divide the fragment groups");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int rg = wave % NRG, ks = wave / NRG;
     f32x4 xv[(BM + T / 8 - 1) / (T / 8)], yv[(KP + T / 8 - 1) / (T / 8)];
     const long nk = (cend - cbeg + BK - 1) / BK;
-    if (nk <= 0) return;
-    const bool rows_in = row0 + BM <= nrows, yrows_in = yrows >= KP;
-    {
-        const bool cin = cbeg + BK <= cend;
-        stage_load<BM, T, FAST>(xv, X, ldx, nrows, cend, row0, cbeg, tid, rows_in && cin);
-        stage_load<KP, T, FAST>(yv, Y, ldy, yrows, cend, 0, cbeg, tid, yrows_in && cin);
-    }
-    stage_store<BM, T>(smem, xv, tid);
-    stage_store<KP, T>(smem + BM * BK, yv, tid);
-    __syncthreads();
-    for (long kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const long c0 = cbeg + (kt + 1) * BK;
+    if (nk > 0) {
+        const bool rows_in = row0 + BM <= nrows, yrows_in = yrows >= KP;
+        // Every workgroup walks the k-tiles in a rotated order starting at a different tile: row tiles are a
+        // power-of-two pitch apart in memory, so workgroups marching in lockstep over the same columns would hit
+        // the same L2 / HBM channels at the same time.  (A sum over tiles: order only changes fp32 rounding.)
+        const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
+        {
+            const long c0 = cbeg + kshift * BK;
             const bool cin = c0 + BK <= cend;
             stage_load<BM, T, FAST>(xv, X, ldx, nrows, cend, row0, c0, tid, rows_in && cin);
             stage_load<KP, T, FAST>(yv, Y, ldy, yrows, cend, 0, c0, tid, yrows_in && cin);
         }
-        const float* xc = smem + cur * STAGE;
-        const float* yc = xc + BM * BK;
+        stage_store<BM, T>(smem, xv, tid);
+        stage_store<KP, T>(smem + BM * BK, yv, tid);
+        __syncthreads();
+        // MFMAs of one staged tile (this wave's share of its fragment groups)
+        auto compute = [&](const float* xc) {
+            const float* yc = xc + BM * BK;
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            f32x4 a[MT], b[KT];
+            for (int sl = 0; sl < NS / KS; ++sl) {
+                const int s = ks * (NS / KS) + sl;
+                f32x4 a[MT], b[KT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(rg * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+                for (int jt = 0; jt < KT; ++jt)
+                    b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
+            }
+        };
+        auto load_tile = [&](f32x4 (&xr)[(BM + T / 8 - 1) / (T / 8)], f32x4 (&yr)[(KP + T / 8 - 1) / (T / 8)], long kt) {
+            kt += kshift;                     // rotated tile order (see kshift)
+            kt = kt >= nk ? kt - nk : kt;
+            const long c0 = cbeg + kt * BK;
+            const bool cin = c0 + BK <= cend;
+            stage_load<BM, T, FAST>(xr, X, ldx, nrows, cend, row0, c0, tid, rows_in && cin);
+            stage_load<KP, T, FAST>(yr, Y, ldy, yrows, cend, 0, c0, tid, yrows_in && cin);
+        };
+        if constexpr (PF == 1) {
+            for (long kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                const bool more = kt + 1 < nk;
+                if (more) load_tile(xv, yv, kt + 1);
+                compute(smem + cur * STAGE);
+                if (more) {
+                    stage_store<BM, T>(smem + (cur ^ 1) * STAGE, xv, tid);
+                    stage_store<KP, T>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
+                }
+                __syncthreads();
+            }
+        } else {
+            // two register sets: (xv, yv) and (xw, yw) alternate; each holds a tile for one whole compute phase
+            f32x4 xw[(BM + T / 8 - 1) / (T / 8)], yw[(KP + T / 8 - 1) / (T / 8)];
+            if (nk > 1) load_tile(xv, yv, 1);
+            for (long kt = 0; kt < nk; kt += 2) {
+                // even phase: tile kt in LDS stage 0, tile kt+1 in flight in (xv, yv); issue tile kt+2 into (xw, yw)
+                if (kt + 2 < nk) load_tile(xw, yw, kt + 2);
+                compute(smem);
+                if (kt + 1 < nk) {
+                    stage_store<BM, T>(smem + STAGE, xv, tid);
+                    stage_store<KP, T>(smem + STAGE + BM * BK, yv, tid);
+                }
+                __syncthreads();
+                if (kt + 1 >= nk) break;
+                // odd phase: tile kt+1 in stage 1, tile kt+2 in flight in (xw, yw); issue tile kt+3 into (xv, yv)
+                if (kt + 3 < nk) load_tile(xv, yv, kt + 3);
+                compute(smem + STAGE);
+                if (kt + 2 < nk) {
+                    stage_store<BM, T>(smem, xw, tid);
+                    stage_store<KP, T>(smem + BM * BK, yw, tid);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if constexpr (KS > 1) {
+        // sum the contraction slices: slice s > 0 parks its accumulators in LDS (lane-contiguous, conflict free),
+        // slice 0 adds them in slice order.  NRG*MT*KT*1024 floats <= 2*STAGE for every instantiated shape.
+        static_assert(NRG * MT * KT * 1024 * (KS - 1) <= 2 * STAGE, "reduction buffer exceeds the staging LDS");
+        if (ks > 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(wave * 32 * MT + mt * 32 + li, 2 * s + h)]);
 #pragma unroll
-            for (int jt = 0; jt < KT; ++jt)
-                b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+                for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int r = 0; r < 16; ++r)
+                        smem[((((ks - 1) * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane] = acc[mt][jt][r];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 0; q < KS - 1; ++q)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
-        }
-        if (more) {
-            stage_store<BM, T>(smem + (cur ^ 1) * STAGE, xv, tid);
-            stage_store<KP, T>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
+                    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[mt][jt][r] += smem[(((q * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane];
         }
         __syncthreads();
     }
 }
 
-template <int KT, int MT, int NW, bool FAST, int MODE>
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF>
 __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BM = 32 * MT * NW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    constexpr int NRG = NW / KS, BM = 32 * MT * NRG;
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int wave = (threadIdx.x >> 6) % NRG, ks = (threadIdx.x >> 6) / NRG;   // row group, contraction slice
     const long row0 = (long)blockIdx.x * BM;
 
     f32x16 acc[MT][KT];
@@ -238,10 +315,11 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
         const long cbeg = (long)blockIdx.y * p.cols_per_split;
         long cend = cbeg + p.cols_per_split;
         if (cend > p.ncols) cend = p.ncols;
-        nt_mainloop<KT, MT, NW, FAST>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        nt_mainloop<KT, MT, NW, KS, FAST, (PF - 1) % 2 + 1, (PF > 2)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
     }
 
     if constexpr (MODE == NT_STORE) {
+        if (KS > 1 && ks != 0) return;       // the sums live in the slice-0 waves
         float* out = p.out + (long)blockIdx.y * p.split_stride;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -262,7 +340,8 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
             for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][jt][r] = 0.f;
-        nt_mainloop<KT, MT, NW, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        nt_mainloop<KT, MT, NW, KS, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        if (KS > 1 && ks != 0) return;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -833,40 +912,58 @@ void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int KT, int MT, int NW, bool FAST, int MODE>
-int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
-    constexpr int BM = 32 * MT * NW;
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF>
+int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
+    constexpr int BM = 32 * MT * (NW / KS);
     constexpr size_t lds = 2ul * (BM + 32 * KT) * BK * sizeof(float);
     static bool once = false;
-    if (!once) { allow_lds(nt_kernel<KT, MT, NW, FAST, MODE>, lds); once = true; }
-    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, FAST, MODE>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
+    if (!once) { allow_lds(nt_kernel<KT, MT, NW, KS, FAST, MODE, PF>, lds); once = true; }
+    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, KS, FAST, MODE, PF>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
                        dim3(64 * NW), lds, st, a);
     return check_launch("nt_kernel");
 }
 
-// Tile configuration per padded rank.  cfg = 0 is the default; other values are experiment switches
-// (env DNMF_NT_CFG) kept so A/B runs can be made from one binary.
-//   KT=1 (k<=32): 256-row tile, 4 waves x 64 rows      KT=4 (k<=128): 128-row tile, 4 waves x 32 rows
-//   KT=2 (k<=64): cfg 0 = 128-row tile, 4 waves x 32 rows; cfg 1 = 256 rows / 8 waves x 32; cfg 2 = 256 rows / 4 waves x 64
-inline int nt_cfg() {
-    static const int cfg = getenv("DNMF_NT_CFG") ? atoi(getenv("DNMF_NT_CFG")) : 0;
-    return cfg;
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE>
+int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
+    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 1;   // experiment switch
+    if (FAST && MODE == NT_FUSED_W && KS == 1) {
+        if (pf == 2) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 2>(a, nsplit, st);
+        if (pf == 3) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 3>(a, nsplit, st);
+        if (pf == 4) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 4>(a, nsplit, st);
+    }
+    return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1>(a, nsplit, st);
+}
+
+// Tile configuration per padded rank (KT = KP/32); every configuration has a 128-row (KT >= 2) or 256-row (KT = 1)
+// tile.  An 8-wave variant with two contraction slices per row group (KS = 2: same tile, twice the waves per SIMD)
+// exists for experiments (env DNMF_NT_KS = 2) but lost at every size measured, as did prefetch distance 2 and a
+// per-workgroup rotated k-tile order (env DNMF_NT_PF = 2 | 3 | 4): the NT kernel is paced by its LDS/barrier
+// structure and the clock the chip holds, not by HBM latency.
+inline int nt_ks(long nrows, int bm) {
+    static const int forced = getenv("DNMF_NT_KS") ? atoi(getenv("DNMF_NT_KS")) : 0;
+    if (forced) return forced;
+    (void)nrows; (void)bm;
+    return 1;   // measured (tools/kbench.py): the two-slice variant is 8-18 % SLOWER at every shard size (32k..262k rows)
 }
 
 template <int MODE>
 int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
-#define NT_CASE(KT_, MT_, NW_)                                                                    \
-    return fast ? launch_nt_inst<KT_, MT_, NW_, true, MODE>(a, nsplit, st)                         \
-                : launch_nt_inst<KT_, MT_, NW_, false, MODE>(a, nsplit, st);
-    if (kt == 1) { NT_CASE(1, 2, 4) }
-    if (kt == 2) {
-        if (MODE == NT_STORE && a.store_all) { NT_CASE(2, 1, 4) }   // gram split tiles: 128-row partial layout
-        const int cfg = nt_cfg();
-        if (cfg == 1) { NT_CASE(2, 1, 8) }
-        if (cfg == 2) { NT_CASE(2, 2, 4) }
-        NT_CASE(2, 1, 4)
+#define NT_CASE(KT_, MT_, NW_, KS_)                                                               \
+    return fast ? launch_nt_inst<KT_, MT_, NW_, KS_, true, MODE>(a, nsplit, st)                    \
+                : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE>(a, nsplit, st);
+    const bool gram = (MODE == NT_STORE && a.store_all);   // split-K gram tiles: partial layout fixed, plenty of blocks
+    if (kt == 1) {
+        if (!gram && nt_ks(a.nrows, 256) == 2) { NT_CASE(1, 2, 8, 2) }
+        NT_CASE(1, 2, 4, 1)
     }
-    if (kt == 4) { NT_CASE(4, 1, 4) }
+    if (kt == 2) {
+        if (!gram && nt_ks(a.nrows, 128) == 2) { NT_CASE(2, 1, 8, 2) }
+        NT_CASE(2, 1, 4, 1)
+    }
+    if (kt == 4) {
+        if (!gram && nt_ks(a.nrows, 128) == 2) { NT_CASE(4, 1, 8, 2) }
+        NT_CASE(4, 1, 4, 1)
+    }
 #undef NT_CASE
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }

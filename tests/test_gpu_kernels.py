@@ -70,6 +70,23 @@ def test_aht_and_wta(ops, m, n, k):
     assert _rel(AtW, W.T.astype(np.float64) @ A.astype(np.float64)) < 2e-6
 
 
+@pytest.mark.parametrize("m,n,k", [(89600, 96, 64), (163968, 40, 16), (82000, 36, 128)])
+def test_tall_shards(ops, m, n, k):
+    """Tall, narrow shards: many row tiles per launch, few k-tiles (the opposite corner from SHAPES)."""
+    from pydnmfk_amd.engine import new_gram
+    A, W, H = _mk(m, n, k)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    AH = ops.aht(_d(A), _d(H), torch.empty(m, k, device="cuda")).cpu().numpy()
+    assert _rel(AH, A64 @ H64.T) < 2e-6
+    G = ops.gram_hht(_d(H), new_gram(k, torch.device("cuda")))
+    Wf = _d(W)
+    ops.aht_update_w(_d(A), _d(H), G, Wf, EPS)
+    assert _rel(Wf.cpu().numpy(), W64 * ((A64 @ H64.T) / (W64 @ (H64 @ H64.T) + EPS))) < 1e-5
+    Wd = _d(W)
+    ops.mu_update_w(Wd, _d(AH), G, EPS)
+    assert _rel(Wd.cpu().numpy(), W64 * (AH.astype(np.float64) / (W64 @ (H64 @ H64.T) + EPS))) < 1e-5
+
+
 def test_strided_views(ops):
     """Leading dimensions larger than the logical width (sub-blocks of bigger buffers)."""
     m, n, k = 200, 136, 64
