@@ -74,7 +74,7 @@ int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ld
 /* ---- KL pieces (dist_nmf.py:776-869; 2D :294-343).  U = A / (W H + eps) is never materialised. ---- */
 /* UHT[m x k] = (A / (W H + eps)) H^T     (glob_UX(axis=0), dist_nmf.py:806,810; UHT_glob :337-338) */
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                int k, float eps, float* UHT, long ldo, void* stream);
+                int k, float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream);
 /* WTU[k x n] = W^T (A / (W H + eps))     (glob_UX(axis=1), dist_nmf.py:806,808; WTU_glob :311-312) */
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                 int k, float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream);

@@ -34,7 +34,7 @@ SIGNATURES = {
     "dnmf_mu_fro_step": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int,
                          c_int, c_void_p, c_size_t, c_void_p],
     "dnmf_kl_uht": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
-                    c_long, c_void_p],
+                    c_long, c_void_p, c_size_t, c_void_p],
     "dnmf_kl_wtu": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
                     c_long, c_void_p, c_size_t, c_void_p],
     "dnmf_rowsum": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],

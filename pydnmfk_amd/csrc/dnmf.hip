@@ -770,18 +770,33 @@ __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     block_atomic_sum(total, p.out);
 }
 
-// KL H-side: P[rowblk-chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)
-// One wave owns a 128-column block and a chunk of 32-row blocks; per row block it forms S (NN tile), turns it
-// into U in place (same C/D registers) and feeds U as the B operand of W^T U: the contraction index i is the
-// C/D row index, i.e. it lives in registers, which is exactly the B-operand layout (row pairs (rho, rho+4)).
+// KL H-side: P[chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)          (dist_nmf.py:806,808)
+// A workgroup = 4 waves that share one block of CW = 32*NT columns and each own a chunk of 32-row blocks.  The
+// KP x CW block of H those columns need is loop invariant: it is staged ONCE per workgroup into LDS (row jj,
+// lane-contiguous columns -> conflict-free ds_read_b64/b128 as the B operand of S = W H).  Per row block a wave forms
+// S (NN tile), turns it into U in place (same C/D registers) and feeds U as the B operand of W^T U: the contraction
+// index i is the C/D row index, i.e. it lives in registers, which is exactly the B-operand layout (row pairs
+// (rho, rho+4)).  The A tile is requested before the S product so its latency hides under it.
 template <int KT, int NT, bool FAST>
-__global__ __launch_bounds__(256) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
-    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = 32 * KT, CW = 32 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const long nchunks = cdiv(p.nrowblk, rowblks_per_chunk);
-    if (gw >= nchunks * p.ncolblk) return;
-    const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;
-    const long col0 = colblk * 32 * NT;
+    const long colblk = blockIdx.x % p.ncolblk;
+    const long chunk = (blockIdx.x / p.ncolblk) * 4 + wid;
+    const long col0 = colblk * CW;
+    // stage H[0:KP][col0:col0+CW] (zero outside k x n)
+    for (int idx = tid; idx < KP * (CW / 4); idx += 256) {
+        const int jj = idx / (CW / 4), c4 = (idx % (CW / 4)) * 4;
+        float d[4];
+        load_vec<4, FAST>(d, p.H + (long)jj * p.ldh, col0 + c4, p.n, jj < p.k);
+        *reinterpret_cast<f32x4*>(&smem[jj * CW + c4]) = f32x4{d[0], d[1], d[2], d[3]};
+    }
+    __syncthreads();
+    if (chunk >= nchunks) return;
+
     f32x16 out[KT][NT];
 #pragma unroll
     for (int ke = 0; ke < KT; ++ke)
@@ -793,17 +808,42 @@ __global__ __launch_bounds__(256) void kl_wtu_kernel(NnArgs p, long rowblks_per_
     if (rb1 > p.nrowblk) rb1 = p.nrowblk;
     for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb) {
         const long row0 = rb * 32;
-        f32x16 acc[NT];
-        nn_tile<KT, NT, FAST>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+        float areg[16][NT];   // A[row0 + crow(r,h)][col0 + NT*li + ne], requested first
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long row = row0 + crow(r, h);
-            float a[NT];
-            load_vec<NT, FAST>(a, p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
-#pragma unroll
-            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = a[ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+            load_vec<NT, FAST>(areg[r], p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
         }
-        // out[ke][ne] += sum_i W[i][KT*li' + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
+        f32x16 acc[NT];
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+        const long wrow = row0 + li;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
+            float a[4];
+            load_vec<4, FAST>(a, p.W + wrow * p.ldw, 8 * s + 4 * h, p.k, wrow < p.m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = 8 * s + 4 * h + e;
+                float b[NT];
+                if constexpr (NT == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[jj * CW + 4 * li]);
+                    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+                } else {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(&smem[jj * CW + 2 * li]);
+                    b[0] = v[0]; b[1] = v[1];
+                }
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+        // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long row = row0 + crow(r, h);
@@ -828,32 +868,54 @@ __global__ __launch_bounds__(256) void kl_wtu_kernel(NnArgs p, long rowblks_per_
         }
 }
 
-// KL W-side: UHT[i][j] = sum_c (A[i][c] / (S[i][c] + eps)) * H[j][c]
-// The contraction index c must end up in registers, so S is formed TRANSPOSED: S^T[c][i] with the MFMA M index = c
-// (A-operand lane (c, h) holds H[jj][c]: coalesced) and N index = i (B-operand lane (i, h) holds W[i][jj]).
-// C/D then has lane = row i of A and registers = columns c; A is read in that layout (16-B pieces of 32
-// different rows per instruction; KL is MFMA-bound by a wide margin), U^T replaces S^T in place and is
-// the B operand of (U H^T)^T[j][i] = sum_c H[j][c] U^T[c][i].
+// KL W-side: UHT[i][j] = sum_c (A[i][c] / (S[i][c] + eps)) * H[j][c]                     (dist_nmf.py:806,810)
+// The contraction index c of the second product must end up in registers, so S is formed TRANSPOSED:
+//   S^T[c][i] = sum_jj H[jj][c] W[i][jj]   MFMA M index = c (A-operand lane (c,h) = H[jj][c]), N index = i (B-operand
+//   lane (i,h) = W[i][jj], the lane's own W row, held in registers for the whole kernel).
+// C/D then has lane = row i of A and registers = columns c; A is read in that layout (four 16-B pieces per lane and
+// 32-column tile, prefetched one tile ahead), U^T replaces S^T in place and is the B operand of
+//   (U H^T)^T[j][i] = sum_c H[j][c] U^T[c][i]   (A-operand lane (j,h) = H[j][c]).
+// Workgroup = 4 waves x 32 rows; the k x 32 tile of H is staged once per workgroup into LDS (same swizzled image as the
+// NT tiles: ds_read_b32 along a row for the first product, ds_read_b128 across rows for the second) and double
+// buffered, one barrier per tile.  blockIdx.y splits the columns; partial UHT slabs are summed by reduce_partials.
 template <int KT, bool FAST>
-__global__ __launch_bounds__(256) void kl_uht_kernel(NnArgs p, float* __restrict__ UHT, long ldo) {
-    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per 32-row block, all columns
-    if (gw >= p.nrowblk) return;
-    const long row0 = gw * 32;
-    const long arow = row0 + li;
+__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, float* __restrict__ out_base, long ldo,
+                                                        long split_stride, long cols_per_split, int out_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = 32 * KT, T = 256, STAGE = KP * BK, NY = KP / (T / 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const long arow = (long)blockIdx.x * 128 + wave * 32 + li;
     const bool rok = arow < p.m;
+    const long cbeg = (long)blockIdx.y * cols_per_split;
+    long cend = cbeg + cols_per_split;
+    if (cend > p.n) cend = p.n;
+    const long nt = (cend - cbeg + BK - 1) / BK;
+
     f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
 #pragma unroll
     for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[jt][r] = 0.f;
-    // this lane's W row as B operand of S^T: W[arow][jj], jj = 8s + 4h + e  (kept in registers for all column blocks)
-    float wreg[4 * KT][4];
+    float wreg[4 * KT][4];   // W[arow][8s + 4h + e]
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) load_vec<4, FAST>(wreg[s], p.W + arow * p.ldw, 8 * s + 4 * h, p.k, rok);
 
-    for (long c0 = 0; c0 < p.n; c0 += 32) {
-        f32x16 st;  // S^T tile: rows c (c0 + crow), lanes i
+    f32x4 hst[NY];
+    float a_cur[4][4];
+    const bool hrows_in = p.k >= KP;
+    if (nt > 0) {
+        stage_load<KP, T, FAST>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid, hrows_in && cbeg + BK <= cend);
+        stage_store<KP, T>(smem, hst, tid);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+    }
+    __syncthreads();
+    for (long t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < nt;
+        const long c1 = cbeg + (t + 1) * BK;
+        const float* Hs = smem + cur * STAGE;
+        f32x16 st;  // S^T tile: rows c, lanes i
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
@@ -861,38 +923,38 @@ __global__ __launch_bounds__(256) void kl_uht_kernel(NnArgs p, float* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int jj = 8 * s + 4 * h + e;
-                const long c = c0 + li;
-                const float hv = (jj < p.k && c < p.n) ? p.H[(long)jj * p.ldh + c] : 0.f;
+                const float hv = Hs[lds_idx(jj, li >> 2) + (li & 3)];
                 st = MFMA32(hv, wreg[s][e], st);
             }
-        // U^T[c][i] = A[i][c] / (S^T + eps): lane i needs A[arow][c0 + 8g + 4h + (0..3)] for register group g
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float a[4];
-            load_vec<4, FAST>(a, p.A + arow * p.lda, c0 + 8 * g + 4 * h, p.n, rok);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[4 * g + e] = a[e] / (st[4 * g + e] + p.eps);
+            for (int e = 0; e < 4; ++e) st[4 * g + e] = a_cur[g][e] / (st[4 * g + e] + p.eps);   // U^T (dist_nmf.py:806)
+        // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
+        if (more) {
+            stage_load<KP, T, FAST>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid, hrows_in && c1 + BK <= cend);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
         }
-        // out[jt] += H[jt*32 + .][c] * U^T[c][i]: contraction c = c0 + crow(r, h); A-operand lane (j, h) holds H[j][c]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int jt = 0; jt < KT; ++jt) {
-                const int j = jt * 32 + li;
-                float hh[4];
-                load_vec<4, FAST>(hh, p.H + (long)j * p.ldh, c0 + 8 * g + 4 * h, p.n, j < p.k);
+                const f32x4 hh = *reinterpret_cast<const f32x4*>(&Hs[lds_idx(jt * 32 + li, 2 * g + h)]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[jt] = MFMA32(hh[e], st[4 * g + e], out[jt]);
             }
-        }
+        if (more) stage_store<KP, T>(smem + (cur ^ 1) * STAGE, hst, tid);
+        __syncthreads();
     }
-    // out[jt] (reg, lane): j = jt*32 + crow(reg, h), i = arow -> UHT[i][j]; registers 4g..4g+3 are 4 consecutive j
+    // out[jt] (reg, lane): j = jt*32 + crow(reg, h), i = arow; registers 4g..4g+3 are 4 consecutive j
+    float* dst = out_base + (long)blockIdx.y * split_stride + arow * ldo;
 #pragma unroll
     for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float d[4] = {out[jt][4 * g], out[jt][4 * g + 1], out[jt][4 * g + 2], out[jt][4 * g + 3]};
-            store_vec<4, FAST>(d, UHT + arow * ldo, jt * 32 + 8 * g + 4 * h, p.k, rok);
+            store_vec<4, FAST>(d, dst, jt * 32 + 8 * g + 4 * h, out_cols, rok);
         }
 }
 
@@ -970,6 +1032,7 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
 
 inline int nt_rows_per_tile(int kt) { return kt == 1 ? 256 : 128; }
 inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
+inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
 
 template <int MODE>
 int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
@@ -1053,8 +1116,9 @@ size_t partial_bytes(long m, long n, int k) {
     {   // wta / kl_wtu: A [m x n]
         TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
         b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, k, n));
-        const long klc = cdiv(cdiv(m, 32), std::max<long>(1, p.rows_per_chunk / 32));  // kl_wtu: same column sets as wta
-        b = std::max(b, (size_t)klc * p.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)klc, k, n));
+        TnPlan q = plan_tn(m, n, kt, kl_nt(kt));
+        const long klc = cdiv(cdiv(m, 32), std::max<long>(1, q.rows_per_chunk / 32));
+        b = std::max(b, (size_t)klc * q.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)klc, k, n));
     }
     {   // gram W^T W: Y = W [m x k]
         TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt);
@@ -1063,6 +1127,13 @@ size_t partial_bytes(long m, long n, int k) {
     {   // gram H H^T
         SplitPlan s = plan_gram_nt(n);
         b = std::max(b, (size_t)s.nsplit * nt_rows_per_tile(kt) * kp * sizeof(float) + reduce_scratch_bytes(s.nsplit, kp, kp));
+    }
+    {   // kl_uht column-split slabs
+        const long rowtiles = cdiv(m, 128);
+        long ns = std::min<long>(std::max<long>(1, cdiv(1536, rowtiles)), std::max<long>(1, n / 256));
+        const long cps = round_up(cdiv(n, ns), BK);
+        const int nsp = (int)cdiv(n, cps);
+        if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
     }
     b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
     return b;
@@ -1286,22 +1357,49 @@ int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, 
     return check_launch("resid_sqnorm");
 }
 
+struct UhtPlan { int nsplit; long cols_per_split; };
+
+static UhtPlan plan_uht(long m, long n) {
+    UhtPlan u;
+    const long rowtiles = cdiv(m, 128);
+    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
+    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
+    u.cols_per_split = round_up(cdiv(n, ns), BK);
+    u.nsplit = (int)cdiv(n, u.cols_per_split);
+    return u;
+}
+
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                float eps, float* UHT, long ldo, void* stream) {
+                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
+    const int kp = 32 * kt;
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
-    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(UHT) && ldo % 4 == 0;
-    const dim3 grid((unsigned)cdiv(a.nrowblk, 4)), block(256);
+    const UhtPlan u = plan_uht(m, n);
+    const size_t pbytes = u.nsplit > 1 ? (size_t)u.nsplit * m * kp * sizeof(float) : 0;
+    const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
+    if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
+    const bool split = u.nsplit > 1;
+    float* out = split ? (float*)ws : UHT;
+    const long ldout = split ? kp : ldo;
+    const int out_cols = split ? kp : k;
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(out) && ldout % 4 == 0;
+    const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
+    const size_t lds = 2ul * kp * BK * sizeof(float);
     hipStream_t st = S(stream);
-#define UH_CASE(KT_)                                                                              \
-    if (kt == KT_) {                                                                              \
-        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, 0, st, a, UHT, ldo); \
-        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, 0, st, a, UHT, ldo);    \
+#define UH_CASE(KT_)                                                                                                  \
+    if (kt == KT_) {                                                                                                  \
+        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
+                                     u.cols_per_split, out_cols);                                                     \
+        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, lds, st, a, out, ldout, (long)m * kp,        \
+                                u.cols_per_split, out_cols);                                                          \
     }
     UH_CASE(1) UH_CASE(2) UH_CASE(4)
 #undef UH_CASE
-    return check_launch("kl_uht");
+    int rc = check_launch("kl_uht");
+    if (rc || !split) return rc;
+    return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k, (int)m, k,
+                         (float*)((char*)ws + pbytes), st);
 }
 
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
@@ -1310,7 +1408,7 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
     const int kp = 32 * kt;
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
-    const int nt = tn_nt(kt);
+    const int nt = kl_nt(kt);
     TnPlan p = plan_tn(m, n, kt, nt);
     a.ncolblk = p.ncolblk;
     const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
@@ -1320,14 +1418,15 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
-    const dim3 grid((unsigned)cdiv(nchunks * a.ncolblk, 4)), block(256);
+    const dim3 grid((unsigned)(cdiv(nchunks, 4) * a.ncolblk)), block(256);   // 4 row chunks (waves) per workgroup
+    const size_t lds = (size_t)kp * 32 * nt * sizeof(float);                   // the H block of the workgroup's columns
     hipStream_t st = S(stream);
-#define WU_CASE(KT_, NT_)                                                                                       \
-    if (kt == KT_) {                                                                                            \
-        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, 0, st, a, rowblks_per_chunk); \
-        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, 0, st, a, rowblks_per_chunk);    \
+#define WU_CASE(KT_, NT_)                                                                                         \
+    if (kt == KT_) {                                                                                              \
+        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
+        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
     }
-    WU_CASE(1, 4) WU_CASE(2, 4) WU_CASE(4, 2)
+    WU_CASE(1, 4) WU_CASE(2, 2) WU_CASE(4, 2)
 #undef WU_CASE
     int rc = check_launch("kl_wtu");
     if (rc) return rc;
@@ -1408,7 +1507,7 @@ int dnmf_mu_kl_step(const float* A, long m, long n, long lda, float* W, long ldw
     if (w_update) {                                                                   // dist_nmf.py:813-830
         const long ldu = round_up(k, 4);
         if ((rc = dnmf_rowsum(H, k, n, ldh, x, stream))) return rc;
-        if ((rc = dnmf_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldu, stream))) return rc;
+        if ((rc = dnmf_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldu, part, part_bytes, stream))) return rc;
         if ((rc = dnmf_kl_update_w(W, m, k, ldw, Sb, ldu, x, eps, stream))) return rc;
     }
     const long ldo = round_up(n, 4);                                                  // dist_nmf.py:832-849

@@ -127,8 +127,9 @@ class HipOps:
         _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "UHT")
         m, n = A.shape
         k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
         check(lib.dnmf_kl_uht(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
-                              out.data_ptr(), _ld(out), _stream()))
+                              out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def kl_wtu(self, A, W, H, eps, out):
