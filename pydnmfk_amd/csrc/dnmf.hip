@@ -128,14 +128,15 @@ struct NtArgs {
 };
 
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
-// `interior` (block-uniform): the whole tile is in bounds -> plain loads with no exec-masked branches.
-template <int R, int T, bool FAST>
+// INTERIOR (compile time): the whole tile is in bounds -> plain loads with no exec-masked branches, so hipcc can
+// keep several tiles' loads in flight with counted vmcnt instead of draining with vmcnt(0).
+template <int R, int T, bool FAST, bool INTERIOR>
 __device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const float* __restrict__ X, long ldx,
-                                           long nrows, long cend, long row0, long c0, int tid, bool interior) {
+                                           long nrows, long cend, long row0, long c0, int tid) {
     constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
     const int ch = tid & 7;
     const long c = c0 + ch * 4;
-    if (FAST && interior) {
+    if constexpr (FAST && INTERIOR) {
 #pragma unroll
         for (int it = 0; it < NP; ++it) {
             const int rl = it * RP + (tid >> 3);
@@ -172,8 +173,8 @@ __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T
 // PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
 // in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
 // with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
-template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false>
-__device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
+template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR>
+__device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
     constexpr int NRG = NW / KS;             // row groups (waves along M)
@@ -186,16 +187,14 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* 
     f32x4 xv[(BM + T / 8 - 1) / (T / 8)], yv[(KP + T / 8 - 1) / (T / 8)];
     const long nk = (cend - cbeg + BK - 1) / BK;
     if (nk > 0) {
-        const bool rows_in = row0 + BM <= nrows, yrows_in = yrows >= KP;
         // Every workgroup walks the k-tiles in a rotated order starting at a different tile: row tiles are a
         // power-of-two pitch apart in memory, so workgroups marching in lockstep over the same columns would hit
         // the same L2 / HBM channels at the same time.  (A sum over tiles: order only changes fp32 rounding.)
         const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
         {
             const long c0 = cbeg + kshift * BK;
-            const bool cin = c0 + BK <= cend;
-            stage_load<BM, T, FAST>(xv, X, ldx, nrows, cend, row0, c0, tid, rows_in && cin);
-            stage_load<KP, T, FAST>(yv, Y, ldy, yrows, cend, 0, c0, tid, yrows_in && cin);
+            stage_load<BM, T, FAST, INTERIOR>(xv, X, ldx, nrows, cend, row0, c0, tid);
+            stage_load<KP, T, FAST, INTERIOR>(yv, Y, ldy, yrows, cend, 0, c0, tid);
         }
         stage_store<BM, T>(smem, xv, tid);
         stage_store<KP, T>(smem + BM * BK, yv, tid);
@@ -225,9 +224,8 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* 
             kt += kshift;                     // rotated tile order (see kshift)
             kt = kt >= nk ? kt - nk : kt;
             const long c0 = cbeg + kt * BK;
-            const bool cin = c0 + BK <= cend;
-            stage_load<BM, T, FAST>(xr, X, ldx, nrows, cend, row0, c0, tid, rows_in && cin);
-            stage_load<KP, T, FAST>(yr, Y, ldy, yrows, cend, 0, c0, tid, yrows_in && cin);
+            stage_load<BM, T, FAST, INTERIOR>(xr, X, ldx, nrows, cend, row0, c0, tid);
+            stage_load<KP, T, FAST, INTERIOR>(yr, Y, ldy, yrows, cend, 0, c0, tid);
         };
         if constexpr (PF == 1) {
             for (long kt = 0; kt < nk; ++kt) {
@@ -293,6 +291,17 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* 
         }
         __syncthreads();
     }
+}
+
+template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false>
+__device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
+                                            long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
+                                            long cend, float* smem) {
+    constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
+    // block-uniform: every tile this workgroup stages is fully in bounds
+    const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
+    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    else nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
 }
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF>
@@ -904,7 +913,8 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
     float a_cur[4][4];
     const bool hrows_in = p.k >= KP;
     if (nt > 0) {
-        stage_load<KP, T, FAST>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid, hrows_in && cbeg + BK <= cend);
+        if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
+        else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
         stage_store<KP, T>(smem, hst, tid);
 #pragma unroll
         for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
@@ -932,7 +942,8 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
             for (int e = 0; e < 4; ++e) st[4 * g + e] = a_cur[g][e] / (st[4 * g + e] + p.eps);   // U^T (dist_nmf.py:806)
         // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
         if (more) {
-            stage_load<KP, T, FAST>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid, hrows_in && c1 + BK <= cend);
+            if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
+            else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
 #pragma unroll
             for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
         }
@@ -987,7 +998,9 @@ int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE>
 int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
-    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 1;   // experiment switch
+    // PF code (experiment switch DNMF_NT_PF): 1 = prefetch distance 1, in-order tiles | 2 = distance 2 |
+    // 3 = distance 1 + rotated tile order per workgroup (default: +3-4 % at 64k-128k rows, neutral elsewhere) | 4 = 2 + rotation
+    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 3;
     if (FAST && MODE == NT_FUSED_W && KS == 1) {
         if (pf == 2) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 2>(a, nsplit, st);
         if (pf == 3) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 3>(a, nsplit, st);
