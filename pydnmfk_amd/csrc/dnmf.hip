@@ -151,14 +151,14 @@ constexpr int BK = 32;  // contraction tile (floats): 128-B LDS rows
 // to distinct 16-B slots of the 256-B bank row).
 __device__ __forceinline__ int lds_idx(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-enum { NT_STORE = 0, NT_FUSED_W = 1, NT_UPDATE_W = 2 };
+enum { NT_STORE = 0, NT_FUSED_W = 1 };
 
 struct NtArgs {
     const float* X; long ldx; long nrows; long ncols;  // streamed operand; contraction over ncols
     const float* Y; long ldy; int yrows;               // small operand [yrows x ncols]
     long cols_per_split;                               // contraction range per blockIdx.y (multiple of BK)
     float* out; long ldo; long split_stride; int store_all;
-    float* W; long ldw; const float* G; const float* AH; long ldah; float eps; int k;
+    float* W; long ldw; const float* G; float eps; int k;   // NT_FUSED_W
 };
 
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
@@ -394,9 +394,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
                     const long row = row0 + wave * 32 * MT + mt * 32 + crow(r, h);
                     const int col = jt * 32 + li;
                     if (row < p.nrows && col < p.k) {
-                        float ah;
-                        if constexpr (MODE == NT_FUSED_W) ah = acc[mt][jt][r];
-                        else ah = p.AH[row * p.ldah + col];
+                        const float ah = acc[mt][jt][r];
                         const float w = p.W[row * p.ldw + col];
                         const float q = ah / (acc2[mt][jt][r] + p.eps);   // dist_nmf.py:731-732
                         p.W[row * p.ldw + col] = w * q;
@@ -406,14 +404,13 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
 }
 
 // =============================================================================================== TN form
-enum { TN_PARTIAL = 0, TN_UPDATE_H = 1 };
+enum { TN_PARTIAL = 0 };
 
 struct TnArgs {
     const float* X; long ldx; int xcols;     // [nrows x xcols]  -> output rows j
     const float* Y; long ldy; long ycols;    // [nrows x ycols]  -> output cols c
     long nrows; long rows_per_chunk; int nchunks; int ncolblk;
-    float* P; long chunk_stride; long ldp;   // TN_PARTIAL: P[chunk][KP][ldp]
-    float* H; long ldh; const float* S; long lds_; float eps; int clamp; int k; long n;  // TN_UPDATE_H
+    float* P; long chunk_stride; long ldp;   // P[chunk][KP][ldp]
 };
 
 template <int KT, int NT, bool FAST, int U>
@@ -556,27 +553,6 @@ __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
 #pragma unroll
                 for (int ne = 0; ne < NT; ++ne) d[ne] = acc[ke][ne][r];
                 store_vec<NT, true>(d, Pc + (long)j * p.ldp, col0 + (long)NT * li, p.ldp, true);
-            }
-    } else {
-        // H[j][c] *= S[j][c] / (acc + eps)   with acc = sum_jj G[jj][j] H[jj][c]   (dist_nmf.py:750-751)
-#pragma unroll
-        for (int ke = 0; ke < KT; ++ke)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = KT * crow(r, h) + ke;
-                const bool ok = j < p.k;
-                const long c = col0 + (long)NT * li;
-                float hv[NT], sv[NT];
-                load_vec<NT, FAST>(hv, p.H + (long)j * p.ldh, c, p.n, ok);
-                load_vec<NT, FAST>(sv, p.S + (long)j * p.lds_, c, p.n, ok);
-#pragma unroll
-                for (int ne = 0; ne < NT; ++ne) {
-                    const float q = sv[ne] / (acc[ke][ne][r] + p.eps);
-                    float v = hv[ne] * q;
-                    if (p.clamp) v = fmaxf(v, p.eps);
-                    hv[ne] = v;
-                }
-                store_vec<NT, FAST>(hv, p.H + (long)j * p.ldh, c, p.n, ok);
             }
     }
 }
@@ -887,7 +863,7 @@ struct NnArgs {
 };
 
 // S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
-template <int KT, int NT, bool FAST>
+template <int KT, int NT, bool FAST, bool INTERIOR>
 __device__ __forceinline__ void nn_tile(f32x16 (&acc)[NT], const float* __restrict__ W, long ldw, long m, int k,
                                         const float* __restrict__ H, long ldh, long n, long row0, long col0, int li,
                                         int h) {
@@ -899,42 +875,50 @@ __device__ __forceinline__ void nn_tile(f32x16 (&acc)[NT], const float* __restri
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {  // 8 contraction indices per step: jj = 8s + 4h + e
         float a[4];
-        load_vec<4, FAST>(a, W + wrow * ldw, 8 * s + 4 * h, k, wrow < m);
+        load_tile_vec<4, FAST, INTERIOR>(a, W + wrow * ldw, 8 * s + 4 * h, k, wrow < m);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int jj = 8 * s + 4 * h + e;
             float b[NT];
-            load_vec<NT, FAST>(b, H + (long)jj * ldh, col0 + NT * li, n, jj < k);
+            load_tile_vec<NT, FAST, INTERIOR>(b, H + (long)jj * ldh, col0 + NT * li, n, jj < k);
 #pragma unroll
             for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
         }
     }
 }
 
+template <int KT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ float resid_tile(const NnArgs& p, long row0, long col0, int li, int h) {
+    f32x16 acc[4];
+    nn_tile<KT, 4, FAST, INTERIOR>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        float a[4];
+        load_tile_vec<4, FAST, INTERIOR>(a, p.A + row * p.lda, col0 + 4 * li, p.n, row < p.m);
+#pragma unroll
+        for (int ne = 0; ne < 4; ++ne) {
+            // rows >= m and cols >= n have a = 0 and acc = 0 (zero-filled operands) -> contribute 0
+            const float d = a[ne] - acc[ne][r];
+            part += d * d;
+        }
+    }
+    return part;
+}
+
 template <int KT, bool FAST>
 __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * 4 + wid;
     double total = 0.0;
     if (gw < p.nrowblk * p.ncolblk) {
         const long rowblk = gw / p.ncolblk, colblk = gw % p.ncolblk;
         const long row0 = rowblk * 32, col0 = colblk * 128;
-        f32x16 acc[4];
-        nn_tile<KT, 4, FAST>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
-        float part = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = row0 + crow(r, h);
-            float a[4];
-            load_vec<4, FAST>(a, p.A + row * p.lda, col0 + 4 * li, p.n, row < p.m);
-#pragma unroll
-            for (int ne = 0; ne < 4; ++ne) {
-                // rows >= m and cols >= n have a = 0 and acc = 0 (zero-filled operands) -> contribute 0
-                const float d = a[ne] - acc[ne][r];
-                part += d * d;
-            }
-        }
-        total = (double)part;
+        const bool interior = FAST && p.k == 32 * KT && row0 + 32 <= p.m && col0 + 128 <= p.n;
+        total = (double)(interior ? resid_tile<KT, FAST, true>(p, row0, col0, li, h)
+                                  : resid_tile<KT, FAST, false>(p, row0, col0, li, h));
     }
     block_atomic_sum(total, p.out);
 }
@@ -946,6 +930,53 @@ __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
 // S (NN tile), turns it into U in place (same C/D registers) and feeds U as the B operand of W^T U: the contraction
 // index i is the C/D row index, i.e. it lives in registers, which is exactly the B-operand layout (row pairs
 // (rho, rho+4)).  The A tile is requested before the S product so its latency hides under it.
+// one 32-row block of the KL H-side product (see kl_wtu_kernel); smem = the workgroup's KP x CW block of H
+template <int KT, int NT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs& p, const float* smem, long row0,
+                                             long col0, int li, int h) {
+    constexpr int CW = 32 * NT;
+    float areg[16][NT];   // A[row0 + crow(r,h)][col0 + NT*li + ne], requested first
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        load_tile_vec<NT, FAST, INTERIOR>(areg[r], p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+    const long wrow = row0 + li;
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
+        float a[4];
+        load_tile_vec<4, FAST, INTERIOR>(a, p.W + wrow * p.ldw, 8 * s + 4 * h, p.k, wrow < p.m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = 8 * s + 4 * h + e;
+            float b[NT];
+            load_vec_raw<NT>(b, &smem[jj * CW + NT * li]);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+    // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        float w[KT];
+        load_tile_vec<KT, FAST, INTERIOR>(w, p.W + row * p.ldw, (long)KT * li, p.k, row < p.m);
+#pragma unroll
+        for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) out[ke][ne] = MFMA32(w[ke], acc[ne][r], out[ke][ne]);
+    }
+}
+
 template <int KT, int NT, bool FAST>
 __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -975,55 +1006,11 @@ __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, 
             for (int r = 0; r < 16; ++r) out[ke][ne][r] = 0.f;
     long rb1 = (chunk + 1) * rowblks_per_chunk;
     if (rb1 > p.nrowblk) rb1 = p.nrowblk;
-    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb) {
-        const long row0 = rb * 32;
-        float areg[16][NT];   // A[row0 + crow(r,h)][col0 + NT*li + ne], requested first
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = row0 + crow(r, h);
-            load_vec<NT, FAST>(areg[r], p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
-        }
-        f32x16 acc[NT];
-#pragma unroll
-        for (int ne = 0; ne < NT; ++ne)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
-        const long wrow = row0 + li;
-#pragma unroll
-        for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
-            float a[4];
-            load_vec<4, FAST>(a, p.W + wrow * p.ldw, 8 * s + 4 * h, p.k, wrow < p.m);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int jj = 8 * s + 4 * h + e;
-                float b[NT];
-                if constexpr (NT == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(&smem[jj * CW + 4 * li]);
-                    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
-                } else {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(&smem[jj * CW + 2 * li]);
-                    b[0] = v[0]; b[1] = v[1];
-                }
-#pragma unroll
-                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
-        // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = row0 + crow(r, h);
-            float w[KT];
-            load_vec<KT, FAST>(w, p.W + row * p.ldw, (long)KT * li, p.k, row < p.m);
-#pragma unroll
-            for (int ke = 0; ke < KT; ++ke)
-#pragma unroll
-                for (int ne = 0; ne < NT; ++ne) out[ke][ne] = MFMA32(w[ke], acc[ne][r], out[ke][ne]);
-        }
-    }
+    // Measured: the branch-free (INTERIOR) form of this block is 8-20 % SLOWER here (its 16 A loads then issue as one
+    // VMEM block ahead of the MFMAs, cf. tn_mainloop); the predicated loads spread out.  Kept predicated until the
+    // block is software pipelined across row blocks.
+    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb)
+        kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
     float* Pc = p.P + chunk * p.chunk_stride;
 #pragma unroll
     for (int ke = 0; ke < KT; ++ke)
@@ -1047,10 +1034,9 @@ __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, 
 // Workgroup = 4 waves x 32 rows; the k x 32 tile of H is staged once per workgroup into LDS (same swizzled image as the
 // NT tiles: ds_read_b32 along a row for the first product, ds_read_b128 across rows for the second) and double
 // buffered, one barrier per tile.  blockIdx.y splits the columns; partial UHT slabs are summed by reduce_partials.
-template <int KT, bool FAST>
-__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, float* __restrict__ out_base, long ldo,
-                                                        long split_stride, long cols_per_split, int out_cols) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int KT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__ out_base, long ldo, long split_stride,
+                                            long cols_per_split, int out_cols, float* smem) {
     constexpr int KP = 32 * KT, T = 256, STAGE = KP * BK, NY = KP / (T / 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const long arow = (long)blockIdx.x * 128 + wave * 32 + li;
@@ -1067,7 +1053,7 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
         for (int r = 0; r < 16; ++r) out[jt][r] = 0.f;
     float wreg[4 * KT][4];   // W[arow][8s + 4h + e]
 #pragma unroll
-    for (int s = 0; s < 4 * KT; ++s) load_vec<4, FAST>(wreg[s], p.W + arow * p.ldw, 8 * s + 4 * h, p.k, rok);
+    for (int s = 0; s < 4 * KT; ++s) load_tile_vec<4, FAST, INTERIOR>(wreg[s], p.W + arow * p.ldw, 8 * s + 4 * h, p.k, rok);
 
     f32x4 hst[NY];
     float a_cur[4][4];
@@ -1076,8 +1062,13 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
         if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
         else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
         stage_store<KP, T>(smem, hst, tid);
+        if (INTERIOR && cbeg + BK <= cend) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+            for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+        }
     }
     __syncthreads();
     for (long t = 0; t < nt; ++t) {
@@ -1104,8 +1095,13 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
         if (more) {
             if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
             else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
+            if (INTERIOR && c1 + BK <= cend) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
+                for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1125,8 +1121,18 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float d[4] = {out[jt][4 * g], out[jt][4 * g + 1], out[jt][4 * g + 2], out[jt][4 * g + 3]};
-            store_vec<4, FAST>(d, dst, jt * 32 + 8 * g + 4 * h, out_cols, rok);
+            store_tile_vec<4, FAST, INTERIOR>(d, dst, jt * 32 + 8 * g + 4 * h, out_cols, rok);
         }
+}
+
+template <int KT, bool FAST>
+__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, float* __restrict__ out_base, long ldo,
+                                                        long split_stride, long cols_per_split, int out_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // block-uniform: all 128 rows in bounds and no rank padding -> branch-free W / A / output accesses
+    const bool interior = FAST && p.k == 32 * KT && ((long)blockIdx.x + 1) * 128 <= p.m && out_cols >= 32 * KT;
+    if (interior) kl_uht_body<KT, FAST, true>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
+    else kl_uht_body<KT, FAST, false>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
 }
 
 // =============================================================================================== host side
