@@ -164,7 +164,7 @@ struct NtArgs {
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
 // INTERIOR (compile time): the whole tile is in bounds -> plain loads with no exec-masked branches, so hipcc can
 // keep several tiles' loads in flight with counted vmcnt instead of draining with vmcnt(0).
-template <int R, int T, bool FAST, bool INTERIOR>
+template <int R, int T, bool FAST, bool INTERIOR, bool NTL = false>
 __device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const float* __restrict__ X, long ldx,
                                            long nrows, long cend, long row0, long c0, int tid) {
     constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
@@ -174,7 +174,10 @@ __device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)]
 #pragma unroll
         for (int it = 0; it < NP; ++it) {
             const int rl = it * RP + (tid >> 3);
-            if (R % RP == 0 || rl < R) v[it] = *reinterpret_cast<const f32x4*>(X + (row0 + rl) * ldx + c);
+            if (R % RP == 0 || rl < R) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(X + (row0 + rl) * ldx + c);
+                v[it] = NTL ? __builtin_nontemporal_load(src) : *src;
+            }
         }
     } else {
 #pragma unroll
@@ -207,7 +210,7 @@ __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T
 // PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
 // in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
 // with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
-template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR>
+template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false>
 __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
@@ -227,7 +230,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
         const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
         {
             const long c0 = cbeg + kshift * BK;
-            stage_load<BM, T, FAST, INTERIOR>(xv, X, ldx, nrows, cend, row0, c0, tid);
+            stage_load<BM, T, FAST, INTERIOR, NTX>(xv, X, ldx, nrows, cend, row0, c0, tid);
             stage_load<KP, T, FAST, INTERIOR>(yv, Y, ldy, yrows, cend, 0, c0, tid);
         }
         stage_store<BM, T>(smem, xv, tid);
@@ -258,7 +261,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
             kt += kshift;                     // rotated tile order (see kshift)
             kt = kt >= nk ? kt - nk : kt;
             const long c0 = cbeg + kt * BK;
-            stage_load<BM, T, FAST, INTERIOR>(xr, X, ldx, nrows, cend, row0, c0, tid);
+            stage_load<BM, T, FAST, INTERIOR, NTX>(xr, X, ldx, nrows, cend, row0, c0, tid);
             stage_load<KP, T, FAST, INTERIOR>(yr, Y, ldy, yrows, cend, 0, c0, tid);
         };
         if constexpr (PF == 1) {
@@ -327,14 +330,14 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
     }
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false>
+template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
-    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true, NTX>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
     else nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
 }
 
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
         const long cbeg = (long)blockIdx.y * p.cols_per_split;
         long cend = cbeg + p.cols_per_split;
         if (cend > p.ncols) cend = p.ncols;
-        nt_mainloop<KT, MT, NW, KS, FAST, (PF - 1) % 2 + 1, (PF > 2)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        nt_mainloop<KT, MT, NW, KS, FAST, (PF == 2 || PF == 4) ? 2 : 1, (PF == 3 || PF == 4 || PF == 5), (PF >= 5)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
     }
 
     if constexpr (MODE == NT_STORE) {
@@ -1165,12 +1168,17 @@ int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE>
 int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // PF code (experiment switch DNMF_NT_PF): 1 = prefetch distance 1, in-order tiles | 2 = distance 2 |
-    // 3 = distance 1 + rotated tile order per workgroup (default: +3-4 % at 64k-128k rows, neutral elsewhere) | 4 = 2 + rotation
-    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 3;
+    // 3 = 1 + rotated tile order per workgroup | 4 = 2 + rotation | 5 = 3 + nontemporal loads of the streamed operand
+    // (default) | 6 = 1 + nontemporal.  Measured (tools/kbench.py, k = 64, n = 8192): 262144 rows 2.54 / 2.51 / 2.42 /
+    // 2.53 ms for codes 1 / 3 / 5 / 6, 65536 rows 0.816 / 0.788 / 0.761 / 0.785 ms; HBM reads per launch (PMC) 8.67 /
+    // 10.99 / 8.47 / 8.50 GB: the rotation alone lets the streamed A evict H from L2, the nontemporal hint fixes that.
+    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 5;
     if (FAST && MODE == NT_FUSED_W && KS == 1) {
         if (pf == 2) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 2>(a, nsplit, st);
         if (pf == 3) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 3>(a, nsplit, st);
         if (pf == 4) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 4>(a, nsplit, st);
+        if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5>(a, nsplit, st);   // 3 + nontemporal X loads
+        if (pf == 6) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 6>(a, nsplit, st);   // 1 + nontemporal X loads
     }
     return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1>(a, nsplit, st);
 }
