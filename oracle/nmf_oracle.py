@@ -19,7 +19,7 @@ import numpy as np
 
 __all__ = [
     "block_range", "data_block", "factor_ranges", "split_problem",
-    "fro_mu_step_local", "kl_mu_step_local", "SimGrid", "fit_single",
+    "fro_mu_step_local", "kl_mu_step_local", "fro_hals_step_local", "SimGrid", "fit_single",
 ]
 
 
@@ -119,6 +119,30 @@ def kl_mu_step_local(A, W, H, eps, W_update=True):
     return W, H
 
 
+def fro_hals_step_local(A, W, H, eps, W_update=True):
+    """One HALS/Frobenius step on one rank, in place (dist_nmf.py:873-934 with p_r=p_c=1).
+
+    W sweep (:884-891): for kk: W[:,kk] = max(W[:,kk]*HHT[kk,kk] + AH[:,kk] - W @ HHT[:,kk], eps); W[:,kk] /= ||W[:,kk]||_2
+    H sweep (:905-909): for kk: H[kk,:] = max(H[kk,:] + AtW[kk,:] - WTW[kk,:] @ H, eps)   (updated rows are used at once)
+    """
+    k = W.shape[1]
+    if W_update:
+        HHT = np.matmul(H, H.T)
+        AH = np.matmul(A, H.T)
+        for kk in range(k):
+            t = W[:, kk] * HHT[kk, kk] + AH[:, kk] - W.dot(HHT[:, kk])
+            W[:, kk] = np.maximum(t, eps)
+            ss = np.sqrt(np.linalg.norm(W[:, kk], ord=2) ** 2)               # utils.py:388-391
+            if ss > 0:
+                W[:, kk] /= ss
+    WTW = np.matmul(W.T, W)
+    AtW = np.matmul(W.T, A)
+    for kk in range(k):
+        t = H[kk, :] + AtW[kk, :] - WTW[kk, :].dot(H)
+        H[kk, :] = np.maximum(t, eps)
+    return W, H
+
+
 # ------------------------------------------------------------------ simulated grid
 class SimGrid:
     """The reference's SPMD program with P = p_r * p_c ranks simulated in one process.
@@ -128,7 +152,8 @@ class SimGrid:
     on every rank; `fit(itr)` = `PyNMF.fit()` (pyDNMF.py:138-182).
     """
 
-    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True):
+    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True, method="mu"):
+        self.method = method
         self.p_r, self.p_c, self.P = p_r, p_c, p_r * p_c
         self.m, self.n = A.shape
         self.dtype = A.dtype
@@ -157,6 +182,12 @@ class SimGrid:
     # ---- one update step
     def update(self):
         fro = self.norm.upper() == "FRO"
+        if self.method.upper() == "HALS":
+            if not fro:
+                raise Exception("Not a valid method: Choose (mu)")     # dist_nmf.py:89,657
+            return (self._hals_1d if self.topo == "1d" else self._hals_2d)()
+        if self.method.upper() != "MU":
+            raise Exception("Not a valid method: Choose (mu/hals/bcd)")
         if self.topo == "1d":
             (self._fro_1d if fro else self._kl_1d)()
         else:
@@ -201,6 +232,69 @@ class SimGrid:
             sk = [_rsum(sk)] * self.P
         for r in R:
             H[r] *= sk[r] / (x1[r][:, None] + eps)                       # :847-849
+
+    # HALS sweeps shared by 1D and 2D (the per-rank loops of dist_nmf.py:884-891 / :905-909 and :428-434 / :449-452)
+    def _hals_w_sweep(self, AH, HHT, allreduce_norm):
+        """AH, HHT: per-rank lists.  Column kk is clamped, then divided by its GLOBAL 2-norm
+        (utils.py:367-391 `norm`: local squared norms are allreduced iff p != 1) before column kk+1 is touched."""
+        k = self.W[0].shape[1]
+        for kk in range(k):
+            sq = []
+            for r in range(self.P):
+                W = self.W[r]
+                t = W[:, kk] * HHT[r][kk, kk] + AH[r][:, kk] - W.dot(HHT[r][:, kk])
+                W[:, kk] = np.maximum(t, self.eps)
+                sq.append(np.linalg.norm(W[:, kk], ord=2) ** 2)
+            for r in range(self.P):
+                ss = np.sqrt(_rsum(sq)) if allreduce_norm else np.sqrt(sq[r])
+                if ss > 0:
+                    self.W[r][:, kk] /= ss
+
+    def _hals_h_sweep(self, AtW, WTW):
+        for r in range(self.P):
+            H = self.H[r]
+            for kk in range(H.shape[0]):
+                t = H[kk, :] + AtW[r][kk, :] - WTW[r][kk, :].dot(H)
+                H[kk, :] = np.maximum(t, self.eps)
+
+    # 1D HALS: dist_nmf.py:873-934
+    def _hals_1d(self):
+        R = range(self.P)
+        A, W, H = self.A, self.W, self.H
+        if self.W_update:
+            HHT = [np.matmul(H[r], H[r].T) for r in R]                   # :882
+            AH = [np.matmul(A[r], H[r].T) for r in R]                    # :883
+            if self.p_c != 1:
+                HHT = [_rsum(HHT)] * self.P
+                AH = [_rsum(AH)] * self.P
+            self._hals_w_sweep(AH, HHT, allreduce_norm=(self.p_r != 1))  # norm(..., p=self.p_r) :889
+        WTW = [np.matmul(W[r].T, W[r]) for r in R]                       # :902
+        AtW = [np.matmul(W[r].T, A[r]) for r in R]                       # :903
+        if self.p_r != 1:
+            WTW = [_rsum(WTW)] * self.P
+            AtW = [_rsum(AtW)] * self.P
+        self._hals_h_sweep(AtW, WTW)
+
+    # 2D HALS: dist_nmf.py:411-470
+    def _hals_2d(self):
+        R = range(self.P)
+        A, W, H = self.A, self.W, self.H
+        if self.W_update:
+            HHT = _rsum([np.matmul(H[r], H[r].T) for r in R])            # :426 (world)
+            V = [np.matmul(A[r], self._gather_H(r).T) for r in R]        # AH_glob :427
+            AH = []
+            for r in R:
+                grp = self._col_group(r)
+                AH.append(self._scatter_rows(r, grp, _rsum([V[q] for q in grp]), [W[q].shape[0] for q in grp]))
+            self._hals_w_sweep(AH, [HHT] * self.P, allreduce_norm=True)  # p = p_r != 1 on a 2D grid (:432)
+        WTW = _rsum([np.matmul(W[r].T, W[r]) for r in R])                # :447
+        Y = [np.matmul(self._gather_W(r).T, A[r]) for r in R]            # ATW_glob :448
+        AtW = []
+        for r in R:
+            grp = self._row_group(r)
+            ks = self._scatter_rows(r, grp, _rsum([Y[q].T.copy() for q in grp]), [H[q].shape[1] for q in grp])
+            AtW.append(ks.T)
+        self._hals_h_sweep(AtW, [WTW] * self.P)
 
     # 2D helpers
     def _gather_W(self, rank):
@@ -306,8 +400,8 @@ class SimGrid:
         raise ValueError("itr must be >= 1")
 
 
-def fit_single(A, W0, H0, itr, norm="fro", W_update=True):
+def fit_single(A, W0, H0, itr, norm="fro", W_update=True, method="mu"):
     """Single-rank convenience wrapper: returns (W, H, err)."""
-    g = SimGrid(A, W0, H0, 1, 1, norm=norm, W_update=W_update)
+    g = SimGrid(A, W0, H0, 1, 1, norm=norm, W_update=W_update, method=method)
     W, H, err = g.fit(itr)
     return W[0], H[0], err

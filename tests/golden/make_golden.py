@@ -111,7 +111,7 @@ def factor_slices(rank, p_r, p_c, m, n):
 
 
 # ----------------------------------------------------------------------------- one case
-def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7):
+def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7, method="mu"):
     A, k = DATASETS[dataset]()
     A = np.asarray(A).astype(dtype)
     m, n = A.shape
@@ -133,7 +133,7 @@ def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7)
             args.itr, args.init = itr, "rand"
             args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
             args.verbose, args.prune = False, False
-            args.norm, args.method = norm, "mu"
+            args.norm, args.method = norm, method
             args.W_update = W_update
             return args
 
@@ -170,7 +170,7 @@ def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7)
         for key, v in o.items():
             flat["r%d_%s" % (r, key)] = v
     meta = dict(name=name, dataset=dataset, grid=list(grid), norm=norm, dtype=np.dtype(dtype).name,
-                itrs=list(itrs), W_update=bool(W_update), init_seed=init_seed, k=int(k), m=int(m), n=int(n),
+                itrs=list(itrs), W_update=bool(W_update), init_seed=init_seed, k=int(k), m=int(m), n=int(n), method=method,
                 generator="reference lanl/pyDNMFk @ /root/reference, python3.9, numpy %s (OpenBLAS, 1 thread), "
                           "mpi4py stand-in with rank-ordered sums" % np.__version__)
     flat["meta"] = np.array(json.dumps(meta))
@@ -219,5 +219,29 @@ def main():
                 run_case("%s_%s_%s_float32" % (ds, g, norm), ds, grid, norm, f32, (10,))
 
 
+def main_hals():
+    """HALS / Frobenius cases (dist_nmf.py:411-470, :873-934) -- SURVEY 8f "next" row 1."""
+    f32, f64 = np.float32, np.float64
+    for grid in ([1, 1], [2, 1], [1, 2], [2, 2]):
+        g = "%dx%d" % tuple(grid)
+        run_case("t24x12_%s_hals_float32" % g, "t24x12", grid, "fro", f32, (1, 10, 100), method="hals")
+    run_case("t24x12_1x1_hals_float64", "t24x12", [1, 1], "fro", f64, (10,), method="hals")
+    for grid in ([3, 1], [2, 2]):
+        g = "%dx%d" % tuple(grid)
+        run_case("r25x13_%s_hals_float32" % g, "r25x13", grid, "fro", f32, (1, 10), method="hals")
+    for grid in ([1, 1], [4, 1], [2, 2]):
+        g = "%dx%d" % tuple(grid)
+        run_case("swim_%s_hals_float32" % g, "swim", grid, "fro", f32, (10,), method="hals")
+    run_case("swim_1x1_hals_float32_noW", "swim", [1, 1], "fro", f32, (10,), W_update=False, method="hals")
+    for ds in ("lr136x100k32", "lr200x136k64", "lr150x140k128"):
+        for grid in ([1, 1], [2, 1], [1, 2]):
+            g = "%dx%d" % tuple(grid)
+            run_case("%s_%s_hals_float32" % (ds, g), ds, grid, "fro", f32, (10,), method="hals")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hals":
+        main_hals()      # adds the HALS cases without touching the MU fixtures
+    else:
+        main()
+        main_hals()
