@@ -71,6 +71,22 @@ int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, 
 int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
                      int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- HALS / Frobenius sweeps (dist_nmf.py:873-934; 2D :411-470).  They reuse dnmf_gram_*, dnmf_aht, dnmf_wta. ---- */
+/* One column of the W sweep (dist_nmf.py:886-887): first applies the pending normalisation of column kk-1
+ * (W[:,kk-1] /= sqrt(*prev_ss2), skipped if prev_ss2 is NULL or 0), then
+ * W[:,kk] = max(W[:,kk]*G[kk][kk] + AH[:,kk] - W G[:,kk], eps) and *ss2_out = sum_i W[i][kk]^2 (device double).
+ * With p_r > 1 the caller allreduces *ss2_out between calls (utils.py:390 inside `norm`, dist_nmf.py:889). */
+int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                    const double* prev_ss2, float eps, double* ss2_out, void* stream);
+/* W[:,col] /= sqrt(*ss2) if > 0 (dist_nmf.py:890-891, the normalisation of the last column) */
+int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream);
+/* the whole W sweep on one rank (no allreduce of the norms): k column launches + the final scale; ss2 = k doubles */
+int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                       double* ss2, void* stream);
+/* H sweep: for kk: H[kk,:] = max(H[kk,:] + AtW[kk,:] - G[kk,:] H, eps), rows updated in sequence (dist_nmf.py:905-909) */
+int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
+                       void* stream);
+
 /* ---- KL pieces (dist_nmf.py:776-869; 2D :294-343).  U = A / (W H + eps) is never materialised. ---- */
 /* UHT[m x k] = (A / (W H + eps)) H^T     (glob_UX(axis=0), dist_nmf.py:806,810; UHT_glob :337-338) */
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,

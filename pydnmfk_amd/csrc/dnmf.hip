@@ -863,6 +863,109 @@ __global__ __launch_bounds__(256, 2) void update_w_kernel(float* __restrict__ W,
     else update_w_tile<KT, FAST, false>(W, k, ldw, Sm, lds_, gs, eps, row, row < m, li, h);
 }
 
+// =============================================================================================== HALS sweeps
+// Frobenius HALS (dist_nmf.py:873-934, :411-470) reuses the MU contractions (A H^T, H H^T, W^T A, W^T W) and replaces
+// the multiply-divide by a column-sequential sweep.
+//
+// W sweep, one launch per column kk (the global 2-norm of column kk must be known before column kk+1 is touched;
+// with p_r > 1 the host allreduces the 8-byte sum of squares between launches, exactly where the reference calls
+// utils.norm, dist_nmf.py:889):
+//   first the pending normalisation of column kk-1 is applied (W[i][kk-1] /= ss, ss = sqrt(*prev_ss2), skipped when 0),
+//   t = W[i][kk] * G[kk][kk] + AH[i][kk] - sum_j W[i][j] G[j][kk];  W[i][kk] = max(t, eps);  *ss2_out += W[i][kk]^2
+// One lane per row; a row of W is k contiguous floats.
+__global__ __launch_bounds__(256) void hals_w_col_kernel(float* __restrict__ W, long m, int k, long ldw,
+                                                        const float* __restrict__ AH, long ldah,
+                                                        const float* __restrict__ G, int kp, int kk,
+                                                        const double* __restrict__ prev_ss2, float eps,
+                                                        double* __restrict__ ss2_out) {
+    __shared__ float gcol[DNMF_MAX_K];
+    for (int j = threadIdx.x; j < k; j += blockDim.x) gcol[j] = G[(long)j * kp + kk];
+    __syncthreads();
+    float inv_den = 0.f;   // ss of the previous column (0 = no pending normalisation)
+    if (kk > 0 && prev_ss2) inv_den = (float)sqrt(*prev_ss2);
+    double sq = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long)gridDim.x * blockDim.x) {
+        float* row = W + i * ldw;
+        if (kk > 0 && inv_den > 0.f) row[kk - 1] = row[kk - 1] / inv_den;
+        float dot = 0.f;
+        for (int j = 0; j < k; ++j) dot = fmaf(row[j], gcol[j], dot);
+        const float t = row[kk] * gcol[kk] + AH[i * ldah + kk] - dot;
+        const float w = fmaxf(t, eps);
+        row[kk] = w;
+        sq += (double)w * (double)w;
+    }
+    block_atomic_sum(sq, ss2_out);
+}
+
+// final normalisation of one column: W[i][col] /= sqrt(*ss2) (skipped when 0)
+__global__ __launch_bounds__(256) void hals_w_scale_kernel(float* __restrict__ W, long m, long ldw, int col,
+                                                          const double* __restrict__ ss2) {
+    const float ss = (float)sqrt(*ss2);
+    if (!(ss > 0.f)) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long)gridDim.x * blockDim.x)
+        W[i * ldw + col] = W[i * ldw + col] / ss;
+}
+
+// H sweep: columns are independent, rows are sequential (row kk uses the already updated rows < kk):
+//   H[kk][c] = max(H[kk][c] + AtW[kk][c] - sum_j G[kk][j] H[j][c], eps)            (dist_nmf.py:905-909)
+// One lane per column with the whole column of H in registers; G (= W^T W, zero padded) is broadcast from LDS.
+template <int KP>
+__global__ __launch_bounds__(256) void hals_h_kernel(float* __restrict__ H, int k, long n, long ldh,
+                                                    const float* __restrict__ AtW, long ldatw,
+                                                    const float* __restrict__ G, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float gs[];
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256)
+        *reinterpret_cast<f32x4*>(&gs[idx * 4]) = *reinterpret_cast<const f32x4*>(G + idx * 4);
+    __syncthreads();
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float hc[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) hc[j] = j < k ? H[(long)j * ldh + c] : 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+        if (kk < k) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j4 = 0; j4 < KP; j4 += 4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(&gs[kk * KP + j4]);
+                dot = fmaf(g[0], hc[j4], dot);
+                dot = fmaf(g[1], hc[j4 + 1], dot);
+                dot = fmaf(g[2], hc[j4 + 2], dot);
+                dot = fmaf(g[3], hc[j4 + 3], dot);
+            }
+            const float t = hc[kk] + AtW[(long)kk * ldatw + c] - dot;
+            hc[kk] = fmaxf(t, eps);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KP; ++j)
+        if (j < k) H[(long)j * ldh + c] = hc[j];
+}
+
+// Same sweep for KP = 128 with the column state in LDS instead of 128 registers per lane (runtime loops, 64 lanes per
+// workgroup: hs[j][lane], G rows broadcast from LDS).
+__global__ __launch_bounds__(64) void hals_h_kernel_lds(float* __restrict__ H, int k, long n, long ldh,
+                                                       const float* __restrict__ AtW, long ldatw,
+                                                       const float* __restrict__ G, int kp, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gs = sm;                 // kp * kp
+    float* hs = sm + kp * kp;       // kp * 64
+    for (int idx = threadIdx.x; idx < kp * kp; idx += 64) gs[idx] = G[idx];
+    const long c = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < n;
+    for (int j = 0; j < k; ++j) hs[j * 64 + threadIdx.x] = live ? H[(long)j * ldh + c] : 0.f;
+    __syncthreads();
+    if (!live) return;
+    for (int kk = 0; kk < k; ++kk) {
+        float dot = 0.f;
+        for (int j = 0; j < k; ++j) dot = fmaf(gs[kk * kp + j], hs[j * 64 + threadIdx.x], dot);
+        const float t = hs[kk * 64 + threadIdx.x] + AtW[(long)kk * ldatw + c] - dot;
+        hs[kk * 64 + threadIdx.x] = fmaxf(t, eps);
+    }
+    for (int j = 0; j < k; ++j) H[(long)j * ldh + c] = hs[j * 64 + threadIdx.x];
+}
+
 // =============================================================================================== NN-small-k form
 // S[i][c] = sum_j W[i][j] H[j][c] computed tile-wise in accumulators, never stored:
 //   acc[mt][ne] (reg, lane) = S[i = row0 + mt*32 + crow(reg,h)] ... wait: here the MFMA M index is the A-row i,
@@ -1185,47 +1288,27 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // (default) | 6 = 1 + nontemporal.  Measured (tools/kbench.py, k = 64, n = 8192): 262144 rows 2.54 / 2.51 / 2.42 /
     // 2.53 ms for codes 1 / 3 / 5 / 6, 65536 rows 0.816 / 0.788 / 0.761 / 0.785 ms; HBM reads per launch (PMC) 8.67 /
     // 10.99 / 8.47 / 8.50 GB: the rotation alone lets the streamed A evict H from L2, the nontemporal hint fixes that.
+    // Only codes 1 and 5 are compiled in; the others were measured and dropped (see above).
     static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 5;
     if (FAST && KS == 1 && (MODE == NT_FUSED_W || !a.store_all)) {
-        if (pf == 2) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 2>(a, nsplit, st);
-        if (pf == 3) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 3>(a, nsplit, st);
-        if (pf == 4) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 4>(a, nsplit, st);
-        if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5>(a, nsplit, st);   // 3 + nontemporal X loads
-        if (pf == 6) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 6>(a, nsplit, st);   // 1 + nontemporal X loads
+        if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5>(a, nsplit, st);
     }
     return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1>(a, nsplit, st);
 }
 
 // Tile configuration per padded rank (KT = KP/32); every configuration has a 128-row (KT >= 2) or 256-row (KT = 1)
-// tile.  An 8-wave variant with two contraction slices per row group (KS = 2: same tile, twice the waves per SIMD)
-// exists for experiments (env DNMF_NT_KS = 2) but lost at every size measured, as did prefetch distance 2 and a
-// per-workgroup rotated k-tile order (env DNMF_NT_PF = 2 | 3 | 4): the NT kernel is paced by its LDS/barrier
-// structure and the clock the chip holds, not by HBM latency.
-inline int nt_ks(long nrows, int bm) {
-    static const int forced = getenv("DNMF_NT_KS") ? atoi(getenv("DNMF_NT_KS")) : 0;
-    if (forced) return forced;
-    (void)nrows; (void)bm;
-    return 1;   // measured (tools/kbench.py): the two-slice variant is 8-18 % SLOWER at every shard size (32k..262k rows)
-}
-
+// tile.  The kernel template also supports an 8-wave form with two contraction slices per row group (KS = 2: same
+// tile, twice the waves per SIMD) and prefetch distance 2; both were measured 0-18 % slower at every shard size
+// (32k..262k rows) and are not instantiated: the NT kernel is paced by its LDS/barrier structure and the clock the
+// chip holds, not by HBM latency.
 template <int MODE>
 int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
 #define NT_CASE(KT_, MT_, NW_, KS_)                                                               \
     return fast ? launch_nt_inst<KT_, MT_, NW_, KS_, true, MODE>(a, nsplit, st)                    \
                 : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE>(a, nsplit, st);
-    const bool gram = (MODE == NT_STORE && a.store_all);   // split-K gram tiles: partial layout fixed, plenty of blocks
-    if (kt == 1) {
-        if (!gram && nt_ks(a.nrows, 256) == 2) { NT_CASE(1, 2, 8, 2) }
-        NT_CASE(1, 2, 4, 1)
-    }
-    if (kt == 2) {
-        if (!gram && nt_ks(a.nrows, 128) == 2) { NT_CASE(2, 1, 8, 2) }
-        NT_CASE(2, 1, 4, 1)
-    }
-    if (kt == 4) {
-        if (!gram && nt_ks(a.nrows, 128) == 2) { NT_CASE(4, 1, 8, 2) }
-        NT_CASE(4, 1, 4, 1)
-    }
+    if (kt == 1) { NT_CASE(1, 2, 4, 1) }
+    if (kt == 2) { NT_CASE(2, 1, 4, 1) }
+    if (kt == 4) { NT_CASE(4, 1, 4, 1) }
 #undef NT_CASE
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }
@@ -1685,6 +1768,58 @@ int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* Sm, long ld
     const unsigned grid = (unsigned)std::min<long>(cdiv((long)k * n, 256), 8192);
     hipLaunchKernelGGL(kl_update_kernel<true>, dim3(grid), dim3(256), 0, S(stream), H, (long)k, n, ldh, Sm, lds_, x, eps, clamp);
     return check_launch("kl_update_h");
+}
+
+int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                    const double* prev_ss2, float eps, double* ss2_out, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
+    hipLaunchKernelGGL(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
+                       eps, ss2_out);
+    return check_launch("hals_w_col");
+}
+
+int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream) {
+    REQUIRE(W && ss2 && m >= 1 && col >= 0 && ldw > col, "hals_w_scale: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
+    hipLaunchKernelGGL(hals_w_scale_kernel, dim3(grid), dim3(256), 0, S(stream), W, m, ldw, col, ss2);
+    return check_launch("hals_w_scale");
+}
+
+int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                       double* ss2, void* stream) {
+    REQUIRE(ss2 != nullptr, "hals_update_w: ss2 scratch (k doubles) required");
+    for (int kk = 0; kk < k; ++kk) {
+        int rc = dnmf_hals_w_col(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, stream);
+        if (rc) return rc;
+    }
+    return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
+}
+
+int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
+                       void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "hals_update_h: bad arguments");
+    const dim3 grid((unsigned)cdiv(n, 256)), block(256);
+    hipStream_t st = S(stream);
+#define HH_CASE(KT_)                                                                                              \
+    if (kt == KT_) {                                                                                              \
+        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
+        hipLaunchKernelGGL((hals_h_kernel<32 * KT_>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps);     \
+    }
+    HH_CASE(1) HH_CASE(2)
+#undef HH_CASE
+    if (kt == 4) {
+        const int kp = 128;
+        const size_t lds = (size_t)(kp * kp + kp * 64) * sizeof(float);   // 96 KiB
+        static bool once = false;
+        if (!once) { allow_lds(hals_h_kernel_lds, lds); once = true; }
+        hipLaunchKernelGGL(hals_h_kernel_lds, dim3((unsigned)cdiv(n, 64)), dim3(64), lds, st, H, k, n, ldh, AtW, ldatw, G, kp, eps);
+    }
+    return check_launch("hals_update_h");
 }
 
 int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,

@@ -10,7 +10,8 @@ module only sequences kernels and the grid exchanges, placed exactly where the r
 mpi4py (allreduce / allgather / Reduce_scatter), minus its barriers.  There is no CPU path: `ops`
 exists as a parameter so the choreography can be exercised by tests with a checker back end.
 
-HALS and BCD (dist_nmf.py:411-579, :873-1047) are not part of this engine yet.
+Methods: 'mu' (Frobenius and KL) and 'hals' (Frobenius; dist_nmf.py:411-470, :873-934 -- the same contractions, with
+the multiply-divide replaced by column-sequential sweeps).  BCD (dist_nmf.py:474-579, :939-1047) is out of scope.
 """
 import torch
 
@@ -49,8 +50,10 @@ class _Base:
         if norm == 'FRO':
             if method == 'MU':
                 self.Fro_MU_update(self.W_update, clamp)
-            elif method in ('HALS', 'BCD'):
-                raise NotImplementedError("method '%s' is not part of the MI355X MU engine (MU only)" % self.method)
+            elif method == 'HALS':
+                self.FRO_HALS_update(self.W_update, clamp)
+            elif method == 'BCD':
+                raise NotImplementedError("method 'bcd' is not part of the MI355X engine (mu / hals)")
             else:
                 raise Exception('Not a valid method: Choose (mu/hals/bcd)')    # dist_nmf.py:84,652
         elif norm == 'KL':
@@ -60,6 +63,21 @@ class _Base:
                 raise Exception('Not a valid method: Choose (mu)')             # dist_nmf.py:89,657
         else:
             raise Exception('Not a valid norm: Choose (fro/kl)')               # dist_nmf.py:91,659
+
+
+    def _hals_w_sweep(self, W, AH, G, allreduce_norm):
+        """Column-sequential W sweep (dist_nmf.py:884-891 / :428-434).  Without a cross-rank norm it is one library
+        call; with p_r > 1 the 8-byte sum of squares of every column is allreduced between the column kernels, where
+        the reference calls utils.norm (utils.py:388-391)."""
+        ops, eps, k = self.ops, self.eps, self.k
+        if not allreduce_norm or self.comm1.size == 1:
+            ops.hals_update_w(W, AH, G, eps)
+            return
+        ss2 = ops.hals_ss2(k, W)
+        for kk in range(k):
+            ops.hals_w_col(W, AH, G, kk, ss2, eps)
+            self.comm1.allreduce_(ss2[kk:kk + 1])
+        ops.hals_w_scale(W, k - 1, ss2)
 
 
 class nmf_algorithms_1D(_Base):
@@ -116,6 +134,32 @@ class nmf_algorithms_1D(_Base):
             self.comm1.allreduce_(buf[: off + kp * kp])
         ops.mu_update_h(H, AtW, G, eps, clamp)
         if clamp:
+            ops.clamp_min(W, eps)
+
+    # ---- HALS / Frobenius (dist_nmf.py:873-934)
+    def FRO_HALS_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_i, self.H_j, self.eps, self.k
+        kp = _kp(k)
+        m_l, n_l = A.shape
+        if W_update:                                               # FRO_HALS_update_W :873-891
+            off = _pad64(m_l * k)
+            buf = _buf(("ahg", m_l, k), off + kp * kp, A)
+            AH, G = buf[: m_l * k].view(m_l, k), buf[off: off + kp * kp].view(kp, kp)
+            ops.gram_hht(H, G)                                     # :882
+            ops.aht(A, H, AH)                                      # :883
+            if self.p_c != 1:
+                self.comm1.allreduce_(buf[: off + kp * kp])
+            self._hals_w_sweep(W, AH, G, allreduce_norm=(self.p_r != 1))   # norm(..., p=self.p_r) :889
+        off = _pad64(k * n_l)                                      # FRO_HALS_update_H :893-909
+        buf = _buf(("atwg", k, n_l), off + kp * kp, A)
+        AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
+        ops.gram_wtw(W, G)                                         # :902
+        ops.wta(A, W, AtW)                                         # :903
+        if self.p_r != 1:
+            self.comm1.allreduce_(buf[: off + kp * kp])
+        ops.hals_update_h(H, AtW, G, eps)                          # :905-909
+        if clamp:                                                  # pyDNMF.py:170-172
+            ops.clamp_min(H, eps)
             ops.clamp_min(W, eps)
 
     # ---- KL (dist_nmf.py:776-869)
@@ -214,6 +258,29 @@ class nmf_algorithms_2D(_Base):
         AtW = self._scatter_to_H(Y)                                # :169-171
         ops.mu_update_h(H, AtW, G, eps, clamp)                     # :224-225
         if clamp:
+            ops.clamp_min(W, eps)
+
+    # ---- HALS / Frobenius (dist_nmf.py:411-470)
+    def FRO_HALS_update(self, W_update=True, clamp=False):
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
+        kp = _kp(k)
+        m_l, n_l = A.shape
+        G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+        if W_update:                                               # FRO_HALS_update_W :411-434
+            ops.gram_hht(H, G)
+            self.comm1.allreduce_(G)                               # :426
+            H_j = self.gather_H()
+            V = ops.aht(A, H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))   # AH_glob :427
+            AH = self._scatter_to_W(V).contiguous()
+            self._hals_w_sweep(W, AH, G, allreduce_norm=True)      # norm(..., p=self.p_r), p_r > 1 on a 2D grid :432
+        ops.gram_wtw(W, G)                                         # FRO_HALS_update_H :436-452
+        self.comm1.allreduce_(G)
+        W_i = self.gather_W()
+        Y = ops.wta(A, W_i, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))       # ATW_glob :448
+        AtW = self._scatter_to_H(Y)
+        ops.hals_update_h(H, AtW, G, eps)                          # :449-452
+        if clamp:
+            ops.clamp_min(H, eps)
             ops.clamp_min(W, eps)
 
     # ---- KL (dist_nmf.py:351-407)

@@ -122,6 +122,35 @@ class HipOps:
                                    float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
                                    _stream()))
 
+    # ---- HALS sweeps
+    def hals_ss2(self, k, like):
+        """k device doubles: per-column sums of squares of the W sweep."""
+        return torch.zeros(k, dtype=torch.float64, device=like.device)
+
+    def hals_w_col(self, W, AH, G, kk, ss2, eps):
+        _req(W, "W"); _req(AH, "AH"); _req(G, "G")
+        m, k = W.shape
+        prev = ss2[kk - 1:].data_ptr() if kk > 0 else None
+        check(lib.dnmf_hals_w_col(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), int(kk), prev,
+                                  float(eps), ss2[kk:].data_ptr(), _stream()))
+
+    def hals_w_scale(self, W, col, ss2):
+        _req(W, "W")
+        check(lib.dnmf_hals_w_scale(W.data_ptr(), W.shape[0], _ld(W), int(col), ss2[col:].data_ptr(), _stream()))
+
+    def hals_update_w(self, W, AH, G, eps):
+        _req(W, "W"); _req(AH, "AH"); _req(G, "G")
+        m, k = W.shape
+        ss2 = self.hals_ss2(k, W)
+        check(lib.dnmf_hals_update_w(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), float(eps),
+                                     ss2.data_ptr(), _stream()))
+
+    def hals_update_h(self, H, AtW, G, eps):
+        _req(H, "H"); _req(AtW, "AtW"); _req(G, "G")
+        k, n = H.shape
+        check(lib.dnmf_hals_update_h(H.data_ptr(), k, n, _ld(H), AtW.data_ptr(), _ld(AtW), G.data_ptr(), float(eps),
+                                     _stream()))
+
     # ---- KL
     def kl_uht(self, A, W, H, eps, out):
         _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "UHT")

@@ -10,7 +10,7 @@ Everything numeric runs in libdnmf_hip.so; there is no CPU path.
 
 Differences from the reference, all deliberate and documented in DESIGN.md:
   * compute dtype is float32 (the engine's only dtype); float64 input raises;
-  * method must be 'mu' (HALS/BCD not in the engine yet); init='nnsvd' is not provided;
+  * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' and init='nnsvd' are not provided;
   * `prune=True` is accepted only when the block has no all-zero row/column (then it is a no-op).
 """
 import numpy as np
@@ -120,8 +120,8 @@ class PyNMF:
 
     def fit(self):
         """pyDNMF.py:138-182.  Returns (W, H, recon_err)."""
-        if self.method.lower() != 'mu':
-            raise NotImplementedError("method '%s' is not part of the MI355X MU engine (MU only)" % self.method)
+        if self.method.lower() not in ('mu', 'hals'):
+            raise NotImplementedError("method '%s' is not part of the MI355X engine (mu / hals)" % self.method)
         ops = self._ops()
         for i in range(self.itr):
             clamp = (i % 10 == 0)                                   # :155 / :170, fused into the step

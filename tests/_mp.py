@@ -45,7 +45,7 @@ def run_case_rank(rank, world, port, name, q, use_hip):
             args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
             args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
             args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
-            args.norm, args.method, args.W_update = meta["norm"], "mu", meta["W_update"]
+            args.norm, args.method, args.W_update = meta["norm"], meta.get("method", "mu"), meta["W_update"]
             s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
             assert [s[0], e[0] + 1, s[1], e[1] + 1] == list(z["r%d_A_range" % rank])
             A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1]
@@ -77,5 +77,6 @@ def run_case(name, use_hip=False, timeout=240):
         p.join(timeout=60)
     for rank, out, err in res:
         assert err is None, "rank %d failed:\n%s" % (rank, err)
+        tol = 2e-3 if meta.get("method") == "hals" else 1e-4   # HALS cancels: see tests/test_oracle_golden.py::test_fit
         for itr, (dw, dh, de) in out.items():
-            assert dw <= 1e-4 and dh <= 1e-4 and de <= 1e-5, (name, rank, itr, dw, dh, de)
+            assert dw <= tol and dh <= tol and de <= 1e-5, (name, rank, itr, dw, dh, de)

@@ -52,6 +52,37 @@ class OracleOps:
         AH = np.matmul(_n(A), _n(H).T)
         self.mu_update_w(W, torch.from_numpy(AH), G, eps)
 
+    # ---- HALS sweeps (dist_nmf.py:884-891, :905-909)
+    def hals_ss2(self, k, like):
+        return torch.zeros(k, dtype=torch.float64)
+
+    def hals_w_col(self, W, AH, G, kk, ss2, eps):
+        k = W.shape[1]
+        w, g = _n(W), _n(G)[:k, :k]
+        if kk > 0 and float(ss2[kk - 1]) > 0:
+            w[:, kk - 1] /= np.float32(np.sqrt(float(ss2[kk - 1])))
+        t = w[:, kk] * g[kk, kk] + _n(AH)[:, kk] - w.dot(g[:, kk])
+        w[:, kk] = np.maximum(t, np.float32(eps))
+        ss2[kk] = float(np.linalg.norm(w[:, kk], ord=2)) ** 2
+
+    def hals_w_scale(self, W, col, ss2):
+        if float(ss2[col]) > 0:
+            _n(W)[:, col] /= np.float32(np.sqrt(float(ss2[col])))
+
+    def hals_update_w(self, W, AH, G, eps):
+        k = W.shape[1]
+        ss2 = self.hals_ss2(k, W)
+        for kk in range(k):
+            self.hals_w_col(W, AH, G, kk, ss2, eps)
+        self.hals_w_scale(W, k - 1, ss2)
+
+    def hals_update_h(self, H, AtW, G, eps):
+        k = H.shape[0]
+        h, g, a = _n(H), _n(G)[:k, :k], _n(AtW)
+        for kk in range(k):
+            t = h[kk, :] + a[kk, :] - g[kk, :].dot(h)
+            h[kk, :] = np.maximum(t, np.float32(eps))
+
     def kl_uht(self, A, W, H, eps, out):
         U = _n(A) / (_n(W) @ _n(H) + np.float32(eps))                   # :806
         out.copy_(torch.from_numpy(U @ _n(H).T))                        # :810

@@ -190,6 +190,51 @@ def test_whole_step_matches_oracle(ops, m, n, k, norm):
         assert _rel(Hd.cpu().numpy(), Hr) < 1e-5, (w_update, clamp)
 
 
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_hals_sweeps(ops, m, n, k):
+    """HALS column sweeps (dist_nmf.py:884-891, :905-909) against the oracle's single-rank step, from identical state."""
+    from oracle import nmf_oracle as orc
+    from pydnmfk_amd.engine import new_gram
+    A, W, H = _mk(m, n, k)
+    dev = torch.device("cuda")
+    # W sweep alone
+    A64, H64 = A.astype(np.float64), H.astype(np.float64)
+    AH = (A64 @ H64.T).astype(np.float32)
+    G = ops.gram_hht(_d(H), new_gram(k, dev))
+    Wd = _d(W)
+    ops.hals_update_w(Wd, _d(AH), G, EPS)
+    Wr = W.copy()
+    HHT = np.matmul(H, H.T)
+    for kk in range(k):
+        t = Wr[:, kk] * HHT[kk, kk] + AH[:, kk] - Wr.dot(HHT[:, kk])
+        Wr[:, kk] = np.maximum(t, np.float32(EPS))
+        ss = np.linalg.norm(Wr[:, kk])
+        if ss > 0:
+            Wr[:, kk] /= ss
+    assert _rel(Wd.cpu().numpy(), Wr) < 2e-4          # cancellation-prone numerator, see tests/test_oracle_golden.py
+    assert np.allclose(np.linalg.norm(Wd.cpu().numpy().astype(np.float64), axis=0), 1.0, atol=1e-5)
+    # column-by-column form (the multi-rank path) gives the same result as the one-call form
+    Wc = _d(W)
+    ss2 = ops.hals_ss2(k, Wc)
+    for kk in range(k):
+        ops.hals_w_col(Wc, _d(AH), G, kk, ss2, EPS)
+    ops.hals_w_scale(Wc, k - 1, ss2)
+    assert _rel(Wc.cpu().numpy(), Wd.cpu().numpy()) < 1e-6
+    # H sweep alone
+    W64 = Wr.astype(np.float64)
+    AtW = (W64.T @ A64).astype(np.float32)
+    G2 = ops.gram_wtw(_d(Wr), new_gram(k, dev))
+    Hd = _d(H)
+    ops.hals_update_h(Hd, _d(AtW), G2, EPS)
+    Hr = H.copy()
+    WTW = np.matmul(Wr.T, Wr)
+    for kk in range(k):
+        t = Hr[kk, :] + AtW[kk, :] - WTW[kk, :].dot(Hr)
+        Hr[kk, :] = np.maximum(t, np.float32(EPS))
+    assert _rel(Hd.cpu().numpy(), Hr) < 2e-4
+    assert float(Hd.min()) >= EPS
+
+
 def test_errors_are_loud(ops):
     from pydnmfk_amd._lib import DnmfError
     with pytest.raises(TypeError):

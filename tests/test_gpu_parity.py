@@ -19,7 +19,15 @@ from tests._golden import case_names, load_case, rel_fro  # noqa: E402
 SINGLE = [c for c in case_names() if "_1x1_" in c and c.endswith(("float32", "float32_noW"))]
 
 
-def _args(k, itr, norm, W_update=True):
+def _tols(meta):
+    """(per-step, fit factors, fit error): HALS sweeps subtract nearly equal terms, so fp32 trajectories are only
+    reproducible to ~1e-3 after 10 sweeps (even between two numpy builds: tests/test_oracle_golden.py::test_fit)."""
+    if meta.get("method") == "hals":
+        return 5e-5, 2e-3, 5e-5
+    return 1e-5, 1e-4, 1e-5
+
+
+def _args(k, itr, norm, W_update=True, method="mu"):
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.utils import parse
     comms = MPI_comm(None, 1, 1)
@@ -27,7 +35,7 @@ def _args(k, itr, norm, W_update=True):
     args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, k
     args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
     args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
-    args.norm, args.method, args.W_update = norm, "mu", W_update
+    args.norm, args.method, args.W_update = norm, method, W_update
     return args
 
 
@@ -35,12 +43,15 @@ def _args(k, itr, norm, W_update=True):
 def test_fit_matches_reference_golden(name):
     from pydnmfk_amd.pyDNMF import PyNMF
     meta, A, W0, H0, z = load_case(name)
+    _, tol_fit, tol_err = _tols(meta)
     for itr in meta["itrs"]:
-        W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"])).fit()
+        W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"],
+                                                             meta.get("method", "mu"))).fit()
         assert isinstance(W, np.ndarray) and W.dtype == np.float32       # numpy in -> numpy out
-        assert rel_fro(W, z["r0_fit%d_W" % itr]) <= 1e-4, itr
-        assert rel_fro(H, z["r0_fit%d_H" % itr]) <= 1e-4, itr
-        assert abs(err - float(z["r0_fit%d_err" % itr])) <= 1e-5, itr
+        assert rel_fro(W, z["r0_fit%d_W" % itr]) <= tol_fit, itr
+        assert rel_fro(H, z["r0_fit%d_H" % itr]) <= tol_fit, itr
+        ref = float(z["r0_fit%d_err" % itr])
+        assert abs(err - ref) <= tol_err * max(1.0, abs(ref)), itr
 
 
 @pytest.mark.parametrize("name", SINGLE)
@@ -48,13 +59,14 @@ def test_single_update_matches_reference_golden(name):
     """One bare nmf_algorithms_1D.update() from identical state (no clamp, no normalisation)."""
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
     meta, A, W0, H0, z = load_case(name)
-    args = _args(meta["k"], 1, meta["norm"], meta["W_update"])
+    tol_step = _tols(meta)[0]
+    args = _args(meta["k"], 1, meta["norm"], meta["W_update"], meta.get("method", "mu"))
     args.m, args.n, args.eps = meta["m"], meta["n"], float(np.finfo(np.float32).eps)
     W, H = torch.from_numpy(W0).cuda(), torch.from_numpy(H0).cuda()
     W1, H1 = nmf_algorithms_1D(torch.from_numpy(A).cuda(), W, H, params=args).update()
     assert W1 is W and H1 is H                                           # in place, same objects returned
-    assert rel_fro(W.cpu().numpy(), z["r0_step1_W"]) <= 1e-5
-    assert rel_fro(H.cpu().numpy(), z["r0_step1_H"]) <= 1e-5
+    assert rel_fro(W.cpu().numpy(), z["r0_step1_W"]) <= tol_step
+    assert rel_fro(H.cpu().numpy(), z["r0_step1_H"]) <= tol_step
 
 
 @pytest.mark.parametrize("m,n,k,norm,itr", [(4096, 1024, 64, "fro", 20), (3000, 1500, 32, "fro", 20),
@@ -82,10 +94,10 @@ def test_reference_convergence_threshold():
     np.random.seed(100)
     m, k, n = 24, 2, 12
     A = (np.random.rand(m, k) @ np.random.rand(k, n)).astype(np.float32)
-    for norm in ("fro", "kl"):
+    for norm, method in (("fro", "mu"), ("kl", "mu"), ("fro", "hals")):
         np.random.seed(5)
-        _, _, err = PyNMF(A, factors=None, params=_args(k, 2000, norm)).fit()
-        assert err < 1e-3, norm
+        _, _, err = PyNMF(A, factors=None, params=_args(k, 2000, norm, method=method)).fit()
+        assert err < 1e-3, (norm, method)
 
 
 def test_config2_size_properties():
