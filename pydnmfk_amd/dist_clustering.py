@@ -1,0 +1,129 @@
+"""Custom clustering of NMF factors across perturbations + cosine silhouettes (NMFk).
+
+Behavioural mirror of reference pyDNMFk/dist_clustering.py (`custom_clustering`, :5-188): given P groups of k column
+vectors (W_all: m_loc x k x P, row-sharded over the p_r grid rows) build k clusters containing one vector of every
+group by a greedy approximation of the linear-sum assignment against median centroids (100 fixed rounds, :114), then
+score the clustering with cosine-distance silhouettes (:130-160).  This is control logic around the MU hot path
+(SURVEY.md 8f row 2): it runs on torch tensors wherever the factors live (GPU in production, CPU in tests); the only
+cross-rank traffic is a handful of tiny allreduces (k x k x P similarities, (kP)^2 Gram matrix).
+
+Differences from the reference, none of which changes results: the P similarity matrices of one round are computed
+and allreduced together (the centroids are fixed within a round, :115-119), and the unused similarity product of
+:111-113 is dropped.
+"""
+import numpy as np
+import torch
+
+
+def _as_tensor(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+
+
+class custom_clustering:
+    def __init__(self, Wall, Hall, params):
+        self.W_all = _as_tensor(Wall).clone()          # m_loc x k x P
+        self.H_all = _as_tensor(Hall).clone()          # k x n_loc x P
+        self.H_all = self.H_all.to(self.W_all.device)
+        self.p_r, self.p_c = params.p_r, params.p_c
+        self.comm1 = params.comm1
+        self.eps = float(params.eps)
+        self.p = self.p_r * self.p_c
+
+    def _allreduce(self, t):
+        """SUM over the world when W is row-sharded (the reference allreduces iff p_r != 1, e.g. :35, :77, :123)."""
+        if self.p_r != 1:
+            return self.comm1.allreduce(t)
+        return t
+
+    def normalize_by_W(self):
+        """:30-40  unit 2-norm columns of W (global norm), H scaled inversely."""
+        nrm = self._allreduce((self.W_all * self.W_all).sum(dim=0)) + self.eps      # k x P
+        temp = torch.sqrt(nrm)
+        self.W_all /= temp.unsqueeze(0)
+        self.H_all *= temp.unsqueeze(1)
+
+    @staticmethod
+    def mad(data, flag=1, axis=-1):
+        """:42-49  median (flag=1) / mean (flag=0) absolute deviation along `axis`."""
+        if flag == 1:
+            med = torch.nanmedian(data, dim=axis, keepdim=True).values
+            return torch.nanmedian((data - med).abs(), dim=axis).values
+        mean = torch.nanmean(data, dim=axis, keepdim=True)
+        return torch.nanmean((data - mean).abs(), dim=axis)
+
+    @staticmethod
+    def greedy_lsa(A):
+        """:59-69  repeatedly take the largest remaining similarity, strike its row and column."""
+        X = np.array(A, dtype=np.float64, copy=True)
+        pairs = []
+        for _ in range(X.shape[0]):
+            ind = np.unravel_index(int(np.argmax(X)), X.shape)
+            pairs.append(ind)
+            X[:, ind[1]] = -np.inf
+            X[ind[0], :] = -np.inf
+        return pairs
+
+    @staticmethod
+    def change_order(pairs):
+        """:51-57  order[centroid] = feature."""
+        ans = list(range(len(pairs)))
+        for c, f in pairs:
+            ans[int(c)] = int(f)
+        return ans
+
+    def dist_custom_clustering(self, centroids=None, vb=0):
+        """:84-127  returns (centroids, W_all, H_all, permute_order)."""
+        permute_order = []
+        self.normalize_by_W()
+        if centroids is None:
+            centroids = self.W_all[:, :, 0].clone()
+        P = self.W_all.shape[-1]
+        for _ in range(100):
+            # similarities of every group's vectors to the centroids: k x k x P, one allreduce per round
+            dist = self._allreduce(torch.einsum("mc,mfp->cfp", centroids, self.W_all)).cpu().numpy()
+            for p in range(P):
+                j = self.change_order(self.greedy_lsa(dist[:, :, p]))
+                permute_order.append(j)
+                idx = torch.as_tensor(j, device=self.W_all.device)
+                self.W_all[:, :, p] = self.W_all[:, :, p].index_select(1, idx)
+                self.H_all[:, :, p] = self.H_all[:, :, p].index_select(0, idx)
+            centroids = _median_lower_upper_mean(self.W_all)
+            cn = self._allreduce((centroids ** 2).sum(dim=0)) + self.eps
+            centroids = centroids / torch.sqrt(cn)
+        return centroids, self.W_all, self.H_all, permute_order
+
+    def dist_silhouettes(self):
+        """:130-160  k x P cosine-distance silhouettes (re-runs the clustering first, as the reference does)."""
+        self.dist_custom_clustering()
+        N, k, n_pert = self.W_all.shape
+        W_flat = self.W_all.reshape(N, k * n_pert)
+        gram = self._allreduce(W_flat.t() @ W_flat).reshape(k, n_pert, k, n_pert)
+        distances = torch.arccos(torch.clamp(gram, -1.0, 1.0)).cpu().numpy().astype(np.float64)
+        if k == 1:
+            return np.ones((k, n_pert))
+        a = np.zeros((k, n_pert))
+        b = np.zeros((k, n_pert))
+        for kk in range(k):
+            for n in range(n_pert):
+                a[kk, n] = 1 / (n_pert - 1) * np.sum(distances[kk, n, kk, :])
+                tmp = np.sum(distances[kk, n, :, :], axis=1)
+                tmp[kk] = np.inf
+                b[kk, n] = 1 / n_pert * np.min(tmp)
+        return (b - a) / np.maximum(a, b)
+
+    def fit(self):
+        """:163-188  [centroids, MAD of W around them, ordered H_all, per-cluster mean silhouette, mean silhouette, orders]."""
+        centroids, _, _, orders = self.dist_custom_clustering()
+        cent_std = self.mad(self.W_all, axis=-1)
+        sils = self.dist_silhouettes()
+        return [centroids, cent_std, self.H_all, sils.mean(axis=1), float(sils.flatten().mean()), orders]
+
+
+def _median_lower_upper_mean(t):
+    """np.median semantics along the last axis (mean of the two middle values for an even count); torch.median alone
+    returns the lower one."""
+    P = t.shape[-1]
+    s = torch.sort(t, dim=-1).values
+    if P % 2:
+        return s[..., P // 2].clone()
+    return 0.5 * (s[..., P // 2 - 1] + s[..., P // 2])
