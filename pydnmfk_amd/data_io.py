@@ -43,3 +43,34 @@ class data_write:
         else:
             np.save(H_pth + 'H_' + str(self.rank) + '.npy', H)
             np.save(W_pth + 'W_' + str(self.rank) + '.npy', W)
+
+    def save_cluster_results(self, params):
+        """Rank 0 writes the per-k NMFk statistics (data_io.py:199-209).  Dataset names are the reference's
+        (clusterSilhouetteCoefficients, avgSilhouetteCoefficients, L_err, L_errDist, avgErr, ErrTol, AIC).  HDF5
+        (`results.h5`) when h5py is importable -- byte-compatible with the reference's readers; otherwise the same
+        keys go to `results.npz` (this image has no h5py)."""
+        if self.rank != 0:
+            return
+        data = {'clusterSilhouetteCoefficients': np.asarray(params['clusterSilhouetteCoefficients']),
+                'avgSilhouetteCoefficients': np.asarray(params['avgSilhouetteCoefficients']),
+                'L_err': np.asarray(params['L_err']), 'L_errDist': np.asarray(params['L_errDist']),
+                'avgErr': np.asarray(params['avgErr']), 'ErrTol': np.asarray(params['recon_err']),
+                'AIC': np.asarray(params['AIC'])}
+        try:
+            import h5py
+        except ImportError:
+            np.savez(self.fpath + 'results.npz', **data)
+            return
+        with h5py.File(self.fpath + 'results.h5', 'w') as hf:
+            for key, val in data.items():
+                hf.create_dataset(key, data=val)
+
+
+def read_cluster_results(path):
+    """Per-k statistics written by save_cluster_results (either container)."""
+    if os.path.exists(path + 'results.h5'):
+        import h5py
+        with h5py.File(path + 'results.h5', 'r') as hf:
+            return {key: np.array(hf[key]) for key in hf.keys()}
+    z = np.load(path + 'results.npz')
+    return {key: z[key] for key in z.files}

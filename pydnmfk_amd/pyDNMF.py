@@ -172,3 +172,30 @@ class PyNMF:
         self.glob_norm_err, self.glob_norm_A = float(np.sqrt(num)), float(np.sqrt(den))
         self.recon_err = self.glob_norm_err / self.glob_norm_A
         return self.recon_err
+
+    def column_err(self):
+        """pyDNMF.py:221-239: per-column relative error sqrt(sum_i (A - W H)^2 / sum_i A^2) over the GLOBAL n columns
+        (each rank fills its own column range, float64 allreduce).  Used once per k by NMFk; the residual is formed in
+        row slabs so that no m_l x n_l temporary is materialised."""
+        from .utils import determine_block_params
+        blk = determine_block_params(self.comm1, (self.p_r, self.p_c), (self.params.m, self.params.n))
+        c0 = blk.determine_block_index_range_asymm()[0][1]
+        ncol = blk.determine_block_shape_asymm()[1]
+        if self.topo == '2d' and not hasattr(self, "W_i"):
+            self.cart_2d_collect_factors()
+        W, H = self.W_i, self.H_j
+        num = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
+        den = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
+        step = max(1, (1 << 26) // max(1, self.n_loc))
+        for r0 in range(0, self.m_loc, step):
+            a = self.A_ij[r0:r0 + step]
+            d = (a - W[r0:r0 + step] @ H).double()
+            num += (d * d).sum(0)
+            den += (a.double() ** 2).sum(0)
+        col_num = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
+        col_den = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
+        col_num[c0:c0 + ncol] = num
+        col_den[c0:c0 + ncol] = den
+        self.comm1.allreduce_(col_num)
+        self.comm1.allreduce_(col_den)
+        return torch.sqrt(col_num / col_den).cpu().numpy()

@@ -1,0 +1,214 @@
+"""NMFk: estimate the number of latent features k by NMF over perturbed copies of the data, custom clustering,
+silhouettes and a Wilcoxon test on the regression errors -- drop-in for reference pyDNMFk/pyDNMFk.py
+(`sample` :8-67, `PyNMFk` :70-299).  This is the main production CALLER of the MU hot path (20 x (k range) `PyNMF.fit`
+calls); everything numeric inside `PyNMF` runs in libdnmf_hip.so, the logic here is host control.
+
+    nopt = PyNMFk(A_ij, factors=None, params=args).fit()
+
+Same `params` contract as the reference (`fpath`, `fname`, `start_k`/`end_k` or `k_range`, `step_k`, `perturbations`,
+`noise_var`, `sampling`, `sill_thr`, `checkpoint`, `results_path`; defaults via var_init, pyDNMFk.py:143-164).
+Differences: statistics are kept in memory for the p-value analysis (and written per k as the reference does; HDF5 when
+h5py exists, else npz); no plots are drawn (plot_results is out of scope).
+"""
+import os
+
+import numpy as np
+import torch
+from scipy.stats import wilcoxon
+
+from .data_io import data_write
+from .dist_clustering import custom_clustering
+from .pyDNMF import PyNMF
+from .utils import Checkpoint, var_init
+
+
+class sample:
+    """Perturbed copy of the data (pyDNMFk.py:8-67).  'uniform': X * (1 + nv + 2 nv U[0,1)) element-wise (:42-44);
+    'poisson': Poisson(X) (:47-49).  numpy input uses the process-global numpy RNG seeded with `seed`, i.e. the
+    reference's exact stream (and the `PyNMF` rand init that follows continues that stream, as in the reference);
+    CUDA tensors are perturbed on the device with a torch generator seeded the same way (same distribution,
+    different stream)."""
+
+    def __init__(self, data, noise_var, method, seed=None):
+        self.X = data
+        self.noise_var = noise_var
+        self.seed = seed
+        if self.seed is not None:
+            np.random.seed(self.seed)
+        self.method = method
+        self.X_per = 0
+
+    def randM(self):
+        nv = self.noise_var
+        if isinstance(self.X, torch.Tensor):
+            g = torch.Generator(device=self.X.device)
+            g.manual_seed(0 if self.seed is None else int(self.seed))
+            M = torch.rand(self.X.shape, dtype=self.X.dtype, device=self.X.device, generator=g)
+            self.X_per = self.X * (2 * nv * M + nv + 1)
+        else:
+            M = 2 * nv * np.random.random_sample(self.X.shape).astype(self.X.dtype) + nv
+            self.X_per = np.multiply(self.X, M + 1)
+
+    def poisson(self):
+        if isinstance(self.X, torch.Tensor):
+            g = torch.Generator(device=self.X.device)
+            g.manual_seed(0 if self.seed is None else int(self.seed))
+            self.X_per = torch.poisson(self.X, generator=g)
+        else:
+            self.X_per = np.random.poisson(self.X).astype(self.X.dtype)
+
+    def fit(self):
+        if self.method == 'uniform':
+            self.randM()
+        elif self.method == 'poisson':
+            self.poisson()
+        return self.X_per
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class PyNMFk:
+    """pyDNMFk.py:70-299."""
+
+    def __init__(self, A_ij, factors=None, params=None, ops=None):
+        self.A_ij = A_ij
+        self.ops = ops
+        self.local_m, self.local_n = self.A_ij.shape
+        self.params = params
+        self.comm1 = self.params.comm1
+        self.rank = self.comm1.rank
+        if "grid" in vars(self.params) and self.params.grid:
+            self.p_r, self.p_c = self.params.grid[0], self.params.grid[1]
+        else:
+            self.p_r, self.p_c = self.params.p_r, self.params.p_c
+        self.fname = self.params.fname
+        self.p = self.p_r * self.p_c
+        self.topo = '2d' if (self.p_r != 1 and self.p_c != 1) else '1d'
+        self.sampling = var_init(self.params, 'sampling', default='uniform')
+        self.perturbations = var_init(self.params, 'perturbations', default=20)
+        self.noise_var = var_init(self.params, 'noise_var', default=.03)
+        self.step_k = var_init(self.params, 'step_k', default=1)
+        if "k_range" in vars(self.params) and getattr(self.params, "grid", None):
+            self.start_k, self.end_k = self.params.k_range[0], self.params.k_range[1]
+        else:
+            self.start_k, self.end_k = self.params.start_k, self.params.end_k
+        self.first_k = self.start_k
+        self.sill_thr = var_init(params, 'sill_thr', default=0.9)
+        self.verbose = var_init(params, 'verbose', default=False)
+        self.params.checkpoint = var_init(params, 'checkpoint', default=True)
+        self.params.rank = self.rank
+        self.params.flag = 0   # 1: all perturbations factorised, 2: clustered, 3: results saved (pyDNMFk.py:165)
+        self.cp = Checkpoint(checkpoint_save=self.params.checkpoint, params=self.params)
+        self.stats = {}        # k -> cluster statistics (also written to disk per k)
+
+    def fit(self):
+        """pyDNMFk.py:169-215.  Returns the estimated number of latent features (same on every rank)."""
+        self.params.results_path = self.params.results_path + self.params.fname + '/'
+        if self.rank == 0:
+            os.makedirs(self.params.results_path, exist_ok=True)
+        if self.params.checkpoint:
+            try:
+                self.cp.load_from_checkpoint()
+                self.start_k = self.cp.k + self.step_k if self.cp.flag > 3 else self.cp.k     # :191-194
+            except (OSError, EOFError, AttributeError):
+                pass
+        for self.k in range(self.start_k, self.end_k + 1, self.step_k):
+            self.params.k = self.k
+            self.pynmfk_per_k()
+        if self.rank == 0:
+            nopt, _ = self.pvalueAnalysis()
+            print('Rank estimated by NMFk = ', nopt)
+        else:
+            nopt = None
+        nopt = self.comm1.bcast(nopt, root=0)
+        self.comm1.barrier()
+        return nopt
+
+    def pynmfk_per_k(self):
+        """pyDNMFk.py:218-258."""
+        self.params.results_paths = self.params.results_path + str(self.k) + '/'
+        if self.rank == 0:
+            os.makedirs(self.params.results_paths, exist_ok=True)
+        results = []
+        if self.rank == 0:
+            print('*************Computing for k=', self.k, '************')
+        perturbation = 0
+        for perturbation in range(self.perturbations):
+            if self.rank == 0 and self.verbose:
+                print('Current perturbation =', perturbation)
+            data = sample(data=self.A_ij, noise_var=self.noise_var, method=self.sampling, seed=perturbation * 1000).fit()
+            self.params.W_update = True
+            results.append(PyNMF(data, factors=None, params=self.params, ops=self.ops).fit())          # :230
+            self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+        self.params.flag = 1
+        self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+        # stack: W m_loc x k x P (column-major over (k, P) as the reference's order='F' reshape, :234-235), H k x n_loc x P
+        Ws = [r[0] if isinstance(r[0], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[0])) for r in results]
+        Hs = [r[1] if isinstance(r[1], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[1])) for r in results]
+        self.Wall = torch.stack(Ws, dim=-1)
+        self.Hall = torch.stack(Hs, dim=-1)
+        self.recon_err = [float(r[2]) for r in results]
+        centroids, _, self.Hall, self.clusterSilhouetteCoefficients, self.avgSilhouetteCoefficients, _ = \
+            custom_clustering(self.Wall, self.Hall, self.params).fit()                                  # :239-240
+        self.params.flag = 2
+        self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+        self.AvgH = _median_np_semantics(self.Hall)                                                     # :243
+        self.AvgW = centroids
+        self.params.W_update = False                                                                    # :245
+        numpy_io = not isinstance(self.A_ij, torch.Tensor)
+        f0 = [_np(self.AvgW), _np(self.AvgH)] if numpy_io else [self.AvgW, self.AvgH]
+        regressH = PyNMF(self.A_ij, factors=f0, params=self.params, ops=self.ops)
+        self.AvgW, self.AvgH, self.L_errDist = regressH.fit()                                           # :246-247
+        self.col_err = regressH.column_err()                                                            # :248
+        self.avgErr = float(np.mean(self.recon_err))
+        mn = self.params.m * self.params.n
+        self.AIC = 2 * self.k + mn * np.log(self.avgErr / mn)                                           # :250
+        cluster_stats = {'clusterSilhouetteCoefficients': self.clusterSilhouetteCoefficients,
+                         'avgSilhouetteCoefficients': self.avgSilhouetteCoefficients, 'L_errDist': self.L_errDist,
+                         'L_err': self.col_err, 'avgErr': self.avgErr, 'recon_err': self.recon_err, 'AIC': self.AIC}
+        self.stats[self.k] = cluster_stats
+        if getattr(self.params, "ftype", None) is None:
+            self.params.ftype = None
+        writer = data_write(self.params)
+        writer.save_factors([_np(self.AvgW), _np(self.AvgH)], reg=True)                                 # :254-256
+        writer.save_cluster_results(cluster_stats)
+        self.params.flag = 3
+        self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+
+    def pvalueAnalysis(self):
+        """pyDNMFk.py:261-299: walk k upwards; whenever the PREVIOUS k clustered well (min silhouette > sill_thr) and
+        this k's column-error distribution differs from the current best (Wilcoxon p < 0.05), this k becomes the
+        estimate."""
+        from .data_io import read_cluster_results
+        ks = list(range(self.first_k, self.end_k + 1, self.step_k))
+        pvalue = np.ones(len(ks))
+        sill_min, err = [], []
+        for k in ks:
+            st = self.stats.get(k)
+            if st is None:                       # resumed run: statistics of finished k's come from disk
+                st = read_cluster_results(self.params.results_path + str(k) + '/')
+                st = {'L_err': st['L_err'], 'clusterSilhouetteCoefficients': st['clusterSilhouetteCoefficients']}
+            err.append(np.asarray(st['L_err']))
+            sill_min.append(round(float(np.min(np.asarray(st['clusterSilhouetteCoefficients']))), 2))
+        one = err[0]
+        nopt = 1
+        i = 1
+        while i < len(ks):
+            if sill_min[i - 1] > self.sill_thr:
+                pvalue[i] = wilcoxon(one, err[i])[1]
+                if pvalue[i] < 0.05:
+                    nopt = i
+                    one = np.copy(err[i])
+            i += 1
+        return ks[nopt - 1], pvalue
+
+
+def _median_np_semantics(t):
+    """np.median over the last axis (pyDNMFk.py:243) for a torch tensor."""
+    P = t.shape[-1]
+    s = torch.sort(t, dim=-1).values
+    if P % 2:
+        return s[..., P // 2].contiguous()
+    return (0.5 * (s[..., P // 2 - 1] + s[..., P // 2])).contiguous()

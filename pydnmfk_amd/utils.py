@@ -4,6 +4,8 @@ Mirrors the hot-path parts of reference pyDNMFk/utils.py: `determine_block_param
 `data_operations.compute_global_dim/compute_local_dim` (:73-115), `var_init` (:473-477),
 `parse` (:480-483).  Pruning, checkpoints and the MLP helpers are out of scope.
 """
+import pickle
+
 import numpy as np
 
 
@@ -90,3 +92,37 @@ class data_operations:
         p.m_loc, p.n_loc = m_loc, n_loc
         p.W_start, p.W_end = w[0][0], w[1][0] + 1
         p.H_start, p.H_end = h[0][1], h[1][1] + 1
+
+
+class Checkpoint:
+    """Coarse NMFk resume state, file-compatible with reference utils.py:486-536: rank 0 pickles an attribute bag
+    (flag, perturbation, k) of class `parse` to results_path + "checkpoint.p"; loading copies the bag's attributes onto
+    this object.  W/H are not part of a checkpoint (the interrupted k restarts from its first perturbation)."""
+
+    def __init__(self, checkpoint_save, params):
+        self.checkpoint_save = checkpoint_save if checkpoint_save else False
+        self.params = params
+        self.perturbation = 0
+        self.k = 0
+        self.flag = 0
+
+    def load_from_checkpoint(self):
+        if self.checkpoint_save:
+            with open(self.params.results_path + "/checkpoint.p", "rb") as f:          # utils.py:514
+                saved = pickle.load(f)
+            if getattr(self.params, "rank", 0) == 0:
+                print("Checkpoint loaded")
+            self._set_params(vars(saved))
+            if getattr(self.params, "rank", 0) == 0:
+                print("Continuing from checkpoint for k=", self.k, "perturbation=", self.perturbation)
+
+    def _save_checkpoint(self, flag, perturbation, k):
+        bag = parse()
+        bag.flag, bag.perturbation, bag.k = flag, perturbation, k
+        if self.checkpoint_save and getattr(self.params, "rank", 0) == 0:
+            with open(self.params.results_path + "checkpoint.p", "wb") as f:           # utils.py:530
+                pickle.dump(bag, f)
+
+    def _set_params(self, class_parameters):
+        for name, value in class_parameters.items():
+            setattr(self, name, value)

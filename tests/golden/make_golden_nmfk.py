@@ -1,0 +1,87 @@
+#!/opt/conda/bin/python3.9
+"""Golden NMFk statistics from the UNMODIFIED reference (build container only):
+
+    OMP_NUM_THREADS=1 /opt/conda/bin/python3.9 tests/golden/make_golden_nmfk.py
+
+Runs reference PyNMFk (pyDNMFk/pyDNMFk.py) with the mpi4py stand-in on a small synthetic problem with a known number
+of latent features (3 Gaussian bumps + noise, 48 x 40), k = 1..5, 6 perturbations, MU/Frobenius, 300 iterations,
+init='rand', on grids 1x1 and 2x1, and records per k: min / mean silhouettes, average reconstruction error, the
+regression error and the column-error vector, plus the estimated k.  Output: tests/golden/nmfk_<grid>.npz.
+(matplotlib plotting in the reference's fit() is redirected to the Agg backend.)
+"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ["MPLBACKEND"] = "Agg"
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "oracle", "mpi_standin"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+from mpi4py import MPI  # noqa: E402
+import h5py  # noqa: E402
+
+import pyDNMFk.config as config  # noqa: E402
+
+config.init(0)
+from pyDNMFk.dist_comm import MPI_comm  # noqa: E402
+from pyDNMFk.pyDNMFk import PyNMFk  # noqa: E402
+from pyDNMFk.utils import determine_block_params, parse  # noqa: E402
+
+
+def dataset():
+    rs = np.random.RandomState(11)
+    m, n, k = 48, 40, 3
+    x = np.linspace(1, m, m)
+    W = np.stack([np.exp(-(x - c) ** 2 / 18.0) for c in (8, 24, 40)], axis=1)
+    H = rs.rand(k, n)
+    return (W @ H + 0.01 * rs.rand(m, n)).astype(np.float32)
+
+
+def run(grid):
+    A = dataset()
+    p_r, p_c = grid
+    tmp = tempfile.mkdtemp()
+    out = {}
+
+    def body(rank):
+        comm = MPI.COMM_WORLD
+        comms = MPI_comm(comm, p_r, p_c)
+        args = parse()
+        args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = comm.size, rank, comms.comm, comms, p_r, p_c
+        args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        args.fpath, args.fname, args.ftype = tmp + "/", "synth", "npy"
+        args.start_k, args.end_k, args.step_k = 1, 5, 1
+        args.sill_thr, args.itr, args.init, args.verbose = 0.8, 300, "rand", False
+        args.norm, args.method, args.prune = "fro", "mu", False
+        args.perturbations, args.noise_var, args.checkpoint = 6, 0.03, False
+        args.results_path = tmp + "/results/"
+        s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+        A_ij = np.ascontiguousarray(A[s[0]:e[0] + 1, s[1]:e[1] + 1])
+        return PyNMFk(A_ij, factors=None, params=args).fit()
+
+    res = MPI.run_ranks(p_r * p_c, body)
+    out["nopt"] = np.array(res[0])
+    for k in range(1, 6):
+        with h5py.File(tmp + "/results/synth/%d/results.h5" % k, "r") as hf:
+            for key in hf.keys():
+                out["k%d_%s" % (k, key)] = np.array(hf[key])
+    out["A"] = A
+    out["meta"] = np.array(json.dumps(dict(grid=list(grid), start_k=1, end_k=5, perturbations=6, noise_var=0.03,
+                                           itr=300, sill_thr=0.8, norm="fro", method="mu")))
+    np.savez_compressed(os.path.join(HERE, "nmfk_%dx%d.npz" % tuple(grid)), **out)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print(grid, "nopt =", res, {k: (round(float(out["k%d_clusterSilhouetteCoefficients" % k].min()), 3),
+                                     round(float(out["k%d_avgErr" % k]), 5)) for k in range(1, 6)})
+
+
+if __name__ == "__main__":
+    # Only the single-rank run is kept as a fixture: `sample` seeds the process-global numpy RNG (pyDNMFk.py:31-32),
+    # and the thread-simulated ranks of the mpi4py stand-in share that RNG, so multi-rank draws interleave
+    # nondeterministically here (real MPI ranks are separate processes).  run((2, 1)) is still useful as a smoke check.
+    run((1, 1))

@@ -1,0 +1,92 @@
+"""NMFk driver (pydnmfk_amd.pyDNMFk) on CPU with the checker back end, against statistics captured from the reference's
+PyNMFk on the same data, seeds and parameters (tests/golden/make_golden_nmfk.py -> nmfk_1x1.npz).  numpy input makes
+`sample` and the rand init consume the reference's exact numpy RNG stream, so the runs differ only by fp32 summation
+order inside NMF (300 iterations): silhouettes agree to a few 1e-2, errors to 1e-3 relative, the estimate exactly."""
+import json
+
+import numpy as np
+import pytest
+
+
+def _args(tmp, comms, ops=None):
+    from pydnmfk_amd.utils import parse
+    args = parse()
+    args.comm1, args.comm, args.p_r, args.p_c = comms.comm, comms, comms.p_r, comms.p_c
+    args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    args.fpath, args.fname, args.ftype = str(tmp) + "/", "synth", "npy"
+    args.start_k, args.end_k, args.step_k = 1, 5, 1
+    args.sill_thr, args.itr, args.init, args.verbose = 0.8, 300, "rand", False
+    args.norm, args.method, args.prune = "fro", "mu", False
+    args.perturbations, args.noise_var, args.checkpoint = 6, 0.03, False
+    args.results_path = str(tmp) + "/results/"
+    return args
+
+
+def check_against_golden(nmfk, nopt, z, sil_tol=0.08):
+    assert nopt == int(z["nopt"]) == 3
+    for k in range(1, 6):
+        st = nmfk.stats[k]
+        ref_sil = z["k%d_clusterSilhouetteCoefficients" % k]
+        sil = np.asarray(st["clusterSilhouetteCoefficients"])
+        assert sil.shape == ref_sil.shape == (k,)
+        if ref_sil.min() > 0.5:       # stable clusterings are reproducible; unstable ones (k > true k) are chaotic
+            assert np.allclose(sil, ref_sil, atol=sil_tol), (k, sil, ref_sil)
+        else:
+            assert sil.min() < 0.6, (k, sil)
+        assert abs(st["avgErr"] / float(z["k%d_avgErr" % k]) - 1) < 5e-3, k
+        if k <= 3:
+            assert abs(float(st["L_errDist"]) / float(z["k%d_L_errDist" % k]) - 1) < 2e-2, k
+            assert np.allclose(st["L_err"], z["k%d_L_err" % k], rtol=0.1, atol=2e-3), k
+        assert np.asarray(st["L_err"]).shape == (40,)
+        assert abs(st["AIC"] / float(z["k%d_AIC" % k]) - 1) < 1e-3
+
+
+def test_nmfk_matches_reference_statistics(tmp_path, golden_dir):
+    from pydnmfk_amd.data_io import read_cluster_results
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from tests._ops_double import OracleOps
+    z = np.load(golden_dir + "/nmfk_1x1.npz")
+    A = z["A"]
+    comms = MPI_comm(None, 1, 1)
+    args = _args(tmp_path, comms)
+    nmfk = PyNMFk(A, factors=None, params=args, ops=OracleOps())
+    nopt = nmfk.fit()
+    check_against_golden(nmfk, nopt, z)
+    # on-disk layout (data_io.py:175-209): per-k folder with regressed factors and the statistics container
+    for k in range(1, 6):
+        base = tmp_path / "results" / "synth" / str(k)
+        assert (base / "W_reg_factors" / "W_0.npy").exists() and (base / "H_reg_factors" / "H_0.npy").exists()
+        st = read_cluster_results(str(base) + "/")
+        assert set(st) == {"clusterSilhouetteCoefficients", "avgSilhouetteCoefficients", "L_err", "L_errDist", "avgErr",
+                           "ErrTol", "AIC"}
+        assert st["ErrTol"].shape == (6,)
+
+
+def test_sample_follows_reference_stream():
+    """pyDNMFk.py:26-49: X * (1 + nv + 2 nv U) with the global numpy RNG seeded per perturbation."""
+    from pydnmfk_amd.pyDNMFk import sample
+    X = np.arange(12, dtype=np.float32).reshape(3, 4) + 1
+    got = sample(X, 0.03, "uniform", seed=3000).fit()
+    np.random.seed(3000)
+    M = 2 * 0.03 * np.random.random_sample(X.shape).astype(X.dtype) + 0.03
+    assert np.array_equal(got, np.multiply(X, M + 1))
+    assert got.dtype == np.float32 and (got >= X * 1.03 - 1e-6).all() and (got <= X * 1.09 + 1e-6).all()
+    p = sample(X, 0.03, "poisson", seed=1).fit()
+    np.random.seed(1)
+    assert np.array_equal(p, np.random.poisson(X).astype(X.dtype))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """utils.py:486-536: the pickle holds a `parse` bag with flag / perturbation / k."""
+    import pickle
+    from pydnmfk_amd.utils import Checkpoint, parse
+    params = parse()
+    params.results_path, params.rank = str(tmp_path) + "/", 0
+    cp = Checkpoint(True, params)
+    cp._save_checkpoint(3, 19, 7)
+    bag = pickle.load(open(tmp_path / "checkpoint.p", "rb"))
+    assert (bag.flag, bag.perturbation, bag.k) == (3, 19, 7) and type(bag).__name__ == "parse"
+    cp2 = Checkpoint(True, params)
+    cp2.load_from_checkpoint()
+    assert (cp2.flag, cp2.perturbation, cp2.k) == (3, 19, 7)
