@@ -1,7 +1,107 @@
 """On-disk factor layout, drop-in with reference pyDNMFk/data_io.py:143-196 (`data_write.save_factors`)."""
+import glob
 import os
 
 import numpy as np
+
+from .utils import determine_block_params
+
+
+class data_read:
+    """Read a dense matrix and return this rank's block -- reference data_io.py:12-105.
+
+    args.fpath + args.fname + '.' + args.ftype with ftype in {npy, csv, txt, mat}; ftype == 'folder' reads the
+    pre-split block fpath + fname + <rank> + '.npy' as is.  The block is rows/cols
+    determine_block_params(rank, [p_r, p_c], shape) (data_io.py:81-83), cast to args.precision (default float32).
+    Like the reference every rank opens the file; .npy files are memory-mapped here so only the block is paged in
+    (the reference loads the whole matrix on every rank, data_io.py:57)."""
+
+    def __init__(self, args):
+        self.fpath = args.fpath
+        if "grid" in vars(args) and args.grid:
+            self.pgrid = args.grid
+        else:
+            self.pgrid = [args.p_r, args.p_c]
+        self.ftype = args.ftype
+        self.fname = args.fname
+        self.comm = args.comm1
+        self.rank = self.comm.rank
+        self.precision = getattr(args, "precision", None) or 'float32'
+        self.data = 0
+        if self.ftype == 'folder':
+            self.file_path = self.fpath + self.fname + str(self.comm.rank) + '.npy'
+        else:
+            self.file_path = self.fpath + self.fname + '.' + self.ftype
+
+    def read(self):
+        return self.read_dat()
+
+    def read_file_npy(self):
+        self.data = np.load(self.file_path, mmap_mode='r')
+
+    def read_file_csv(self):
+        self.data = np.loadtxt(self.file_path, delimiter=',', ndmin=2)
+
+    def read_file_mat(self):
+        from scipy.io import loadmat
+        self.data = loadmat(self.file_path)['X']
+
+    def data_partition(self):
+        blk = determine_block_params(self.rank, self.pgrid, self.data.shape)
+        s, e = blk.determine_block_index_range_asymm()
+        self.data = self.data[s[0]:e[0] + 1, s[1]:e[1] + 1]
+
+    def read_dat(self):
+        if self.ftype == 'npy':
+            self.read_file_npy()
+            self.data_partition()
+        elif self.ftype in ('csv', 'txt'):
+            self.read_file_csv()
+            self.data_partition()
+        elif self.ftype == 'mat':
+            self.read_file_mat()
+            self.data_partition()
+        elif self.ftype == 'folder':
+            self.read_file_npy()
+        else:
+            raise ValueError("unknown ftype '%s' (npy/csv/txt/mat/folder)" % self.ftype)
+        return np.ascontiguousarray(self.data).astype(self.precision)
+
+
+class read_factors:
+    """Re-assemble saved regression factors -- reference data_io.py:212-261.  W blocks are stacked by rank along
+    rows.  H blocks: on a 2D grid rank r = i * p_c + j holds the i-th column slice of column block j, so the global
+    column order is (j, i) -> rank i * p_c + j.  (The reference's transform_H_index uses i * p_r + j, utils.py:357,
+    which is only right for square grids.)"""
+
+    def __init__(self, factors_path, pgrid):
+        self.factors_path = factors_path
+        self.W_path = self.factors_path + 'W_reg_factors/*'
+        self.H_path = self.factors_path + 'H_reg_factors/*'
+        self.p_grid = pgrid
+
+    @staticmethod
+    def _by_rank(files):
+        def rank_of(f):
+            stem = os.path.splitext(os.path.basename(f))[0]
+            return int(stem.split('_')[1]) if '_' in stem else 0
+        return sorted(files, key=rank_of)
+
+    def load_factors(self):
+        wf, hf = self._by_rank(glob.glob(self.W_path)), self._by_rank(glob.glob(self.H_path))
+        W = [np.load(f) for f in wf]
+        H = [np.load(f) for f in hf]
+        W_data = np.vstack(W) if len(W) > 1 else W[0]
+        if len(H) > 1:
+            if len(W) > 1:
+                p_r, p_c = self.p_grid
+                order = [i * p_c + j for j in range(p_c) for i in range(p_r)]
+                H_data = np.hstack([H[r] for r in order])
+            else:
+                H_data = np.hstack(H)
+        else:
+            H_data = H[0]
+        return W_data, H_data
 
 
 class data_write:

@@ -32,3 +32,24 @@ def test_nmfk_device_resident_input(tmp_path, golden_dir):
     for k, tol in ((1, 0.05), (2, 0.05), (3, 0.6)):   # k = 3 is at the noise floor: its level depends on the draws
         assert abs(nmfk.stats[k]["avgErr"] / float(z["k%d_avgErr" % k]) - 1) < tol, k
     assert np.min(nmfk.stats[3]["clusterSilhouetteCoefficients"]) > 0.8
+
+
+def test_cli_end_to_end(tmp_path, golden_dir):
+    """main.py (reference main.py:13-88 flags): read a .npy, factorise on the GPU, write the factor layout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A = np.load(golden_dir + "/data_swim.npz")["A"].astype(np.float32)
+    np.save(tmp_path / "swimcopy.npy", A)
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--process=pyDNMF", "--p_r=1", "--p_c=1",
+           "--fpath=%s/" % tmp_path, "--fname=swimcopy", "--ftype=npy", "--k=4", "--itr=30", "--norm=fro",
+           "--method=mu", "--results_path=%s/res/" % tmp_path]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float(out.stdout.strip().split("relative error =")[-1])
+    assert 0.5 < err < 0.7                          # swim k=4: 0.646 after 10, 0.606 after 100 iterations (fixtures)
+    W = np.load(tmp_path / "res" / "W_factors" / "W_0.npy")
+    H = np.load(tmp_path / "res" / "H_factors" / "H_0.npy")
+    assert W.shape == (1024, 4) and H.shape == (4, 256) and W.dtype == np.float32
+    assert abs(np.linalg.norm(A - W @ H) / np.linalg.norm(A) - err) < 1e-4
