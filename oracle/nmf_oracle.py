@@ -152,8 +152,9 @@ class SimGrid:
     on every rank; `fit(itr)` = `PyNMF.fit()` (pyDNMF.py:138-182).
     """
 
-    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True, method="mu"):
+    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True, method="mu", prune=False):
         self.method = method
+        self.prune = prune
         self.p_r, self.p_c, self.P = p_r, p_c, p_r * p_c
         self.m, self.n = A.shape
         self.dtype = A.dtype
@@ -167,6 +168,48 @@ class SimGrid:
         self.H = [b[2] for b in blocks]
         if norm.upper() not in ("FRO", "KL"):
             raise Exception("Not a valid norm: Choose (fro/kl)")  # dist_nmf.py:91,659
+        if prune:
+            self._prune_all()
+
+    # ---- zero row / column pruning (pyDNMF.py:99-101; utils.py:117-217), restated literally
+    def _prune_all(self):
+        R = range(self.P)
+        row_sum = [np.sum(self.A[r] != 0, 1) for r in R]                 # utils.py:119-120
+        col_sum = [np.sum(self.A[r] != 0, 0) for r in R]
+        if self.topo == "2d":                                            # utils.py:121-123: sums inside the sub-groups
+            row_sum = [_rsum([row_sum[q] for q in self._col_group(r)]) for r in R]
+            col_sum = [_rsum([col_sum[q] for q in self._row_group(r)]) for r in R]
+        else:                                                            # :124-126: world sums along the split axis
+            if self.p_c > 1:
+                row_sum = [_rsum(row_sum)] * self.P
+            if self.p_r > 1:
+                col_sum = [_rsum(col_sum)] * self.P
+        self._wmask, self._hmask = [], []
+        for r in R:
+            rx, cx = row_sum[r] > 0, col_sum[r] > 0
+            if self.topo == "2d":                                        # :129-131: the factor slices of the block
+                (w0, w1), (h0, h1) = factor_ranges(r, self.p_r, self.p_c, self.m, self.n)
+                r0, _, c0, _ = data_block(r, self.p_r, self.p_c, self.m, self.n)
+                rw, ch = rx[w0 - r0: w1 - r0], cx[h0 - c0: h1 - c0]
+            else:
+                rw, ch = rx, cx
+            self.A[r] = self.A[r][np.ix_(rx, cx)]                        # :151
+            self.W[r] = self.W[r][rw]
+            self.H[r] = self.H[r][:, ch]
+            self._wmask.append(rw)
+            self._hmask.append(ch)
+
+    def _unprune(self):
+        """utils.py:176-217: scatter the factors back into zero matrices (float64, as np.zeros defaults)."""
+        W, H = [], []
+        for r in range(self.P):
+            Wf = np.zeros((len(self._wmask[r]), self.W[r].shape[1]))
+            Wf[self._wmask[r], :] = self.W[r]
+            Hf = np.zeros((self.H[r].shape[0], len(self._hmask[r])))
+            Hf[:, self._hmask[r]] = self.H[r]
+            W.append(Wf)
+            H.append(Hf)
+        return W, H
 
     # ---- communicator membership (dist_comm.py:25-51)
     def _row_group(self, rank):
@@ -396,6 +439,9 @@ class SimGrid:
             if i == itr - 1:                                             # :158 / :173
                 self.normalize_features()
                 err = self.relative_err()
+                if self.prune:                                           # pyDNMF.py:180-181
+                    W, H = self._unprune()
+                    return W, H, float(err)
                 return self.W, self.H, float(err)
         raise ValueError("itr must be >= 1")
 

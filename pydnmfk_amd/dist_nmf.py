@@ -208,13 +208,18 @@ class nmf_algorithms_2D(_Base):
         self.local_W_m = self.W_ij.shape[0]
         self.local_H_n = self.H_ij.shape[1]
         self.ops = ops if ops is not None else _default_ops()
-        # per-member slice sizes inside the sub-communicators (utils.py:99-103), needed for ragged grids
+        # per-member slice sizes inside the sub-communicators: the partition rule (utils.py:99-103), unless pruning
+        # changed them (then PyNMF has exchanged the actual sizes once and left them on params)
         from .utils import determine_block_params
         m_l, n_l = A_ij.shape
-        self.w_counts = [determine_block_params(q, (self.p_c, 1), (m_l, self.k)).determine_block_shape_asymm()[0]
-                         for q in range(self.p_c)]
-        self.h_counts = [determine_block_params(q, (1, self.p_r), (self.k, n_l)).determine_block_shape_asymm()[1]
-                         for q in range(self.p_r)]
+        counts = getattr(params, "_slice_counts", None)
+        if counts is not None:
+            self.w_counts, self.h_counts = counts
+        else:
+            self.w_counts = [determine_block_params(q, (self.p_c, 1), (m_l, self.k)).determine_block_shape_asymm()[0]
+                             for q in range(self.p_c)]
+            self.h_counts = [determine_block_params(q, (1, self.p_r), (self.k, n_l)).determine_block_shape_asymm()[1]
+                             for q in range(self.p_r)]
 
     def update(self, clamp=False):
         self._dispatch(clamp)

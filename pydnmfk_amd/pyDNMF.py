@@ -11,7 +11,8 @@ Everything numeric runs in libdnmf_hip.so; there is no CPU path.
 Differences from the reference, all deliberate and documented in DESIGN.md:
   * compute dtype is float32 (the engine's only dtype); float64 input raises;
   * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' and init='nnsvd' are not provided;
-  * `prune=True` is accepted only when the block has no all-zero row/column (then it is a no-op).
+  * `prune=True` (the reference's default when the attribute is absent) drops all-zero rows / columns before the
+    iterations and scatters the factors back afterwards; they stay float32 (the reference hands back float64).
 """
 import numpy as np
 import torch
@@ -84,11 +85,18 @@ class PyNMF:
             self.W_i, self.H_j = W0, H0
         else:
             self.W_ij, self.H_ij = W0, H0
-        if self.prune:
-            nz = self.A_ij != 0
-            if bool((nz.sum(1) == 0).any()) or bool((nz.sum(0) == 0).any()):
-                raise NotImplementedError("PyNMF: zero rows/columns present; pruning (utils.py:117-217) is not part "
-                                          "of the MI355X engine -- remove them or pass params.prune=False")
+        if self.prune:                                              # :99-101
+            if self.topo == '1d':
+                self.A_ij, self.W_i, self.H_j = self.data_op.prune_all(self.W_i, self.H_j)
+            else:
+                self.A_ij, self.W_ij, self.H_ij = self.data_op.prune_all(self.W_ij, self.H_ij)
+            self.m_loc, self.n_loc = self.A_ij.shape
+            if self.topo == '2d':   # pruned slices are ragged: exchange the actual sizes once per fit
+                self.params._slice_counts = (
+                    [int(c) for c in self.cart_1d_column.allgather(int(self.W_ij.shape[0]))],
+                    [int(c) for c in self.cart_1d_row.allgather(int(self.H_ij.shape[1]))])
+        elif hasattr(self.params, "_slice_counts"):
+            del self.params._slice_counts
 
     def init_factors(self):
         """pyDNMF.py:107-135, init='rand': uniform [0,1) from the process-global numpy RNG (so seeding numpy
@@ -140,6 +148,8 @@ class PyNMF:
                 if self.verbose is True and self.rank == 0:
                     print('relative error is:', self.recon_err)
                 W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
+                if self.prune:                                      # :166,:180-181 (before the save here, so that the
+                    W, H = self.data_op.unprune_factors(W, H)       # saved blocks have the un-pruned shapes)
                 if self.save_factors:
                     from .data_io import data_write
                     data_write(self.params).save_factors([W.cpu().numpy(), H.cpu().numpy()])
@@ -184,6 +194,9 @@ class PyNMF:
         if self.topo == '2d' and not hasattr(self, "W_i"):
             self.cart_2d_collect_factors()
         W, H = self.W_i, self.H_j
+        if W.shape[0] != self.A_ij.shape[0] or H.shape[1] != self.A_ij.shape[1]:   # factors were un-pruned by fit()
+            W = W[self.params.row_zero_idx_x] if W.shape[0] != self.A_ij.shape[0] else W
+            H = H[:, self.params.col_zero_idx_x] if H.shape[1] != self.A_ij.shape[1] else H
         num = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
         den = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
         step = max(1, (1 << 26) // max(1, self.n_loc))
@@ -194,8 +207,13 @@ class PyNMF:
             den += (a.double() ** 2).sum(0)
         col_num = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
         col_den = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
-        col_num[c0:c0 + ncol] = num
-        col_den[c0:c0 + ncol] = den
+        keep = getattr(self.params, "col_zero_idx_x", None) if self.prune else None
+        if keep is not None and int(keep.numel()) == ncol and num.numel() != ncol:
+            col_num[c0:c0 + ncol][keep] = num           # pruned (all-zero) columns stay 0 / 0 -> nan, as in numpy
+            col_den[c0:c0 + ncol][keep] = den
+        else:
+            col_num[c0:c0 + ncol] = num
+            col_den[c0:c0 + ncol] = den
         self.comm1.allreduce_(col_num)
         self.comm1.allreduce_(col_den)
         return torch.sqrt(col_num / col_den).cpu().numpy()

@@ -93,6 +93,53 @@ class data_operations:
         p.W_start, p.W_end = w[0][0], w[1][0] + 1
         p.H_start, p.H_end = h[0][1], h[1][1] + 1
 
+    # ---- zero row / column pruning (utils.py:117-217) on torch tensors
+    def zero_idx_prune(self):
+        """Boolean keep-masks (rows of A, cols of A, rows of W, cols of H).  Non-zero counts are summed inside the
+        sub-groups on a 2D grid (utils.py:121-123) and over the world along the split axis on a 1D grid (:124-126)."""
+        import torch
+        nz = self.ten != 0
+        row_sum, col_sum = nz.sum(1), nz.sum(0)
+        if self.topo == '2d':
+            row_sum = self.cart_1d_column.allreduce(row_sum)
+            col_sum = self.cart_1d_row.allreduce(col_sum)
+        else:
+            if self.p_c > 1:
+                row_sum = self.comm1.allreduce(row_sum)
+            if self.p_r > 1:
+                col_sum = self.comm1.allreduce(col_sum)
+        row_x, col_x = row_sum > 0, col_sum > 0
+        if self.topo == '2d':
+            col_h = col_x[self.params.H_start:self.params.H_end]
+            row_w = row_x[self.params.W_start:self.params.W_end]
+        else:
+            row_w, col_h = row_x, col_x
+        return row_x, col_x, row_w, col_h
+
+    def prune_all(self, W, H):
+        """utils.py:156-172: drop all-zero rows / columns of the block and the matching factor rows / columns."""
+        p = self.params
+        p.row_zero_idx_x, p.col_zero_idx_x, p.row_zero_idx_w, p.col_zero_idx_h = self.zero_idx_prune()
+        if bool(p.row_zero_idx_x.all()) and bool(p.col_zero_idx_x.all()):
+            return self.ten, W, H                      # nothing to prune: keep the caller's buffers (no copy)
+        self.ten = self.ten[p.row_zero_idx_x][:, p.col_zero_idx_x].contiguous()
+        return self.ten, W[p.row_zero_idx_w].contiguous(), H[:, p.col_zero_idx_h].contiguous()
+
+    def unprune_factors(self, W, H):
+        """utils.py:176-217: scatter the factors back (zeros at pruned rows / columns).  Stays float32 on the device
+        (the reference returns float64 here because np.zeros defaults to it, utils.py:195,198)."""
+        import torch
+        p = self.params
+        if W.shape[0] != p.row_zero_idx_w.numel():
+            Wf = torch.zeros(p.row_zero_idx_w.numel(), W.shape[1], dtype=W.dtype, device=W.device)
+            Wf[p.row_zero_idx_w] = W
+            W = Wf
+        if H.shape[1] != p.col_zero_idx_h.numel():
+            Hf = torch.zeros(H.shape[0], p.col_zero_idx_h.numel(), dtype=H.dtype, device=H.device)
+            Hf[:, p.col_zero_idx_h] = H
+            H = Hf
+        return W, H
+
 
 class Checkpoint:
     """Coarse NMFk resume state, file-compatible with reference utils.py:486-536: rank 0 pickles an attribute bag

@@ -44,7 +44,7 @@ def run_case_rank(rank, world, port, name, q, use_hip):
             args = parse()
             args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
             args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-            args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+            args.itr, args.init, args.verbose, args.prune = itr, "rand", False, meta.get("prune", False)
             args.norm, args.method, args.W_update = meta["norm"], meta.get("method", "mu"), meta["W_update"]
             s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
             assert [s[0], e[0] + 1, s[1], e[1] + 1] == list(z["r%d_A_range" % rank])
@@ -53,6 +53,7 @@ def run_case_rank(rank, world, port, name, q, use_hip):
             W, H, err = PyNMF(A_ij, factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops).fit()
             assert (args.m, args.n) == (meta["m"], meta["n"])
             assert [args.m_loc, args.n_loc] == list(z["r%d_m_loc_n_loc" % rank])
+            assert tuple(W.shape) == z["r%d_fit%d_W" % (rank, itr)].shape and str(W.dtype).endswith("float32")
             out[itr] = (rel_fro(W, z["r%d_fit%d_W" % (rank, itr)]), rel_fro(H, z["r%d_fit%d_H" % (rank, itr)]),
                         abs(err - float(z["r0_fit%d_err" % itr])))
         q.put((rank, out, None))

@@ -74,7 +74,17 @@ def ds_lowrank(m, n, k, seed=100):
     return np.abs(W @ H + 0.01 * rs.randn(m, n)), k
 
 
+def ds_t24x12z():
+    """t24x12 with two all-zero rows and one all-zero column (exercises utils.py:117-217 pruning)."""
+    A, k = ds_t24x12()
+    A = A.copy()
+    A[[3, 17], :] = 0
+    A[:, 5] = 0
+    return A, k
+
+
 DATASETS = {
+    "t24x12z": ds_t24x12z,
     "t24x12": ds_t24x12,
     "r25x13": ds_r25x13,
     "swim": ds_swim,
@@ -111,7 +121,7 @@ def factor_slices(rank, p_r, p_c, m, n):
 
 
 # ----------------------------------------------------------------------------- one case
-def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7, method="mu"):
+def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7, method="mu", prune=False):
     A, k = DATASETS[dataset]()
     A = np.asarray(A).astype(dtype)
     m, n = A.shape
@@ -132,7 +142,7 @@ def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7,
             args.m, args.n = m, n
             args.itr, args.init = itr, "rand"
             args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-            args.verbose, args.prune = False, False
+            args.verbose, args.prune = False, prune
             args.norm, args.method = norm, method
             args.W_update = W_update
             return args
@@ -170,7 +180,7 @@ def run_case(name, dataset, grid, norm, dtype, itrs, W_update=True, init_seed=7,
         for key, v in o.items():
             flat["r%d_%s" % (r, key)] = v
     meta = dict(name=name, dataset=dataset, grid=list(grid), norm=norm, dtype=np.dtype(dtype).name,
-                itrs=list(itrs), W_update=bool(W_update), init_seed=init_seed, k=int(k), m=int(m), n=int(n), method=method,
+                itrs=list(itrs), W_update=bool(W_update), init_seed=init_seed, k=int(k), m=int(m), n=int(n), method=method, prune=bool(prune),
                 generator="reference lanl/pyDNMFk @ /root/reference, python3.9, numpy %s (OpenBLAS, 1 thread), "
                           "mpi4py stand-in with rank-ordered sums" % np.__version__)
     flat["meta"] = np.array(json.dumps(meta))
@@ -239,9 +249,23 @@ def main_hals():
             run_case("%s_%s_hals_float32" % (ds, g), ds, grid, "fro", f32, (10,), method="hals")
 
 
+def main_prune():
+    """Zero-row/column pruning (pyDNMF.py:99-101, utils.py:117-217): factors come back un-pruned (and float64)."""
+    A, k = DATASETS["t24x12z"]()
+    W0, H0 = init_factors(A.shape[0], A.shape[1], k, 7)
+    np.savez_compressed(os.path.join(HERE, "data_t24x12z.npz"), A=A, W0=W0, H0=H0, k=np.array(k))
+    for grid in ([1, 1], [2, 1], [1, 2], [2, 2]):
+        g = "%dx%d" % tuple(grid)
+        run_case("t24x12z_%s_fro_float32_prune" % g, "t24x12z", grid, "fro", np.float32, (10,), prune=True)
+    run_case("t24x12z_1x1_kl_float32_prune", "t24x12z", [1, 1], "kl", np.float32, (10,), prune=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "hals":
+    if len(sys.argv) > 1 and sys.argv[1] == "prune":
+        main_prune()
+    elif len(sys.argv) > 1 and sys.argv[1] == "hals":
         main_hals()      # adds the HALS cases without touching the MU fixtures
     else:
         main()
         main_hals()
+        main_prune()

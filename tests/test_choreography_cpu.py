@@ -20,6 +20,9 @@ CASES = [
     "r25x13_3x1_fro_float32", "r25x13_1x3_kl_float32", "r25x13_2x2_fro_float32", "r25x13_2x2_kl_float32",
     "swim_4x1_fro_float32", "swim_2x2_kl_float32", "t24x12_2x1_kl_float32_noW",
     "lr200x136k64_2x2_fro_float32", "lr150x140k128_2x1_kl_float32",
+    # zero row / column pruning
+    "t24x12z_1x1_fro_float32_prune", "t24x12z_2x1_fro_float32_prune", "t24x12z_1x2_fro_float32_prune",
+    "t24x12z_2x2_fro_float32_prune", "t24x12z_1x1_kl_float32_prune",
     # HALS / Frobenius
     "t24x12_1x1_hals_float32", "t24x12_2x1_hals_float32", "t24x12_1x2_hals_float32", "t24x12_2x2_hals_float32",
     "r25x13_3x1_hals_float32", "r25x13_2x2_hals_float32", "swim_4x1_hals_float32", "lr200x136k64_1x2_hals_float32",

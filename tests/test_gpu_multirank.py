@@ -12,7 +12,8 @@ CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_floa
          "lr200x136k64_2x2_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
          "lr136x100k32_2x2_kl_float32",
          "t24x12_2x1_hals_float32", "t24x12_2x2_hals_float32", "r25x13_3x1_hals_float32", "swim_4x1_hals_float32",
-         "lr200x136k64_1x2_hals_float32"]
+         "lr200x136k64_1x2_hals_float32",
+         "t24x12z_2x1_fro_float32_prune", "t24x12z_1x2_fro_float32_prune", "t24x12z_2x2_fro_float32_prune"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from tests._golden import case_names, load_case, rel_fro  # noqa: E402
 
-SINGLE = [c for c in case_names() if "_1x1_" in c and c.endswith(("float32", "float32_noW"))]
+SINGLE = [c for c in case_names() if "_1x1_" in c and c.endswith(("float32", "float32_noW", "float32_prune"))]
 
 
 def _tols(meta):
@@ -27,14 +27,14 @@ def _tols(meta):
     return 1e-5, 1e-4, 1e-5
 
 
-def _args(k, itr, norm, W_update=True, method="mu"):
+def _args(k, itr, norm, W_update=True, method="mu", prune=False):
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.utils import parse
     comms = MPI_comm(None, 1, 1)
     args = parse()
     args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, k
     args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-    args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+    args.itr, args.init, args.verbose, args.prune = itr, "rand", False, prune
     args.norm, args.method, args.W_update = norm, method, W_update
     return args
 
@@ -46,7 +46,7 @@ def test_fit_matches_reference_golden(name):
     _, tol_fit, tol_err = _tols(meta)
     for itr in meta["itrs"]:
         W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"],
-                                                             meta.get("method", "mu"))).fit()
+                                                             meta.get("method", "mu"), meta.get("prune", False))).fit()
         assert isinstance(W, np.ndarray) and W.dtype == np.float32       # numpy in -> numpy out
         assert rel_fro(W, z["r0_fit%d_W" % itr]) <= tol_fit, itr
         assert rel_fro(H, z["r0_fit%d_H" % itr]) <= tol_fit, itr
@@ -59,6 +59,8 @@ def test_single_update_matches_reference_golden(name):
     """One bare nmf_algorithms_1D.update() from identical state (no clamp, no normalisation)."""
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
     meta, A, W0, H0, z = load_case(name)
+    if meta.get("prune"):
+        pytest.skip("pruned cases are pinned through fit()")
     tol_step = _tols(meta)[0]
     args = _args(meta["k"], 1, meta["norm"], meta["W_update"], meta.get("method", "mu"))
     args.m, args.n, args.eps = meta["m"], meta["n"], float(np.finfo(np.float32).eps)
