@@ -215,6 +215,29 @@ __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T
     }
 }
 
+// LDS-DMA: one wave-instruction moves 64 x 16 B global -> LDS with no VGPR destination.  The LDS side is lane-linear
+// (wave-uniform base + lane * 16 B), the global side is per lane -- so the XOR swizzle of the tile image is applied to
+// the SOURCE address (cdna_hip_programming.md rule 21): lane L of the instruction that covers tile rows 8q..8q+7 fills
+// (row 8q + L/8, slot L%8) and therefore fetches chunk slot ^ ((row>>1)&7) of that row.
+template <bool NTL>
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, NTL ? 2 : 0);
+}
+
+template <int R, int NW, bool NTL>
+__device__ __forceinline__ void dma_tile(float* tile, const float* __restrict__ X, long ldx, long row0, long c0,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int q0 = 0; q0 < R / 8; q0 += NW) {
+        const int q = q0 + wave;
+        if (R / 8 % NW == 0 || q < R / 8) {
+            const int row = 8 * q + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+            glds16<NTL>(X + (row0 + row) * ldx + c0 + chunk * 4, tile + 8 * q * BK);
+        }
+    }
+}
+
 // acc[mt][jt] += X[row0 + rg*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T
 // NW waves per workgroup = (NW / KS) row groups x KS contraction slices: with KS = 2 the two waves that share a row
 // group each take half of every k-tile's fragment groups and the partial accumulators are summed through LDS at the
@@ -223,7 +246,7 @@ __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T
 // PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
 // in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
 // with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
-template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false>
+template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false>
 __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
@@ -241,6 +264,46 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
         // power-of-two pitch apart in memory, so workgroups marching in lockstep over the same columns would hit
         // the same L2 / HBM channels at the same time.  (A sum over tiles: order only changes fp32 rounding.)
         const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
+        if constexpr (DMA && INTERIOR && FAST) {
+            // LDS-DMA staging: no staging VGPRs, no ds_write; the DMA of tile t+1 flies during the MFMAs of tile t and
+            // is retired (vmcnt(0)) right before the tile barrier.
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            auto issue = [&](long kt, float* stage) {
+                kt += kshift;
+                kt = kt >= nk ? kt - nk : kt;
+                const long c0 = cbeg + kt * BK;
+                dma_tile<BM, NW, NTX>(stage, X, ldx, row0, c0, wv, lane);
+                dma_tile<KP, NW, false>(stage + BM * BK, Y, ldy, 0, c0, wv, lane);
+            };
+            issue(0, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (long kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < nk) issue(kt + 1, smem + (cur ^ 1) * STAGE);
+                const float* xc = smem + cur * STAGE;
+                const float* yc = xc + BM * BK;
+#pragma unroll
+                for (int sl = 0; sl < NS / KS; ++sl) {
+                    const int s = ks * (NS / KS) + sl;
+                    f32x4 a[MT], b[KT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(rg * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+                    for (int jt = 0; jt < KT; ++jt)
+                        b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        } else {
         {
             const long c0 = cbeg + kshift * BK;
             stage_load<BM, T, FAST, INTERIOR, NTX>(xv, X, ldx, nrows, cend, row0, c0, tid);
@@ -313,6 +376,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
                 __syncthreads();
             }
         }
+        }   // register-staged path
     }
     if constexpr (KS > 1) {
         // sum the contraction slices: slice s > 0 parks its accumulators in LDS (lane-contiguous, conflict free),
@@ -343,14 +407,14 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
     }
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false>
+template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
-    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true, NTX>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
     else nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
 }
 
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
         const long cbeg = (long)blockIdx.y * p.cols_per_split;
         long cend = cbeg + p.cols_per_split;
         if (cend > p.ncols) cend = p.ncols;
-        nt_mainloop<KT, MT, NW, KS, FAST, (PF == 2 || PF == 4) ? 2 : 1, (PF == 3 || PF == 4 || PF == 5), (PF >= 5)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        nt_mainloop<KT, MT, NW, KS, FAST, 1, (PF == 5 || PF == 7), (PF >= 5), (PF == 7)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
     }
 
     if constexpr (MODE == NT_STORE) {
@@ -1288,10 +1352,14 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // (default) | 6 = 1 + nontemporal.  Measured (tools/kbench.py, k = 64, n = 8192): 262144 rows 2.54 / 2.51 / 2.42 /
     // 2.53 ms for codes 1 / 3 / 5 / 6, 65536 rows 0.816 / 0.788 / 0.761 / 0.785 ms; HBM reads per launch (PMC) 8.67 /
     // 10.99 / 8.47 / 8.50 GB: the rotation alone lets the streamed A evict H from L2, the nontemporal hint fixes that.
-    // Only codes 1 and 5 are compiled in; the others were measured and dropped (see above).
+    // Codes 1, 5 and 7 are compiled in.  7 = 5 with LDS-DMA staging (global_load_lds, no staging VGPRs / ds_write):
+    // correct, and within +-2 % of 5 at every size.  Timing-only diagnostics (not kept) showed that dropping the LDS
+    // fragment reads or the per-tile barrier does not speed the kernel up either, and that with X cache-resident it
+    // reaches 126-133 TFLOP/s: what remains is the clock the chip holds under MFMA + HBM load (~2.0 GHz).
     static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 5;
     if (FAST && KS == 1 && (MODE == NT_FUSED_W || !a.store_all)) {
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5>(a, nsplit, st);
+        if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7>(a, nsplit, st);   // 5 + LDS-DMA staging
     }
     return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1>(a, nsplit, st);
 }
