@@ -10,7 +10,7 @@ Everything numeric runs in libdnmf_hip.so; there is no CPU path.
 
 Differences from the reference, all deliberate and documented in DESIGN.md:
   * compute dtype is float32 (the engine's only dtype); float64 input raises;
-  * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' and init='nnsvd' are not provided;
+  * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' is not provided; init is 'rand' or 'nnsvd' (1D grids);
   * `prune=True` (the reference's default when the attribute is absent) drops all-zero rows / columns before the
     iterations and scatters the factors back afterwards; they stay float32 (the reference hands back float64).
 """
@@ -101,8 +101,13 @@ class PyNMF:
     def init_factors(self):
         """pyDNMF.py:107-135, init='rand': uniform [0,1) from the process-global numpy RNG (so seeding numpy
         reproduces the reference's draw order), cast to float32; the replicated factor is broadcast from rank 0."""
+        if self.init == 'nnsvd':                                    # pyDNMF.py:130-135
+            if self.topo != '1d':
+                raise Exception('NNSVD init only available for 1D topology, please try with 1d topo.')
+            from .dist_svd import DistSVD
+            return DistSVD(self.params, self.A_ij).nnsvd(flag=1, verbose=0)
         if self.init != 'rand':
-            raise NotImplementedError("init='%s': only 'rand' (or factors=...) is provided by the MI355X engine" % self.init)
+            raise NotImplementedError("init='%s': 'rand', 'nnsvd' or factors=... are provided" % self.init)
         f32 = np.float32
         if self.topo == '2d':
             W = np.random.rand(self.params.m_loc, self.k).astype(f32)

@@ -1,0 +1,64 @@
+"""Object-style front end, drop-in for reference pyDNMFk/runner.py (`pyDNMFk_Runner`, :12-176): the Runner instance
+itself is the `params` bag handed to data_read / PyNMF / PyNMFk (it carries `grid` and `k_range`, which those classes
+look for with `"grid" in vars(params)`, pyDNMF.py:60-63).  One process per GPU; launch multi-rank runs with
+torch.distributed.run (the reference: mpirun)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .data_io import data_read
+from .dist_comm import COMM_WORLD, MPI_comm
+from .pyDNMF import PyNMF
+from .pyDNMFk import PyNMFk
+
+
+class pyDNMFk_Runner:
+    def __init__(self, init="rand", itr=5000, norm="kl", method="mu", verbose=False, checkpoint=False,
+                 timing_stats=False, prune=False, precision="float32", perturbations=20, noise_var=0.015,
+                 sill_thr=0.6, sampling="uniform", process="pyDNMF"):
+        self.init, self.itr, self.norm, self.method = init, itr, norm, method
+        self.verbose, self.checkpoint, self.timing_stats, self.prune = verbose, checkpoint, timing_stats, prune
+        self.precision = precision
+        self.perturbations, self.noise_var, self.sill_thr, self.sampling = perturbations, noise_var, sill_thr, sampling
+        self.process = process
+        self.fpath = self.ftype = self.fname = self.results_path = None
+        self.k_range = self.step_k = None
+        if self.process not in ["pyDNMFk", "pyDNMF"]:
+            raise ValueError("process should be either pyDNMFk or pyDNMF")      # runner.py:75-76
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and not dist.is_initialized():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl")
+        self.main_comm = COMM_WORLD()
+        self.rank = self.main_comm.rank
+        self.p_r = self.p_c = self.start_k = self.end_k = None
+
+    def run(self, grid, fpath="data/", ftype="mat", fname="A_", results_path="results/", k_range=[1, 10], step_k=1, k=4):
+        """runner.py:91-176.  Returns {"W", "H", "err"} (pyDNMF) or {"nopt"} (pyDNMFk)."""
+        if len(grid) != 2 or len(k_range) != 2:
+            raise ValueError("grid and k_range needs to be a list sized 2")
+        self.p_r, self.p_c = grid[0], grid[1]
+        self.start_k, self.end_k = k_range[0], k_range[1]
+        self.fpath, self.ftype, self.fname, self.results_path = fpath, ftype, fname, results_path
+        self.results_paths = results_path
+        self.k_range, self.step_k, self.grid, self.k = k_range, step_k, grid, k
+        self.comm = MPI_comm(self.main_comm, self.grid[0], self.grid[1])
+        self.comm1 = self.comm.comm
+        self.col_comm = self.comm.cart_1d_column()
+        self.row_comm = self.comm.cart_1d_row()
+        if self.verbose and self.rank == 0:
+            print("Reading data now")
+        A_ij = data_read(self).read()
+        if self.verbose and self.rank == 0:
+            print('Starting ' + self.process + '...')
+        results = dict()
+        if self.process == "pyDNMFk":
+            results["nopt"] = PyNMFk(A_ij, factors=None, params=self).fit()
+        else:
+            W, H, err = PyNMF(A_ij, factors=None, params=self).fit()
+            results["W"], results["H"], results["err"] = W, H, err
+        if self.rank == 0 and self.verbose:
+            print('Done ' + self.process + '.')
+        return results

@@ -1,0 +1,97 @@
+"""NNDSVD initialisation against the reference's own golden files (tests/nnsvd_factors_24x16.npy / _16x24.npy of
+lanl/pyDNMFk, derived from sklearn; kept as tests/golden/ref_nnsvd_*.npz): same recipe and tolerances as the
+reference's tests/test_dist_nnsvd.py:14-73 (rtol = atol = 1e-3, SVD reconstruction error ~0, NNSVD error < .11)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _run(A, p_r, p_c, rank, comm1):
+    from pydnmfk_amd.dist_svd import DistSVD
+    from pydnmfk_amd.utils import determine_block_params, parse
+    args = parse()
+    args.comm1, args.p_r, args.p_c = comm1, p_r, p_c
+    args.m, args.n, args.k, args.eps = A.shape[0], A.shape[1], 2, np.finfo(A.dtype).eps
+    s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+    A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1]
+    return DistSVD(args, A_ij).nnsvd(flag=1, verbose=1)
+
+
+def _problems():
+    np.random.seed(0)
+    m, k, n = 24, 2, 16
+    A1 = np.random.rand(m, k) @ np.random.rand(k, n)
+    m, k, n = 16, 2, 24
+    A2 = np.random.rand(m, k) @ np.random.rand(k, n)
+    return A1, A2
+
+
+def test_single_rank_matches_reference_golden(golden_dir):
+    from pydnmfk_amd.dist_comm import COMM_WORLD
+    A1, A2 = _problems()
+    for A, tag in ((A1, "24x16"), (A2, "16x24")):
+        (W, H), err = _run(A, 1, 1, 0, COMM_WORLD())
+        ref = np.load(golden_dir + "/ref_nnsvd_%s.npz" % tag)
+        assert err["recon_err_svd"] < 1e-6 and err["recon_err_nnsvd"] < .11
+        assert np.allclose(W.numpy(), ref["W"], rtol=1e-3, atol=1e-3)
+        assert W.dtype == torch.float32 and float(W.min()) >= 0 and float(H.min()) >= 0
+        assert np.allclose(W.numpy().sum(0), 1.0, atol=1e-5)
+
+
+def _rank_body(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from pydnmfk_amd.dist_comm import MPI_comm
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A1, A2 = _problems()
+        c1 = MPI_comm(None, 2, 1)
+        (W1, H1), e1 = _run(A1, 2, 1, rank, c1.comm)                 # tall: W sharded (test_dist_nnsvd.py:22-44)
+        W1 = torch.cat(c1.comm.allgather_blocks(W1, [(12, 2), (12, 2)]), dim=0)
+        c2 = MPI_comm(None, 1, 2)
+        (W2, H2), e2 = _run(A2, 1, 2, rank, c2.comm)                 # wide: H sharded (:51-73)
+        q.put((rank, W1.numpy(), W2.numpy(), e1, e2, None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, None, None, traceback.format_exc()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_reference_golden(golden_dir):
+    import torch.multiprocessing as mp
+    from tests._mp import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_rank_body, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    r1, r2 = np.load(golden_dir + "/ref_nnsvd_24x16.npz"), np.load(golden_dir + "/ref_nnsvd_16x24.npz")
+    for rank, W1, W2, e1, e2, err in res:
+        assert err is None, err
+        assert e1["recon_err_svd"] < 1e-6 and e1["recon_err_nnsvd"] < .11 and e2["recon_err_nnsvd"] < .11
+        assert np.allclose(W1, r1["W"], rtol=1e-3, atol=1e-3)
+        assert np.allclose(W2, r2["W"], rtol=1e-3, atol=1e-3)
+
+
+def test_nnsvd_init_through_pynmf_reaches_reference_threshold():
+    """tests/test_dist_nmf_1d_nnsvd_init.py:14-46 of the reference: init='nnsvd', rel_error < 1e-1 (checker back end)."""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMF import PyNMF
+    from pydnmfk_amd.utils import parse
+    from tests._ops_double import OracleOps
+    np.random.seed(100)
+    A = (np.random.rand(24, 2) @ np.random.rand(2, 12)).astype(np.float32)
+    comms = MPI_comm(None, 1, 1)
+    for method, norm in (("mu", "fro"), ("mu", "kl"), ("hals", "fro")):
+        args = parse()
+        args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, 2
+        args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        args.itr, args.init, args.verbose, args.prune, args.norm, args.method = 200, "nnsvd", False, False, norm, method
+        _, _, err = PyNMF(A, factors=None, params=args, ops=OracleOps()).fit()
+        assert err < 1e-1, (method, norm, err)
