@@ -121,6 +121,22 @@ int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* str
 int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                       int k, double* out, void* stream);
 
+/* ---- bf16 STORAGE of the data matrix (BASELINE config 5, "mixed precision"; no reference counterpart: numpy has no
+ * bf16).  A is bfloat16 in device memory (pointer to 16-bit words, lda in elements, rows 8-byte aligned for the vector
+ * path), widened exactly to fp32 in registers; W, H, every product and every accumulation stay fp32, so each call equals
+ * its fp32 twin applied to float(A).  Same arguments otherwise. ---- */
+int dnmf_aht_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
+                   float* AH, long ldah, void* stream);
+int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw,
+                   float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+int dnmf_aht_update_w_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
+                            const float* G, float* W, long ldw, float eps, void* stream);
+int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
+                           int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void* stream);
+int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H,
+                            long ldh, int k, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

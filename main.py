@@ -42,7 +42,7 @@ def parser_pyNMF(parser):
     parser.add_argument('--checkpoint', type=str2bool, default=False, help='Enable checkpoint to track the pyNMFk state')
     parser.add_argument('--timing_stats', type=str2bool, default=False, help='accepted for compatibility; ignored')
     parser.add_argument('--prune', type=str2bool, default=False, help='Prune zero row/column.')
-    parser.add_argument('--precision', type=str, default='float32', help='Precision of the data(float32 only).')
+    parser.add_argument('--precision', type=str, default='float32', help='Storage precision of the data: float32, or bfloat16 (Frobenius mu/hals; arithmetic stays float32).')
     return parser
 
 

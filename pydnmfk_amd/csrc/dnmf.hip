@@ -16,6 +16,7 @@
 //   C/D: col = li, row = (reg & 3) + 8 * (reg >> 2) + 4 * h   (reg in [0,16))
 // The contraction order inside a tile and the output row/column order inside a tile are permuted freely
 // (sums are order-agnostic up to fp32 rounding; outputs are written to their true addresses).
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,6 +33,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// bf16 STORAGE of the data matrix A (BASELINE config 5): A is held as bfloat16 in HBM (half the bytes of the HBM-bound
+// small-k regime), widened to fp32 in registers (exact: bf16 -> fp32 is a 16-bit shift) and fed to the same fp32 MFMAs.
+// W, H and every intermediate stay fp32.
+typedef unsigned short bf16_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
 namespace {
 
@@ -156,6 +165,86 @@ __device__ __forceinline__ void store_tile_vec(const float (&d)[V], float* __res
     }
 }
 
+// bf16 flavours of the element loaders (V in {1, 2, 4}: 2 / 4 / 8 bytes per lane)
+template <int V>
+__device__ __forceinline__ void load_vec_raw(float (&d)[V], const bf16_t* __restrict__ p) {
+    if constexpr (V == 4) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+        d[0] = bf16_lo(w[0]); d[1] = bf16_hi(w[0]); d[2] = bf16_lo(w[1]); d[3] = bf16_hi(w[1]);
+    } else if constexpr (V == 2) {
+        const unsigned int w = *reinterpret_cast<const unsigned int*>(p);
+        d[0] = bf16_lo(w); d[1] = bf16_hi(w);
+    } else {
+        d[0] = bf16_lo((unsigned int)p[0]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void load_vec_raw_nt(float (&d)[V], const bf16_t* __restrict__ p) {
+    if constexpr (V == 4) {
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+        d[0] = bf16_lo(w[0]); d[1] = bf16_hi(w[0]); d[2] = bf16_lo(w[1]); d[3] = bf16_hi(w[1]);
+    } else if constexpr (V == 2) {
+        const unsigned int w = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(p));
+        d[0] = bf16_lo(w); d[1] = bf16_hi(w);
+    } else {
+        d[0] = bf16_lo((unsigned int)__builtin_nontemporal_load(p));
+    }
+}
+
+// Raw<T, V>: V elements as they arrive from memory.  For bf16 the widening to fp32 is deferred to get(): a conversion
+// right after the load would make the wave wait for the load at once and undo the software prefetch.
+template <typename T, int V> struct Raw;
+template <int V> struct Raw<float, V> {
+    float v[V];
+    __device__ __forceinline__ void load(const float* __restrict__ p) { load_vec_raw<V>(v, p); }
+    __device__ __forceinline__ void load_nt(const float* __restrict__ p) { load_vec_raw_nt<V>(v, p); }
+    __device__ __forceinline__ void get(float (&d)[V]) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = v[e];
+    }
+};
+template <int V> struct Raw<bf16_t, V> {
+    unsigned int w[(V + 1) / 2];
+    template <bool NTL>
+    __device__ __forceinline__ void load_(const bf16_t* __restrict__ p) {
+        if constexpr (V == 4) {
+            const u32x2 x = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
+            w[0] = x[0]; w[1] = x[1];
+        } else if constexpr (V == 2) {
+            w[0] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(p)) : *reinterpret_cast<const unsigned int*>(p);
+        } else {
+            w[0] = NTL ? __builtin_nontemporal_load(p) : p[0];
+        }
+    }
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ p) { load_<false>(p); }
+    __device__ __forceinline__ void load_nt(const bf16_t* __restrict__ p) { load_<true>(p); }
+    __device__ __forceinline__ void get(float (&d)[V]) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (e & 1) ? bf16_hi(w[e >> 1]) : bf16_lo(w[e >> 1]);
+    }
+};
+
+template <int V, bool FAST>
+__device__ __forceinline__ void load_vec(float (&d)[V], const bf16_t* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) load_vec_raw<V>(d, row + col);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (ok && col + e < ncols) ? bf16_lo((unsigned int)row[col + e]) : 0.f;
+    }
+}
+
+template <int V, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void load_tile_vec(float (&d)[V], const bf16_t* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST && INTERIOR) load_vec_raw<V>(d, row + col);
+    else load_vec<V, FAST>(d, row, col, ncols, ok);
+}
+
 // =============================================================================================== NT form
 constexpr int BK = 32;  // contraction tile (floats): 128-B LDS rows
 
@@ -167,7 +256,7 @@ __device__ __forceinline__ int lds_idx(int row, int chunk) { return row * BK + (
 enum { NT_STORE = 0, NT_FUSED_W = 1 };
 
 struct NtArgs {
-    const float* X; long ldx; long nrows; long ncols;  // streamed operand; contraction over ncols
+    const void* X; long ldx; long nrows; long ncols;   // streamed operand (float, or bf16 bits: TX of nt_kernel); contraction over ncols
     const float* Y; long ldy; int yrows;               // small operand [yrows x ncols]
     long cols_per_split;                               // contraction range per blockIdx.y (multiple of BK)
     float* out; long ldo; long split_stride; int store_all;
@@ -177,8 +266,8 @@ struct NtArgs {
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
 // INTERIOR (compile time): the whole tile is in bounds -> plain loads with no exec-masked branches, so hipcc can
 // keep several tiles' loads in flight with counted vmcnt instead of draining with vmcnt(0).
-template <int R, int T, bool FAST, bool INTERIOR, bool NTL = false>
-__device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const float* __restrict__ X, long ldx,
+template <int R, int T, bool FAST, bool INTERIOR, bool NTL = false, typename TX = float>
+__device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const TX* __restrict__ X, long ldx,
                                            long nrows, long cend, long row0, long c0, int tid) {
     constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
     const int ch = tid & 7;
@@ -188,8 +277,15 @@ __device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)]
         for (int it = 0; it < NP; ++it) {
             const int rl = it * RP + (tid >> 3);
             if (R % RP == 0 || rl < R) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(X + (row0 + rl) * ldx + c);
-                v[it] = NTL ? __builtin_nontemporal_load(src) : *src;
+                if constexpr (std::is_same<TX, float>::value) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(X + (row0 + rl) * ldx + c);
+                    v[it] = NTL ? __builtin_nontemporal_load(src) : *src;
+                } else {
+                    float d[4];
+                    if constexpr (NTL) load_vec_raw_nt<4>(d, X + (row0 + rl) * ldx + c);
+                    else load_vec_raw<4>(d, X + (row0 + rl) * ldx + c);
+                    v[it] = f32x4{d[0], d[1], d[2], d[3]};
+                }
             }
         }
     } else {
@@ -246,8 +342,8 @@ __device__ __forceinline__ void dma_tile(float* tile, const float* __restrict__ 
 // PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
 // in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
 // with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
-template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false>
-__device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
+template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false, typename TX = float>
+__device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
     constexpr int NRG = NW / KS;             // row groups (waves along M)
@@ -264,7 +360,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
         // power-of-two pitch apart in memory, so workgroups marching in lockstep over the same columns would hit
         // the same L2 / HBM channels at the same time.  (A sum over tiles: order only changes fp32 rounding.)
         const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
-        if constexpr (DMA && INTERIOR && FAST) {
+        if constexpr (DMA && INTERIOR && FAST && std::is_same<TX, float>::value) {
             // LDS-DMA staging: no staging VGPRs, no ds_write; the DMA of tile t+1 flies during the MFMAs of tile t and
             // is retired (vmcnt(0)) right before the tile barrier.
             const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -407,8 +503,8 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const float*
     }
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false>
-__device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long nrows,
+template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false, typename TX = float>
+__device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
                                             long cend, float* smem) {
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
@@ -418,7 +514,154 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const float* 
     else nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF>
+
+// ---------------------------------------------------------------------------------------------- NT form, bf16-stored X
+// Same structure as nt_mainloop_ (register-staged double-buffered LDS tiles, one barrier per k-tile), but a k-tile is
+// BKH = 64 contraction indices: the X tile is kept in LDS as it is in HBM (bf16, 128 B per row = the same bytes, the
+// same 16-B-per-lane full-line loads and the same swizzled image as an fp32 tile of 32) and widened to fp32 only after
+// the fragment read; the fp32 Y tile is 64 floats (256 B = one whole LDS bank row) per row.  A ds_read_b128 of X gives
+// lane (li, h) the 8 contraction indices 8*(2s+h)..+7 of row li; the matching Y values are two ds_read_b128.
+constexpr int BKH = 64;
+// Y tile: row pitch = all 64 banks, so the 16 lanes of a read group (consecutive rows, same chunk) must land in 16
+// different 16-B slots: XOR with the low 4 row bits.
+__device__ __forceinline__ int ydx(int row, int chunk) { return row * BKH + ((chunk ^ (row & 15)) << 2); }
+
+template <int R, int T, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void stage_load_y64(f32x4 (&v)[(R + T / 16 - 1) / (T / 16)], const float* __restrict__ Y,
+                                               long ldy, int yrows, long cend, long c0, int tid) {
+    constexpr int RP = T / 16, NP = (R + RP - 1) / RP;
+    const int ch = tid & 15;
+    const long c = c0 + ch * 4;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int rl = it * RP + (tid >> 4);
+        if constexpr (FAST && INTERIOR) {
+            // rows >= yrows (k < KP) read a clamped, valid row instead of being predicated: an MFMA output column
+            // depends only on the matching B-operand lane, so they only pollute output columns >= k, never stored
+            const int rc = rl < yrows ? rl : yrows - 1;
+            if (R % RP == 0 || rl < R) v[it] = *reinterpret_cast<const f32x4*>(Y + (long)rc * ldy + c);
+        } else {
+            float d[4];
+            load_vec<4, FAST>(d, Y + (long)rl * ldy, c, cend, rl < yrows && (R % RP == 0 || rl < R));
+            v[it] = f32x4{d[0], d[1], d[2], d[3]};
+        }
+    }
+}
+
+template <int R, int T>
+__device__ __forceinline__ void stage_store_y64(float* tile, const f32x4 (&v)[(R + T / 16 - 1) / (T / 16)], int tid) {
+    constexpr int RP = T / 16, NP = (R + RP - 1) / RP;
+    const int ch = tid & 15;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int r = it * RP + (tid >> 4);
+        if (R % RP == 0 || r < R) *reinterpret_cast<f32x4*>(&tile[ydx(r, ch)]) = v[it];
+    }
+}
+
+// X tile of R rows x 64 bf16, raw: thread t owns the 16-B chunk (t & 7) = elements 8*(t&7)..+7 of rows (t >> 3) + it*T/8
+template <int R, int T, bool FAST, bool INTERIOR, bool NTL>
+__device__ __forceinline__ void stage_load_xb(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], const bf16_t* __restrict__ X, long ldx,
+                                              long nrows, long cend, long row0, long c0, int tid) {
+    constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
+    const int ch = tid & 7;
+    const long c = c0 + ch * 8;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int rl = it * RP + (tid >> 3);
+        const long r = row0 + rl;
+        if constexpr (FAST && INTERIOR) {
+            if (R % RP == 0 || rl < R) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(X + r * ldx + c);
+                v[it] = NTL ? __builtin_nontemporal_load(src) : *src;
+            }
+        } else {
+            const bool ok = r < nrows && (R % RP == 0 || rl < R);
+            const bf16_t* row = X + r * ldx;
+            unsigned int w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned int lo = (ok && c + 2 * q < cend) ? row[c + 2 * q] : 0u;
+                const unsigned int hi = (ok && c + 2 * q + 1 < cend) ? row[c + 2 * q + 1] : 0u;
+                w[q] = lo | (hi << 16);
+            }
+            v[it] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+        }
+    }
+}
+
+template <int KT, int MT, int NW, bool FAST, bool STAGGER, bool INTERIOR, bool NTX>
+__device__ __forceinline__ void nt_mainloop_b16_(f32x16 (&acc)[MT][KT], const bf16_t* __restrict__ X, long ldx, long nrows,
+                                                long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
+                                                long cend, float* smem) {
+    constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
+    constexpr int XT = BM * BK;              // floats (= 4-byte words) of the raw X tile: BM rows x 128 B
+    constexpr int STAGE = XT + KP * BKH;     // [X tile raw | Y tile fp32]
+    const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6, li = lane & 31, h = lane >> 5;
+    f32x4 xv[(BM + T / 8 - 1) / (T / 8)], yv[(KP + T / 16 - 1) / (T / 16)];
+    const long nk = (cend - cbeg + BKH - 1) / BKH;
+    if (nk <= 0) return;
+    const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;   // see nt_mainloop_
+    auto load_tile = [&](long kt) {
+        kt += kshift;
+        kt = kt >= nk ? kt - nk : kt;
+        const long c0 = cbeg + kt * BKH;
+        stage_load_xb<BM, T, FAST, INTERIOR, NTX>(xv, X, ldx, nrows, cend, row0, c0, tid);
+        stage_load_y64<KP, T, FAST, INTERIOR>(yv, Y, ldy, yrows, cend, c0, tid);
+    };
+    auto store_tile = [&](float* stage) {
+        stage_store<BM, T>(stage, xv, tid);
+        stage_store_y64<KP, T>(stage + XT, yv, tid);
+    };
+    auto compute = [&](const float* xc) {
+        const float* yc = xc + XT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 a[MT], b0[KT], b1[KT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(rg * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) {
+                b0[jt] = *reinterpret_cast<const f32x4*>(&yc[ydx(jt * 32 + li, 2 * (2 * s + h))]);
+                b1[jt] = *reinterpret_cast<const f32x4*>(&yc[ydx(jt * 32 + li, 2 * (2 * s + h) + 1)]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const unsigned int w = __float_as_uint(a[mt][e >> 1]);
+                    const float av = (e & 1) ? bf16_hi(w) : bf16_lo(w);
+#pragma unroll
+                    for (int jt = 0; jt < KT; ++jt)
+                        acc[mt][jt] = MFMA32(av, e < 4 ? b0[jt][e & 3] : b1[jt][e & 3], acc[mt][jt]);
+                }
+        }
+    };
+    load_tile(0);
+    store_tile(smem);
+    __syncthreads();
+    for (long kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        compute(smem + cur * STAGE);
+        if (more) store_tile(smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+    }
+}
+
+template <int KT, int MT, int NW, bool FAST, bool STAGGER, bool NTX>
+__device__ __forceinline__ void nt_mainloop_b16(f32x16 (&acc)[MT][KT], const bf16_t* __restrict__ X, long ldx, long nrows,
+                                               long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
+                                               long cend, float* smem) {
+    constexpr int BM = 32 * MT * NW;
+    const bool interior = FAST && row0 + BM <= nrows && (cend - cbeg) % BKH == 0;   // any yrows: see stage_load_y64
+    if (interior) nt_mainloop_b16_<KT, MT, NW, FAST, STAGGER, true, NTX>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    else nt_mainloop_b16_<KT, MT, NW, FAST, STAGGER, false, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+}
+
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF, typename TX = float>
 __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NRG = NW / KS, BM = 32 * MT * NRG;
@@ -438,7 +681,12 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
         const long cbeg = (long)blockIdx.y * p.cols_per_split;
         long cend = cbeg + p.cols_per_split;
         if (cend > p.ncols) cend = p.ncols;
-        nt_mainloop<KT, MT, NW, KS, FAST, 1, (PF == 5 || PF == 7), (PF >= 5), (PF == 7)>(acc, p.X, p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        if constexpr (std::is_same<TX, bf16_t>::value) {
+            static_assert(KS == 1, "bf16 X: one contraction slice");
+            nt_mainloop_b16<KT, MT, NW, FAST, (PF == 5), (PF == 5)>(acc, static_cast<const bf16_t*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        } else {
+            nt_mainloop<KT, MT, NW, KS, FAST, 1, (PF == 5 || PF == 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+        }
     }
 
     if constexpr (MODE == NT_STORE) {
@@ -488,14 +736,14 @@ enum { TN_PARTIAL = 0 };
 
 struct TnArgs {
     const float* X; long ldx; int xcols;     // [nrows x xcols]  -> output rows j
-    const float* Y; long ldy; long ycols;    // [nrows x ycols]  -> output cols c
+    const void* Y; long ldy; long ycols;     // [nrows x ycols]  -> output cols c (float, or bf16 bits: TY of tn_kernel)
     long nrows; long rows_per_chunk; int nchunks; int ncolblk;
     float* P; long chunk_stride; long ldp;   // P[chunk][KP][ldp]
 };
 
-template <int KT, int NT, bool FAST, int U>
+template <int KT, int NT, bool FAST, int U, typename TY>
 __device__ __forceinline__ void tn_load(float (&a)[U][KT], float (&b)[U][NT], const float* __restrict__ X, long ldx,
-                                        int xcols, const float* __restrict__ Y, long ldy, long ycols, long col0,
+                                        int xcols, const TY* __restrict__ Y, long ldy, long ycols, long col0,
                                         long r, long rend, int li, int h) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -526,12 +774,13 @@ __device__ __forceinline__ void tn_comp(f32x16 (&acc)[KT][NT], const float (&a)[
 // batch base is a wave-uniform pointer, the per-lane part (2u + h) * ld + column a loop-invariant 32-bit offset.
 // Lanes whose output row j >= xcols or output column c >= ycols read a clamped (valid) column instead: an MFMA output
 // row / column depends only on the matching A- / B-operand lane, so they only pollute outputs that are never stored.
-template <int KT, int NT, bool FAST, bool NTY = false>
+template <int KT, int NT, bool FAST, bool NTY = false, typename TY = float>
 __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* __restrict__ X, long ldx, int xcols,
-                                            const float* __restrict__ Y, long ldy, long ycols, long col0, long rbeg,
+                                            const TY* __restrict__ Y, long ldy, long ycols, long col0, long rbeg,
                                             long rend, int li, int h) {
     constexpr int U = 4;  // row pairs per register batch
-    float a0[U][KT], b0[U][NT], a1[U][KT], b1[U][NT];
+    float a0[U][KT], b0[U][NT], a1[U][KT];
+    Raw<TY, NT> q0[U], q1[U];                // the streamed operand as loaded (bf16: widened right before its MFMAs)
     long r = rbeg;
     if constexpr (FAST) {
         const long nb = (rend - rbeg) / (2 * U);
@@ -547,11 +796,11 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
             }
             const long rlastb = rbeg + (nb - 1) * 2 * U;   // first row of the last full batch
             {
-                const float* X0 = X + r * ldx; const float* Y0 = Y + r * ldy;
+                const float* X0 = X + r * ldx; const TY* Y0 = Y + r * ldy;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     load_vec_raw<KT>(a0[u], X0 + xo[u]);
-                    if constexpr (NTY) load_vec_raw_nt<NT>(b0[u], Y0 + yo[u]); else load_vec_raw<NT>(b0[u], Y0 + yo[u]);
+                    if constexpr (NTY) q0[u].load_nt(Y0 + yo[u]); else q0[u].load(Y0 + yo[u]);
                 }
             }
             long b = 0;
@@ -559,33 +808,39 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
                 const long r1 = r + 2 * U;
                 long r2 = r + 4 * U;
                 r2 = r2 < rlastb ? r2 : rlastb;              // prefetch past the end re-reads the last batch (unused)
-                const float* X1 = X + r1 * ldx; const float* Y1 = Y + r1 * ldy;
-                const float* X2 = X + r2 * ldx; const float* Y2 = Y + r2 * ldy;
+                const float* X1 = X + r1 * ldx; const TY* Y1 = Y + r1 * ldy;
+                const float* X2 = X + r2 * ldx; const TY* Y2 = Y + r2 * ldy;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     load_vec_raw<KT>(a1[u], X1 + xo[u]);
-                    if constexpr (NTY) load_vec_raw_nt<NT>(b1[u], Y1 + yo[u]); else load_vec_raw<NT>(b1[u], Y1 + yo[u]);
+                    if constexpr (NTY) q1[u].load_nt(Y1 + yo[u]); else q1[u].load(Y1 + yo[u]);
                     __builtin_amdgcn_sched_barrier(0);
+                    float bb[NT];
+                    q0[u].get(bb);
 #pragma unroll
                     for (int ke = 0; ke < KT; ++ke)
 #pragma unroll
-                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a0[u][ke], b0[u][ne], acc[ke][ne]);
+                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a0[u][ke], bb[ne], acc[ke][ne]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     load_vec_raw<KT>(a0[u], X2 + xo[u]);
-                    if constexpr (NTY) load_vec_raw_nt<NT>(b0[u], Y2 + yo[u]); else load_vec_raw<NT>(b0[u], Y2 + yo[u]);
+                    if constexpr (NTY) q0[u].load_nt(Y2 + yo[u]); else q0[u].load(Y2 + yo[u]);
                     __builtin_amdgcn_sched_barrier(0);
+                    float bb[NT];
+                    q1[u].get(bb);
 #pragma unroll
                     for (int ke = 0; ke < KT; ++ke)
 #pragma unroll
-                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a1[u][ke], b1[u][ne], acc[ke][ne]);
+                        for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a1[u][ke], bb[ne], acc[ke][ne]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 r += 4 * U;
             }
             if (b < nb) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) q0[u].get(b0[u]);
                 tn_comp<KT, NT, U>(acc, a0, b0);
                 r += 2 * U;
             }
@@ -593,12 +848,12 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
     }
     // ragged tail of the FAST path and the whole generic path: predicated loads, zero fill
     for (; r < rend; r += 2 * U) {
-        tn_load<KT, NT, FAST, U>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r, rend, li, h);
+        tn_load<KT, NT, FAST, U, TY>(a0, b0, X, ldx, xcols, Y, ldy, ycols, col0, r, rend, li, h);
         tn_comp<KT, NT, U>(acc, a0, b0);
     }
 }
 
-template <int KT, int NT, bool FAST, int MODE, bool NTY = false>
+template <int KT, int NT, bool FAST, int MODE, bool NTY = false, typename TY = float>
 __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     // wave-uniform quantities kept provably scalar (readfirstlane) so row bases live in SGPRs
@@ -620,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ke][ne][r] = 0.f;
 
-    tn_mainloop<KT, NT, FAST, NTY>(acc, p.X, p.ldx, p.xcols, p.Y, p.ldy, p.ycols, col0, rbeg, rend, li, h);
+    tn_mainloop<KT, NT, FAST, NTY, TY>(acc, p.X, p.ldx, p.xcols, static_cast<const TY*>(p.Y), p.ldy, p.ycols, col0, rbeg, rend, li, h);
 
     if constexpr (MODE == TN_PARTIAL) {
         float* Pc = p.P + chunk * p.chunk_stride;
@@ -728,21 +983,23 @@ __device__ __forceinline__ void block_atomic_sum(double v, double* out) {
 }
 
 // sum of squares of an m x n matrix; fp32 products, fp64 accumulation
-template <bool FAST>
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ A, long m, long n, long lda, double* out) {
+template <bool FAST, typename TA = float>
+__global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, long m, long n, long lda, double* out) {
     double acc = 0.0;
     if constexpr (FAST) {
         const long n4 = n / 4, total = m * n4;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
             const long r = idx / n4, c = (idx % n4) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(A + r * lda + c);
+            float v[4];
+            load_vec_raw<4>(v, A + r * lda + c);
             acc += (double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
         }
     } else {
         const long total = m * n;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-            const float v = A[(idx / n) * lda + idx % n];
-            acc += (double)(v * v);
+            float v[1];
+            load_vec_raw<1>(v, A + (idx / n) * lda + idx % n);
+            acc += (double)(v[0] * v[0]);
         }
     }
     block_atomic_sum(acc, out);
@@ -1070,16 +1327,27 @@ __device__ __forceinline__ void nn_tile(f32x16 (&acc)[NT], const float* __restri
     }
 }
 
-template <int KT, bool FAST, bool INTERIOR>
+// INTERIOR: the W / H loads need no predication (k == KP and the tile is in bounds); AI: the A tile is in bounds
+template <int KT, bool FAST, bool INTERIOR, bool AI, typename TA>
 __device__ __forceinline__ float resid_tile(const NnArgs& p, long row0, long col0, int li, int h) {
     f32x16 acc[4];
+    // bf16 A on the vector path: request the whole 32 x 128 tile (raw, 2 registers per row) BEFORE the W H product so
+    // its latency hides under the MFMAs; widened at the point of use.
+    constexpr bool PRE = FAST && AI && std::is_same<TA, bf16_t>::value;
+    Raw<TA, 4> araw[PRE ? 16 : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            araw[r].load_nt(reinterpret_cast<const TA*>(p.A) + (row0 + crow(r, h)) * p.lda + col0 + 4 * li);
+    }
     nn_tile<KT, 4, FAST, INTERIOR>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
     float part = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long row = row0 + crow(r, h);
         float a[4];
-        load_tile_vec<4, FAST, INTERIOR>(a, p.A + row * p.lda, col0 + 4 * li, p.n, row < p.m);
+        if constexpr (PRE) araw[r].get(a);
+        else load_tile_vec<4, FAST, AI>(a, reinterpret_cast<const TA*>(p.A) + row * p.lda, col0 + 4 * li, p.n, row < p.m);
 #pragma unroll
         for (int ne = 0; ne < 4; ++ne) {
             // rows >= m and cols >= n have a = 0 and acc = 0 (zero-filled operands) -> contribute 0
@@ -1090,7 +1358,8 @@ __device__ __forceinline__ float resid_tile(const NnArgs& p, long row0, long col
     return part;
 }
 
-template <int KT, bool FAST>
+// TA = storage type of A (float, or bf16_t: p.A then carries the bf16 pointer reinterpreted)
+template <int KT, bool FAST, typename TA = float>
 __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1099,9 +1368,14 @@ __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     if (gw < p.nrowblk * p.ncolblk) {
         const long rowblk = gw / p.ncolblk, colblk = gw % p.ncolblk;
         const long row0 = rowblk * 32, col0 = colblk * 128;
-        const bool interior = FAST && p.k == 32 * KT && row0 + 32 <= p.m && col0 + 128 <= p.n;
-        total = (double)(interior ? resid_tile<KT, FAST, true>(p, row0, col0, li, h)
-                                  : resid_tile<KT, FAST, false>(p, row0, col0, li, h));
+        const bool inb = FAST && row0 + 32 <= p.m && col0 + 128 <= p.n;
+        const bool interior = inb && p.k == 32 * KT;
+        // k < KP: W / H loads stay predicated.  Un-predicating only the A loads pays for bf16 (they are hoisted above
+        // the product, 3.8 -> 2.0 ms at 262144 x 8192, k = 16) but is slower for fp32 (2.3 -> 3.7 ms), so fp32 keeps them predicated.
+        const bool ai = inb && std::is_same<TA, bf16_t>::value;
+        total = (double)(interior ? resid_tile<KT, FAST, true, true, TA>(p, row0, col0, li, h)
+                         : ai     ? resid_tile<KT, FAST, false, true, TA>(p, row0, col0, li, h)
+                                  : resid_tile<KT, FAST, false, false, TA>(p, row0, col0, li, h));
     }
     block_atomic_sum(total, p.out);
 }
@@ -1334,18 +1608,20 @@ void allow_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF>
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF, typename TX>
 int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
     constexpr int BM = 32 * MT * (NW / KS);
-    constexpr size_t lds = 2ul * (BM + 32 * KT) * BK * sizeof(float);
+    constexpr size_t lds32 = 2ul * (BM + 32 * KT) * BK * sizeof(float);                     // fp32 tiles (also the W.G loop)
+    constexpr size_t lds16 = 2ul * (BM * BK + 32 * KT * BKH) * sizeof(float);               // bf16 X: [X raw | Y 64 wide]
+    constexpr size_t lds = std::is_same<TX, bf16_t>::value ? (lds16 > lds32 ? lds16 : lds32) : lds32;
     static bool once = false;
-    if (!once) { allow_lds(nt_kernel<KT, MT, NW, KS, FAST, MODE, PF>, lds); once = true; }
-    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, KS, FAST, MODE, PF>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
+    if (!once) { allow_lds(nt_kernel<KT, MT, NW, KS, FAST, MODE, PF, TX>, lds); once = true; }
+    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, KS, FAST, MODE, PF, TX>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
                        dim3(64 * NW), lds, st, a);
     return check_launch("nt_kernel");
 }
 
-template <int KT, int MT, int NW, int KS, bool FAST, int MODE>
+template <int KT, int MT, int NW, int KS, bool FAST, int MODE, typename TX>
 int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // PF code (experiment switch DNMF_NT_PF): 1 = prefetch distance 1, in-order tiles | 2 = distance 2 |
     // 3 = 1 + rotated tile order per workgroup | 4 = 2 + rotation | 5 = 3 + nontemporal loads of the streamed operand
@@ -1357,11 +1633,12 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // fragment reads or the per-tile barrier does not speed the kernel up either, and that with X cache-resident it
     // reaches 126-133 TFLOP/s: what remains is the clock the chip holds under MFMA + HBM load (~2.0 GHz).
     static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 5;
-    if (FAST && KS == 1 && (MODE == NT_FUSED_W || !a.store_all)) {
-        if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5>(a, nsplit, st);
-        if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7>(a, nsplit, st);   // 5 + LDS-DMA staging
+    if constexpr (FAST && KS == 1) if (MODE == NT_FUSED_W || !a.store_all) {
+        if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
+        if constexpr (std::is_same<TX, float>::value)
+            if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7, TX>(a, nsplit, st);   // 5 + LDS-DMA staging
     }
-    return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1>(a, nsplit, st);
+    return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1, TX>(a, nsplit, st);
 }
 
 // Tile configuration per padded rank (KT = KP/32); every configuration has a 128-row (KT >= 2) or 256-row (KT = 1)
@@ -1369,12 +1646,16 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
 // tile, twice the waves per SIMD) and prefetch distance 2; both were measured 0-18 % slower at every shard size
 // (32k..262k rows) and are not instantiated: the NT kernel is paced by its LDS/barrier structure and the clock the
 // chip holds, not by HBM latency.
-template <int MODE>
+template <int MODE, typename TX = float>
 int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
 #define NT_CASE(KT_, MT_, NW_, KS_)                                                               \
-    return fast ? launch_nt_inst<KT_, MT_, NW_, KS_, true, MODE>(a, nsplit, st)                    \
-                : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE>(a, nsplit, st);
-    if (kt == 1) { NT_CASE(1, 2, 4, 1) }
+    return fast ? launch_nt_inst<KT_, MT_, NW_, KS_, true, MODE, TX>(a, nsplit, st)                \
+                : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE, TX>(a, nsplit, st);
+    if constexpr (std::is_same<TX, bf16_t>::value) {
+        if (kt == 1) { NT_CASE(1, 1, 4, 1) }        // 128-row tile: 48 KiB of LDS per workgroup -> 3 per CU
+    } else {
+        if (kt == 1) { NT_CASE(1, 2, 4, 1) }
+    }
     if (kt == 2) { NT_CASE(2, 1, 4, 1) }
     if (kt == 4) { NT_CASE(4, 1, 4, 1) }
 #undef NT_CASE
@@ -1385,7 +1666,7 @@ inline int nt_rows_per_tile(int kt) { return kt == 1 ? 256 : 128; }
 inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
 inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
 
-template <int MODE>
+template <int MODE, typename TY = float>
 int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     const long waves = (long)a.nchunks * a.ncolblk;
     const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
@@ -1394,9 +1675,9 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     static const bool nty = !(getenv("DNMF_TN_NT") && atoi(getenv("DNMF_TN_NT")) == 0);
 #define TN_CASE(KT_, NT_)                                                                                \
     if (kt == KT_) {                                                                                     \
-        if (fast && nty) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, true>), grid, block, 0, st, a); \
-        else if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE>), grid, block, 0, st, a);      \
-        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, MODE>), grid, block, 0, st, a);              \
+        if (fast && nty) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, true, TY>), grid, block, 0, st, a); \
+        else if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, false, TY>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, MODE, false, TY>), grid, block, 0, st, a);          \
         return check_launch("tn_kernel");                                                                \
     }
     TN_CASE(1, 4)
@@ -1575,7 +1856,15 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
                          (float*)((char*)ws + pbytes), st);
 }
 
-int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
+}  // extern "C"  (typed implementations shared by the fp32 and the bf16-A entry points)
+namespace {
+// alignment the vector path needs from A: 16 B for fp32 rows, 8 B for bf16 rows (4 elements per lane either way)
+template <typename TA> bool a_aligned(const TA* A) { return ((uintptr_t)A % (4 * sizeof(TA))) == 0; }
+// the NT form reads 16 B per lane from A whatever its type: bf16 rows need lda % 8 == 0 and a 16-byte aligned base
+template <typename TA> bool a_rows16(const TA* A, long lda) { return aligned16(A) && (lda * sizeof(TA)) % 16 == 0; }
+
+template <typename TA>
+int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
              void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldh >= n && ldah >= k, "aht: bad arguments");
@@ -1584,11 +1873,12 @@ int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, lo
     a.Y = H; a.ldy = ldh; a.yrows = k;
     a.cols_per_split = round_up(n, BK);
     a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
-    const bool fast = aligned16(A) && aligned16(H) && lda % 4 == 0 && ldh % 4 == 0 && n % 4 == 0;
-    return launch_nt<NT_STORE>(kt, fast, a, 1, S(stream));
+    const bool fast = a_rows16(A, lda) && aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
+    return launch_nt<NT_STORE, TA>(kt, fast, a, 1, S(stream));
 }
 
-int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
+template <typename TA>
+int aht_update_w_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
                       float* W, long ldw, float eps, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
@@ -1597,9 +1887,28 @@ int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, 
     a.Y = H; a.ldy = ldh; a.yrows = k;
     a.cols_per_split = round_up(n, BK);
     a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
-    const bool fast = aligned16(A) && aligned16(H) && aligned16(W) && lda % 4 == 0 && ldh % 4 == 0 && n % 4 == 0 &&
+    const bool fast = a_rows16(A, lda) && aligned16(H) && aligned16(W) && ldh % 4 == 0 && n % 4 == 0 &&
                       ldw % 4 == 0 && k % 4 == 0;
-    return launch_nt<NT_FUSED_W>(kt, fast, a, 1, S(stream));
+    return launch_nt<NT_FUSED_W, TA>(kt, fast, a, 1, S(stream));
+}
+}  // namespace
+extern "C" {
+
+int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
+             void* stream) {
+    return aht_impl<float>(A, m, n, lda, H, k, ldh, AH, ldah, stream);
+}
+int dnmf_aht_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
+                   void* stream) {
+    return aht_impl<bf16_t>((const bf16_t*)A, m, n, lda, H, k, ldh, AH, ldah, stream);
+}
+int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
+                      float* W, long ldw, float eps, void* stream) {
+    return aht_update_w_impl<float>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
+}
+int dnmf_aht_update_w_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
+                            float* W, long ldw, float eps, void* stream) {
+    return aht_update_w_impl<bf16_t>((const bf16_t*)A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
 }
 
 int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
@@ -1622,7 +1931,10 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
     return check_launch("mu_update_w");
 }
 
-int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+}  // extern "C"
+namespace {
+template <typename TA>
+int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
              void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldw >= k && ldatw >= n, "wta: bad arguments");
@@ -1635,11 +1947,22 @@ int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, lo
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
     a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
     a.P = (float*)ws; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
-    const bool fast = aligned16(A) && aligned16(W) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0;
-    int rc = launch_tn<TN_PARTIAL>(kt, fast, a, S(stream));
+    const bool fast = a_aligned(A) && aligned16(W) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0;
+    int rc = launch_tn<TN_PARTIAL, TA>(kt, fast, a, S(stream));
     if (rc) return rc;
     return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n,
                          (float*)((char*)ws + pbytes), S(stream));
+}
+}  // namespace
+extern "C" {
+
+int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+             void* ws, size_t ws_bytes, void* stream) {
+    return wta_impl<float>(A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
+}
+int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+                   void* ws, size_t ws_bytes, void* stream) {
+    return wta_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
 }
 
 int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
@@ -1682,16 +2005,28 @@ int dnmf_scale_rows_mul(float* H, int k, long n, long ldh, const float* s, void*
     return check_launch("scale_rows_mul");
 }
 
-int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* stream) {
+}  // extern "C"
+namespace {
+template <typename TA>
+int sqnorm_impl(const TA* A, long m, long n, long lda, double* out, void* stream) {
     REQUIRE(A && out && m >= 1 && n >= 1 && lda >= n, "sqnorm: bad arguments");
     hipStream_t st = S(stream);
     if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "sqnorm: memset failed");
-    const bool fast = aligned16(A) && lda % 4 == 0 && n % 4 == 0;
+    const bool fast = a_aligned(A) && lda % 4 == 0 && n % 4 == 0;
     const long work = fast ? m * (n / 4) : m * n;
     const unsigned grid = (unsigned)std::min<long>(cdiv(work, 256), 2048);
-    if (fast) hipLaunchKernelGGL(sqnorm_kernel<true>, dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
-    else hipLaunchKernelGGL(sqnorm_kernel<false>, dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    if (fast) hipLaunchKernelGGL((sqnorm_kernel<true, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    else hipLaunchKernelGGL((sqnorm_kernel<false, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
     return check_launch("sqnorm");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* stream) {
+    return sqnorm_impl<float>(A, m, n, lda, out, stream);
+}
+int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void* stream) {
+    return sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, out, stream);
 }
 
 static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
@@ -1707,24 +2042,38 @@ static bool nn_fast(const float* A, long n, long lda, const float* W, long ldw, 
            ldh % 4 == 0;
 }
 
-int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+}  // extern "C"
+namespace {
+template <typename TA>
+int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                       int k, double* out, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
     hipStream_t st = S(stream);
     if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
-    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, 0.f);
+    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
     a.out = out;
-    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
+    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
     const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
 #define RS_CASE(KT_)                                                                   \
     if (kt == KT_) {                                                                   \
-        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((resid_kernel<KT_, false>), grid, block, 0, st, a);    \
+        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true, TA>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((resid_kernel<KT_, false, TA>), grid, block, 0, st, a);    \
     }
     RS_CASE(1) RS_CASE(2) RS_CASE(4)
 #undef RS_CASE
     return check_launch("resid_sqnorm");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, double* out, void* stream) {
+    return resid_sqnorm_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, out, stream);
+}
+int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                            int k, double* out, void* stream) {
+    return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream);
 }
 
 struct UhtPlan { int nsplit; long cols_per_split; };
@@ -1890,7 +2239,10 @@ int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long
     return check_launch("hals_update_h");
 }
 
-int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+}  // extern "C"
+namespace {
+template <typename TA>
+int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
                      float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_fro_step: bad arguments");
@@ -1904,14 +2256,25 @@ int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ld
     int rc;
     if (w_update) {                                                                   // dist_nmf.py:716-732
         if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
-        if ((rc = dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
+        if ((rc = aht_update_w_impl<TA>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
     }
     const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
     if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
-    if ((rc = dnmf_wta(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream))) return rc;
+    if ((rc = wta_impl<TA>(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream))) return rc;
     if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
     return DNMF_OK;
+}
+}  // namespace
+extern "C" {
+
+int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+                     float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    return mu_fro_step_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
+}
+int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+                           float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    return mu_fro_step_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
 }
 
 int dnmf_mu_kl_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,

@@ -65,7 +65,8 @@ class data_read:
             self.read_file_npy()
         else:
             raise ValueError("unknown ftype '%s' (npy/csv/txt/mat/folder)" % self.ftype)
-        return np.ascontiguousarray(self.data).astype(self.precision)
+        prec = 'float32' if str(self.precision).lower() in ('bfloat16', 'bf16') else self.precision
+        return np.ascontiguousarray(self.data).astype(prec)   # bf16: numpy has no such dtype; PyNMF rounds on upload
 
 
 class read_factors:

@@ -2,7 +2,9 @@
 
 PyTorch is plumbing here: it owns device memory and the stream; every arithmetic operation
 of the hot path runs in libdnmf_hip.so.  All tensors must be float32, on a CUDA device and
-row-major with unit inner stride; anything else raises (no silent host fallback).
+row-major with unit inner stride; anything else raises (no silent host fallback).  The one
+exception is the data matrix A of the Frobenius paths, which may be STORED as bfloat16 (the
+`*_bf16a` entry points: half the HBM bytes, fp32 arithmetic).
 """
 import torch
 
@@ -21,6 +23,20 @@ def _req(t, name, ndim=2):
     if t.dim() != ndim or (t.numel() and t.stride(-1) != 1):
         raise ValueError("%s: must be %d-D row-major with unit inner stride" % (name, ndim))
     return t
+
+
+def _req_a(t, name="A"):
+    """The data matrix: float32, or bfloat16 STORAGE (Frobenius paths only; arithmetic stays float32)."""
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16:
+        if t.dim() != 2 or (t.numel() and t.stride(-1) != 1):
+            raise ValueError("%s: must be 2-D row-major with unit inner stride" % name)
+        return "_bf16a"
+    _req(t, name)
+    return ""
+
+
+def _fn(base, sfx):
+    return getattr(lib, "dnmf_" + base + sfx)
 
 
 def _ld(t):
@@ -78,18 +94,18 @@ class HipOps:
 
     # ---- big contractions
     def aht(self, A, H, out):
-        _req(A, "A"); _req(H, "H"); _req(out, "AH")
+        sfx = _req_a(A); _req(H, "H"); _req(out, "AH")
         m, n = A.shape
         k = H.shape[0]
-        check(lib.dnmf_aht(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), _stream()))
+        check(_fn("aht", sfx)(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), _stream()))
         return out
 
     def wta(self, A, W, out):
-        _req(A, "A"); _req(W, "W"); _req(out, "AtW")
+        sfx = _req_a(A); _req(W, "W"); _req(out, "AtW")
         m, n = A.shape
         k = W.shape[1]
         ws = workspace(m, n, k, A.device)
-        check(lib.dnmf_wta(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
+        check(_fn("wta", sfx)(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
                            ws.data_ptr(), ws.numel(), _stream()))
         return out
 
@@ -107,18 +123,18 @@ class HipOps:
                                    int(bool(clamp)), _stream()))
 
     def aht_update_w(self, A, H, G, W, eps):
-        _req(A, "A"); _req(H, "H"); _req(G, "G"); _req(W, "W")
+        sfx = _req_a(A); _req(H, "H"); _req(G, "G"); _req(W, "W")
         m, n = A.shape
         k = H.shape[0]
-        check(lib.dnmf_aht_update_w(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
+        check(_fn("aht_update_w", sfx)(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
                                     _ld(W), float(eps), _stream()))
 
     def mu_fro_step(self, A, W, H, eps, w_update=True, clamp=False):
-        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        sfx = _req_a(A); _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
         ws = workspace(m, n, k, A.device)
-        check(lib.dnmf_mu_fro_step(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+        check(_fn("mu_fro_step", sfx)(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
                                    float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
                                    _stream()))
 
@@ -219,15 +235,15 @@ class HipOps:
         check(lib.dnmf_scale_rows_mul(H.data_ptr(), H.shape[0], H.shape[1], _ld(H), s.data_ptr(), _stream()))
 
     def sqnorm(self, A):
-        _req(A, "A")
+        sfx = _req_a(A)
         out = torch.empty(1, dtype=torch.float64, device=A.device)
-        check(lib.dnmf_sqnorm(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), out.data_ptr(), _stream()))
+        check(_fn("sqnorm", sfx)(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), out.data_ptr(), _stream()))
         return out
 
     def resid_sqnorm(self, A, W, H):
-        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        sfx = _req_a(A); _req(W, "W"); _req(H, "H")
         out = torch.empty(1, dtype=torch.float64, device=A.device)
-        check(lib.dnmf_resid_sqnorm(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), W.data_ptr(), _ld(W), H.data_ptr(),
+        check(_fn("resid_sqnorm", sfx)(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), W.data_ptr(), _ld(W), H.data_ptr(),
                                     _ld(H), W.shape[1], out.data_ptr(), _stream()))
         return out
 

@@ -9,7 +9,9 @@ eps when i % 10 == 0 (after that step's update), and on the last step column-nor
 Everything numeric runs in libdnmf_hip.so; there is no CPU path.
 
 Differences from the reference, all deliberate and documented in DESIGN.md:
-  * compute dtype is float32 (the engine's only dtype); float64 input raises;
+  * compute dtype is float32 (the engine's only dtype); float64 input raises; `params.precision = 'bfloat16'` (or a
+    bfloat16 tensor) keeps the data block in HBM as bf16 -- storage only, Frobenius mu / hals -- with W, H and every
+    product in float32: the fit equals the float32 fit of the bf16-rounded data (BASELINE config 5);
   * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' is not provided; init is 'rand' or 'nnsvd' (1D grids);
   * `prune=True` (the reference's default when the attribute is absent) drops all-zero rows / columns before the
     iterations and scatters the factors back afterwards; they stay float32 (the reference hands back float64).
@@ -21,14 +23,25 @@ from .dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
 from .utils import data_operations, var_init
 
 
-def _to_device(x, device):
+def _to_device(x, device, dtype=torch.float32):
     if isinstance(x, torch.Tensor):
         t = x
     else:
         t = torch.from_numpy(np.ascontiguousarray(x))
     if t.dtype == torch.float64:
         raise TypeError("PyNMF: float64 input; the MI355X engine computes in float32 -- cast with .astype('float32')")
-    return t.to(device=device, dtype=torch.float32).contiguous()
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+def storage_dtype(A_ij, params):
+    """How the data block is held in HBM: float32, or bfloat16 when `params.precision` says so ('bfloat16' / 'bf16')
+    or the caller hands over a bfloat16 tensor.  bf16 is storage only -- W, H and all arithmetic stay float32."""
+    prec = getattr(params, "precision", None)
+    if isinstance(prec, str) and prec.lower() in ("bfloat16", "bf16") or prec is torch.bfloat16:
+        return torch.bfloat16
+    if isinstance(A_ij, torch.Tensor) and A_ij.dtype == torch.bfloat16:
+        return torch.bfloat16
+    return torch.float32
 
 
 class PyNMF:
@@ -46,7 +59,8 @@ class PyNMF:
         else:
             device = A_ij.device if isinstance(A_ij, torch.Tensor) else torch.device("cpu")
         self.device = device
-        self.A_ij = _to_device(A_ij, device)
+        self.a_dtype = storage_dtype(A_ij, params)
+        self.A_ij = _to_device(A_ij, device, self.a_dtype)
         self.params = params
         self.m_loc, self.n_loc = self.A_ij.shape
         self.init = self.params.init if getattr(self.params, "init", None) else 'rand'
@@ -63,6 +77,8 @@ class PyNMF:
         self.params.eps = self.eps
         self.norm = var_init(self.params, 'norm', default='kl')     # :70
         self.method = var_init(self.params, 'method', default='mu')
+        if self.a_dtype == torch.bfloat16 and str(self.norm).lower() == 'kl':
+            raise TypeError("PyNMF: bfloat16 storage of A is provided for the Frobenius updates (mu / hals) only")
         self.prune = var_init(self.params, 'prune', default=True)
         self.save_factors = save_factors
         self.params.itr = var_init(self.params, 'itr', default=5000)

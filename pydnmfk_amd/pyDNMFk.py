@@ -43,8 +43,8 @@ class sample:
         if isinstance(self.X, torch.Tensor):
             g = torch.Generator(device=self.X.device)
             g.manual_seed(0 if self.seed is None else int(self.seed))
-            M = torch.rand(self.X.shape, dtype=self.X.dtype, device=self.X.device, generator=g)
-            self.X_per = self.X * (2 * nv * M + nv + 1)
+            M = torch.rand(self.X.shape, dtype=torch.float32, device=self.X.device, generator=g)
+            self.X_per = (self.X * (2 * nv * M + nv + 1)).to(self.X.dtype)   # bf16 storage: perturb in fp32, round once
         else:
             M = 2 * nv * np.random.random_sample(self.X.shape).astype(self.X.dtype) + nv
             self.X_per = np.multiply(self.X, M + 1)
@@ -53,7 +53,7 @@ class sample:
         if isinstance(self.X, torch.Tensor):
             g = torch.Generator(device=self.X.device)
             g.manual_seed(0 if self.seed is None else int(self.seed))
-            self.X_per = torch.poisson(self.X, generator=g)
+            self.X_per = torch.poisson(self.X.float(), generator=g).to(self.X.dtype)
         else:
             self.X_per = np.random.poisson(self.X).astype(self.X.dtype)
 
