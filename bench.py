@@ -104,9 +104,14 @@ def pmc_traffic_bytes():
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        for name, c in d.items():
-            if name.startswith("nt_kernel<2,") and name.rstrip().endswith(", 1>") and "hbm_bytes" in c:
-                best = {"bytes": c["hbm_bytes"], "source": os.path.basename(f)}
+        # the k = 64 (KT = 2) NT instantiations of the step: the gram H H^T launch only reads H, the fused
+        # A H^T + W-update launch streams A -> it is the one with the most HBM bytes (template argument lists
+        # change between rounds, so the kernel is picked by role, not by its exact name)
+        cand = [(c["hbm_bytes"], name) for name, c in d.items()
+                if name.startswith("nt_kernel<2,") and isinstance(c, dict) and "hbm_bytes" in c]
+        if cand:
+            by, name = max(cand)
+            best = {"bytes": by, "source": os.path.basename(f), "kernel": name}
     return best
 
 
@@ -130,10 +135,7 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
+        dist.init_process_group(a.backend)      # nccl = RCCL; communicators are created lazily on the current device
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -159,20 +161,26 @@ def main():
     if world > 1:
         H = comms.comm.bcast(H, root=0)
 
+    def barrier():
+        if a.backend == "nccl":
+            dist.barrier(device_ids=[local])
+        else:
+            dist.barrier()
+
     def step(i):
         nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
 
     for i in range(a.warmup):
         step(i)
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -263,7 +271,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, k, m)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

@@ -182,7 +182,10 @@ class MPI_comm:
         mine = None
         for ranks in groups:                                   # new_group is collective over the world
             world = [self.comm.ranks[r] for r in ranks]
-            g = dist.new_group(world) if (self.size > 1 and len(world) > 1) else None
+            whole = len(world) == self.size                    # a 1D grid's long axis: reuse the parent group
+            g = dist.new_group(world) if (self.size > 1 and len(world) > 1 and not whole) else None
+            if whole:
+                g = self.comm.group
             if self.rank in ranks:
                 if self.size == 1:
                     mine = TorchComm(None)
