@@ -334,6 +334,34 @@ __device__ __forceinline__ void dma_tile(float* tile, const float* __restrict__ 
     }
 }
 
+// sum the contraction slices of a KS > 1 workgroup: slice s > 0 parks its accumulators in LDS (lane-contiguous, conflict
+// free), slice 0 adds them in slice order.  Needs NRG*MT*KT*1024*(KS-1) floats of LDS.
+template <int KT, int MT, int NRG, int KS>
+__device__ __forceinline__ void sum_slices(f32x16 (&acc)[MT][KT], float* smem, int rg, int ks, int lane) {
+    if (ks > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[((((ks - 1) * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane] = acc[mt][jt][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mt][jt][r] += smem[(((q * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane];
+    }
+    __syncthreads();
+}
+
 // acc[mt][jt] += X[row0 + rg*32*MT + mt*32 + .][cbeg:cend] . Y[jt*32 + .][cbeg:cend]^T
 // NW waves per workgroup = (NW / KS) row groups x KS contraction slices: with KS = 2 the two waves that share a row
 // group each take half of every k-tile's fragment groups and the partial accumulators are summed through LDS at the
@@ -475,31 +503,91 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
         }   // register-staged path
     }
     if constexpr (KS > 1) {
-        // sum the contraction slices: slice s > 0 parks its accumulators in LDS (lane-contiguous, conflict free),
-        // slice 0 adds them in slice order.  NRG*MT*KT*1024 floats <= 2*STAGE for every instantiated shape.
         static_assert(NRG * MT * KT * 1024 * (KS - 1) <= 2 * STAGE, "reduction buffer exceeds the staging LDS");
-        if (ks > 0) {
+        sum_slices<KT, MT, NRG, KS>(acc, smem, rg, ks, lane);
+    }
+}
+
+
+// Interior tiles, two k-tiles in flight (fp32 X).  The PF = 1 loop above keeps ONE tile of loads in flight per
+// workgroup; a shard with only as many row tiles as CUs (m_l = 32768: one 4-wave workgroup per CU) is then paced by
+// the HBM latency, not by the MFMAs (MFMA busy 65 % vs 83 % with two workgroups per CU).  Here the loads of tile t+2
+// are issued at the top of tile t into a second register set, and the tile that arrived one tile ago is written to
+// the other LDS stage BEFORE the last fragment group, so its ds_writes and the barrier overlap MFMAs.  The loop body
+// is branch-free (two tiles per trip, prefetches past the end clamp to the last tile and are never used): with
+// conditional loads hipcc drains vmcnt(0) at every join and the second tile in flight is lost.
+template <int KT, int MT, int NW, int KS, bool STAGGER, bool NTX>
+__device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
+                                               const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem) {
+    constexpr int NRG = NW / KS, BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
+    constexpr int STAGE = (BM + KP) * BK, NS = BK / 8 / KS;   // NS = fragment groups per tile of ONE wave (slice ks)
+    constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int rg = wave % NRG, ks = wave / NRG;
+    f32x4 x0[NPX], y0[NPY], x1[NPX], y1[NPY];
+    const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
+    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long kt) {
+        kt = kt < nk ? kt : nk - 1;
+        kt += kshift;
+        kt = kt >= nk ? kt - nk : kt;
+        const long c0 = cbeg + kt * BK;
+        stage_load<BM, T, true, true, NTX>(xr, X, ldx, 0, 0, row0, c0, tid);
+        stage_load<KP, T, true, true>(yr, Y, ldy, KP, 0, 0, c0, tid);
+    };
+    auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
+        stage_store<BM, T>(st, xr, tid);
+        stage_store<KP, T>(st + BM * BK, yr, tid);
+    };
+    auto group = [&](const float* xc, int sl) {
+        const float* yc = xc + BM * BK;
+        const int s = ks * NS + sl;
+        f32x4 a[MT], b[KT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(rg * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+            b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int jt = 0; jt < KT; ++jt)
+                for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
+    };
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    load(x0, y0, 0);
+    store(st0, x0, y0);
+    __syncthreads();
+    load(x1, y1, 1);
+    long kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        load(x0, y0, kt + 2);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        smem[((((ks - 1) * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane] = acc[mt][jt][r];
-        }
+        for (int s = 0; s < NS - 1; ++s) group(st0, s);
+        __builtin_amdgcn_sched_barrier(0);
+        store(st1, x1, y1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(st0, NS - 1);
         __syncthreads();
-        if (ks == 0) {
+        load(x1, y1, kt + 3);
 #pragma unroll
-            for (int q = 0; q < KS - 1; ++q)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int jt = 0; jt < KT; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[mt][jt][r] += smem[(((q * NRG + rg) * MT + mt) * KT + jt) * 1024 + r * 64 + lane];
-        }
+        for (int s = 0; s < NS - 1; ++s) group(st1, s);
+        __builtin_amdgcn_sched_barrier(0);
+        store(st0, x0, y0);
+        __builtin_amdgcn_sched_barrier(0);
+        group(st1, NS - 1);
         __syncthreads();
+    }
+    if (kt < nk) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) group(st0, s);
+        __syncthreads();
+    }
+    if constexpr (KS > 1) {
+        static_assert(NRG * MT * KT * 1024 * (KS - 1) <= 2 * STAGE, "reduction buffer exceeds the staging LDS");
+        sum_slices<KT, MT, NRG, KS>(acc, smem, rg, ks, lane);
     }
 }
 
@@ -510,8 +598,14 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __r
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
-    if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
-    else nt_mainloop_<KT, MT, NW, KS, FAST, PF, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    constexpr int PF1 = PF == 3 ? 1 : PF;
+    if constexpr (PF == 3 && std::is_same<TX, float>::value) {
+        if (interior) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    } else {
+        if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    }
 }
 
 
@@ -685,7 +779,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
             static_assert(KS == 1, "bf16 X: one contraction slice");
             nt_mainloop_b16<KT, MT, NW, FAST, (PF == 5), (PF == 5)>(acc, static_cast<const bf16_t*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
         } else {
-            nt_mainloop<KT, MT, NW, KS, FAST, 1, (PF == 5 || PF == 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+            nt_mainloop<KT, MT, NW, KS, FAST, (PF == 10 ? 3 : 1), (PF == 5 || PF >= 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
         }
     }
 
@@ -1623,46 +1717,51 @@ int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE, typename TX>
 int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
-    // PF code (experiment switch DNMF_NT_PF): 1 = prefetch distance 1, in-order tiles | 2 = distance 2 |
-    // 3 = 1 + rotated tile order per workgroup | 4 = 2 + rotation | 5 = 3 + nontemporal loads of the streamed operand
-    // (default) | 6 = 1 + nontemporal.  Measured (tools/kbench.py, k = 64, n = 8192): 262144 rows 2.54 / 2.51 / 2.42 /
-    // 2.53 ms for codes 1 / 3 / 5 / 6, 65536 rows 0.816 / 0.788 / 0.761 / 0.785 ms; HBM reads per launch (PMC) 8.67 /
-    // 10.99 / 8.47 / 8.50 GB: the rotation alone lets the streamed A evict H from L2, the nontemporal hint fixes that.
-    // Codes 1, 5 and 7 are compiled in.  7 = 5 with LDS-DMA staging (global_load_lds, no staging VGPRs / ds_write):
-    // correct, and within +-2 % of 5 at every size.  Timing-only diagnostics (not kept) showed that dropping the LDS
-    // fragment reads or the per-tile barrier does not speed the kernel up either, and that with X cache-resident it
-    // reaches 126-133 TFLOP/s: what remains is the clock the chip holds under MFMA + HBM load (~2.0 GHz).
-    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 5;
+    // PF code (switch DNMF_NT_PF for A/B runs) -- what the interior tiles of the streamed operand do:
+    //   1  loads of k-tile t+1 issued at the top of tile t, tiles in order (also the generic / edge path)
+    //   5  1 + every workgroup starts at a different k-tile (rotated order) + nontemporal loads of A
+    //   7  5 with LDS-DMA staging (global_load_lds: no staging VGPRs, no ds_write)
+    //  10  5 with TWO k-tiles in flight and a branch-free loop (nt_mainloop_p2) -- the default
+    // Measured on MI355X (tools/kbench.py, k = 64, n = 8192; ms at 262144 / 65536 / 32768 rows):
+    //   1: 2.54 / 0.82 / -     5: 2.42-2.49 / 0.76 / 0.44     7: +-2 % of 5     10: 2.43-2.47 / 0.76 / 0.40
+    // HBM reads per launch at 262144 rows (PMC): 8.67 GB for 1, 10.99 GB with the rotation alone (the streamed A evicts
+    // H from L2), 8.47 GB with the nontemporal hint on top.  What did NOT help (measured, not kept): a prefetch
+    // distance of 2 with conditional loads (hipcc then drains vmcnt(0) at every join: 0-18 % slower), fragment reads
+    // one group ahead in a second register set (-0..4 %), 8-wave workgroups with two contraction slices (+-3 %),
+    // 64-row tiles, capping workgroups per CU through the LDS request (+-5 %).  With A cache-resident the same
+    // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-87 / 91 / 113 from HBM, while
+    // the TN form loses only 2-8 %: the remaining gap is the memory system under this access shape (128 B per row
+    // per visit, 128 rows apart by the 32 KiB row pitch), not the instruction schedule.
+    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 10;
     if constexpr (FAST && KS == 1) if (MODE == NT_FUSED_W || !a.store_all) {
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
-        if constexpr (std::is_same<TX, float>::value)
-            if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7, TX>(a, nsplit, st);   // 5 + LDS-DMA staging
+        if constexpr (std::is_same<TX, float>::value) {
+            if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7, TX>(a, nsplit, st);
+            if (pf == 10) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 10, TX>(a, nsplit, st);
+        } else {
+            if (pf == 10) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);   // bf16 X: one 64-wide tile in flight
+        }
     }
     return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 1, TX>(a, nsplit, st);
 }
 
-// Tile configuration per padded rank (KT = KP/32); every configuration has a 128-row (KT >= 2) or 256-row (KT = 1)
-// tile.  The kernel template also supports an 8-wave form with two contraction slices per row group (KS = 2: same
-// tile, twice the waves per SIMD) and prefetch distance 2; both were measured 0-18 % slower at every shard size
-// (32k..262k rows) and are not instantiated: the NT kernel is paced by its LDS/barrier structure and the clock the
-// chip holds, not by HBM latency.
+// Tile configuration per padded rank (KT = KP/32).  The kernel template also supports 8-wave workgroups with two contraction slices per row group (KS = 2: same
+// tile, twice the waves per SIMD); measured within +-3 % of the 4-wave form at every shard size and not instantiated.
 template <int MODE, typename TX = float>
 int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
 #define NT_CASE(KT_, MT_, NW_, KS_)                                                               \
     return fast ? launch_nt_inst<KT_, MT_, NW_, KS_, true, MODE, TX>(a, nsplit, st)                \
                 : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE, TX>(a, nsplit, st);
-    if constexpr (std::is_same<TX, bf16_t>::value) {
-        if (kt == 1) { NT_CASE(1, 1, 4, 1) }        // 128-row tile: 48 KiB of LDS per workgroup -> 3 per CU
-    } else {
-        if (kt == 1) { NT_CASE(1, 2, 4, 1) }
-    }
+    // 128-row tiles for every rank.  (k <= 32 used 256-row tiles, MT = 2, in an earlier version: equal at 262144 rows,
+    // 1.8x slower at 32768 rows where it left half the CUs without a workgroup.)
+    if (kt == 1) { NT_CASE(1, 1, 4, 1) }
     if (kt == 2) { NT_CASE(2, 1, 4, 1) }
     if (kt == 4) { NT_CASE(4, 1, 4, 1) }
 #undef NT_CASE
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }
 
-inline int nt_rows_per_tile(int kt) { return kt == 1 ? 256 : 128; }
+inline int nt_rows_per_tile(int) { return 128; }
 inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
 inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
 
