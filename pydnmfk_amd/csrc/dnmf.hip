@@ -261,6 +261,7 @@ struct NtArgs {
     long cols_per_split;                               // contraction range per blockIdx.y (multiple of BK)
     float* out; long ldo; long split_stride; int store_all;
     float* W; long ldw; const float* G; float eps; int k;   // NT_FUSED_W
+    int wfast;                                              // NT_FUSED_W: rows of W are 16-byte aligned (k, ldw % 4 == 0)
 };
 
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
@@ -805,7 +806,9 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
             for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][jt][r] = 0.f;
-        nt_mainloop<KT, MT, NW, KS, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        // W's alignment is independent of A's (an NMFk sweep visits k = 2, 3, 5 ...): block-uniform choice
+        if (FAST && p.wfast) nt_mainloop<KT, MT, NW, KS, FAST>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        else nt_mainloop<KT, MT, NW, KS, false>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
         if (KS > 1 && ks != 0) return;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -1986,8 +1989,8 @@ int aht_update_w_impl(const TA* A, long m, long n, long lda, const float* H, int
     a.Y = H; a.ldy = ldh; a.yrows = k;
     a.cols_per_split = round_up(n, BK);
     a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
-    const bool fast = a_rows16(A, lda) && aligned16(H) && aligned16(W) && ldh % 4 == 0 && n % 4 == 0 &&
-                      ldw % 4 == 0 && k % 4 == 0;
+    const bool fast = a_rows16(A, lda) && aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
+    a.wfast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
     return launch_nt<NT_FUSED_W, TA>(kt, fast, a, 1, S(stream));
 }
 }  // namespace
@@ -2046,7 +2049,9 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
     a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
     a.P = (float*)ws; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
-    const bool fast = a_aligned(A) && aligned16(W) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0;
+    // the streamed A is read 4 elements per lane, W only KT per lane (1 float for k <= 32): W's alignment need is KT-wide
+    const bool fast = a_aligned(A) && lda % 4 == 0 && n % 4 == 0 &&
+                      ((uintptr_t)W % (4 * kt)) == 0 && ldw % kt == 0 && k % kt == 0;
     int rc = launch_tn<TN_PARTIAL, TA>(kt, fast, a, S(stream));
     if (rc) return rc;
     return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n,
@@ -2286,16 +2291,21 @@ int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* Sm, long ld
     return check_launch("kl_update_h");
 }
 
-int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
-                    const double* prev_ss2, float eps, double* ss2_out, void* stream) {
+static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                             const double* prev_ss2, float eps, double* ss2_out, bool zero, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
     hipStream_t st = S(stream);
-    if (hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
+    if (zero && hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
     const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
     hipLaunchKernelGGL(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
                        eps, ss2_out);
     return check_launch("hals_w_col");
+}
+
+int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                    const double* prev_ss2, float eps, double* ss2_out, void* stream) {
+    return hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, prev_ss2, eps, ss2_out, true, stream);
 }
 
 int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream) {
@@ -2307,9 +2317,10 @@ int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, vo
 
 int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                        double* ss2, void* stream) {
-    REQUIRE(ss2 != nullptr, "hals_update_w: ss2 scratch (k doubles) required");
-    for (int kk = 0; kk < k; ++kk) {
-        int rc = dnmf_hals_w_col(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, stream);
+    REQUIRE(ss2 != nullptr && k >= 1, "hals_update_w: ss2 scratch (k doubles) required");
+    if (hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "hals_update_w: memset failed");
+    for (int kk = 0; kk < k; ++kk) {   // one launch per column: the column norm is a grid-wide dependency
+        int rc = hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, false, stream);
         if (rc) return rc;
     }
     return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
