@@ -18,15 +18,17 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def _stale():
     if not os.path.exists(LIB):
         return True
-    deps = [SRC, os.path.join(ROOT, "include", "dnmf.h")]
+    import glob
+    deps = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(ROOT, "include", "dnmf.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
 def build_lib(force=False, report=False):
-    """Compile csrc/dnmf.hip -> libdnmf_hip.so.  Returns the library path."""
+    """Compile csrc/dnmf.hip (one translation unit, kernels in csrc/dnmf_*.h) -> libdnmf_hip.so.  Returns the library path."""
     if not force and not report and not _stale():
         return LIB
     cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(HERE, "csrc"),
            "-shared", "-fPIC", "-o", LIB, SRC]
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")

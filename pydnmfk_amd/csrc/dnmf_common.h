@@ -1,0 +1,233 @@
+// dnmf_common.h -- types, error plumbing and the element loaders shared by every kernel family.
+// Part of libdnmf_hip.so (single translation unit: csrc/dnmf.hip includes every header once).
+#pragma once
+#include <type_traits>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "dnmf.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// bf16 STORAGE of the data matrix A (BASELINE config 5): A is held as bfloat16 in HBM (half the bytes of the HBM-bound
+// small-k regime), widened to fp32 in registers (exact: bf16 -> fp32 is a 16-bit shift) and fed to the same fp32 MFMAs.
+// W, H and every intermediate stay fp32.
+typedef unsigned short bf16_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------- errors
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// hipGetLastError is sticky per thread and shared with the host framework: clear before each launch sequence
+inline void clear_hip_error() { (void)hipGetLastError(); }
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DNMF_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return DNMF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+inline long round_up(long a, long b) { return cdiv(a, b) * b; }
+
+// C/D row of accumulator register `reg` for lane-half h
+__device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ----------------------------------------------------------------------------------------------- loads
+// V contiguous floats starting at column `col` of a row; zero outside [0, ncols).
+// FAST: col % V == 0, ncols % 4 == 0, row pointer 16-B aligned, so a vector is wholly in or out.
+template <int V, bool FAST>
+__device__ __forceinline__ void load_vec(float (&d)[V], const float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) {
+            if constexpr (V == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(row + col);
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            } else if constexpr (V == 2) {
+                f32x2 v = *reinterpret_cast<const f32x2*>(row + col);
+                d[0] = v[0]; d[1] = v[1];
+            } else {
+                d[0] = row[col];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (ok && col + e < ncols) ? row[col + e] : 0.f;
+    }
+}
+
+template <int V, bool FAST>
+__device__ __forceinline__ void store_vec(const float (&d)[V], float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) {
+            if constexpr (V == 4) {
+                f32x4 v = {d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<f32x4*>(row + col) = v;
+            } else if constexpr (V == 2) {
+                f32x2 v = {d[0], d[1]};
+                *reinterpret_cast<f32x2*>(row + col) = v;
+            } else {
+                row[col] = d[0];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            if (ok && col + e < ncols) row[col + e] = d[e];
+    }
+}
+
+// unconditional vector load of V floats (address must be valid)
+template <int V>
+__device__ __forceinline__ void load_vec_raw(float (&d)[V], const float* __restrict__ p) {
+    if constexpr (V == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else if constexpr (V == 2) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        d[0] = v[0]; d[1] = v[1];
+    } else {
+        d[0] = p[0];
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void load_vec_raw_nt(float (&d)[V], const float* __restrict__ p) {
+    if constexpr (V == 4) {
+        f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else if constexpr (V == 2) {
+        f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+        d[0] = v[0]; d[1] = v[1];
+    } else {
+        d[0] = __builtin_nontemporal_load(p);
+    }
+}
+
+// INTERIOR (compile time) = the caller has established, with ONE block/wave-uniform test, that every access of the tile is
+// in bounds: plain vector accesses, no per-lane exec-masked branches.  (hipcc serialises exec-masked loads: it
+// drains with vmcnt(0) at every branch join, so a tile of N predicated loads costs N memory latencies.)
+template <int V, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void load_tile_vec(float (&d)[V], const float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST && INTERIOR) load_vec_raw<V>(d, row + col);
+    else load_vec<V, FAST>(d, row, col, ncols, ok);
+}
+
+template <int V, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void store_tile_vec(const float (&d)[V], float* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST && INTERIOR) {
+        if constexpr (V == 4) *reinterpret_cast<f32x4*>(row + col) = f32x4{d[0], d[1], d[2], d[3]};
+        else if constexpr (V == 2) *reinterpret_cast<f32x2*>(row + col) = f32x2{d[0], d[1]};
+        else row[col] = d[0];
+    } else {
+        store_vec<V, FAST>(d, row, col, ncols, ok);
+    }
+}
+
+// bf16 flavours of the element loaders (V in {1, 2, 4}: 2 / 4 / 8 bytes per lane)
+template <int V>
+__device__ __forceinline__ void load_vec_raw(float (&d)[V], const bf16_t* __restrict__ p) {
+    if constexpr (V == 4) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+        d[0] = bf16_lo(w[0]); d[1] = bf16_hi(w[0]); d[2] = bf16_lo(w[1]); d[3] = bf16_hi(w[1]);
+    } else if constexpr (V == 2) {
+        const unsigned int w = *reinterpret_cast<const unsigned int*>(p);
+        d[0] = bf16_lo(w); d[1] = bf16_hi(w);
+    } else {
+        d[0] = bf16_lo((unsigned int)p[0]);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void load_vec_raw_nt(float (&d)[V], const bf16_t* __restrict__ p) {
+    if constexpr (V == 4) {
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+        d[0] = bf16_lo(w[0]); d[1] = bf16_hi(w[0]); d[2] = bf16_lo(w[1]); d[3] = bf16_hi(w[1]);
+    } else if constexpr (V == 2) {
+        const unsigned int w = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(p));
+        d[0] = bf16_lo(w); d[1] = bf16_hi(w);
+    } else {
+        d[0] = bf16_lo((unsigned int)__builtin_nontemporal_load(p));
+    }
+}
+
+// Raw<T, V>: V elements as they arrive from memory.  For bf16 the widening to fp32 is deferred to get(): a conversion
+// right after the load would make the wave wait for the load at once and undo the software prefetch.
+template <typename T, int V> struct Raw;
+template <int V> struct Raw<float, V> {
+    float v[V];
+    __device__ __forceinline__ void load(const float* __restrict__ p) { load_vec_raw<V>(v, p); }
+    __device__ __forceinline__ void load_nt(const float* __restrict__ p) { load_vec_raw_nt<V>(v, p); }
+    __device__ __forceinline__ void get(float (&d)[V]) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = v[e];
+    }
+};
+template <int V> struct Raw<bf16_t, V> {
+    unsigned int w[(V + 1) / 2];
+    template <bool NTL>
+    __device__ __forceinline__ void load_(const bf16_t* __restrict__ p) {
+        if constexpr (V == 4) {
+            const u32x2 x = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
+            w[0] = x[0]; w[1] = x[1];
+        } else if constexpr (V == 2) {
+            w[0] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(p)) : *reinterpret_cast<const unsigned int*>(p);
+        } else {
+            w[0] = NTL ? __builtin_nontemporal_load(p) : p[0];
+        }
+    }
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ p) { load_<false>(p); }
+    __device__ __forceinline__ void load_nt(const bf16_t* __restrict__ p) { load_<true>(p); }
+    __device__ __forceinline__ void get(float (&d)[V]) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (e & 1) ? bf16_hi(w[e >> 1]) : bf16_lo(w[e >> 1]);
+    }
+};
+
+template <int V, bool FAST>
+__device__ __forceinline__ void load_vec(float (&d)[V], const bf16_t* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST) {
+        if (ok && col < ncols) load_vec_raw<V>(d, row + col);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = (ok && col + e < ncols) ? bf16_lo((unsigned int)row[col + e]) : 0.f;
+    }
+}
+
+template <int V, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void load_tile_vec(float (&d)[V], const bf16_t* __restrict__ row, long col, long ncols, bool ok) {
+    if constexpr (FAST && INTERIOR) load_vec_raw<V>(d, row + col);
+    else load_vec<V, FAST>(d, row, col, ncols, ok);
+}
+
+}  // namespace

@@ -1,0 +1,315 @@
+// dnmf_nn.h -- NN-small-k form: S = W H tiles in accumulators (residual norm, the two KL products).
+// Part of libdnmf_hip.so (single translation unit: csrc/dnmf.hip includes every header once).
+#pragma once
+#include "dnmf_common.h"
+#include "dnmf_nt.h"
+
+namespace {
+
+// =============================================================================================== NN-small-k form
+// S[i][c] = sum_j W[i][j] H[j][c] computed tile-wise in accumulators, never stored:
+//   acc[mt][ne] (reg, lane) = S[i = row0 + mt*32 + crow(reg,h)] ... wait: here the MFMA M index is the A-row i,
+//   so C/D rows are i and C/D columns (lanes) are the data columns c = col0 + 4*li + ne.
+// Used for the residual norm (pyDNMF.py:205-218) and the KL H-side product W^T U (dist_nmf.py:806-808).
+enum { NN_RESID = 0, NN_KL_WTU = 1 };
+
+struct NnArgs {
+    const float* A; long lda; long m; long n;
+    const float* W; long ldw; const float* H; long ldh; int k;
+    float eps; double* out;                          // NN_RESID
+    float* P; long chunk_stride; long ldp;           // NN_KL_WTU partials [rowblk][KP][ldp]
+    long nrowblk; int ncolblk;
+};
+
+// S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
+template <int KT, int NT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void nn_tile(f32x16 (&acc)[NT], const float* __restrict__ W, long ldw, long m, int k,
+                                        const float* __restrict__ H, long ldh, long n, long row0, long col0, int li,
+                                        int h) {
+#pragma unroll
+    for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+    const long wrow = row0 + li;
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) {  // 8 contraction indices per step: jj = 8s + 4h + e
+        float a[4];
+        load_tile_vec<4, FAST, INTERIOR>(a, W + wrow * ldw, 8 * s + 4 * h, k, wrow < m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = 8 * s + 4 * h + e;
+            float b[NT];
+            load_tile_vec<NT, FAST, INTERIOR>(b, H + (long)jj * ldh, col0 + NT * li, n, jj < k);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
+        }
+    }
+}
+
+// INTERIOR: the W / H loads need no predication (k == KP and the tile is in bounds); AI: the A tile is in bounds
+template <int KT, bool FAST, bool INTERIOR, bool AI, typename TA>
+__device__ __forceinline__ float resid_tile(const NnArgs& p, long row0, long col0, int li, int h) {
+    f32x16 acc[4];
+    // bf16 A on the vector path: request the whole 32 x 128 tile (raw, 2 registers per row) BEFORE the W H product so
+    // its latency hides under the MFMAs; widened at the point of use.
+    constexpr bool PRE = FAST && AI && std::is_same<TA, bf16_t>::value;
+    Raw<TA, 4> araw[PRE ? 16 : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            araw[r].load_nt(reinterpret_cast<const TA*>(p.A) + (row0 + crow(r, h)) * p.lda + col0 + 4 * li);
+    }
+    nn_tile<KT, 4, FAST, INTERIOR>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        float a[4];
+        if constexpr (PRE) araw[r].get(a);
+        else load_tile_vec<4, FAST, AI>(a, reinterpret_cast<const TA*>(p.A) + row * p.lda, col0 + 4 * li, p.n, row < p.m);
+#pragma unroll
+        for (int ne = 0; ne < 4; ++ne) {
+            // rows >= m and cols >= n have a = 0 and acc = 0 (zero-filled operands) -> contribute 0
+            const float d = a[ne] - acc[ne][r];
+            part += d * d;
+        }
+    }
+    return part;
+}
+
+// TA = storage type of A (float, or bf16_t: p.A then carries the bf16 pointer reinterpreted)
+template <int KT, bool FAST, typename TA = float>
+__global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * 4 + wid;
+    double total = 0.0;
+    if (gw < p.nrowblk * p.ncolblk) {
+        const long rowblk = gw / p.ncolblk, colblk = gw % p.ncolblk;
+        const long row0 = rowblk * 32, col0 = colblk * 128;
+        const bool inb = FAST && row0 + 32 <= p.m && col0 + 128 <= p.n;
+        const bool interior = inb && p.k == 32 * KT;
+        // k < KP: W / H loads stay predicated.  Un-predicating only the A loads pays for bf16 (they are hoisted above
+        // the product, 3.8 -> 2.0 ms at 262144 x 8192, k = 16) but is slower for fp32 (2.3 -> 3.7 ms), so fp32 keeps them predicated.
+        const bool ai = inb && std::is_same<TA, bf16_t>::value;
+        total = (double)(interior ? resid_tile<KT, FAST, true, true, TA>(p, row0, col0, li, h)
+                         : ai     ? resid_tile<KT, FAST, false, true, TA>(p, row0, col0, li, h)
+                                  : resid_tile<KT, FAST, false, false, TA>(p, row0, col0, li, h));
+    }
+    block_atomic_sum(total, p.out);
+}
+
+// KL H-side: P[chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)          (dist_nmf.py:806,808)
+// A workgroup = 4 waves that share one block of CW = 32*NT columns and each own a chunk of 32-row blocks.  The
+// KP x CW block of H those columns need is loop invariant: it is staged ONCE per workgroup into LDS (row jj,
+// lane-contiguous columns -> conflict-free ds_read_b64/b128 as the B operand of S = W H).  Per row block a wave forms
+// S (NN tile), turns it into U in place (same C/D registers) and feeds U as the B operand of W^T U: the contraction
+// index i is the C/D row index, i.e. it lives in registers, which is exactly the B-operand layout (row pairs
+// (rho, rho+4)).  The A tile is requested before the S product so its latency hides under it.
+// one 32-row block of the KL H-side product (see kl_wtu_kernel); smem = the workgroup's KP x CW block of H
+template <int KT, int NT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs& p, const float* smem, long row0,
+                                             long col0, int li, int h) {
+    constexpr int CW = 32 * NT;
+    float areg[16][NT];   // A[row0 + crow(r,h)][col0 + NT*li + ne], requested first
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        load_tile_vec<NT, FAST, INTERIOR>(areg[r], p.A + row * p.lda, col0 + NT * li, p.n, row < p.m);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+    const long wrow = row0 + li;
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
+        float a[4];
+        load_tile_vec<4, FAST, INTERIOR>(a, p.W + wrow * p.ldw, 8 * s + 4 * h, p.k, wrow < p.m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = 8 * s + 4 * h + e;
+            float b[NT];
+            load_vec_raw<NT>(b, &smem[jj * CW + NT * li]);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(a[e], b[ne], acc[ne]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+    // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = row0 + crow(r, h);
+        float w[KT];
+        load_tile_vec<KT, FAST, INTERIOR>(w, p.W + row * p.ldw, (long)KT * li, p.k, row < p.m);
+#pragma unroll
+        for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) out[ke][ne] = MFMA32(w[ke], acc[ne][r], out[ke][ne]);
+    }
+}
+
+template <int KT, int NT, bool FAST>
+__global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = 32 * KT, CW = 32 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const long nchunks = cdiv(p.nrowblk, rowblks_per_chunk);
+    const long colblk = blockIdx.x % p.ncolblk;
+    const long chunk = (blockIdx.x / p.ncolblk) * 4 + wid;
+    const long col0 = colblk * CW;
+    // stage H[0:KP][col0:col0+CW] (zero outside k x n)
+    for (int idx = tid; idx < KP * (CW / 4); idx += 256) {
+        const int jj = idx / (CW / 4), c4 = (idx % (CW / 4)) * 4;
+        float d[4];
+        load_vec<4, FAST>(d, p.H + (long)jj * p.ldh, col0 + c4, p.n, jj < p.k);
+        *reinterpret_cast<f32x4*>(&smem[jj * CW + c4]) = f32x4{d[0], d[1], d[2], d[3]};
+    }
+    __syncthreads();
+    if (chunk >= nchunks) return;
+
+    f32x16 out[KT][NT];
+#pragma unroll
+    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[ke][ne][r] = 0.f;
+    long rb1 = (chunk + 1) * rowblks_per_chunk;
+    if (rb1 > p.nrowblk) rb1 = p.nrowblk;
+    // Measured: the branch-free (INTERIOR) form of this block is 8-20 % SLOWER here (its 16 A loads then issue as one
+    // VMEM block ahead of the MFMAs, cf. tn_mainloop); the predicated loads spread out.  Kept predicated until the
+    // block is software pipelined across row blocks.
+    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb)
+        kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
+    float* Pc = p.P + chunk * p.chunk_stride;
+#pragma unroll
+    for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = KT * crow(r, h) + ke;
+            float d[NT];
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) d[ne] = out[ke][ne][r];
+            store_vec<NT, true>(d, Pc + (long)j * p.ldp, col0 + (long)NT * li, p.ldp, true);
+        }
+}
+
+// KL W-side: UHT[i][j] = sum_c (A[i][c] / (S[i][c] + eps)) * H[j][c]                     (dist_nmf.py:806,810)
+// The contraction index c of the second product must end up in registers, so S is formed TRANSPOSED:
+//   S^T[c][i] = sum_jj H[jj][c] W[i][jj]   MFMA M index = c (A-operand lane (c,h) = H[jj][c]), N index = i (B-operand
+//   lane (i,h) = W[i][jj], the lane's own W row, held in registers for the whole kernel).
+// C/D then has lane = row i of A and registers = columns c; A is read in that layout (four 16-B pieces per lane and
+// 32-column tile, prefetched one tile ahead), U^T replaces S^T in place and is the B operand of
+//   (U H^T)^T[j][i] = sum_c H[j][c] U^T[c][i]   (A-operand lane (j,h) = H[j][c]).
+// Workgroup = 4 waves x 32 rows; the k x 32 tile of H is staged once per workgroup into LDS (same swizzled image as the
+// NT tiles: ds_read_b32 along a row for the first product, ds_read_b128 across rows for the second) and double
+// buffered, one barrier per tile.  blockIdx.y splits the columns; partial UHT slabs are summed by reduce_partials.
+template <int KT, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__ out_base, long ldo, long split_stride,
+                                            long cols_per_split, int out_cols, float* smem) {
+    constexpr int KP = 32 * KT, T = 256, STAGE = KP * BK, NY = KP / (T / 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const long arow = (long)blockIdx.x * 128 + wave * 32 + li;
+    const bool rok = arow < p.m;
+    const long cbeg = (long)blockIdx.y * cols_per_split;
+    long cend = cbeg + cols_per_split;
+    if (cend > p.n) cend = p.n;
+    const long nt = (cend - cbeg + BK - 1) / BK;
+
+    f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[jt][r] = 0.f;
+    float wreg[4 * KT][4];   // W[arow][8s + 4h + e]
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) load_tile_vec<4, FAST, INTERIOR>(wreg[s], p.W + arow * p.ldw, 8 * s + 4 * h, p.k, rok);
+
+    f32x4 hst[NY];
+    float a_cur[4][4];
+    const bool hrows_in = p.k >= KP;
+    if (nt > 0) {
+        if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
+        else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
+        stage_store<KP, T>(smem, hst, tid);
+        if (INTERIOR && cbeg + BK <= cend) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
+        }
+    }
+    __syncthreads();
+    for (long t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < nt;
+        const long c1 = cbeg + (t + 1) * BK;
+        const float* Hs = smem + cur * STAGE;
+        f32x16 st;  // S^T tile: rows c, lanes i
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = 8 * s + 4 * h + e;
+                const float hv = Hs[lds_idx(jj, li >> 2) + (li & 3)];
+                st = MFMA32(hv, wreg[s][e], st);
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[4 * g + e] = a_cur[g][e] / (st[4 * g + e] + p.eps);   // U^T (dist_nmf.py:806)
+        // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
+        if (more) {
+            if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
+            else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
+            if (INTERIOR && c1 + BK <= cend) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) load_vec<4, FAST>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) {
+                const f32x4 hh = *reinterpret_cast<const f32x4*>(&Hs[lds_idx(jt * 32 + li, 2 * g + h)]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[jt] = MFMA32(hh[e], st[4 * g + e], out[jt]);
+            }
+        if (more) stage_store<KP, T>(smem + (cur ^ 1) * STAGE, hst, tid);
+        __syncthreads();
+    }
+    // out[jt] (reg, lane): j = jt*32 + crow(reg, h), i = arow; registers 4g..4g+3 are 4 consecutive j
+    float* dst = out_base + (long)blockIdx.y * split_stride + arow * ldo;
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float d[4] = {out[jt][4 * g], out[jt][4 * g + 1], out[jt][4 * g + 2], out[jt][4 * g + 3]};
+            store_tile_vec<4, FAST, INTERIOR>(d, dst, jt * 32 + 8 * g + 4 * h, out_cols, rok);
+        }
+}
+
+template <int KT, bool FAST>
+__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, float* __restrict__ out_base, long ldo,
+                                                        long split_stride, long cols_per_split, int out_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // block-uniform: all 128 rows in bounds and no rank padding -> branch-free W / A / output accesses
+    const bool interior = FAST && p.k == 32 * KT && ((long)blockIdx.x + 1) * 128 <= p.m && out_cols >= 32 * KT;
+    if (interior) kl_uht_body<KT, FAST, true>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
+    else kl_uht_body<KT, FAST, false>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
+}
+
+
+}  // namespace

@@ -81,3 +81,67 @@ def run_case(name, use_hip=False, timeout=240):
         tol = 2e-3 if meta.get("method") == "hals" else 1e-4   # HALS cancels: see tests/test_oracle_golden.py::test_fit
         for itr, (dw, dh, de) in out.items():
             assert dw <= tol and dh <= tol and de <= 1e-5, (name, rank, itr, dw, dh, de)
+
+
+def run_bf16_rank(rank, world, port, grid, method, q, use_hip):
+    """PyNMF with params.precision = 'bfloat16' on a p_r x p_c grid == the oracle's grid simulation on float(bf16(A))."""
+    try:
+        import numpy as np
+        import torch.distributed as dist
+        from oracle import nmf_oracle as orc
+        from pydnmfk_amd.dist_comm import MPI_comm
+        from pydnmfk_amd.pyDNMF import PyNMF
+        from pydnmfk_amd.utils import determine_block_params, parse
+
+        torch.set_num_threads(1)
+        if use_hip:
+            torch.cuda.set_device(0)
+            ops = None
+        else:
+            from tests._ops_double import OracleOps
+            ops = OracleOps()
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        p_r, p_c = grid
+        m, n, k, itr = 50, 38, 4, 12
+        rs = np.random.RandomState(11)
+        A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.05 * rs.randn(m, n)).astype(np.float32)
+        W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+        Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy()
+        Wr, Hr, err_r = orc.SimGrid(Ar, W0, H0, p_r, p_c, norm="fro", W_update=True, method=method).fit(itr)
+        comms = MPI_comm(None, p_r, p_c)
+        args = parse()
+        args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, k
+        args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+        args.norm, args.method, args.W_update, args.precision = "fro", method, True, "bfloat16"
+        s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+        (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, m, n)
+        nmf = PyNMF(A[s[0]:e[0] + 1, s[1]:e[1] + 1], factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops)
+        assert nmf.A_ij.dtype == torch.bfloat16
+        W, H, err = nmf.fit()
+        q.put((rank, (rel_fro(W, Wr[rank]), rel_fro(H, Hr[rank]), abs(err - err_r)), None))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def run_bf16(grid, method, use_hip=False, timeout=240):
+    world = grid[0] * grid[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_bf16_rank, args=(r, world, port, grid, method, q, use_hip)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    tol = 2e-3 if method == "hals" else 1e-4
+    for rank, out, err in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+        dw, dh, de = out
+        assert dw <= tol and dh <= tol and de <= 1e-5, (grid, method, rank, dw, dh, de)

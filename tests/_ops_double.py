@@ -10,7 +10,8 @@ import torch
 
 
 def _n(t):
-    return t.numpy()
+    # a bfloat16-STORED data block (params.precision = 'bfloat16') means its exact float32 widening
+    return t.float().numpy() if t.dtype == torch.bfloat16 else t.numpy()
 
 
 class OracleOps:

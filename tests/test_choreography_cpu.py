@@ -34,6 +34,14 @@ def test_choreography_matches_reference(name):
     _run(name)
 
 
+@pytest.mark.parametrize("grid,method", [((1, 1), "mu"), ((2, 1), "mu"), ((1, 2), "hals"), ((2, 2), "hals"), ((2, 2), "mu")])
+def test_bf16_storage_precision_on_a_grid(grid, method):
+    """params.precision = 'bfloat16' (config 5): the data block is held as bf16, factors and arithmetic stay float32 --
+    the fit equals the oracle's grid simulation on float(bf16(A)) with the float32 tolerances."""
+    from tests._mp import run_bf16
+    run_bf16(grid, method, use_hip=False)
+
+
 def test_invalid_method_and_norm_raise():
     """Error behaviour of update() (dist_nmf.py:84-91, 652-659)."""
     from pydnmfk_amd.dist_comm import MPI_comm

@@ -20,3 +20,10 @@ CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_floa
 def test_multirank_hip_matches_reference(name):
     from tests._mp import run_case
     run_case(name, use_hip=True, timeout=400)
+
+
+@pytest.mark.parametrize("grid,method", [((2, 1), "hals"), ((1, 2), "mu"), ((2, 2), "hals")])
+def test_multirank_hip_bf16_storage(grid, method):
+    """bf16-stored data blocks on a grid, real HIP kernels (the *_bf16a entry points), gloo transport."""
+    from tests._mp import run_bf16
+    run_bf16(grid, method, use_hip=True)
