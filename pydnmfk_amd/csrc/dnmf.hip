@@ -68,7 +68,9 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // H from L2), 8.47 GB with the nontemporal hint on top.  What did NOT help (measured, not kept): a prefetch
     // distance of 2 with conditional loads (hipcc then drains vmcnt(0) at every join: 0-18 % slower), fragment reads
     // one group ahead in a second register set (-0..4 %), 8-wave workgroups with two contraction slices (+-3 %),
-    // 64-row tiles, capping workgroups per CU through the LDS request (+-5 %).  With A cache-resident the same
+    // 64-row tiles, capping workgroups per CU through the LDS request (+-5 %), loads issued for PAIRS of adjacent tiles
+    // (256 B per row per visit, two register super-sets: the held clock rose 1.92 -> 1.99 GHz -- fewer DRAM row
+    // activations -- but 208 registers leave two workgroups per CU, MFMA busy 85 -> 81 %, net +-2 %).  With A cache-resident the same
     // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-87 / 91 / 113 from HBM, while
     // the TN form loses only 2-8 %: the remaining gap is the memory system under this access shape (128 B per row
     // per visit, 128 rows apart by the 32 KiB row pitch), not the instruction schedule.
