@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void update_h_kernel(float* __restrict__ H,
     extern __shared__ __attribute__((aligned(16))) float gs[];   // G staged once per workgroup: rows jj, KP floats each
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long col0 = ((long)blockIdx.x * 4 + wid) * 32 * NT;
+    const long col0 = ((long)blockIdx.x * (blockDim.x >> 6) + wid) * 32 * NT;   // 1 or 4 waves per workgroup
     const long c = col0 + (long)NT * li;
-    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256)
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += blockDim.x)
         *reinterpret_cast<f32x4*>(&gs[idx * 4]) = *reinterpret_cast<const f32x4*>(G + idx * 4);
     __syncthreads();
     if (col0 >= n) return;

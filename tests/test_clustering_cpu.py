@@ -82,3 +82,32 @@ def test_two_ranks_match_reference_golden(golden_dir):
     for rank, sils, err in res:
         assert err is None, err
         assert np.allclose(ref, sils, rtol=1e-3, atol=1e-3)
+
+
+def test_early_exit_is_bitwise_the_full_100_rounds():
+    """The fixed-point exit of dist_custom_clustering must not change anything: compare with all 100 rounds (the
+    reference's loop, dist_clustering.py:114) on shuffled, noisy groups -- centroids, reordered W / H, the MAD, the
+    silhouettes and the complete list of orders."""
+    import numpy as np
+    import torch
+    from pydnmfk_amd.dist_clustering import custom_clustering
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.utils import parse
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.p_r, args.p_c, args.eps = comms.comm, 1, 1, 1.1920929e-07
+    rs = np.random.RandomState(3)
+    for (m, n, k, P, noise) in ((60, 40, 5, 7, 0.05), (33, 21, 3, 4, 0.4), (50, 30, 6, 6, 0.0)):
+        W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+        Wall, Hall = np.empty((m, k, P), np.float32), np.empty((k, n, P), np.float32)
+        for p in range(P):
+            perm = rs.permutation(k)
+            Wall[:, :, p] = W0[:, perm] + noise * rs.rand(m, k)
+            Hall[:, :, p] = H0[perm, :] + noise * rs.rand(k, n)
+        fast = custom_clustering(Wall, Hall, args)
+        full = custom_clustering(Wall, Hall, args)
+        full.early_exit = False
+        a, b = fast.fit(), full.fit()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3]) and a[4] == b[4]
+        assert a[5] == b[5] and len(a[5]) == 100 * P
