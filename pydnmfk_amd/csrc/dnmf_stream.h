@@ -65,11 +65,22 @@ template <bool FAST, typename TA = float>
 __global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, long m, long n, long lda, double* out) {
     double acc = 0.0;
     if constexpr (FAST) {
-        const long n4 = n / 4, total = m * n4;
-        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-            const long r = idx / n4, c = (idx % n4) * 4;
+        // four independent nontemporal 4-element loads in flight per lane and trip; a matrix without row padding is
+        // walked as one flat array (no 64-bit division per element).  Measured: 5.5 -> see DESIGN.md (stream ceiling 6.8 TB/s)
+        const long n4 = n / 4, total = m * n4, stride = (long)gridDim.x * blockDim.x;
+        const bool flat = lda == n;
+        auto off = [&](long i) { return flat ? i * 4 : (i / n4) * lda + (i % n4) * 4; };
+        long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; idx + 3 * stride < total; idx += 4 * stride) {
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_vec_raw_nt<4>(v[u], A + off(idx + u * stride));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (double)(v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+        }
+        for (; idx < total; idx += stride) {
             float v[4];
-            load_vec_raw<4>(v, A + r * lda + c);
+            load_vec_raw<4>(v, A + off(idx));
             acc += (double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
         }
     } else {
