@@ -70,7 +70,11 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // one group ahead in a second register set (-0..4 %), 8-wave workgroups with two contraction slices (+-3 %),
     // 64-row tiles, capping workgroups per CU through the LDS request (+-5 %), loads issued for PAIRS of adjacent tiles
     // (256 B per row per visit, two register super-sets: the held clock rose 1.92 -> 1.99 GHz -- fewer DRAM row
-    // activations -- but 208 registers leave two workgroups per CU, MFMA busy 85 -> 81 %, net +-2 %).  With A cache-resident the same
+    // activations -- but 208 registers leave two workgroups per CU, MFMA busy 85 -> 81 %, net +-2 %), and an NT form
+    // WITHOUT LDS in the style of the TN kernel (lane (li, h) loads 16 B of its own row of X and of the factor, four
+    // consecutive steps consume each row's 128-B line from L1): correct, but a load instruction then touches 32 rows x
+    // 32 B and the texture-address unit, not the matrix pipe, paces the kernel -- 2.6x SLOWER at k = 32 and k = 64 (MFMA
+    // busy 21-31 %, HBM reads 1.8x algorithmic).  The transpose of X has to go through LDS.  With A cache-resident the same
     // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-87 / 91 / 113 from HBM, while
     // the TN form loses only 2-8 %: the remaining gap is the memory system under this access shape (128 B per row
     // per visit, 128 rows apart by the 32 KiB row pitch), not the instruction schedule.
