@@ -135,3 +135,56 @@ def test_config2_size_properties():
     AH = ops.aht(A, H, torch.empty(m, k, device=dev)).double()
     lhs, rhs = float((AH * W.double()).sum()), float((AtW * H.double()).sum())
     assert abs(lhs - rhs) / abs(rhs) < 1e-6
+
+
+def test_config3_size_row_sharding_and_checksums():
+    """BASELINE config 3 at FULL size (262144 x 8192 fp32 = 8.6 GB, k = 64: offsets beyond 4 GiB) on one GPU.
+    (1) What 8 ranks of a p_r = 8 grid compute -- every rank its 32768-row shard, the exchanged quantity being the sum of
+    the per-shard [W^T A | W^T W] -- is replayed shard by shard through the same entry points and must equal the
+    single-shot step on the whole matrix (the decomposition the RCCL allreduce implements; only fp32 summation order
+    differs).  (2) The checksum-of-checksums identity and the adjoint identity of test_config2_size_properties hold at
+    this size, i.e. no kernel mis-addresses a matrix larger than 2^32 bytes."""
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    m, n, k, P = 262144, 8192, 64, 8
+    EPS = float(np.finfo(np.float32).eps)
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.rand(m, n, device=dev, generator=g)
+    W0 = torch.rand(m, k, device=dev, generator=g)
+    H0 = torch.rand(k, n, device=dev, generator=g)
+    # single shot
+    W1, H1 = W0.clone(), H0.clone()
+    ops.mu_fro_step(A, W1, H1, EPS, True, False)
+    # the same step as 8 row shards + a sum
+    W2, H2 = W0.clone(), H0.clone()
+    G = ops.gram_hht(H2, new_gram(k, dev))
+    ms = m // P
+    AtW, WtW = torch.zeros(k, n, device=dev), torch.zeros_like(G)
+    for s in range(P):
+        ops.aht_update_w(A[s * ms:(s + 1) * ms], H2, G, W2[s * ms:(s + 1) * ms], EPS)
+    for s in range(P):
+        AtW += ops.wta(A[s * ms:(s + 1) * ms], W2[s * ms:(s + 1) * ms], torch.empty(k, n, device=dev))
+        WtW += ops.gram_wtw(W2[s * ms:(s + 1) * ms], new_gram(k, dev))
+    ops.mu_update_h(H2, AtW, WtW, EPS, False)
+    assert float((W1 - W2).norm() / W1.norm()) < 1e-6
+    assert float((H1 - H2).norm() / H1.norm()) < 1e-5
+    assert torch.isfinite(W1).all() and torch.isfinite(H1).all() and float(W1.min()) >= 0 and float(H1.min()) >= 0
+    # checksums at this size (W scaled so that the residual is not dominated by W H)
+    W, H = W1 * 0.02, H1
+    AtWd = ops.wta(A, W, torch.empty(k, n, device=dev)).double()
+    WtWd = ops.gram_wtw(W, new_gram(k, dev))[:k, :k].double()
+    HHt = ops.gram_hht(H, new_gram(k, dev))[:k, :k].double()
+    a2 = float(ops.sqnorm(A))
+    assert abs(a2 / (m * n / 3.0) - 1) < 1e-3                      # E[u^2] = 1/3 for U[0,1)
+    direct = float(ops.resid_sqnorm(A, W, H))
+    identity = a2 - 2 * float((AtWd * H.double()).sum()) + float((WtWd * HHt).sum())
+    assert abs(direct - identity) / a2 < 1e-6
+    AH = ops.aht(A, H, torch.empty(m, k, device=dev)).double()
+    lhs, rhs = float((AH * W.double()).sum()), float((AtWd * H.double()).sum())
+    assert abs(lhs - rhs) / abs(rhs) < 1e-6
+    # the last rows / columns are really reached: a spike in the far corner must show up in both contractions
+    A[m - 1, n - 1] += 1000.0
+    AH2 = ops.aht(A, H, torch.empty(m, k, device=dev))
+    assert torch.allclose((AH2[m - 1] - AH[m - 1].float()), 1000.0 * H[:, n - 1], rtol=1e-3, atol=1e-2)
+    AtW2 = ops.wta(A, W, torch.empty(k, n, device=dev))
+    assert torch.allclose((AtW2[:, n - 1] - AtWd[:, n - 1].float()), 1000.0 * W[m - 1], rtol=1e-3, atol=1e-2)
