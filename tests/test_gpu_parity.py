@@ -188,3 +188,39 @@ def test_config3_size_row_sharding_and_checksums():
     assert torch.allclose((AH2[m - 1] - AH[m - 1].float()), 1000.0 * H[:, n - 1], rtol=1e-3, atol=1e-2)
     AtW2 = ops.wta(A, W, torch.empty(k, n, device=dev))
     assert torch.allclose((AtW2[:, n - 1] - AtWd[:, n - 1].float()), 1000.0 * W[m - 1], rtol=1e-3, atol=1e-2)
+
+
+def test_config4_block_kl_checksums():
+    """One rank's block of BASELINE config 4 (131072 x 65536 on a 4 x 2 grid -> 32768 x 32768 fp32 = 4 GiB, k = 128, KL).
+    With U = A / (W H + eps) both KL products contract the same U against W H:
+        <U H^T, W> = <W^T U, H> = sum(U * (W H)) = sum(A * WH / (WH + eps)) ~= sum(A),
+    which ties dnmf_kl_uht and dnmf_kl_wtu to each other and to a plain sum at a size whose offsets exceed 2^32 bytes;
+    then one whole MU/KL step must keep the factors finite, non-negative and lower the generalised KL divergence."""
+    from pydnmfk_amd.engine import HIP_OPS as ops
+    m, n, k = 32768, 32768, 128
+    EPS = float(np.finfo(np.float32).eps)
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = torch.rand(m, n, device=dev, generator=g)
+    W = torch.rand(m, k, device=dev, generator=g)
+    H = torch.rand(k, n, device=dev, generator=g)
+    UHT = ops.kl_uht(A, W, H, EPS, torch.empty(m, k, device=dev))
+    WTU = ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, device=dev))
+    lhs, rhs = float((UHT.double() * W.double()).sum()), float((WTU.double() * H.double()).sum())
+    sa = float(A.double().sum())
+    assert abs(lhs - rhs) / abs(rhs) < 1e-6
+    assert abs(lhs - sa) / sa < 1e-5
+
+    def kl_div(W, H):          # sum(A log(A / WH) - A + WH), chunked over rows (the product is 4 GiB)
+        tot = 0.0
+        for r0 in range(0, m, 4096):
+            a = A[r0:r0 + 4096]
+            wh = W[r0:r0 + 4096] @ H
+            tot += float((torch.xlogy(a, a / (wh + EPS)) - a + wh).double().sum())
+        return tot
+
+    d0 = kl_div(W, H)
+    ops.mu_kl_step(A, W, H, EPS, True, False)
+    assert torch.isfinite(W).all() and torch.isfinite(H).all() and float(W.min()) >= 0 and float(H.min()) >= 0
+    d1 = kl_div(W, H)
+    assert d1 < d0
