@@ -485,6 +485,8 @@ static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, 
     NnArgs a{};
     a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
     a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
+    static const int kl_pipe = getenv("DNMF_KL_PIPE") ? atoi(getenv("DNMF_KL_PIPE")) : 1;
+    a.pipe = kl_pipe;
     return a;
 }
 

@@ -19,6 +19,7 @@ struct NnArgs {
     float eps; double* out;                          // NN_RESID
     float* P; long chunk_stride; long ldp;           // NN_KL_WTU partials [rowblk][KP][ldp]
     long nrowblk; int ncolblk;
+    int pipe;                                        // NN_KL_*: software-pipelined interior path (DNMF_KL_PIPE=0 switches it off)
 };
 
 // S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
@@ -153,6 +154,74 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
     }
 }
 
+
+// The same row blocks, software pipelined across blocks for a chunk whose tiles are all in bounds (k == KP): every load
+// is unconditional and is issued one phase before its data is needed, ONE load per MFMA group, with the issue order
+// pinned --
+//   phase 1 (S = W H, 16 steps):   step s issues the load of w3[s] (the W rows the third phase of THIS block needs)
+//   phase 2 (U = A / (S + eps))
+//   phase 3 (out += W^T U, 16 steps): step r issues the loads of areg[r] and wfrag[r] of the NEXT block
+// -- and each register set is refilled in the phase after the one that consumed it, so nothing is double buffered.
+// With predicated loads (kl_wtu_block) hipcc drains vmcnt(0) at every one of the 48 loads of a block and the single
+// wave per SIMD waits out each latency: MFMA busy 51 % at a 2.39 GHz clock (32768 x 32768, k = 128).
+template <int KT, int NT>
+__device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const NnArgs& p, const float* smem, long rb0,
+                                                  long rb1, long col0, int li, int h) {
+    constexpr int CW = 32 * NT;
+    float areg[16][NT], wfrag[4 * KT][4], w3[16][KT];
+    const float* Ab = p.A + col0 + NT * li;                 // + row * lda
+    const float* Wf = p.W + 4 * h;                          // + wrow * ldw + 8 s     (S product: lane = row li)
+    const float* W3 = p.W + (long)KT * li;                  // + row * ldw            (third phase: lane = column group)
+    auto issue_next = [&](long rb, int r) {                 // block rb's A row crow(r,h) and W fragment s = r
+        load_vec_raw_nt<NT>(areg[r], Ab + (rb * 32 + crow(r, h)) * p.lda);
+        if (r < 4 * KT) load_vec_raw<4>(wfrag[r], Wf + (rb * 32 + li) * p.ldw + 8 * r);
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) issue_next(rb0, r);
+    static_assert(4 * KT <= 16, "one W fragment per third-phase step");
+    for (long rb = rb0; rb < rb1; ++rb) {
+        const long row0 = rb * 32;
+        const long nxt = rb + 1 < rb1 ? rb + 1 : rb;        // past the end: re-read this block (unused)
+        f32x16 acc[NT];
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s) {                  // phase 1
+            if (s < 16) load_vec_raw<KT>(w3[s], W3 + (row0 + crow(s, h)) * p.ldw);
+            if (4 * KT < 16 && s == 4 * KT - 1) {
+#pragma unroll
+                for (int q = 4 * KT; q < 16; ++q) load_vec_raw<KT>(w3[q], W3 + (row0 + crow(q, h)) * p.ldw);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = 8 * s + 4 * h + e;
+                float b[NT];
+                load_vec_raw<NT>(b, &smem[jj * CW + NT * li]);
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wfrag[s][e], b[ne], acc[ne]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)                        // phase 2
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);   // U (dist_nmf.py:806)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                      // phase 3
+            issue_next(nxt, r);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) out[ke][ne] = MFMA32(w3[r][ke], acc[ne][r], out[ke][ne]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int KT, int NT, bool FAST>
 __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,11 +251,15 @@ __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, 
             for (int r = 0; r < 16; ++r) out[ke][ne][r] = 0.f;
     long rb1 = (chunk + 1) * rowblks_per_chunk;
     if (rb1 > p.nrowblk) rb1 = p.nrowblk;
-    // Measured: the branch-free (INTERIOR) form of this block is 8-20 % SLOWER here (its 16 A loads then issue as one
-    // VMEM block ahead of the MFMAs, cf. tn_mainloop); the predicated loads spread out.  Kept predicated until the
-    // block is software pipelined across row blocks.
-    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb)
-        kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
+    // A chunk that is completely in bounds takes the software-pipelined path; edges keep the predicated blocks.
+    // (A merely branch-free block, its 16 A loads issued as one VMEM block ahead of the MFMAs, was 8-20 % slower than
+    // the predicated one.)
+    const long rb0 = chunk * rowblks_per_chunk;
+    if (FAST && p.pipe && p.k == KP && col0 + CW <= p.n && rb1 * 32 <= p.m) {
+        kl_wtu_chunk_pipe<KT, NT>(out, p, smem, rb0, rb1, col0, li, h);
+    } else {
+        for (long rb = rb0; rb < rb1; ++rb) kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
+    }
     float* Pc = p.P + chunk * p.chunk_stride;
 #pragma unroll
     for (int ke = 0; ke < KT; ++ke)
