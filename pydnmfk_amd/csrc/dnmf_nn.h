@@ -187,6 +187,9 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
         for (int ne = 0; ne < NT; ++ne)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+        float hb[2][4][NT];                                 // H operand of step s+1 read from LDS during step s
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[0][e], &smem[(4 * h + e) * CW + NT * li]);
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {                  // phase 1
             if (s < 16) load_vec_raw<KT>(w3[s], W3 + (row0 + crow(s, h)) * p.ldw);
@@ -194,15 +197,15 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
 #pragma unroll
                 for (int q = 4 * KT; q < 16; ++q) load_vec_raw<KT>(w3[q], W3 + (row0 + crow(q, h)) * p.ldw);
             }
+            if (s + 1 < 4 * KT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[(s + 1) & 1][e], &smem[(8 * (s + 1) + 4 * h + e) * CW + NT * li]);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int jj = 8 * s + 4 * h + e;
-                float b[NT];
-                load_vec_raw<NT>(b, &smem[jj * CW + NT * li]);
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wfrag[s][e], b[ne], acc[ne]);
-            }
+                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wfrag[s][e], hb[s & 1][e][ne], acc[ne]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
