@@ -418,10 +418,10 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
     const int nt = 4 / kt;                                  // KT * NT == 4: three 64-register tiles per wave
     const bool fast = aligned16(H) && aligned16(AtW) && ldh % 4 == 0 && ldatw % 4 == 0 && n % 4 == 0;
-    // one wave per workgroup while that still leaves fewer workgroups than CUs-times-two (H of config 3 has 128 wave
-    // tiles: 32 four-wave workgroups would use an eighth of the chip: 16.6 -> 9 us), four waves (G staged once) beyond
+    // four waves per workgroup (G staged once per workgroup).  One-wave workgroups for small H (128 wave tiles at
+    // config 3 = 32 workgroups) were measured: 17.6 -> 20.3 us, slower (four times the G staging).
     const long tiles = cdiv(n, 32 * nt);
-    const int wpb = tiles >= 2048 ? 4 : 1;
+    const int wpb = 4;
     const dim3 grid((unsigned)cdiv(tiles, wpb)), block(64 * wpb);
     hipStream_t st = S(stream);
 #define UH_CASE(KT_, NT_)                                                                                         \
