@@ -25,7 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+# measured on an MI355X with tools/ceilbench.hip (profiles/r01d_ceilings.txt): what the matrix pipe sustains while the
+# contraction's HBM stream (128 B per 32x32x2 MFMA at k = 64) runs beside it, and plain streaming reads
+MEASURED_MFMA_WITH_STREAM_TFLOPS = {128: 138.9, 64: 126.2, 32: 108.4}
+MEASURED_STREAM_GBS = 6760.0
 
 
 def parse_args():
@@ -257,13 +261,17 @@ def main():
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                "flops_per_launch": fl_nt, "ms_per_launch": t["aht_update_w"]}
+            if k in MEASURED_MFMA_WITH_STREAM_TFLOPS:       # informational: fraction of the MEASURED mixed ceiling
+                out["roofline"]["measured_ceiling"] = MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
+                out["roofline"]["frac_of_measured_ceiling"] = ach / MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
             tr = pmc_traffic_bytes() if (m, n, k, world) == (262144, 8192, 64, 1) else None
             if tr is not None:
                 out["roofline"]["traffic"] = tr["bytes"]
                 out["roofline"]["traffic_note"] = "HBM bytes per launch, PMC pass %s (FETCH_SIZE x2 + WRITE_SIZE)" % tr["source"]
             out["roofline_hbm"] = {"kernel": "sqnorm_kernel", "bound": "hbm", "achieved": 4.0 * m_l * n / t3 / 1e6,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS,
-                                   "traffic": None}
+                                   "traffic": None, "measured_ceiling": MEASURED_STREAM_GBS,
+                                   "frac_of_measured_ceiling": 4.0 * m_l * n / t3 / 1e6 / MEASURED_STREAM_GBS}
             out["kernels"] = kern
 
     if rank == 0:
