@@ -23,6 +23,7 @@
 #include "dnmf_update.h"
 #include "dnmf_hals.h"
 #include "dnmf_nn.h"
+#include "dnmf_k16.h"
 
 namespace {
 
@@ -191,9 +192,33 @@ struct WsLayout {
     size_t g_off, s_off, x_off, part_off, total;  // G [KP*KP] | S = AtW / AH / UHT / WTU | x [KP] | partials
 };
 
+// k <= 16 kernels (dnmf_k16.h): DNMF_K16=0 switches them off (A/B runs)
+inline bool k16_on() {
+    static const bool on = !(getenv("DNMF_K16") && atoi(getenv("DNMF_K16")) == 0);
+    return on;
+}
+// row chunking of tn16_kernel: waves = nchunks x (n / (16 V)), 16-row partial slabs of ld = n
+struct Tn16Plan { int ncolblk; int nchunks; long rows_per_chunk; };
+Tn16Plan plan_tn16(long m, long n, int v) {
+    Tn16Plan p;
+    p.ncolblk = (int)(n / (16 * v));
+    long nchunks = std::max<long>(1, 4096 / std::max(1, p.ncolblk));   // ~4 waves per SIMD
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(m, 256)));
+    p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
+    p.nchunks = (int)cdiv(m, p.rows_per_chunk);
+    return p;
+}
+
 size_t partial_bytes(long m, long n, int k) {
     const int kt = kt_of(k), kp = 32 * kt;
     size_t b = 0;
+    if (k <= 16 && n % 64 == 0) {   // tn16 partial slabs (fp32: V = 4; bf16: V = 8 has fewer column blocks, more chunks)
+        for (int v = 4; v <= 8; v += 4) {
+            if (n % (16 * v)) continue;
+            Tn16Plan q = plan_tn16(m, n, v);
+            b = std::max(b, (size_t)q.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(q.nchunks, k, n));
+        }
+    }
     {   // wta / kl_wtu: A [m x n]
         TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
         b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, k, n));
@@ -308,6 +333,16 @@ template <typename TA> bool a_aligned(const TA* A) { return ((uintptr_t)A % (4 *
 // the NT form reads 16 B per lane from A whatever its type: bf16 rows need lda % 8 == 0 and a 16-byte aligned base
 template <typename TA> bool a_rows16(const TA* A, long lda) { return aligned16(A) && (lda * sizeof(TA)) % 16 == 0; }
 
+// rank k <= 16 with aligned operands and a column count that is a whole number of k-tiles: the 16-wide kernel.
+// Returns 1 when not applicable (caller falls through to the 32-wide kernels), else the launch status.
+template <int MODE, typename TA>
+int try_nt16(const NtArgs& a, bool fast, long n, int k, hipStream_t st) {
+    constexpr bool b16 = std::is_same<TA, bf16_t>::value;
+    if (!(k <= 16 && fast && k16_on() && n % (b16 ? BKH : BK) == 0)) return 1;
+    hipLaunchKernelGGL((nt16_kernel<TA, MODE>), dim3((unsigned)cdiv(a.nrows, 128)), dim3(256), nt16_lds_bytes(b16), st, a);
+    return check_launch("nt16_kernel");
+}
+
 template <typename TA>
 int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
              void* stream) {
@@ -319,6 +354,7 @@ int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long 
     a.cols_per_split = round_up(n, BK);
     a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
     const bool fast = a_rows16(A, lda) && aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
+    if (int rc16 = try_nt16<NT_STORE, TA>(a, fast, n, k, S(stream)); rc16 != 1) return rc16;
     return launch_nt<NT_STORE, TA>(kt, fast, a, 1, S(stream));
 }
 
@@ -334,6 +370,7 @@ int aht_update_w_impl(const TA* A, long m, long n, long lda, const float* H, int
     a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
     const bool fast = a_rows16(A, lda) && aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
     a.wfast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    if (int rc16 = try_nt16<NT_FUSED_W, TA>(a, fast, n, k, S(stream)); rc16 != 1) return rc16;
     return launch_nt<NT_FUSED_W, TA>(kt, fast, a, 1, S(stream));
 }
 }  // namespace
@@ -383,6 +420,24 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
              void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldw >= k && ldatw >= n, "wta: bad arguments");
+    {   // rank k <= 16: 16-wide kernel (16-byte aligned rows of A, whole column blocks, workspace permitting)
+        constexpr int V = std::is_same<TA, bf16_t>::value ? 8 : 4;
+        if (k <= 16 && k16_on() && a_rows16(A, lda) && n % (16 * V) == 0 && lda != 0) {
+            const Tn16Plan q = plan_tn16(m, n, V);
+            const size_t pb = (size_t)q.nchunks * 16 * n * sizeof(float);
+            if (pb + reduce_scratch_bytes(q.nchunks, k, n) <= ws_bytes) {
+                TnArgs a{};
+                a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
+                a.nrows = m; a.rows_per_chunk = q.rows_per_chunk; a.nchunks = q.nchunks; a.ncolblk = q.ncolblk;
+                a.P = (float*)ws; a.chunk_stride = 16 * n; a.ldp = n;
+                hipStream_t st = S(stream);
+                hipLaunchKernelGGL((tn16_kernel<TA>), dim3((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4)), dim3(256), 0, st, a);
+                int rc = check_launch("tn16_kernel");
+                if (rc) return rc;
+                return launch_reduce((const float*)ws, 16 * n, n, q.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)ws + pb), st);
+            }
+        }
+    }
     const int nt = tn_nt(kt);
     TnPlan p = plan_tn(m, n, kt, nt);
     const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);

@@ -153,7 +153,12 @@ __device__ __forceinline__ void store_tile_vec(const float (&d)[V], float* __res
 // bf16 flavours of the element loaders (V in {1, 2, 4}: 2 / 4 / 8 bytes per lane)
 template <int V>
 __device__ __forceinline__ void load_vec_raw(float (&d)[V], const bf16_t* __restrict__ p) {
-    if constexpr (V == 4) {
+    if constexpr (V == 8) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d[2 * q] = bf16_lo(w[q]); d[2 * q + 1] = bf16_hi(w[q]); }
+    } else if constexpr (V == 4) {
         const u32x2 w = *reinterpret_cast<const u32x2*>(p);
         d[0] = bf16_lo(w[0]); d[1] = bf16_hi(w[0]); d[2] = bf16_lo(w[1]); d[3] = bf16_hi(w[1]);
     } else if constexpr (V == 2) {
@@ -193,7 +198,11 @@ template <int V> struct Raw<bf16_t, V> {
     unsigned int w[(V + 1) / 2];
     template <bool NTL>
     __device__ __forceinline__ void load_(const bf16_t* __restrict__ p) {
-        if constexpr (V == 4) {
+        if constexpr (V == 8) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 x = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+            w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+        } else if constexpr (V == 4) {
             const u32x2 x = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
             w[0] = x[0]; w[1] = x[1];
         } else if constexpr (V == 2) {

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 EPS = float(np.finfo(np.float32).eps)
 SHAPES = [(512, 384, 64), (300, 260, 32), (257, 131, 33), (130, 72, 128), (24, 12, 2), (1024, 256, 4),
-          (97, 53, 7), (640, 200, 16), (2048, 1024, 64), (33, 515, 65), (4099, 1026, 8)]
+          (97, 53, 7), (640, 200, 16), (2048, 1024, 64), (33, 515, 65), (4099, 1026, 8),
+          # rank <= 16 with whole k-tiles of columns: the 16x16x4 kernels (ragged rows, k = 1, k % 4 != 0, a single tile)
+          (300, 256, 16), (1000, 512, 5), (129, 128, 1), (4100, 1024, 13), (257, 128, 16), (8192, 2048, 9)]
 
 
 def _rel(x, ref):

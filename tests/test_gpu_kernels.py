@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 EPS = float(np.finfo(np.float32).eps)
 # (m, n, k): tile-aligned, ragged, tiny, k on both sides of the KP boundaries, unaligned leading dims
 SHAPES = [(512, 384, 64), (300, 260, 32), (257, 131, 33), (130, 72, 128), (24, 12, 2), (1024, 256, 4),
-          (97, 53, 7), (640, 200, 96), (2048, 1024, 64), (33, 515, 65)]
+          (97, 53, 7), (640, 200, 96), (2048, 1024, 64), (33, 515, 65),
+          # rank <= 16 with whole k-tiles of columns: the 16x16x4 kernels (ragged rows, k = 1, k % 4 != 0, a single tile)
+          (300, 256, 16), (1000, 512, 5), (129, 128, 1), (4100, 1024, 13), (257, 64, 16), (8192, 2048, 9)]
 
 
 def _rel(x, ref):
