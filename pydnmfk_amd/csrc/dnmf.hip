@@ -163,18 +163,23 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
 // ---- chunking heuristics (shared by the ws-size query and the launches)
 struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
 
-TnPlan plan_tn(long nrows, long ycols, int kt, int nt) {
+TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
     TnPlan p;
     p.ncolblk = (int)cdiv(ycols, 32 * nt);
     static const long target_waves = getenv("DNMF_TN_WAVES") ? atol(getenv("DNMF_TN_WAVES")) : 2048;  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
     long nchunks = std::max<long>(1, target_waves / p.ncolblk);
-    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, 256)));
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, min_rows)));
     p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
     p.nchunks = (int)cdiv(nrows, p.rows_per_chunk);
     p.ldp = (long)p.ncolblk * 32 * nt;
     p.chunk_stride = p.ldp * 32 * kt;
     return p;
 }
+
+// W^T W streams only W (m x k): with 256-row chunks a 32768-row shard gives 128 waves on 32 CUs and the launch is one long
+// latency chain; 128-row chunks spread it over the chip (28.8 -> 21.5 us at 32768 rows, 30.2 -> 22.2 us at 65536, k = 64)
+// but cost a second reduction stage on tall matrices (34 -> 42 us at 262144 rows), which keep 256.
+inline long gram_min_rows(long m) { return m <= 131072 ? 128 : 256; }
 
 struct SplitPlan { int nsplit; long cols_per_split; };
 
@@ -227,7 +232,7 @@ size_t partial_bytes(long m, long n, int k) {
         b = std::max(b, (size_t)klc * q.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)klc, k, n));
     }
     {   // gram W^T W: Y = W [m x k]
-        TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt);
+        TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt, gram_min_rows(m));
         b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, kp, kp));
     }
     {   // gram H H^T
@@ -301,7 +306,7 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
     const int kp = 32 * kt;
     // TN form with X = Y = W; NT column sets per wave (KT = 4 uses 2 column blocks of 64 to bound registers)
     const int nt = kt == 4 ? 2 : kt;
-    TnPlan p = plan_tn(m, kp, kt, nt);
+    TnPlan p = plan_tn(m, kp, kt, nt, gram_min_rows(m));
     const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
     const size_t need = pbytes + reduce_scratch_bytes(p.nchunks, kp, kp);
     if (ws_bytes < need) return fail(DNMF_EWS, "gram_wtw: workspace %zu < %zu", ws_bytes, need);
