@@ -257,7 +257,8 @@ def main():
         }
         if rank == 0:
             ach = fl_nt / t["aht_update_w"] / 1e9
-            out["roofline"] = {"kernel": "nt_kernel<KT=%d,FUSED_W> (dnmf_aht_update_w)" % (max(1, (k + 31) // 32)),
+            kname = "nt16_kernel<FUSED_W>" if (k <= 16 and n % 32 == 0) else "nt_kernel<KT=%d,FUSED_W>" % max(1, (k + 31) // 32)
+            out["roofline"] = {"kernel": kname + " (dnmf_aht_update_w)",
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                "flops_per_launch": fl_nt, "ms_per_launch": t["aht_update_w"]}
