@@ -128,9 +128,8 @@ __device__ __forceinline__ void sum_slices(f32x16 (&acc)[MT][KT], float* smem, i
 // group each take half of every k-tile's fragment groups and the partial accumulators are summed through LDS at the
 // end (result in the slice-0 waves).  KS = 2 doubles the waves per SIMD when the shard has too few row tiles to fill
 // the chip (m_l = 32768 at 8 GPUs = 256 tiles = one 4-wave workgroup per CU).
-// PF = prefetch distance in k-tiles: 1 = loads for tile t+1 are issued at the top of tile t; 2 = one more tile is kept
-// in flight in registers (loads for t+2 issued at the top of tile t, written to LDS at the end of t+1), for shards
-// with so few row tiles that a CU holds a single workgroup and nothing else hides the HBM latency.
+// PF = 1: the loads for tile t+1 are issued at the top of tile t (conditional on there being one: this is the generic /
+// edge loop; interior tiles of fp32 X run the branch-free nt_mainloop_p2 with two tiles in flight).
 template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
@@ -225,41 +224,17 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
             stage_load<BM, T, FAST, INTERIOR, NTX>(xr, X, ldx, nrows, cend, row0, c0, tid);
             stage_load<KP, T, FAST, INTERIOR>(yr, Y, ldy, yrows, cend, 0, c0, tid);
         };
-        if constexpr (PF == 1) {
-            for (long kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                const bool more = kt + 1 < nk;
-                if (more) load_tile(xv, yv, kt + 1);
-                compute(smem + cur * STAGE);
-                if (more) {
-                    stage_store<BM, T>(smem + (cur ^ 1) * STAGE, xv, tid);
-                    stage_store<KP, T>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
-                }
-                __syncthreads();
+        static_assert(PF == 1, "one k-tile in flight here; two tiles in flight: nt_mainloop_p2");
+        for (long kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) load_tile(xv, yv, kt + 1);
+            compute(smem + cur * STAGE);
+            if (more) {
+                stage_store<BM, T>(smem + (cur ^ 1) * STAGE, xv, tid);
+                stage_store<KP, T>(smem + (cur ^ 1) * STAGE + BM * BK, yv, tid);
             }
-        } else {
-            // two register sets: (xv, yv) and (xw, yw) alternate; each holds a tile for one whole compute phase
-            f32x4 xw[(BM + T / 8 - 1) / (T / 8)], yw[(KP + T / 8 - 1) / (T / 8)];
-            if (nk > 1) load_tile(xv, yv, 1);
-            for (long kt = 0; kt < nk; kt += 2) {
-                // even phase: tile kt in LDS stage 0, tile kt+1 in flight in (xv, yv); issue tile kt+2 into (xw, yw)
-                if (kt + 2 < nk) load_tile(xw, yw, kt + 2);
-                compute(smem);
-                if (kt + 1 < nk) {
-                    stage_store<BM, T>(smem + STAGE, xv, tid);
-                    stage_store<KP, T>(smem + STAGE + BM * BK, yv, tid);
-                }
-                __syncthreads();
-                if (kt + 1 >= nk) break;
-                // odd phase: tile kt+1 in stage 1, tile kt+2 in flight in (xw, yw); issue tile kt+3 into (xv, yv)
-                if (kt + 3 < nk) load_tile(xv, yv, kt + 3);
-                compute(smem + STAGE);
-                if (kt + 2 < nk) {
-                    stage_store<BM, T>(smem, xw, tid);
-                    stage_store<KP, T>(smem + BM * BK, yw, tid);
-                }
-                __syncthreads();
-            }
+            __syncthreads();
         }
         }   // register-staged path
     }
