@@ -83,17 +83,21 @@ def cpu_baseline(n, k, m_full):
             orc.fro_mu_step_local(A, W, H, eps)
         return (time.perf_counter() - t0) / iters
 
+    def timed():
+        # bounded sample of about 10 s of CPU work: one warm-up step sizes the number of timed steps
+        t1 = run(1)
+        steps = int(min(100, max(6, round(10.0 / max(t1, 1e-3)))))
+        return run(steps), steps
+
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            run(1)
-            t = run(6)
+            t, steps = timed()
     else:
-        run(1)
-        t = run(6)
+        t, steps = timed()
     t_full = t * (m_full / m_s)
     return {"value": 1.0 / t_full, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": "oracle fro_mu_step_local on a %dx%d row slab (1/%d of X), k=%d, 1 BLAS thread, 6 timed steps; "
-                      "%.3f s/step on the slab, scaled by rows to the full X" % (m_s, n, m_full // m_s, k, t),
+            "sample": "oracle fro_mu_step_local on a %dx%d row slab (1/%d of X), k=%d, 1 BLAS thread, %d timed steps; "
+                      "%.3f s/step on the slab, scaled by rows to the full X" % (m_s, n, m_full // m_s, k, steps, t),
             "slab_seconds_per_step": t,
             "gflops": (4.0 * m_s * n * k + 4.0 * (m_s + n) * k * k) / t / 1e9}
 
