@@ -136,7 +136,7 @@ def main():
             sys.exit("bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks" % a.gpus)
         a.gpus = world
     ndev = torch.cuda.device_count()
-    if world > ndev and a.backend == "nccl":
+    if world > ndev and a.backend == "nccl" and not os.environ.get("DNMF_BENCH_OVERSUBSCRIBE"):   # (the override exercises the fallback below)
         sys.exit("bench.py: %d ranks but %d GPUs" % (world, ndev))
     local = local % max(1, ndev)            # gloo debugging runs may stack ranks on one device
     torch.cuda.set_device(local)
@@ -144,6 +144,23 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.backend)      # nccl = RCCL; communicators are created lazily on the current device
+        if a.backend == "nccl":
+            # one tiny collective up front: if RCCL cannot come up on this node the run continues over gloo (host staged,
+            # slower, and labelled as such in config.parallelism) instead of producing no number at all
+            try:
+                t = torch.ones(1, device=dev)
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                if int(t.item()) != world:
+                    raise RuntimeError("allreduce returned %s" % t.item())
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("bench.py: RCCL unavailable (%s); falling back to gloo\n" % exc)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                a.backend = "gloo"
+                dist.init_process_group("gloo")
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -208,7 +225,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)" % (
                 a.norm.upper(), m, n, k, world), "m": m, "n": n, "k": k, "rows_per_gpu": m_l,
-                "parallelism": "row-sharded X, allreduce[W^T A | W^T W]" if world > 1 else "single GPU"},
+                "parallelism": ("row-sharded X, allreduce[W^T A | W^T W] over %s" % ("RCCL" if a.backend == "nccl" else a.backend + " (host staged)")) if world > 1 else "single GPU"},
             "step_tflops_per_gpu": flops_iter / world / (ms * 1e-3) / 1e12,
             "step_mfma_frac": flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
