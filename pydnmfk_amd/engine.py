@@ -56,13 +56,15 @@ def kp(k):
 
 
 def workspace(m, n, k, device):
-    """Scratch buffer large enough for any entry point on an m x n block (cached per device/shape)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(m), int(n), int(k))
+    """Scratch buffer large enough for any entry point on an m x n block: one buffer per device, grown on demand (an
+    NMFk sweep over k would otherwise keep one buffer per rank alive).  Stream-ordered reuse: every entry point is
+    enqueued on the current stream, so consecutive calls never overlap on the scratch."""
+    nbytes = lib.dnmf_ws_bytes(int(m), int(n), int(k))
+    if nbytes == 0:
+        raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
-    if ws is None:
-        nbytes = lib.dnmf_ws_bytes(int(m), int(n), int(k))
-        if nbytes == 0:
-            raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+    if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
