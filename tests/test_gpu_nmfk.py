@@ -55,6 +55,29 @@ def test_cli_end_to_end(tmp_path, golden_dir):
     assert abs(np.linalg.norm(A - W @ H) / np.linalg.norm(A) - err) < 1e-4
 
 
+def test_cli_bf16_precision(tmp_path, golden_dir):
+    """main.py --precision bfloat16 --method hals (BASELINE config 5 flags): X is held as bf16 on the GPU, the factors
+    come back float32 and reproduce the rounded matrix as well as the reported error says."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A = np.load(golden_dir + "/data_swim.npz")["A"].astype(np.float32)
+    np.save(tmp_path / "swimcopy.npy", A)
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--process=pyDNMF", "--p_r=1", "--p_c=1",
+           "--fpath=%s/" % tmp_path, "--fname=swimcopy", "--ftype=npy", "--k=4", "--itr=30", "--norm=fro",
+           "--method=hals", "--precision=bfloat16", "--results_path=%s/res/" % tmp_path]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float(out.stdout.strip().split("relative error =")[-1])
+    W = np.load(tmp_path / "res" / "W_factors" / "W_0.npy")
+    H = np.load(tmp_path / "res" / "H_factors" / "H_0.npy")
+    assert W.shape == (1024, 4) and H.shape == (4, 256) and W.dtype == np.float32
+    Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy()
+    assert abs(np.linalg.norm(Ar - W @ H) / np.linalg.norm(Ar) - err) < 1e-4
+    assert 0.4 < err < 0.7
+
+
 def test_runner_front_end(tmp_path, golden_dir):
     """pyDNMFk_Runner (runner.py:12-176): the Runner object is the params bag."""
     from pydnmfk_amd.runner import pyDNMFk_Runner
