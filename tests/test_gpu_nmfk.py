@@ -108,3 +108,23 @@ def test_wtsi_known_answer(tmp_path, golden_dir):
     args.itr, args.init, args.verbose, args.norm, args.method = 1000, "nnsvd", False, "fro", "mu"
     args.checkpoint, args.results_path = False, str(tmp_path) + "/results/"
     assert PyNMFk(A, factors=None, params=args).fit() == 4
+
+
+def test_wtsi_known_answer_with_bf16_storage(tmp_path, golden_dir):
+    """The same known answer with the data held as bfloat16 (params.precision, BASELINE config 5) and HALS: the rank
+    estimate of the wtsi example must survive the 8-bit rounding of X (nopt == 4)."""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from pydnmfk_amd.utils import parse
+    A = np.load(golden_dir + "/data_wtsi.npz")["A"].astype(np.float32)
+    for method in ("mu", "hals"):
+        comms = MPI_comm(None, 1, 1)
+        args = parse()
+        args.comm1, args.comm, args.p_r, args.p_c = comms.comm, comms, 1, 1
+        args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        args.fpath, args.fname, args.ftype = str(tmp_path) + "/", "wtsi", "mat"
+        args.start_k, args.end_k, args.step_k, args.sill_thr = 1, 8, 1, 0.6
+        args.itr, args.init, args.verbose, args.norm, args.method = 1000, "nnsvd", False, "fro", method
+        args.checkpoint, args.results_path = False, str(tmp_path) + "/results_%s/" % method
+        args.precision = "bfloat16"
+        assert PyNMFk(A, factors=None, params=args).fit() == 4, method
