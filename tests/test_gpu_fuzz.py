@@ -1,0 +1,65 @@
+"""Seeded random shapes through the big entry points (every dispatch branch: 16-wide / 32-wide kernels, vector /
+generic paths, interior / edge tiles, fp32 / bf16-stored X) against a float64 numpy evaluation of the reference
+formulas (dist_nmf.py:705, 716-751).  Tolerances as in test_gpu_kernels.py."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def _rel(x, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(np.asarray(x, dtype=np.float64) - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+def _shapes(seed, count):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        k = int(rs.choice([1, 2, 3, 4, 5, 8, 11, 16, 17, 24, 32, 33, 48, 64, 65, 96, 128]))
+        m = int(rs.choice([1, 7, 31, 32, 33, 100, 127, 128, 129, 255, 256, 257, 500, 1000, 1025, 2049]))
+        n = int(rs.choice([4, 12, 31, 32, 33, 60, 64, 96, 100, 128, 129, 192, 256, 260, 384, 512, 1000, 1024]))
+        out.append((m, n, k, bool(rs.rand() < 0.4), int(rs.randint(1 << 30))))
+    return out
+
+
+import os  # noqa: E402  (DNMF_FUZZ="seed,count" widens the sweep for ad-hoc runs)
+
+_SEED, _COUNT = (int(x) for x in os.environ.get("DNMF_FUZZ", "2024,160").split(","))
+
+
+@pytest.mark.parametrize("m,n,k,bf16,seed", _shapes(_SEED, _COUNT))
+def test_random_shapes(m, n, k, bf16, seed):
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    rs = np.random.RandomState(seed)
+    A = rs.rand(m, n).astype(np.float32)
+    A[rs.rand(m, n) < 0.1] = 0.0
+    W = rs.rand(m, k).astype(np.float32)
+    H = rs.rand(k, n).astype(np.float32)
+    dev = torch.device("cuda")
+    dA = torch.from_numpy(A).to(dev)
+    if bf16:
+        dA = dA.to(torch.bfloat16)
+        A = dA.float().cpu().numpy()
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    dW, dH = torch.from_numpy(W).to(dev), torch.from_numpy(H).to(dev)
+    AH = ops.aht(dA, dH, torch.full((m, k), 3.0, device=dev)).cpu().numpy()
+    assert _rel(AH, A64 @ H64.T) < 2e-6
+    AtW = ops.wta(dA, dW, torch.full((k, n), 3.0, device=dev)).cpu().numpy()
+    assert _rel(AtW, W64.T @ A64) < 2e-6
+    G = ops.gram_hht(dH, new_gram(k, dev))
+    Wf = dW.clone()
+    ops.aht_update_w(dA, dH, G, Wf, EPS)
+    W_ref = W64 * ((A64 @ H64.T) / (W64 @ (H64 @ H64.T) + EPS))
+    assert _rel(Wf.cpu().numpy(), W_ref) < 1e-5
+    Ws, Hs = dW.clone(), dH.clone()
+    ops.mu_fro_step(dA, Ws, Hs, EPS, True, False)
+    H_ref = H64 * ((W_ref.T @ A64) / ((W_ref.T @ W_ref) @ H64 + EPS))
+    assert _rel(Ws.cpu().numpy(), W_ref) < 1e-5
+    assert _rel(Hs.cpu().numpy(), H_ref) < 2e-5
+    a2 = max(float((A64 ** 2).sum()), 1e-30)       # the residual itself can be ~0 (m = 1): compare on the scale of ||A||^2
+    assert abs(float(ops.resid_sqnorm(dA, Ws, Hs)) - float(((A64 - W_ref @ H_ref) ** 2).sum())) / a2 < 2e-5
+    assert abs(float(ops.sqnorm(dA)) / a2 - 1) < 1e-6
