@@ -63,3 +63,46 @@ def test_random_shapes(m, n, k, bf16, seed):
     a2 = max(float((A64 ** 2).sum()), 1e-30)       # the residual itself can be ~0 (m = 1): compare on the scale of ||A||^2
     assert abs(float(ops.resid_sqnorm(dA, Ws, Hs)) - float(((A64 - W_ref @ H_ref) ** 2).sum())) / a2 < 2e-5
     assert abs(float(ops.sqnorm(dA)) / a2 - 1) < 1e-6
+
+
+def _shapes_kl(seed, count):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        k = int(rs.choice([1, 3, 4, 8, 16, 20, 32, 40, 64, 72, 128]))
+        m = int(rs.choice([5, 32, 33, 96, 128, 130, 256, 300, 640, 1024, 1500]))
+        n = int(rs.choice([8, 31, 32, 64, 100, 128, 160, 256, 300, 512, 1024, 1100]))
+        out.append((m, n, k, int(rs.randint(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k,seed", _shapes_kl(_SEED + 1, max(40, _COUNT // 2)))
+def test_random_shapes_kl_and_hals(m, n, k, seed):
+    """Whole MU/KL and HALS/FRO steps (dist_nmf.py:851-869, 873-934) against the oracle's single-rank steps."""
+    from oracle import nmf_oracle as orc
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
+    from pydnmfk_amd.engine import HIP_OPS as ops
+    from pydnmfk_amd.utils import parse
+    rs = np.random.RandomState(seed)
+    A = (rs.rand(m, n) + 0.05).astype(np.float32)
+    A[rs.rand(m, n) < 0.1] = 0.0
+    W = (rs.rand(m, k) + 0.05).astype(np.float32)
+    H = (rs.rand(k, n) + 0.05).astype(np.float32)
+    dev = torch.device("cuda")
+    dA = torch.from_numpy(A).to(dev)
+    Wd, Hd = torch.from_numpy(W).to(dev), torch.from_numpy(H).to(dev)
+    ops.mu_kl_step(dA, Wd, Hd, EPS, True, False)
+    Wr, Hr = W.copy(), H.copy()
+    orc.kl_mu_step_local(A, Wr, Hr, np.float32(EPS), W_update=True)
+    assert _rel(Wd.cpu().numpy(), Wr) < 1e-5 and _rel(Hd.cpu().numpy(), Hr) < 1e-5
+    comms = MPI_comm(None, 1, 1)
+    p = parse()
+    p.comm1, p.comm, p.p_r, p.p_c, p.k, p.m, p.n = comms.comm, comms, 1, 1, k, m, n
+    p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    p.norm, p.method, p.W_update, p.eps = "fro", "hals", True, EPS
+    Wd, Hd = torch.from_numpy(W).to(dev), torch.from_numpy(H).to(dev)
+    nmf_algorithms_1D(dA, Wd, Hd, params=p).update()
+    Wr, Hr = W.copy(), H.copy()
+    orc.fro_hals_step_local(A, Wr, Hr, np.float32(EPS), W_update=True)
+    assert _rel(Wd.cpu().numpy(), Wr) < 5e-5 and _rel(Hd.cpu().numpy(), Hr) < 5e-5
