@@ -62,7 +62,8 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     //   1  loads of k-tile t+1 issued at the top of tile t, tiles in order (also the generic / edge path)
     //   5  1 + every workgroup starts at a different k-tile (rotated order) + nontemporal loads of A
     //   7  5 with LDS-DMA staging (global_load_lds: no staging VGPRs, no ds_write)
-    //  10  5 with TWO k-tiles in flight and a branch-free loop (nt_mainloop_p2) -- the default
+    //  10  5 with TWO k-tiles in flight and a branch-free loop (nt_mainloop_p2) -- the default; grids of at most one
+    //      workgroup per CU take three tiles in flight (nt_mainloop_p3t, code 13)
     // Measured on MI355X (tools/kbench.py, k = 64, n = 8192; ms at 262144 / 65536 / 32768 rows):
     //   1: 2.54 / 0.82 / -     5: 2.42-2.49 / 0.76 / 0.44     7: +-2 % of 5     10: 2.43-2.47 / 0.76 / 0.40
     // HBM reads per launch at 262144 rows (PMC): 8.67 GB for 1, 10.99 GB with the rotation alone (the streamed A evicts
@@ -84,6 +85,11 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
         if constexpr (std::is_same<TX, float>::value) {
             if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7, TX>(a, nsplit, st);
+            // 13 = 10 with three tiles in flight: chosen when the grid has at most one workgroup per CU (a 32768-row
+            // shard = the per-GPU work of the 8-GPU configuration), where a single wave per SIMD has to cover the HBM latency
+            constexpr int BM = 32 * MT * (NW / KS);
+            if (pf == 13 || (pf == 10 && cdiv(a.nrows, BM) * nsplit <= 256))
+                return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 13, TX>(a, nsplit, st);
             if (pf == 10) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 10, TX>(a, nsplit, st);
         } else {
             if (pf == 10) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);   // bf16 X: one 64-wide tile in flight

@@ -327,6 +327,86 @@ __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const floa
     }
 }
 
+
+// nt_mainloop_p2 with THREE k-tiles in flight (three register sets).  A shard with at most one workgroup per CU (32768
+// rows) has a single wave per SIMD and nothing else to cover the loaded HBM latency, which exceeds two tile times
+// there: 0.43 -> 0.39-0.40 ms at 32768 x 8192, k = 64 (four in flight: 0.41).  No gain once two or three workgroups
+// share a CU, and the extra registers cost 2 % at 262144 rows, so the launch picks this loop from the grid size.
+template <int KT, int MT, int NW, bool STAGGER, bool NTX>
+__device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
+                                                 const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem) {
+    constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
+    constexpr int STAGE = (BM + KP) * BK, NS = BK / 8;
+    constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
+    const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6, li = lane & 31, h = lane >> 5;
+    f32x4 x0[NPX], y0[NPY], x1[NPX], y1[NPY], x2[NPX], y2[NPY];
+    const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
+    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long kt) {
+        kt = kt < nk ? kt : nk - 1;
+        kt += kshift;
+        kt = kt >= nk ? kt - nk : kt;
+        const long c0 = cbeg + kt * BK;
+        stage_load<BM, T, true, true, NTX>(xr, X, ldx, 0, 0, row0, c0, tid);
+        stage_load<KP, T, true, true>(yr, Y, ldy, KP, 0, 0, c0, tid);
+    };
+    auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
+        stage_store<BM, T>(st, xr, tid);
+        stage_store<KP, T>(st + BM * BK, yr, tid);
+    };
+    auto group = [&](const float* xc, int s) {
+        const float* yc = xc + BM * BK;
+        f32x4 a[MT], b[KT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            a[mt] = *reinterpret_cast<const f32x4*>(&xc[lds_idx(rg * 32 * MT + mt * 32 + li, 2 * s + h)]);
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+            b[jt] = *reinterpret_cast<const f32x4*>(&yc[lds_idx(jt * 32 + li, 2 * s + h)]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < KT; ++jt) acc[mt][jt] = MFMA32(a[mt][e], b[jt][e], acc[mt][jt]);
+    };
+    // tile in `cur`; (xl, yl) receive tile t+3; (xr, yr) hold tile t+1, written into `nxt`
+    auto tile = [&](const float* cur, float* nxt, f32x4 (&xl)[NPX], f32x4 (&yl)[NPY], const f32x4 (&xr)[NPX],
+                    const f32x4 (&yr)[NPY], long t3) {
+        load(xl, yl, t3);
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) group(cur, s);
+        __builtin_amdgcn_sched_barrier(0);
+        store(nxt, xr, yr);
+        __builtin_amdgcn_sched_barrier(0);
+        group(cur, NS - 1);
+        __syncthreads();
+    };
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    load(x0, y0, 0);
+    store(st0, x0, y0);
+    __syncthreads();
+    load(x1, y1, 1);
+    load(x2, y2, 2);
+    long kt = 0;
+    // invariant at the top of a trip: st0 = tile kt, x1 = tile kt+1, x2 = tile kt+2, x0 free (6 tiles: lcm of the three
+    // register sets and the two LDS stages)
+    for (; kt + 6 <= nk; kt += 6) {
+        tile(st0, st1, x0, y0, x1, y1, kt + 3);
+        tile(st1, st0, x1, y1, x2, y2, kt + 4);
+        tile(st0, st1, x2, y2, x0, y0, kt + 5);
+        tile(st1, st0, x0, y0, x1, y1, kt + 6);
+        tile(st0, st1, x1, y1, x2, y2, kt + 7);
+        tile(st1, st0, x2, y2, x0, y0, kt + 8);
+    }
+    const long rem = nk - kt;   // 0..5 tiles left: the same sequence, stopping after the last real tile
+    if (rem >= 1) tile(st0, st1, x0, y0, x1, y1, kt + 3);
+    if (rem >= 2) tile(st1, st0, x1, y1, x2, y2, kt + 4);
+    if (rem >= 3) tile(st0, st1, x2, y2, x0, y0, kt + 5);
+    if (rem >= 4) tile(st1, st0, x0, y0, x1, y1, kt + 6);
+    if (rem >= 5) tile(st0, st1, x1, y1, x2, y2, kt + 7);
+}
+
 template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
@@ -334,8 +414,11 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __r
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
-    constexpr int PF1 = PF == 3 ? 1 : PF;
-    if constexpr (PF == 3 && std::is_same<TX, float>::value) {
+    constexpr int PF1 = (PF == 3 || PF == 4) ? 1 : PF;
+    if constexpr (PF == 4 && KS == 1 && std::is_same<TX, float>::value) {
+        if (interior) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+    } else if constexpr (PF == 3 && std::is_same<TX, float>::value) {
         if (interior) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
         else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
     } else {
@@ -515,7 +598,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
             static_assert(KS == 1, "bf16 X: one contraction slice");
             nt_mainloop_b16<KT, MT, NW, FAST, (PF == 5), (PF == 5)>(acc, static_cast<const bf16_t*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
         } else {
-            nt_mainloop<KT, MT, NW, KS, FAST, (PF == 10 ? 3 : 1), (PF == 5 || PF >= 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+            nt_mainloop<KT, MT, NW, KS, FAST, (PF == 10 ? 3 : PF == 13 ? 4 : 1), (PF == 5 || PF >= 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
         }
     }
 
