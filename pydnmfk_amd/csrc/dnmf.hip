@@ -77,9 +77,9 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // consecutive steps consume each row's 128-B line from L1): correct, but a load instruction then touches 32 rows x
     // 32 B and the texture-address unit, not the matrix pipe, paces the kernel -- 2.6x SLOWER at k = 32 and k = 64 (MFMA
     // busy 21-31 %, HBM reads 1.8x algorithmic).  The transpose of X has to go through LDS.  With A cache-resident the same
-    // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-87 / 91 / 113 from HBM, while
-    // the TN form loses only 2-8 %: the remaining gap is the memory system under this access shape (128 B per row
-    // per visit, 128 rows apart by the 32 KiB row pitch), not the instruction schedule.
+    // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-89 / 91 / 113 from HBM -- with
+    // IDENTICAL cycle counts (PMC): the difference is the core clock the chip holds (1.8-2.0 GHz with the HBM stream,
+    // 2.2-2.4 GHz without), i.e. power, not the instruction schedule (measured ceilings).
     static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 10;
     if constexpr (FAST && KS == 1) if (MODE == NT_FUSED_W || !a.store_all) {
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
