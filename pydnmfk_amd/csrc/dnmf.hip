@@ -153,6 +153,13 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
     const long total = (long)rows_out * cdiv(cols_out, 4);
     const unsigned gx = (unsigned)cdiv(total, 64);
     const int ny = reduce_slices(nsplit);
+    static const bool wide = !(getenv("DNMF_REDUCE_WIDE") && atoi(getenv("DNMF_REDUCE_WIDE")) == 0);
+    if (wide && ny == 1 && rows == rows_out && cols == cols_out && cols % 4 == 0 && cols >= 4096 && ldo % 4 == 0 &&
+        aligned16(out) && aligned16(P) && ldp % 4 == 0 && stride % 4 == 0) {
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, P, stride, ldp,
+                           nsplit, out, ldo, rows, cols);
+        return check_launch("reduce_partials_wide");
+    }
     if (ny == 1) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
                            0L, rows, cols, rows_out, cols_out);

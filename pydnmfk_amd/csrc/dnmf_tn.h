@@ -207,5 +207,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// Wide outputs (W^T A: k x n with n >= 4096): one lane per float4 output, 256 consecutive outputs (4 KiB of every slab)
+// per workgroup, the lane adds the slabs in order with eight loads in flight.  Same sums as above in a different
+// association; single stage only (nsplit <= 64).
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ P, long stride, long ldp,
+                                                                   int nsplit, float* __restrict__ out, long ldo, int rows,
+                                                                   long cols) {
+    const long c4 = cols / 4;                       // cols % 4 == 0 (host checked)
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * c4) return;
+    const int j = idx / c4;
+    const long c = (idx % c4) * 4;
+    const float* src = P + (long)j * ldp + c;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < nsplit; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + k * stride));
+    *reinterpret_cast<f32x4*>(out + (long)j * ldo + c) = s;
+}
 
 }  // namespace
