@@ -491,7 +491,9 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
                      int clamp, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
-    const int nt = 4 / kt;                                  // KT * NT == 4: three 64-register tiles per wave
+    // KT * NT == 4 (three 64-register tiles per wave, 16-byte loads) streams best; a short H (fewer than 1024 such tiles:
+    // n = 8192 gives 128 at k = 64) is a latency chain on a few CUs, so it takes 32-column tiles instead (18.0 -> 15.0 us)
+    const int nt = (kt <= 2 && cdiv(n, 32 * (4 / kt)) < 1024) ? 1 : 4 / kt;
     const bool fast = aligned16(H) && aligned16(AtW) && ldh % 4 == 0 && ldatw % 4 == 0 && n % 4 == 0;
     // four waves per workgroup (G staged once per workgroup).  One-wave workgroups for small H (128 wave tiles at
     // config 3 = 32 workgroups) were measured: 17.6 -> 20.3 us, slower (four times the G staging).
@@ -505,6 +507,15 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
         if (fast) hipLaunchKernelGGL((update_h_kernel<KT_, NT_, true>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp); \
         else hipLaunchKernelGGL((update_h_kernel<KT_, NT_, false>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);    \
     }
+#define UH_CASE1(KT_)                                                                                              \
+    if (kt == KT_ && nt == 1) {                                                                                   \
+        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
+        if (fast) hipLaunchKernelGGL((update_h_kernel<KT_, 1, true>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp); \
+        else hipLaunchKernelGGL((update_h_kernel<KT_, 1, false>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);    \
+        return check_launch("mu_update_h");                                                                       \
+    }
+    UH_CASE1(1) UH_CASE1(2)
+#undef UH_CASE1
     UH_CASE(1, 4) UH_CASE(2, 2) UH_CASE(4, 1)
 #undef UH_CASE
     return check_launch("mu_update_h");
