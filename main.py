@@ -15,51 +15,59 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def str2bool(v):
-    if isinstance(v, bool):
-        return v
-    if v.lower() in ('yes', 'true', 't', 'y', '1'):
+def _flag(text):
+    """yes/no style command-line booleans"""
+    if isinstance(text, bool):
+        return text
+    word = text.strip().lower()
+    if word in {'1', 'y', 'yes', 't', 'true'}:
         return True
-    if v.lower() in ('no', 'false', 'f', 'n', '0'):
+    if word in {'0', 'n', 'no', 'f', 'false'}:
         return False
     raise NameError('Boolean value expected.')
 
 
-def parser_pyNMF(parser):
-    parser.add_argument('--process', type=str, default='pyDNMF', help='pyDNMF/pyDNMFk')
-    parser.add_argument('--p_r', type=int, required=True, help='Now of row processors')
-    parser.add_argument('--p_c', type=int, required=True, help='Now of column processors')
-    parser.add_argument('--k', type=int, default=4, help='feature count')
-    parser.add_argument('--fpath', type=str, default='data/', help='data path to read(eg: tmp/)')
-    parser.add_argument('--ftype', type=str, default='mat', help='data type : mat/folder/h5')
-    parser.add_argument('--fname', type=str, default='swim', help='File name')
-    parser.add_argument('--init', type=str, default='rand', help='NMF initializations: rand/nnsvd')
-    parser.add_argument('--itr', type=int, default=5000, help='NMF iterations, default:1000')
-    parser.add_argument('--norm', type=str, default='kl', help='Reconstruction Norm for NMF to optimize:KL/FRO')
-    parser.add_argument('--method', type=str, default='mu', help='NMF update method:MU/BCD/HALS')
-    parser.add_argument('--verbose', type=str2bool, default=False)
-    parser.add_argument('--results_path', type=str, default='results/', help='Path for saving results')
-    parser.add_argument('--checkpoint', type=str2bool, default=False, help='Enable checkpoint to track the pyNMFk state')
-    parser.add_argument('--timing_stats', type=str2bool, default=False, help='accepted for compatibility; ignored')
-    parser.add_argument('--prune', type=str2bool, default=False, help='Prune zero row/column.')
-    parser.add_argument('--precision', type=str, default='float32', help='Storage precision of the data: float32, or bfloat16 (Frobenius mu/hals; arithmetic stays float32).')
-    return parser
+# The reference CLI surface (main.py:13-58), kept flag for flag so existing launch scripts work:
+#   (flag, type, default, required, help)
+FLAGS = [
+    # single factorisation
+    ('process', str, 'pyDNMF', False, 'pyDNMF (one factorisation) or pyDNMFk (rank estimation)'),
+    ('p_r', int, None, True, 'process-grid rows'),
+    ('p_c', int, None, True, 'process-grid columns'),
+    ('k', int, 4, False, 'rank of the factorisation'),
+    ('fpath', str, 'data/', False, 'directory of the input (with trailing slash)'),
+    ('ftype', str, 'mat', False, 'input format: mat / npy / csv / txt / folder'),
+    ('fname', str, 'swim', False, 'input file name without extension'),
+    ('init', str, 'rand', False, 'factor initialisation: rand / nnsvd'),
+    ('itr', int, 5000, False, 'update iterations'),
+    ('norm', str, 'kl', False, 'objective: kl / fro'),
+    ('method', str, 'mu', False, 'update rule: mu / hals'),
+    ('verbose', _flag, False, False, 'print the relative error of every fit'),
+    ('results_path', str, 'results/', False, 'output directory'),
+    ('checkpoint', _flag, False, False, 'keep a coarse NMFk checkpoint'),
+    ('timing_stats', _flag, False, False, 'accepted for compatibility; ignored'),
+    ('prune', _flag, False, False, 'drop all-zero rows / columns before factorising'),
+    ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
+    # NMFk
+    ('perturbations', int, 20, False, 'perturbed copies per rank'),
+    ('noise_var', float, 0.015, False, 'perturbation amplitude'),
+    ('start_k', int, 1, False, 'first rank of the sweep'),
+    ('end_k', int, 10, False, 'last rank of the sweep'),
+    ('step_k', int, 1, False, 'rank increment'),
+    ('sill_thr', float, 0.6, False, 'silhouette threshold of the rank estimate'),
+    ('sampling', str, 'uniform', False, 'perturbation law: uniform / poisson'),
+]
 
 
-def parser_pyNMFk(parser):
-    parser.add_argument('--perturbations', type=int, default=20, help='perturbation for NMFk')
-    parser.add_argument('--noise_var', type=float, default=0.015, help='Noise variance for NMFk')
-    parser.add_argument('--start_k', type=int, default=1, help='Start index of K for NMFk')
-    parser.add_argument('--end_k', type=int, default=10, help='End index of K for NMFk')
-    parser.add_argument('--step_k', type=int, default=1, help='step for K search')
-    parser.add_argument('--sill_thr', type=float, default=0.6, help='SIll Threshold for K estimation')
-    parser.add_argument('--sampling', type=str, default='uniform', help='Sampling noise for NMFk i.e uniform/poisson')
-    return parser
+def build_parser():
+    ap = argparse.ArgumentParser(description='pyDNMF / pyDNMFk on MI355X (reference-compatible flags)')
+    for name, kind, default, required, text in FLAGS:
+        ap.add_argument('--' + name, type=kind, default=default, required=required, help=text)
+    return ap
 
 
 def main():
-    parser = parser_pyNMFk(parser_pyNMF(argparse.ArgumentParser(description='Arguments for pyDNMF/pyDNMFk on MI355X')))
-    args = parser.parse_args()
+    args = build_parser().parse_args()
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
