@@ -83,7 +83,16 @@ def ds_t24x12z():
     return A, k
 
 
+def ds_r50x39():
+    """Ragged on every non-square grid used below (50 % 4, 39 % 3, 39 % 2 != 0, and the slices of the blocks again)."""
+    rs = np.random.RandomState(104)
+    W = rs.rand(50, 5)
+    H = rs.rand(5, 39)
+    return W @ H + 0.01 * rs.rand(50, 39), 5
+
+
 DATASETS = {
+    "r50x39": ds_r50x39,
     "t24x12z": ds_t24x12z,
     "t24x12": ds_t24x12,
     "r25x13": ds_r25x13,
@@ -260,8 +269,31 @@ def main_prune():
     run_case("t24x12z_1x1_kl_float32_prune", "t24x12z", [1, 1], "kl", np.float32, (10,), prune=True)
 
 
+def main_nonsquare():
+    """Non-square 2D grids (BASELINE config 4 is 4x2): the slice rule (utils.py:99-103) and the allgather / Reduce_scatter
+    pairing (dist_nmf.py:145-205, :268-343) only distinguish the size-p_r group from the size-p_c group when p_r != p_c."""
+    A, k = DATASETS["r50x39"]()
+    W0, H0 = init_factors(A.shape[0], A.shape[1], k, 7)
+    np.savez_compressed(os.path.join(HERE, "data_r50x39.npz"), A=A, W0=W0, H0=H0, k=np.array(k))
+    f32 = np.float32
+    for grid in ([4, 2], [2, 3], [3, 2], [2, 4]):
+        g = "%dx%d" % tuple(grid)
+        for norm, method in (("fro", "mu"), ("kl", "mu"), ("fro", "hals")):
+            tag = "hals" if method == "hals" else norm
+            run_case("r50x39_%s_%s_float32" % (g, tag), "r50x39", grid, norm, f32, (1, 10), method=method)
+    for grid in ([4, 2], [2, 3]):
+        g = "%dx%d" % tuple(grid)
+        for norm, method in (("fro", "mu"), ("kl", "mu"), ("fro", "hals")):
+            tag = "hals" if method == "hals" else norm
+            run_case("lr200x136k64_%s_%s_float32" % (g, tag), "lr200x136k64", grid, norm, f32, (10,), method=method)
+    run_case("lr150x140k128_4x2_kl_float32", "lr150x140k128", [4, 2], "kl", f32, (10,))     # config 4's rank and grid
+    run_case("swim_4x2_kl_float32", "swim", [4, 2], "kl", f32, (10,))                      # zeros in X on 4x2
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "prune":
+    if len(sys.argv) > 1 and sys.argv[1] == "nonsquare":
+        main_nonsquare()
+    elif len(sys.argv) > 1 and sys.argv[1] == "prune":
         main_prune()
     elif len(sys.argv) > 1 and sys.argv[1] == "hals":
         main_hals()      # adds the HALS cases without touching the MU fixtures
@@ -269,3 +301,4 @@ if __name__ == "__main__":
         main()
         main_hals()
         main_prune()
+        main_nonsquare()

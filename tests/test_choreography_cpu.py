@@ -26,6 +26,12 @@ CASES = [
     # HALS / Frobenius
     "t24x12_1x1_hals_float32", "t24x12_2x1_hals_float32", "t24x12_1x2_hals_float32", "t24x12_2x2_hals_float32",
     "r25x13_3x1_hals_float32", "r25x13_2x2_hals_float32", "swim_4x1_hals_float32", "lr200x136k64_1x2_hals_float32",
+    # non-square 2D grids (BASELINE config 4 is 4x2): the size-p_r and size-p_c groups differ
+    "r50x39_4x2_fro_float32", "r50x39_4x2_kl_float32", "r50x39_4x2_hals_float32",
+    "r50x39_2x3_fro_float32", "r50x39_2x3_kl_float32", "r50x39_2x3_hals_float32",
+    "r50x39_3x2_kl_float32", "r50x39_2x4_fro_float32", "r50x39_2x4_hals_float32",
+    "lr200x136k64_4x2_fro_float32", "lr200x136k64_2x3_kl_float32", "lr200x136k64_4x2_hals_float32",
+    "lr150x140k128_4x2_kl_float32", "swim_4x2_kl_float32",
 ]
 
 

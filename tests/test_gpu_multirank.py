@@ -13,7 +13,13 @@ CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_floa
          "lr136x100k32_2x2_kl_float32",
          "t24x12_2x1_hals_float32", "t24x12_2x2_hals_float32", "r25x13_3x1_hals_float32", "swim_4x1_hals_float32",
          "lr200x136k64_1x2_hals_float32",
-         "t24x12z_2x1_fro_float32_prune", "t24x12z_1x2_fro_float32_prune", "t24x12z_2x2_fro_float32_prune"]
+         "t24x12z_2x1_fro_float32_prune", "t24x12z_1x2_fro_float32_prune", "t24x12z_2x2_fro_float32_prune",
+         # non-square 2D grids (config 4 is 4x2): 6 or 8 ranks on the one GPU
+         "r50x39_4x2_fro_float32", "r50x39_4x2_kl_float32", "r50x39_4x2_hals_float32",
+         "r50x39_2x3_fro_float32", "r50x39_2x3_kl_float32", "r50x39_2x3_hals_float32",
+         "r50x39_3x2_fro_float32", "r50x39_2x4_kl_float32",
+         "lr200x136k64_4x2_fro_float32", "lr200x136k64_4x2_kl_float32", "lr200x136k64_2x3_hals_float32",
+         "lr150x140k128_4x2_kl_float32", "swim_4x2_kl_float32"]
 
 
 @pytest.mark.parametrize("name", CASES)
