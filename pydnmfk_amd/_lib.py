@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  isort:skip
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdnmf_hip.so")
+# DNMF_LIB_PATH: measurement tools point this at the tuning build (tools/_build/libdnmf_hip_tune.so, same ABI)
+LIB_PATH = os.environ.get("DNMF_LIB_PATH") or os.path.join(_HERE, "libdnmf_hip.so")
 
 c_float_p = ctypes.c_void_p
 c_long, c_int, c_float, c_size_t, c_void_p = ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "dnmf.hip")
 LIB = os.path.join(HERE, "libdnmf_hip.so")
+TUNE_LIB = os.path.join(ROOT, "tools", "_build", "libdnmf_hip_tune.so")   # -DDNMF_TUNING: experiment switches (tools only)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -23,13 +24,20 @@ def _stale():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build_lib(force=False, report=False):
-    """Compile csrc/dnmf.hip (one translation unit, kernels in csrc/dnmf_*.h) -> libdnmf_hip.so.  Returns the library path."""
-    if not force and not report and not _stale():
+def build_lib(force=False, report=False, tuning=False):
+    """Compile csrc/dnmf.hip (one translation unit, kernels in csrc/dnmf_*.h) -> libdnmf_hip.so.  Returns the library path.
+    `tuning=True` builds tools/_build/libdnmf_hip_tune.so instead: the same source with -DDNMF_TUNING, in which the
+    DNMF_* environment switches and the extra kernel variants of the A/B runs exist (tools/README.md); the shipped
+    library reads no environment."""
+    out = TUNE_LIB if tuning else LIB
+    if not tuning and not force and not report and not _stale():
         return LIB
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(HERE, "csrc"),
-           "-shared", "-fPIC", "-o", LIB, SRC]
+           "-shared", "-fPIC", "-o", out, SRC]
+    if tuning:
+        cmd.insert(1, "-DDNMF_TUNING")
     if report:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -38,7 +46,7 @@ def build_lib(force=False, report=False):
         raise RuntimeError("hipcc failed (%d)" % res.returncode)
     if report:
         print(resource_report(res.stderr))
-    return LIB
+    return out
 
 
 def resource_report(log):
@@ -63,5 +71,4 @@ def resource_report(log):
 
 
 if __name__ == "__main__":
-    build_lib(force=True, report="--report" in sys.argv)
-    print(LIB)
+    print(build_lib(force=True, report="--report" in sys.argv, tuning="--tuning" in sys.argv))

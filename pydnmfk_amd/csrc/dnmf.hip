@@ -80,7 +80,7 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // kernel reaches 103 / 118 / 128 TFLOP/s at 32768 / 65536 / 262144 rows against 82-89 / 91 / 113 from HBM -- with
     // IDENTICAL cycle counts (PMC): the difference is the core clock the chip holds (1.8-2.0 GHz with the HBM stream,
     // 2.2-2.4 GHz without), i.e. power, not the instruction schedule (measured ceilings).
-    static const int pf = getenv("DNMF_NT_PF") ? atoi(getenv("DNMF_NT_PF")) : 10;
+    static const int pf = (int)tune("DNMF_NT_PF", 10);
     if constexpr (FAST && KS == 1) if (MODE == NT_FUSED_W || !a.store_all) {
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
         if constexpr (std::is_same<TX, float>::value) {
@@ -124,7 +124,7 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
     // nontemporal loads of the streamed operand (A): +2 % at 262144 rows, +7 % at 65536 rows, slightly less HBM
     // traffic (the reused W rows stay in L2).  DNMF_TN_NT=0 switches them off for A/B runs.
-    static const bool nty = !(getenv("DNMF_TN_NT") && atoi(getenv("DNMF_TN_NT")) == 0);
+    static const bool nty = tune("DNMF_TN_NT", 1) != 0;
 #define TN_CASE(KT_, NT_)                                                                                \
     if (kt == KT_) {                                                                                     \
         if (fast && nty) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, true, TY>), grid, block, 0, st, a); \
@@ -153,7 +153,7 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
     const long total = (long)rows_out * cdiv(cols_out, 4);
     const unsigned gx = (unsigned)cdiv(total, 64);
     const int ny = reduce_slices(nsplit);
-    static const bool wide = !(getenv("DNMF_REDUCE_WIDE") && atoi(getenv("DNMF_REDUCE_WIDE")) == 0);
+    static const bool wide = tune("DNMF_REDUCE_WIDE", 1) != 0;
     if (wide && ny == 1 && rows == rows_out && cols == cols_out && cols % 4 == 0 && cols >= 4096 && ldo % 4 == 0 &&
         aligned16(out) && aligned16(P) && ldp % 4 == 0 && stride % 4 == 0) {
         hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, P, stride, ldp,
@@ -179,7 +179,7 @@ struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long ch
 TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
     TnPlan p;
     p.ncolblk = (int)cdiv(ycols, 32 * nt);
-    static const long target_waves = getenv("DNMF_TN_WAVES") ? atol(getenv("DNMF_TN_WAVES")) : 2048;  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
+    static const long target_waves = tune("DNMF_TN_WAVES", 2048);  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
     long nchunks = std::max<long>(1, target_waves / p.ncolblk);
     nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, min_rows)));
     p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
@@ -214,7 +214,7 @@ struct WsLayout {
 
 // k <= 16 kernels (dnmf_k16.h): DNMF_K16=0 switches them off (A/B runs)
 inline bool k16_on() {
-    static const bool on = !(getenv("DNMF_K16") && atoi(getenv("DNMF_K16")) == 0);
+    static const bool on = tune("DNMF_K16", 1) != 0;
     return on;
 }
 // row chunking of tn16_kernel: waves = nchunks x (n / (16 V)), 16-row partial slabs of ld = n
@@ -413,13 +413,37 @@ int dnmf_aht_update_w_bf16a(const void* A, long m, long n, long lda, const float
     return aht_update_w_impl<bf16_t>((const bf16_t*)A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
 }
 
+}  // extern "C"
+namespace {
+template <int KT, bool FAST, int OCC>
+int launch_update_w_seq(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, hipStream_t st) {
+    constexpr size_t lds = (size_t)(32 * KT) * (32 * KT + 4) * sizeof(float);
+    static bool once = false;
+    if (!once) { allow_lds(update_w_seq_kernel<KT, FAST, OCC>, lds); once = true; }
+    // persistent workgroups: G is staged once per workgroup; OCC x 256 CUs of them cover the chip
+    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(m, 32), 4), 256L * OCC);
+    hipLaunchKernelGGL((update_w_seq_kernel<KT, FAST, OCC>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+    return check_launch("mu_update_w");
+}
+}  // namespace
+extern "C" {
+
 int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                      void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && AH && G && m >= 1 && ldw >= k && ldah >= k, "mu_update_w: bad arguments");
     const bool fast = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;
-    const dim3 grid((unsigned)cdiv(cdiv(m, 32), 4)), block(256);
     hipStream_t st = S(stream);
+    static const int var = (int)tune("DNMF_UPD_W", 4);   // waves per SIMD requested from the compiler
+#define UWS(KT_, OCC_)                                                                                            \
+    if (kt == KT_ && var == OCC_)                                                                                 \
+        return fast ? launch_update_w_seq<KT_, true, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st)                    \
+                    : launch_update_w_seq<KT_, false, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st);
+    UWS(1, 4) UWS(2, 4) UWS(4, 4)
+#ifdef DNMF_TUNING
+    UWS(1, 3) UWS(2, 3) UWS(4, 3) UWS(1, 5) UWS(2, 5) UWS(4, 5) UWS(1, 6) UWS(2, 6) UWS(1, 8) UWS(2, 2) UWS(4, 2)
+    if (var == 0) {   // the all-at-once form (r01), kept in the tuning build for A/B runs
+        const dim3 grid((unsigned)cdiv(cdiv(m, 32), 4)), block(256);
 #define UW_CASE(KT_)                                                                                              \
     if (kt == KT_) {                                                                                              \
         const size_t lds = (size_t)(32 * KT_) * (32 * KT_ + 4) * sizeof(float);                                    \
@@ -428,9 +452,13 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
         if (fast) hipLaunchKernelGGL((update_w_kernel<KT_, true>), grid, block, lds, st, W, m, k, ldw, AH, ldah, G, eps); \
         else hipLaunchKernelGGL((update_w_kernel<KT_, false>), grid, block, lds, st, W, m, k, ldw, AH, ldah, G, eps);    \
     }
-    UW_CASE(1) UW_CASE(2) UW_CASE(4)
+        UW_CASE(1) UW_CASE(2) UW_CASE(4)
 #undef UW_CASE
-    return check_launch("mu_update_w");
+        return check_launch("mu_update_w");
+    }
+#endif
+#undef UWS
+    return fail(DNMF_EINVAL, "mu_update_w: no kernel for k tile %d / variant %d", kt, var);
 }
 
 }  // extern "C"
@@ -487,38 +515,55 @@ int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int 
     return wta_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
 }
 
+}  // extern "C"
+namespace {
+template <int KT, int NT, bool FAST, int OCC>
+int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps, int clamp,
+                        hipStream_t st) {
+    constexpr size_t lds = (size_t)(32 * KT) * (32 * KT + 4) * sizeof(float);
+    static bool once = false;
+    if (!once) { allow_lds(update_h_seq_kernel<KT, NT, FAST, OCC>, lds); once = true; }
+    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32 * NT), 4), 256L * OCC);
+    hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, FAST, OCC>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+    return check_launch("mu_update_h");
+}
+}  // namespace
+extern "C" {
+
 int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
                      int clamp, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
-    // KT * NT == 4 (three 64-register tiles per wave, 16-byte loads) streams best; a short H (fewer than 1024 such tiles:
-    // n = 8192 gives 128 at k = 64) is a latency chain on a few CUs, so it takes 32-column tiles instead (18.0 -> 15.0 us)
-    const int nt = (kt <= 2 && cdiv(n, 32 * (4 / kt)) < 1024) ? 1 : 4 / kt;
     const bool fast = aligned16(H) && aligned16(AtW) && ldh % 4 == 0 && ldatw % 4 == 0 && n % 4 == 0;
-    // four waves per workgroup (G staged once per workgroup).  One-wave workgroups for small H (128 wave tiles at
-    // config 3 = 32 workgroups) were measured: 17.6 -> 20.3 us, slower (four times the G staging).
-    const long tiles = cdiv(n, 32 * nt);
-    const int wpb = 4;
-    const dim3 grid((unsigned)cdiv(tiles, wpb)), block(64 * wpb);
     hipStream_t st = S(stream);
+    // variant code = 10 * NT (columns per lane) + waves per SIMD requested from the compiler
+    static const int var = (int)tune("DNMF_UPD_H", 14);
+#define UHS(KT_, NT_, OCC_)                                                                                       \
+    if (kt == KT_ && var == 10 * NT_ + OCC_)                                                                      \
+        return fast ? launch_update_h_seq<KT_, NT_, true, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st)      \
+                    : launch_update_h_seq<KT_, NT_, false, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st);
+    UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4)
+#ifdef DNMF_TUNING
+    UHS(1, 1, 5) UHS(2, 1, 5) UHS(1, 1, 6) UHS(2, 1, 6) UHS(1, 1, 8) UHS(4, 1, 3) UHS(4, 1, 5)
+    UHS(1, 2, 3) UHS(2, 2, 3) UHS(1, 2, 4) UHS(2, 2, 4) UHS(4, 2, 2) UHS(4, 2, 3) UHS(1, 2, 5) UHS(1, 2, 6)
+    UHS(1, 4, 3) UHS(1, 4, 4) UHS(2, 4, 2) UHS(1, 4, 2)
+    if (var == 0) {   // the all-at-once form (r01), kept in the tuning build for A/B runs
+        const int nt = (kt <= 2 && cdiv(n, 32 * (4 / kt)) < 1024) ? 1 : 4 / kt;
+        const long tiles = cdiv(n, 32 * nt);
+        const dim3 grid((unsigned)cdiv(tiles, 4)), block(256);
 #define UH_CASE(KT_, NT_)                                                                                         \
-    if (kt == KT_) {                                                                                              \
+    if (kt == KT_ && nt == NT_) {                                                                                 \
         const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
         if (fast) hipLaunchKernelGGL((update_h_kernel<KT_, NT_, true>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp); \
         else hipLaunchKernelGGL((update_h_kernel<KT_, NT_, false>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);    \
-    }
-#define UH_CASE1(KT_)                                                                                              \
-    if (kt == KT_ && nt == 1) {                                                                                   \
-        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
-        if (fast) hipLaunchKernelGGL((update_h_kernel<KT_, 1, true>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp); \
-        else hipLaunchKernelGGL((update_h_kernel<KT_, 1, false>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);    \
         return check_launch("mu_update_h");                                                                       \
     }
-    UH_CASE1(1) UH_CASE1(2)
-#undef UH_CASE1
-    UH_CASE(1, 4) UH_CASE(2, 2) UH_CASE(4, 1)
+        UH_CASE(1, 1) UH_CASE(2, 1) UH_CASE(1, 4) UH_CASE(2, 2) UH_CASE(4, 1)
 #undef UH_CASE
-    return check_launch("mu_update_h");
+    }
+#endif
+#undef UHS
+    return fail(DNMF_EINVAL, "mu_update_h: no kernel for k tile %d / variant %d", kt, var);
 }
 
 int dnmf_clamp_min(float* X, long rows, long cols, long ldx, float eps, void* stream) {
@@ -571,7 +616,7 @@ static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, 
     NnArgs a{};
     a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
     a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
-    static const int kl_pipe = getenv("DNMF_KL_PIPE") ? atoi(getenv("DNMF_KL_PIPE")) : 1;
+    static const int kl_pipe = (int)tune("DNMF_KL_PIPE", 1);
     a.pipe = kl_pipe;
     return a;
 }

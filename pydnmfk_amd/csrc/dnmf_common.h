@@ -49,6 +49,14 @@ int check_launch(const char* what) {
     return DNMF_OK;
 }
 
+// Experiment switches exist only in the tuning build (-DDNMF_TUNING -> tools/_build/libdnmf_hip_tune.so, tools/README.md);
+// the shipped library has the defaults compiled in and never reads the environment.
+#ifdef DNMF_TUNING
+inline long tune(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
+#else
+constexpr long tune(const char*, long dflt) { return dflt; }
+#endif
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
