@@ -208,6 +208,30 @@ SplitPlan plan_gram_nt(long n) {
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// element-wise pass (dnmf_stream.h): 16-byte vectors when X (and S) allow it; a long-row or a patch launch
+template <int OP>
+int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long lds_, const float* x, float eps, int clamp,
+              const char* what, hipStream_t st) {
+    const bool vec = aligned16(X) && ldx % 4 == 0 && cols % 4 == 0 && (!Sm || (aligned16(Sm) && lds_ % 4 == 0)) &&
+                     (!x || OP == EW_ROWS_MUL || OP == EW_KL_BYROW || aligned16(x));
+    const long cvecs = vec ? cols / 4 : cols;
+    constexpr int U = 4;
+    if (cvecs > 256 && rows <= 65535) {                       // long rows
+        const dim3 grid((unsigned)cdiv(cvecs, 256 * U), (unsigned)rows);
+        if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+        else hipLaunchKernelGGL((ew_kernel<OP, 1, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+        return check_launch(what);
+    }
+    if (cvecs > 256) return fail(DNMF_EINVAL, "%s: %ld rows x %ld columns: neither a long-row nor a patch shape", what, rows, cols);
+    int txs = 0;
+    while (txs < 8 && (1L << txs) < cvecs) ++txs;
+    const long TY = 256 >> txs;
+    const dim3 grid((unsigned)cdiv(rows, TY * U));
+    if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+    else hipLaunchKernelGGL((ew_kernel<OP, 1, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+    return check_launch(what);
+}
+
 struct WsLayout {
     size_t g_off, s_off, x_off, part_off, total;  // G [KP*KP] | S = AtW / AH / UHT / WTU | x [KP] | partials
 };
@@ -415,14 +439,18 @@ int dnmf_aht_update_w_bf16a(const void* A, long m, long n, long lda, const float
 
 }  // extern "C"
 namespace {
-template <int KT, bool FAST, int OCC>
+template <int KT, int V, int OCC>
 int launch_update_w_seq(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, hipStream_t st) {
     constexpr size_t lds = (size_t)(32 * KT) * (32 * KT + 4) * sizeof(float);
     static bool once = false;
-    if (!once) { allow_lds(update_w_seq_kernel<KT, FAST, OCC>, lds); once = true; }
-    // persistent workgroups: G is staged once per workgroup; OCC x 256 CUs of them cover the chip
-    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(m, 32), 4), 256L * OCC);
-    hipLaunchKernelGGL((update_w_seq_kernel<KT, FAST, OCC>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+    if (!once) { allow_lds(update_w_seq_kernel<KT, V, OCC, false>, lds); allow_lds(update_w_seq_kernel<KT, V, OCC, true>, lds); once = true; }
+    // one tile per wave (the kernel's tile loop only matters beyond 2^31 workgroups): measured on the 3.2 GB pass at
+    // k = 64, workgroups that loop over tiles (256 x OCC of them, G staged once each) 4.5 TB/s, one tile per wave 4.75
+    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(m, 32), 4), tune("DNMF_UPD_GRID", 1L << 30));
+    if (k == 32 * KT && m % 32 == 0)
+        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, false>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+    else
+        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, true>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
     return check_launch("mu_update_w");
 }
 }  // namespace
@@ -432,30 +460,20 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
                      void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && AH && G && m >= 1 && ldw >= k && ldah >= k, "mu_update_w: bad arguments");
+    REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "mu_update_w: leading dimension beyond the 32-bit tile offsets");
     const bool fast = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;
     hipStream_t st = S(stream);
-    static const int var = (int)tune("DNMF_UPD_W", 4);   // waves per SIMD requested from the compiler
+    // waves per SIMD requested from the compiler (3.2 GB pass, k = 64: 3 / 4 / 5 / 6 -> 4.68 / 4.72 / 4.76 / 4.67 TB/s;
+    // k = 128 holds 120 registers: 4)
+    static const int var0 = (int)tune("DNMF_UPD_W", 0);
+    const int var = var0 ? var0 : (kt == 4 ? 4 : 5);
 #define UWS(KT_, OCC_)                                                                                            \
     if (kt == KT_ && var == OCC_)                                                                                 \
-        return fast ? launch_update_w_seq<KT_, true, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st)                    \
-                    : launch_update_w_seq<KT_, false, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st);
-    UWS(1, 4) UWS(2, 4) UWS(4, 4)
+        return fast ? launch_update_w_seq<KT_, 4, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st)                       \
+                    : launch_update_w_seq<KT_, 1, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st);
+    UWS(1, 5) UWS(2, 5) UWS(4, 4)
 #ifdef DNMF_TUNING
-    UWS(1, 3) UWS(2, 3) UWS(4, 3) UWS(1, 5) UWS(2, 5) UWS(4, 5) UWS(1, 6) UWS(2, 6) UWS(1, 8) UWS(2, 2) UWS(4, 2)
-    if (var == 0) {   // the all-at-once form (r01), kept in the tuning build for A/B runs
-        const dim3 grid((unsigned)cdiv(cdiv(m, 32), 4)), block(256);
-#define UW_CASE(KT_)                                                                                              \
-    if (kt == KT_) {                                                                                              \
-        const size_t lds = (size_t)(32 * KT_) * (32 * KT_ + 4) * sizeof(float);                                    \
-        static bool once = false;                                                                                 \
-        if (!once) { allow_lds(update_w_kernel<KT_, true>, lds); allow_lds(update_w_kernel<KT_, false>, lds); once = true; } \
-        if (fast) hipLaunchKernelGGL((update_w_kernel<KT_, true>), grid, block, lds, st, W, m, k, ldw, AH, ldah, G, eps); \
-        else hipLaunchKernelGGL((update_w_kernel<KT_, false>), grid, block, lds, st, W, m, k, ldw, AH, ldah, G, eps);    \
-    }
-        UW_CASE(1) UW_CASE(2) UW_CASE(4)
-#undef UW_CASE
-        return check_launch("mu_update_w");
-    }
+    UWS(1, 3) UWS(2, 3) UWS(4, 3) UWS(1, 4) UWS(2, 4) UWS(4, 5) UWS(1, 6) UWS(2, 6) UWS(1, 8) UWS(2, 2) UWS(4, 2)
 #endif
 #undef UWS
     return fail(DNMF_EINVAL, "mu_update_w: no kernel for k tile %d / variant %d", kt, var);
@@ -517,14 +535,17 @@ int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int 
 
 }  // extern "C"
 namespace {
-template <int KT, int NT, bool FAST, int OCC>
+template <int KT, int NT, int OCC>
 int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps, int clamp,
                         hipStream_t st) {
     constexpr size_t lds = (size_t)(32 * KT) * (32 * KT + 4) * sizeof(float);
     static bool once = false;
-    if (!once) { allow_lds(update_h_seq_kernel<KT, NT, FAST, OCC>, lds); once = true; }
-    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32 * NT), 4), 256L * OCC);
-    hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, FAST, OCC>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+    if (!once) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false>, lds); allow_lds(update_h_seq_kernel<KT, NT, OCC, true>, lds); once = true; }
+    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32 * NT), 4), tune("DNMF_UPD_GRID", 1L << 30));
+    if (k == 32 * KT && n % (32 * NT) == 0)
+        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+    else
+        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, true>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     return check_launch("mu_update_h");
 }
 }  // namespace
@@ -534,33 +555,30 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
                      int clamp, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
-    const bool fast = aligned16(H) && aligned16(AtW) && ldh % 4 == 0 && ldatw % 4 == 0 && n % 4 == 0;
+    // 32-bit tile offsets of the buffer accesses: (27 + 4) rows of a 32-row block plus the column part stay below 2 GiB
+    REQUIRE(ldh < (1L << 24) && ldatw < (1L << 24), "mu_update_h: leading dimension beyond the 32-bit tile offsets");
+    const bool even = ((uintptr_t)H % 8 == 0) && ((uintptr_t)AtW % 8 == 0) && ldh % 2 == 0 && ldatw % 2 == 0 && n % 2 == 0;
     hipStream_t st = S(stream);
-    // variant code = 10 * NT (columns per lane) + waves per SIMD requested from the compiler
-    static const int var = (int)tune("DNMF_UPD_H", 14);
+    // variant code = 10 * NT (columns per lane) + waves per SIMD requested from the compiler.  Measured on the 3.2 GB pass
+    // (k x 2^22): k = 64: 14 / 16 -> 4.76 / 4.78 TB/s, 23 -> 4.97, 24 (spills) -> 4.0; k = 32: 14 -> 4.93, 23 -> 5.26;
+    // k = 128: 14 -> 3.44, 23 -> 2.58.  Two columns per lane (256 B per row and wave) stream better but need 8-byte
+    // aligned rows, and a short H (fewer than 1024 such tiles: a latency chain on a few CUs) keeps 32-column tiles.
+    static const int var0 = (int)tune("DNMF_UPD_H", 0);
+    int var = var0 ? var0 : ((kt <= 2 && even && k == 32 * kt && n % 64 == 0 && n / 64 >= 1024) ? 23 : 14);
+    if (var >= 20 && !even) var = 14;
 #define UHS(KT_, NT_, OCC_)                                                                                       \
     if (kt == KT_ && var == 10 * NT_ + OCC_)                                                                      \
-        return fast ? launch_update_h_seq<KT_, NT_, true, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st)      \
-                    : launch_update_h_seq<KT_, NT_, false, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st);
-    UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4)
+        return launch_update_h_seq<KT_, NT_, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st);
+    UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4) UHS(1, 2, 3) UHS(2, 2, 3)
 #ifdef DNMF_TUNING
+    if (var == 99 && kt == 2 && k == 64 && n % 32 == 0) {   // memory pattern of the k = 64 kernel without its matrix work
+        constexpr size_t lds = 64 * 68 * sizeof(float);
+        const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32), 4), tune("DNMF_UPD_GRID", 1024L));
+        hipLaunchKernelGGL((update_h_seq_kernel<2, 1, 4, false, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        return check_launch("mu_update_h(nomma)");
+    }
     UHS(1, 1, 5) UHS(2, 1, 5) UHS(1, 1, 6) UHS(2, 1, 6) UHS(1, 1, 8) UHS(4, 1, 3) UHS(4, 1, 5)
-    UHS(1, 2, 3) UHS(2, 2, 3) UHS(1, 2, 4) UHS(2, 2, 4) UHS(4, 2, 2) UHS(4, 2, 3) UHS(1, 2, 5) UHS(1, 2, 6)
-    UHS(1, 4, 3) UHS(1, 4, 4) UHS(2, 4, 2) UHS(1, 4, 2)
-    if (var == 0) {   // the all-at-once form (r01), kept in the tuning build for A/B runs
-        const int nt = (kt <= 2 && cdiv(n, 32 * (4 / kt)) < 1024) ? 1 : 4 / kt;
-        const long tiles = cdiv(n, 32 * nt);
-        const dim3 grid((unsigned)cdiv(tiles, 4)), block(256);
-#define UH_CASE(KT_, NT_)                                                                                         \
-    if (kt == KT_ && nt == NT_) {                                                                                 \
-        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
-        if (fast) hipLaunchKernelGGL((update_h_kernel<KT_, NT_, true>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp); \
-        else hipLaunchKernelGGL((update_h_kernel<KT_, NT_, false>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);    \
-        return check_launch("mu_update_h");                                                                       \
-    }
-        UH_CASE(1, 1) UH_CASE(2, 1) UH_CASE(1, 4) UH_CASE(2, 2) UH_CASE(4, 1)
-#undef UH_CASE
-    }
+    UHS(1, 2, 4) UHS(2, 2, 4) UHS(4, 2, 2) UHS(4, 2, 3) UHS(1, 2, 5) UHS(1, 2, 6)
 #endif
 #undef UHS
     return fail(DNMF_EINVAL, "mu_update_h: no kernel for k tile %d / variant %d", kt, var);
@@ -568,23 +586,17 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
 
 int dnmf_clamp_min(float* X, long rows, long cols, long ldx, float eps, void* stream) {
     REQUIRE(X && rows >= 1 && cols >= 1 && ldx >= cols, "clamp_min: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv(rows * cols, 256), 8192);
-    hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, S(stream), X, rows, cols, ldx, eps);
-    return check_launch("clamp");
+    return launch_ew<EW_CLAMP>(X, rows, cols, ldx, nullptr, 0, nullptr, eps, 0, "clamp", S(stream));
 }
 
 int dnmf_scale_cols_div(float* W, long m, int k, long ldw, const float* s, float eps, void* stream) {
     REQUIRE(W && s && m >= 1 && k >= 1 && ldw >= k, "scale_cols_div: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv(m * k, 256), 8192);
-    hipLaunchKernelGGL(scale_kernel<0>, dim3(grid), dim3(256), 0, S(stream), W, m, (long)k, ldw, s, eps);
-    return check_launch("scale_cols_div");
+    return launch_ew<EW_COLS_DIV>(W, m, k, ldw, nullptr, 0, s, eps, 0, "scale_cols_div", S(stream));
 }
 
 int dnmf_scale_rows_mul(float* H, int k, long n, long ldh, const float* s, void* stream) {
     REQUIRE(H && s && n >= 1 && k >= 1 && ldh >= n, "scale_rows_mul: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv((long)k * n, 256), 8192);
-    hipLaunchKernelGGL(scale_kernel<1>, dim3(grid), dim3(256), 0, S(stream), H, (long)k, n, ldh, s, 0.f);
-    return check_launch("scale_rows_mul");
+    return launch_ew<EW_ROWS_MUL>(H, k, n, ldh, nullptr, 0, s, 0.f, 0, "scale_rows_mul", S(stream));
 }
 
 }  // extern "C"
@@ -758,17 +770,13 @@ int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, siz
 int dnmf_kl_update_w(float* W, long m, int k, long ldw, const float* Sm, long lds_, const float* x, float eps,
                      void* stream) {
     REQUIRE(W && Sm && x && m >= 1 && k >= 1 && ldw >= k && lds_ >= k, "kl_update_w: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv(m * k, 256), 8192);
-    hipLaunchKernelGGL(kl_update_kernel<false>, dim3(grid), dim3(256), 0, S(stream), W, m, (long)k, ldw, Sm, lds_, x, eps, 0);
-    return check_launch("kl_update_w");
+    return launch_ew<EW_KL_BYCOL>(W, m, k, ldw, Sm, lds_, x, eps, 0, "kl_update_w", S(stream));
 }
 
 int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* Sm, long lds_, const float* x, float eps,
                      int clamp, void* stream) {
     REQUIRE(H && Sm && x && n >= 1 && k >= 1 && ldh >= n && lds_ >= n, "kl_update_h: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv((long)k * n, 256), 8192);
-    hipLaunchKernelGGL(kl_update_kernel<true>, dim3(grid), dim3(256), 0, S(stream), H, (long)k, n, ldh, Sm, lds_, x, eps, clamp);
-    return check_launch("kl_update_h");
+    return launch_ew<EW_KL_BYROW>(H, k, n, ldh, Sm, lds_, x, eps, clamp, "kl_update_h", S(stream));
 }
 
 static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,

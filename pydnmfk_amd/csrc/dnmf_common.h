@@ -61,6 +61,50 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 
+// ----------------------------------------------------------------------------------------------- buffer addressing
+// MUBUF loads / stores: address = descriptor base (4 SGPRs) + one 32-bit VGPR offset + one SGPR offset + immediate.  A
+// tile whose rows differ only by a wave-uniform offset then needs ONE address register per lane for all its loads and
+// stores, where flat/global addressing makes hipcc keep a 64-bit VGPR pair per row alive from the load to the store (the
+// update kernels spilled because of exactly that).  The descriptor claims 2 GiB from its base and every valid offset
+// (VGPR + SGPR + immediate) stays below that; a lane is switched off by giving it the offset BUF_OOB (>= the claimed size:
+// the hardware returns 0 for such a load and drops such a store), so edge tiles need no exec-masked branches.
+// RULE: a store of more than 8 bytes must not use the SGPR offset (pass 0 and add constants to the VGPR offset, they
+// fold into the immediate): with an SGPR offset the gfx950 hardware may still be reading the data registers when the
+// next VALU write hits them, and hipcc pads that hazard only for the immediate form (see update_w_seq_tile).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int BUF_OOB = (int)0x80000000u;
+__device__ float buf_ld_f32(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x2 buf_ld_f32x2(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ f32x4 buf_ld_f32x4(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void buf_st_f32(float v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void buf_st_f32x2(f32x2 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+// descriptor for `base` (wave-uniform): raw buffer (stride 0), 2 GiB window, gfx9 data format word
+__device__ __forceinline__ i32x4 buf_rsrc(const void* base) {
+    const unsigned long a = (unsigned long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = (int)0x80000000u;
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int V>
+__device__ __forceinline__ void buf_load(float (&d)[V], i32x4 rsrc, int voff, int soff) {
+    if constexpr (V == 4) { const f32x4 v = buf_ld_f32x4(rsrc, voff, soff, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+    else if constexpr (V == 2) { const f32x2 v = buf_ld_f32x2(rsrc, voff, soff, 0); d[0] = v[0]; d[1] = v[1]; }
+    else d[0] = buf_ld_f32(rsrc, voff, soff, 0);
+}
+
+template <int V>
+__device__ __forceinline__ void buf_store(const float (&d)[V], i32x4 rsrc, int voff, int soff) {
+    if constexpr (V == 4) buf_st_f32x4(f32x4{d[0], d[1], d[2], d[3]}, rsrc, voff, soff, 0);
+    else if constexpr (V == 2) buf_st_f32x2(f32x2{d[0], d[1]}, rsrc, voff, soff, 0);
+    else buf_st_f32(d[0], rsrc, voff, soff, 0);
+}
+
 // C/D row of accumulator register `reg` for lane-half h
 __device__ __forceinline__ int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
