@@ -33,6 +33,10 @@ int kt_of(int k) {
     return k <= 32 ? 1 : (k <= 64 ? 2 : 4);
 }
 
+// lda == 0 (every row of A aliases one row: A becomes cache resident) is an experiment of the tuning build only
+// (tools/kbench.py ALIAS=1); the shipped library requires lda >= n everywhere, as include/dnmf.h says
+inline bool alias_ok(long lda) { return lda == 0 && tune("DNMF_ALLOW_ALIAS", 0) != 0; }
+
 hipStream_t S(void* s) {
     clear_hip_error();
     return reinterpret_cast<hipStream_t>(s);
@@ -406,7 +410,7 @@ template <typename TA>
 int aht_update_w_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
                       float* W, long ldw, float eps, void* stream) {
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
+    REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && (lda >= n || alias_ok(lda)) && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
     a.Y = H; a.ldy = ldh; a.yrows = k;
@@ -485,7 +489,7 @@ template <typename TA>
 int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
              void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || lda == 0) && ldw >= k && ldatw >= n, "wta: bad arguments");
+    REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || alias_ok(lda)) && ldw >= k && ldatw >= n, "wta: bad arguments");
     {   // rank k <= 16: 16-wide kernel (16-byte aligned rows of A, whole column blocks, workspace permitting)
         constexpr int V = std::is_same<TA, bf16_t>::value ? 8 : 4;
         if (k <= 16 && k16_on() && a_rows16(A, lda) && n % (16 * V) == 0 && lda != 0) {

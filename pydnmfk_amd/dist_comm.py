@@ -21,6 +21,14 @@ def _dist_on():
 class TorchComm:
     """Communicator handle: a torch.distributed process group with an mpi4py-shaped surface."""
 
+    # A communicator of one rank needs no exchange and every collective below returns at once.  Set to True (tests do, on
+    # a one-GPU box) a single-rank communicator still issues the real torch.distributed call, so that the RCCL code path
+    # -- device buffers, sub-groups, stream ordering against the HIP kernels -- runs without a second GPU.
+    always_collective = False
+
+    def _solo(self):
+        return self.size == 1 and not (TorchComm.always_collective and _dist_on())
+
     def __init__(self, group=None, ranks=None):
         self.group = group
         if _dist_on():
@@ -44,8 +52,11 @@ class TorchComm:
         return self.size
 
     def barrier(self):
-        if self.size > 1:
-            dist.barrier(group=self.group)
+        if not self._solo():
+            if self.backend == "nccl":
+                dist.barrier(group=self.group, device_ids=[self.device.index])
+            else:
+                dist.barrier(group=self.group)
 
     Barrier = barrier
 
@@ -71,29 +82,25 @@ class TorchComm:
 
     def allreduce(self, x, op=None):
         """SUM allreduce returning a new object (mpi4py lowercase semantics)."""
-        if self.size == 1:
+        if self._solo():
             return x
         t, kind = self._to_tensor(x)
         self.allreduce_(t)
         return self._from_tensor(t, kind, x)
 
     def bcast(self, x, root=0):
-        if self.size == 1:
+        if self._solo():
             return x
         if isinstance(x, torch.Tensor):
-            if self._host_staged(x):
-                c = x.cpu()
-                dist.broadcast(c, src=self.ranks[root], group=self.group)
-                return c.to(x.device)
-            t = x.clone()
-            dist.broadcast(t, src=self.ranks[root], group=self.group)
-            return t
+            c = self._wire(x).clone()
+            dist.broadcast(c, src=self.ranks[root], group=self.group)
+            return c.to(x.device)
         box = [x]
         dist.broadcast_object_list(box, src=self.ranks[root], group=self.group)
         return box[0]
 
     def allgather(self, x):
-        if self.size == 1:
+        if self._solo():
             return [x]
         if isinstance(x, torch.Tensor):
             shapes = [None] * self.size
@@ -103,15 +110,24 @@ class TorchComm:
         dist.all_gather_object(out, x, group=self.group)
         return out
 
-    # ---- in-place device collectives used by the update choreography
-    def _host_staged(self, t):
-        """gloo transport (tests / debugging) moves bytes through host memory; RCCL works on device buffers."""
-        return self.backend == "gloo" and t.is_cuda
+    # ---- device collectives used by the update choreography
+    def _staged(self, t):
+        """A tensor the transport cannot take where it lives: gloo (tests / debugging) moves bytes through host memory,
+        RCCL only works on device buffers (the NMFk driver hands CPU tensors to the clustering when the data came in as
+        numpy).  Such tensors make the trip through the other memory; the product path (device tensors over RCCL) never
+        stages."""
+        return (self.backend == "gloo" and t.is_cuda) or (self.backend == "nccl" and not t.is_cuda)
+
+    def _wire(self, t):
+        """`t` where the transport wants it (a copy iff staged)."""
+        if not self._staged(t):
+            return t
+        return t.cpu() if self.backend == "gloo" else t.to(self.device)
 
     def allreduce_(self, t):
-        if self.size > 1:
-            if self._host_staged(t):
-                c = t.cpu()
+        if not self._solo():
+            if self._staged(t):
+                c = self._wire(t)
                 dist.all_reduce(c, group=self.group)
                 t.copy_(c)
             else:
@@ -120,29 +136,25 @@ class TorchComm:
 
     def allgather_blocks(self, x, shapes):
         """All-gather row-major blocks whose per-rank shapes are known (ragged allowed: padded to the largest)."""
-        if self.size == 1:
+        if self._solo():
             return [x]
         numels = [int(np.prod(s)) for s in shapes]
         mx = max(numels)
         send = x.reshape(-1)
         if send.numel() < mx:
             send = torch.cat([send, send.new_zeros(mx - send.numel())])
-        if self._host_staged(send):
-            c = send.contiguous().cpu()
-            rc = c.new_empty(self.size * mx)
-            dist.all_gather_into_tensor(rc, c, group=self.group)
-            recv = rc.to(send.device)
-        else:
-            recv = send.new_empty(self.size * mx)
-            dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+        c = self._wire(send.contiguous())
+        rc = c.new_empty(self.size * mx)
+        dist.all_gather_into_tensor(rc, c, group=self.group)
+        recv = rc.to(send.device)
         return [recv[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)]
 
     def reduce_scatter_rows(self, full, counts):
         """SUM reduce-scatter of a (sum(counts) x c) row-major buffer by row blocks (MPI Reduce_scatter)."""
-        if self.size == 1:
+        if self._solo():
             return full
         c = full.shape[1]
-        if len(set(counts)) == 1 and not self._host_staged(full) and self.backend != "gloo":
+        if len(set(counts)) == 1 and self.backend != "gloo" and not self._staged(full):
             out = full.new_empty(counts[0], c)
             dist.reduce_scatter_tensor(out, full.contiguous(), group=self.group)
             return out
@@ -219,4 +231,7 @@ class _SelfComm(TorchComm):
 
     def __init__(self, world_rank):
         self.group, self.world_rank, self.ranks, self.rank, self.size = None, world_rank, [world_rank], 0, 1
-        self.device = torch.device("cpu")
+        self.device, self.backend = torch.device("cpu"), None
+
+    def _solo(self):
+        return True

@@ -19,14 +19,22 @@ _cache = {}
 
 
 def _buf(key, numel, like):
-    """Persistent scratch tensors: a fresh nmf_algorithms_* object is built every iteration
-    (pyDNMF.py:154,169), so buffers live in a module cache keyed by shape/device."""
-    key = (like.device,) + key
+    """Persistent scratch tensors: a fresh nmf_algorithms_* object is built every iteration (pyDNMF.py:154,169), so
+    buffers live in a module cache -- ONE buffer per role and device, grown on demand (an NMFk sweep over k reuses it;
+    every use is stream-ordered).  `release_buffers()` drops them."""
+    key = (like.device, key[0])
     t = _cache.get(key)
     if t is None or t.numel() < numel:
         t = torch.zeros(numel, dtype=torch.float32, device=like.device)
         _cache[key] = t
     return t
+
+
+def release_buffers():
+    """Free the exchange buffers of this module and the kernel workspaces of the engine (the next step re-creates them)."""
+    _cache.clear()
+    from . import engine
+    engine._ws_cache.clear()
 
 
 def _default_ops():

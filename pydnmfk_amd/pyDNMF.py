@@ -14,7 +14,8 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
     product in float32: the fit equals the float32 fit of the bf16-rounded data (BASELINE config 5);
   * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' is not provided; init is 'rand' or 'nnsvd' (1D grids);
   * `prune=True` (the reference's default when the attribute is absent) drops all-zero rows / columns before the
-    iterations and scatters the factors back afterwards; they stay float32 (the reference hands back float64).
+    iterations and scatters the factors back afterwards.  numpy callers get float64 factors back in that case, exactly
+    as from the reference (its unprune scatters into np.zeros, utils.py:195,198); tensor callers keep float32 on the GPU.
 """
 import numpy as np
 import torch
@@ -145,7 +146,10 @@ class PyNMF:
         return self.ops
 
     def _out(self, t):
-        return t.cpu().numpy() if self._numpy_io else t
+        if not self._numpy_io:
+            return t
+        a = t.cpu().numpy()
+        return a.astype(np.float64) if self.prune else a        # the reference's dtype after unprune (utils.py:195,198)
 
     def fit(self):
         """pyDNMF.py:138-182.  Returns (W, H, recon_err)."""

@@ -8,7 +8,9 @@ calls); everything numeric inside `PyNMF` runs in libdnmf_hi
 Same `params` contract as the reference (`fpath`, `fname`, `start_k`/`end_k` or `k_range`, `step_k`, `perturbations`,
 `noise_var`, `sampling`, `sill_thr`, `checkpoint`, `results_path`; defaults via var_init, pyDNMFk.py:143-164).
 Differences: statistics are kept in memory for the p-value analysis (and written per k as the reference does; HDF5 when
-h5py exists, else npz); no plots are drawn (plot_results is out of scope).
+h5py exists, else npz); no plots are drawn (plot_results is out of scope).  `params.hall_layout = 'aligned'` (not the
+default) stacks the perturbations' H matrices as Hall[:, :, p] = H_p; the default 'reference' reproduces the reference's
+vstack + C-order reshape (pyDNMFk.py:236-237), whose fibres mix perturbations -- it only seeds the regression fit.
 """
 import os
 
@@ -95,6 +97,9 @@ class PyNMFk:
         else:
             self.start_k, self.end_k = self.params.start_k, self.params.end_k
         self.first_k = self.start_k
+        # how the P factor matrices H are stacked for the clustering / median (see pynmfk_per_k): 'reference' (default)
+        # or 'aligned' (the layout the reference's comments describe)
+        self.hall_layout = var_init(self.params, 'hall_layout', default='reference')
         self.sill_thr = var_init(params, 'sill_thr', default=0.9)
         self.verbose = var_init(params, 'verbose', default=False)
         self.params.checkpoint = var_init(params, 'checkpoint', default=True)
@@ -124,6 +129,8 @@ class PyNMFk:
             nopt = None
         nopt = self.comm1.bcast(nopt, root=0)
         self.comm1.barrier()
+        from .dist_nmf import release_buffers
+        release_buffers()                       # the sweep's scratch (sized for the largest k) is not kept alive
         return nopt
 
     def pynmfk_per_k(self):
@@ -148,7 +155,14 @@ class PyNMFk:
         Ws = [r[0] if isinstance(r[0], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[0])) for r in results]
         Hs = [r[1] if isinstance(r[1], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[1])) for r in results]
         self.Wall = torch.stack(Ws, dim=-1)
-        self.Hall = torch.stack(Hs, dim=-1)
+        if self.hall_layout == 'reference':
+            # exactly the reference's array: np.vstack(H_0 .. H_{P-1}) (P k x n) re-read in C order as (k, n, P), :236-237.
+            # That is NOT "H of perturbation p in [:, :, p]" (entries of different perturbations, features and columns
+            # share a fibre), but it is what its clustering permutes and what its median -- the initial H of the
+            # regression fit below -- is taken over, so the default reproduces it.
+            self.Hall = torch.cat(Hs, dim=0).reshape(self.k, Hs[0].shape[1], len(Hs)).contiguous()
+        else:                                              # 'aligned': Hall[:, :, p] = H of perturbation p
+            self.Hall = torch.stack(Hs, dim=-1)
         self.recon_err = [float(r[2]) for r in results]
         centroids, _, self.Hall, self.clusterSilhouetteCoefficients, self.avgSilhouetteCoefficients, _ = \
             custom_clustering(self.Wall, self.Hall, self.params).fit()                                  # :239-240

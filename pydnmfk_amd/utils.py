@@ -2,7 +2,7 @@
 
 Mirrors the hot-path parts of reference pyDNMFk/utils.py: `determine_block_params` (:15-46),
 `data_operations.compute_global_dim/compute_local_dim` (:73-115), `var_init` (:473-477),
-`parse` (:480-483).  Pruning, checkpoints and the MLP helpers are out of scope.
+`parse` (:480-483), zero row / column pruning (:117-217) and the NMFk `Checkpoint` (:486-536).
 """
 import pickle
 
@@ -141,10 +141,27 @@ class data_operations:
         return W, H
 
 
+_REF_PARSE = b"cpyDNMFk.utils\nparse\n"          # how a protocol-2 pickle names the reference's bag class
+_OUR_PARSE = b"cpydnmfk_amd.utils\nparse\n"
+
+
+class _BagUnpickler(pickle.Unpickler):
+    """Restricted unpickler for checkpoint.p: the only class a checkpoint may name is the attribute bag -- the reference's
+    `pyDNMFk.utils.parse` (a checkpoint written by lanl/pyDNMFk) or this package's -- and both load as `parse` here."""
+
+    def find_class(self, module, name):
+        if name == "parse" and module in ("pyDNMFk.utils", "pydnmfk_amd.utils"):
+            return parse
+        raise pickle.UnpicklingError("checkpoint.p may only contain a parse bag, found %s.%s" % (module, name))
+
+
 class Checkpoint:
-    """Coarse NMFk resume state, file-compatible with reference utils.py:486-536: rank 0 pickles an attribute bag
-    (flag, perturbation, k) of class `parse` to results_path + "checkpoint.p"; loading copies the bag's attributes onto
-    this object.  W/H are not part of a checkpoint (the interrupted k restarts from its first perturbation)."""
+    """Coarse NMFk resume state, file-compatible with reference utils.py:486-536 in BOTH directions: rank 0 pickles an
+    attribute bag (flag, perturbation, k) to results_path + "checkpoint.p".  The file names the bag class the way the
+    reference does (`pyDNMFk.utils.parse`, protocol 2), so lanl/pyDNMFk can resume from a checkpoint written here, and
+    the loader maps that name (and this package's own) to `parse`, so a checkpoint written by lanl/pyDNMFk resumes here
+    (tests/golden/ref_checkpoint.p is one).  Loading copies the bag's attributes onto this object.  W/H are not part of
+    a checkpoint (the interrupted k restarts from its first perturbation)."""
 
     def __init__(self, checkpoint_save, params):
         self.checkpoint_save = checkpoint_save if checkpoint_save else False
@@ -156,19 +173,26 @@ class Checkpoint:
     def load_from_checkpoint(self):
         if self.checkpoint_save:
             with open(self.params.results_path + "/checkpoint.p", "rb") as f:          # utils.py:514
-                saved = pickle.load(f)
+                saved = _BagUnpickler(f).load()
             if getattr(self.params, "rank", 0) == 0:
                 print("Checkpoint loaded")
             self._set_params(vars(saved))
             if getattr(self.params, "rank", 0) == 0:
                 print("Continuing from checkpoint for k=", self.k, "perturbation=", self.perturbation)
 
-    def _save_checkpoint(self, flag, perturbation, k):
+    @staticmethod
+    def dumps(flag, perturbation, k):
+        """The checkpoint bytes: a protocol-2 pickle of the bag, its class named as the reference names it."""
         bag = parse()
         bag.flag, bag.perturbation, bag.k = flag, perturbation, k
+        raw = pickle.dumps(bag, protocol=2)
+        assert raw.count(_OUR_PARSE) == 1
+        return raw.replace(_OUR_PARSE, _REF_PARSE)
+
+    def _save_checkpoint(self, flag, perturbation, k):
         if self.checkpoint_save and getattr(self.params, "rank", 0) == 0:
             with open(self.params.results_path + "checkpoint.p", "wb") as f:           # utils.py:530
-                pickle.dump(bag, f)
+                f.write(self.dumps(flag, perturbation, k))
 
     def _set_params(self, class_parameters):
         for name, value in class_parameters.items():

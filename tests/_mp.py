@@ -53,7 +53,8 @@ def run_case_rank(rank, world, port, name, q, use_hip):
             W, H, err = PyNMF(A_ij, factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops).fit()
             assert (args.m, args.n) == (meta["m"], meta["n"])
             assert [args.m_loc, args.n_loc] == list(z["r%d_m_loc_n_loc" % rank])
-            assert tuple(W.shape) == z["r%d_fit%d_W" % (rank, itr)].shape and str(W.dtype).endswith("float32")
+            assert tuple(W.shape) == z["r%d_fit%d_W" % (rank, itr)].shape
+            assert W.dtype == z["r%d_fit%d_W" % (rank, itr)].dtype and H.dtype == z["r%d_fit%d_H" % (rank, itr)].dtype
             out[itr] = (rel_fro(W, z["r%d_fit%d_W" % (rank, itr)]), rel_fro(H, z["r%d_fit%d_H" % (rank, itr)]),
                         abs(err - float(z["r0_fit%d_err" % itr])))
         q.put((rank, out, None))

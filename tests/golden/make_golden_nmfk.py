@@ -80,8 +80,33 @@ def run(grid):
                                      round(float(out["k%d_avgErr" % k]), 5)) for k in range(1, 6)})
 
 
+def checkpoint_fixture():
+    """A checkpoint.p written by the reference's own Checkpoint (utils.py:486-536) -> tests/golden/ref_checkpoint.p, and
+    the reverse direction checked on the spot: a checkpoint written by pydnmfk_amd.utils.Checkpoint (bytes produced by
+    `python -c "from pydnmfk_amd.utils import Checkpoint; open('/tmp/our_checkpoint.p','wb').write(Checkpoint.dumps(3,19,7))"`
+    under the system interpreter) must load in the reference."""
+    from pyDNMFk.utils import Checkpoint
+    tmp = tempfile.mkdtemp()
+    p = parse()
+    p.results_path, p.rank = tmp + "/", 0
+    Checkpoint(True, p)._save_checkpoint(2, 11, 5)
+    shutil.copy(tmp + "/checkpoint.p", os.path.join(HERE, "ref_checkpoint.p"))
+    ours = "/tmp/our_checkpoint.p"
+    if os.path.exists(ours):
+        shutil.copy(ours, tmp + "/checkpoint.p")
+        cp = Checkpoint(True, p)
+        cp.load_from_checkpoint()
+        assert (cp.flag, cp.perturbation, cp.k) == (3, 19, 7)
+        print("reference resumed from a pydnmfk_amd checkpoint:", cp.flag, cp.perturbation, cp.k)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
     # Only the single-rank run is kept as a fixture: `sample` seeds the process-global numpy RNG (pyDNMFk.py:31-32),
     # and the thread-simulated ranks of the mpi4py stand-in share that RNG, so multi-rank draws interleave
     # nondeterministically here (real MPI ranks are separate processes).  run((2, 1)) is still useful as a smoke check.
-    run((1, 1))
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
+        checkpoint_fixture()
+    else:
+        run((1, 1))
+        checkpoint_fixture()

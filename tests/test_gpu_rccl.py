@@ -1,0 +1,124 @@
+"""The RCCL transport on a one-GPU box: `init_process_group("nccl", world_size=1)` in a spawned child, with
+`TorchComm.always_collective` switched on so that single-rank communicators still issue the real torch.distributed
+calls.  What this proves: the nccl code path of pydnmfk_amd.dist_comm loads, creates sub-groups, takes device buffers of
+every dtype the path exchanges (float32 packed products, float64 norms, int64 shapes), stages CPU tensors through the
+device, and is stream-ordered against the HIP kernels (kernel -> collective -> kernel sequences give the single-rank
+result).  What it cannot show is a second rank: scaling over xGMI stays unmeasured until the driver has an 8-GPU node."""
+import traceback
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _child(port, q):
+    try:
+        import os
+        import torch.distributed as dist
+        from oracle import nmf_oracle as orc
+        from pydnmfk_amd.dist_comm import MPI_comm, TorchComm
+        from pydnmfk_amd.dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
+        from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+        from pydnmfk_amd.pyDNMF import PyNMF
+        from pydnmfk_amd.utils import parse
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        TorchComm.always_collective = True
+        world = TorchComm(None)
+        assert world.backend == "nccl" and world.device.type == "cuda" and not world._solo()
+        log = {}
+        # --- every collective of the path on device buffers (1 rank: SUM / gather = identity)
+        x = torch.rand(64 * 8192 + 64 * 64, device=dev)                      # the packed [W^T A | W^T W] buffer of config 3
+        ref = x.clone()
+        world.allreduce_(x)
+        assert torch.equal(x, ref)
+        d = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+        world.allreduce_(d)
+        assert d.tolist() == [1.5, 2.5]
+        assert world.allreduce(7) == 7 and world.allreduce(2.5) == 2.5       # int64 / float64 scalars (compute_global_dim)
+        assert np.array_equal(world.allreduce(np.arange(5.0)), np.arange(5.0))
+        c = torch.rand(3, 4)                                                 # CPU tensor: staged through the device
+        assert torch.equal(world.allreduce(c), c) and not world.allreduce(c).is_cuda
+        blk = torch.rand(5, 7, device=dev)
+        g = world.allgather_blocks(blk, [(5, 7)])
+        assert len(g) == 1 and torch.equal(g[0], blk)
+        rs = world.reduce_scatter_rows(blk, [5])
+        assert torch.equal(rs, blk)
+        assert torch.equal(world.bcast(blk, root=0), blk)
+        assert world.allgather(3) == [3]
+        world.barrier()
+        # --- sub-groups (dist.new_group under nccl) and a collective on them
+        sub = TorchComm(dist.new_group([0]), [0])
+        y = torch.rand(1000, device=dev)
+        yr = y.clone()
+        sub.allreduce_(y)
+        assert torch.equal(y, yr)
+        comms = MPI_comm(None, 1, 1)
+        assert comms.cart_1d_row().size == 1 and comms.cart_1d_column().size == 1
+        # --- HIP kernels and collectives interleaved on the stream: the 1D-row exchange sequence of dist_nmf.py
+        rsn = np.random.RandomState(3)
+        m, n, k = 4096, 1024, 64
+        A = np.abs(rsn.rand(m, k) @ rsn.rand(k, n) + 0.01 * rsn.randn(m, n)).astype(np.float32)
+        W0, H0 = rsn.rand(m, k).astype(np.float32), rsn.rand(k, n).astype(np.float32)
+        eps = float(np.finfo(np.float32).eps)
+        Wr, Hr = orc.fro_mu_step_local(A, W0.copy(), H0.copy(), np.float32(eps))
+        Ad, Wd, Hd = (torch.from_numpy(v).to(dev) for v in (A, W0, H0))
+        G = ops.gram_hht(Hd, new_gram(k, dev))
+        ops.aht_update_w(Ad, Hd, G, Wd, eps)
+        buf = torch.zeros(k * n + 64 * 64, device=dev)
+        AtW, G2 = buf[: k * n].view(k, n), buf[k * n:].view(64, 64)
+        for _ in range(3):                                                   # kernel -> RCCL -> kernel, repeatedly
+            ops.gram_wtw(Wd, G2)
+            ops.wta(Ad, Wd, AtW)
+            world.allreduce_(buf)
+        ops.mu_update_h(Hd, AtW, G2, eps, False)
+        log["dW"] = float(np.linalg.norm(Wd.cpu().numpy() - Wr) / np.linalg.norm(Wr))
+        log["dH"] = float(np.linalg.norm(Hd.cpu().numpy() - Hr) / np.linalg.norm(Hr))
+        # --- the 2D choreography (allgather / reduce-scatter on sub-groups) with one-rank groups == the 1D step
+        args = parse()
+        args.comm1, args.comm, args.p_r, args.p_c, args.k, args.m, args.n = world, comms, 1, 1, k, m, n
+        args.row_comm, args.col_comm = TorchComm(dist.new_group([0]), [0]), TorchComm(dist.new_group([0]), [0])
+        args.eps, args.W_update, args.norm, args.method = eps, True, "fro", "mu"
+        for norm in ("fro", "kl"):
+            args.norm = norm
+            W1, H1 = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+            W2, H2 = W1.clone(), H1.clone()
+            TorchComm.always_collective = False
+            nmf_algorithms_1D(Ad, W1, H1, params=args).update()
+            TorchComm.always_collective = True
+            nmf_algorithms_2D(Ad, W2, H2, params=args).update()
+            log["2d_%s" % norm] = (float((W1 - W2).norm() / W1.norm()), float((H1 - H2).norm() / H1.norm()))
+        # --- a whole fit with the nccl group up (relative_err allreduces a float64 pair on the device)
+        args2 = parse()
+        args2.comm1, args2.comm, args2.p_r, args2.p_c, args2.k = world, comms, 1, 1, k
+        args2.row_comm, args2.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        args2.itr, args2.init, args2.verbose, args2.prune, args2.norm, args2.method = 12, "rand", False, False, "fro", "mu"
+        Wf, Hf, err = PyNMF(A, factors=[W0, H0], params=args2).fit()
+        Wo, Ho, erro = orc.fit_single(A, W0, H0, 12, norm="fro")
+        log["fit"] = (float(np.linalg.norm(Wf - Wo) / np.linalg.norm(Wo)), float(np.linalg.norm(Hf - Ho) / np.linalg.norm(Ho)),
+                      abs(err - erro))
+        dist.barrier(device_ids=[0])
+        dist.destroy_process_group()
+        q.put((log, None))
+    except Exception:  # noqa: BLE001
+        q.put((None, traceback.format_exc()))
+
+
+def test_rccl_code_path_on_one_gpu():
+    import torch.multiprocessing as mp
+    from tests._mp import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_child, args=(free_port(), q))
+    p.start()
+    log, err = q.get(timeout=300)
+    p.join(timeout=60)
+    assert err is None, err
+    assert log["dW"] <= 1e-5 and log["dH"] <= 1e-5, log
+    for norm in ("fro", "kl"):
+        assert max(log["2d_%s" % norm]) <= 1e-6, log
+    assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log

@@ -34,9 +34,10 @@ def check_against_golden(nmfk, nopt, z, sil_tol=0.08):
         else:
             assert sil.min() < 0.6, (k, sil)
         assert abs(st["avgErr"] / float(z["k%d_avgErr" % k]) - 1) < 5e-3, k
-        if k <= 3:
-            assert abs(float(st["L_errDist"]) / float(z["k%d_L_errDist" % k]) - 1) < 2e-2, k
-            assert np.allclose(st["L_err"], z["k%d_L_err" % k], rtol=0.1, atol=2e-3), k
+        if k <= 3:    # with the reference's own stacking of the H matrices (hall_layout = 'reference') the regression fit
+            # starts from the reference's initial H: its error statistics are reproduced, not just approximated
+            assert abs(float(st["L_errDist"]) / float(z["k%d_L_errDist" % k]) - 1) < 2e-4, k
+            assert np.allclose(st["L_err"], z["k%d_L_err" % k], rtol=2e-3, atol=1e-5), k
         assert np.asarray(st["L_err"]).shape == (40,)
         assert abs(st["AIC"] / float(z["k%d_AIC" % k]) - 1) < 1e-3
 
@@ -78,15 +79,68 @@ def test_sample_follows_reference_stream():
 
 
 def test_checkpoint_roundtrip(tmp_path):
-    """utils.py:486-536: the pickle holds a `parse` bag with flag / perturbation / k."""
+    """utils.py:486-536: the pickle holds a `parse` bag with flag / perturbation / k, named as the reference names it."""
     import pickle
-    from pydnmfk_amd.utils import Checkpoint, parse
+    from pydnmfk_amd.utils import Checkpoint, _BagUnpickler, parse
     params = parse()
     params.results_path, params.rank = str(tmp_path) + "/", 0
     cp = Checkpoint(True, params)
     cp._save_checkpoint(3, 19, 7)
-    bag = pickle.load(open(tmp_path / "checkpoint.p", "rb"))
-    assert (bag.flag, bag.perturbation, bag.k) == (3, 19, 7) and type(bag).__name__ == "parse"
+    raw = open(tmp_path / "checkpoint.p", "rb").read()
+    assert b"pyDNMFk.utils" in raw and b"pydnmfk_amd" not in raw       # loadable by lanl/pyDNMFk (verified by the generator)
+    bag = _BagUnpickler(open(tmp_path / "checkpoint.p", "rb")).load()
+    assert (bag.flag, bag.perturbation, bag.k) == (3, 19, 7) and type(bag) is parse
     cp2 = Checkpoint(True, params)
     cp2.load_from_checkpoint()
     assert (cp2.flag, cp2.perturbation, cp2.k) == (3, 19, 7)
+    # anything but the bag class is refused
+    evil = pickle.dumps(print)
+    (tmp_path / "bad").mkdir()
+    open(tmp_path / "bad" / "checkpoint.p", "wb").write(evil)
+    params.results_path = str(tmp_path / "bad") + "/"
+    with pytest.raises(pickle.UnpicklingError):
+        Checkpoint(True, params).load_from_checkpoint()
+
+
+def test_reference_written_checkpoint_loads(tmp_path, golden_dir):
+    """tests/golden/ref_checkpoint.p was written by the reference's own Checkpoint._save_checkpoint(2, 11, 5)
+    (make_golden_nmfk.py): its pickle names pyDNMFk.utils.parse, which must load here."""
+    import shutil
+    from pydnmfk_amd.utils import Checkpoint, parse
+    shutil.copy(golden_dir + "/ref_checkpoint.p", tmp_path / "checkpoint.p")
+    params = parse()
+    params.results_path, params.rank = str(tmp_path) + "/", 0
+    cp = Checkpoint(True, params)
+    cp.load_from_checkpoint()
+    assert (cp.flag, cp.perturbation, cp.k) == (2, 11, 5)
+
+
+def test_resume_at_k_from_a_reference_checkpoint(tmp_path, golden_dir):
+    """pyDNMFk.py:188-196: with a checkpoint for (k = 4, flag = 2) in the results folder a new PyNMFk run starts at
+    k = 4; the statistics of k < 4 come from the per-k result files of the interrupted run, and the estimate equals
+    the uninterrupted run's."""
+    import shutil
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from tests._ops_double import OracleOps
+    z = np.load(golden_dir + "/nmfk_1x1.npz")
+    comms = MPI_comm(None, 1, 1)
+    args = _args(tmp_path, comms)
+    args.checkpoint = True
+    full = PyNMFk(z["A"], factors=None, params=args, ops=OracleOps())
+    nopt = full.fit()
+    assert nopt == 3
+    res = tmp_path / "results" / "synth"
+    assert (res / "checkpoint.p").exists()
+    # the interrupted state: k = 4 clustered but not saved, written in the reference's own pickle format
+    ref_cp = open(golden_dir + "/ref_checkpoint.p", "rb").read()
+    ref_cp = ref_cp.replace(b"K\x05ub.", b"K\x04ub.")                   # k = 5 -> 4 in the fixture's last field
+    open(res / "checkpoint.p", "wb").write(ref_cp)
+    shutil.rmtree(res / "4"); shutil.rmtree(res / "5")
+    args2 = _args(tmp_path, comms)
+    args2.checkpoint = True
+    again = PyNMFk(z["A"], factors=None, params=args2, ops=OracleOps())
+    assert again.fit() == nopt
+    assert sorted(again.stats) == [4, 5]                                  # only the unfinished k's were recomputed
+    for k in (4, 5):
+        assert abs(again.stats[k]["avgErr"] - full.stats[k]["avgErr"]) < 1e-6
