@@ -12,8 +12,15 @@ allreduce of [W^T A | W^T W] when N > 1, and the clamp on every 10th step), X al
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     : the dominant kernel (fused A H^T + W update, one launch), algorithmic flops / HIP-event time
-  kernels      : the same measurement for every kernel class of the step
-  cpu_baseline : the numpy oracle (port of the reference's path) timed on the host, bounded sample (N=1 only)
+  rooflines    : the same for every big kernel (fused NT, TN, residual) and the HBM-bound class
+  roofline_hbm : the eltwise multiply-divide kernel (dnmf_mu_update_h) in isolation on SURVEY 8d's shape (k x 2^22,
+                 12 B per element = 3.2 GB at k = 64), beside it the norm kernel on X
+  kernels      : per-kernel HIP-event times measured in situ (the step replayed primitive by primitive)
+  sustained    : when the timed region asked for is shorter than 2 s, the same step timed again over >= 300 steps
+                 (its own ms/step: shows the clock the chip HOLDS under the load, not its boost)
+  cpu_baseline : the numpy oracle (port of the reference's path) in the reference's process model -- P = min(8, cores)
+                 single-thread processes, each on its 1/P row slab of X -- timed on the host (N=1 only)
+With no flags: N = 1 and 500 timed steps (about 2.3 s of GPU time).
 """
 import argparse
 import json
@@ -35,7 +42,7 @@ MEASURED_STREAM_GBS = 6760.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", dest="m", type=int, default=262144)
     ap.add_argument("--cols", dest="n", type=int, default=8192)
@@ -44,6 +51,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
     return ap.parse_args()
 
 
@@ -61,50 +69,88 @@ def event_time_ms(fn, reps=5, warm=2):
     return sum(ts) / len(ts), ts[0]
 
 
-def cpu_baseline(n, k, m_full):
-    """The oracle's single-rank MU/FRO step (same numpy calls as dist_nmf.py:716-751) on a row slab, 1 BLAS thread
-    (the reference forces OMP_NUM_THREADS=1 per rank, main.py:3)."""
+def _cpu_rank(rank, P, m_l, n, k, steps, q):
+    """One rank of the reference's process model: single BLAS thread (main.py:3 pins OMP_NUM_THREADS=1), its own row
+    slab of X, the oracle's step (the numpy calls of dist_nmf.py:716-751)."""
+    os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     from oracle import nmf_oracle as orc
     try:
         from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
     except ImportError:
-        threadpool_limits = None
-    m_s = 8192
-    rs = np.random.RandomState(0)
-    A = rs.rand(m_s, n).astype(np.float32)
-    W = rs.rand(m_s, k).astype(np.float32)
-    H = rs.rand(k, n).astype(np.float32)
+        ctx = None
+    rng = np.random.default_rng(1234 + rank)
+    A = rng.random((m_l, n), dtype=np.float32)
+    W = rng.random((m_l, k), dtype=np.float32)
+    H = np.random.default_rng(99).random((k, n), dtype=np.float32)
     eps = np.finfo(np.float32).eps
-
-    def run(iters):
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            orc.fro_mu_step_local(A, W, H, eps)
-        return (time.perf_counter() - t0) / iters
-
-    def timed():
-        # bounded sample of about 10 s of CPU work: one warm-up step sizes the number of timed steps
-        t1 = run(1)
-        steps = int(min(100, max(6, round(10.0 / max(t1, 1e-3)))))
-        return run(steps), steps
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            t, steps = timed()
-    else:
-        t, steps = timed()
-    t_full = t * (m_full / m_s)
-    return {"value": 1.0 / t_full, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": "oracle fro_mu_step_local on a %dx%d row slab (1/%d of X), k=%d, 1 BLAS thread, %d timed steps; "
-                      "%.3f s/step on the slab, scaled by rows to the full X" % (m_s, n, m_full // m_s, k, steps, t),
-            "slab_seconds_per_step": t,
-            "gflops": (4.0 * m_s * n * k + 4.0 * (m_s + n) * k * k) / t / 1e9}
+    orc.fro_mu_step_local(A, W, H, eps)                      # warm-up (page faults, BLAS init)
+    q.put(("ready", rank))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.fro_mu_step_local(A, W, H, eps)
+    q.put(("done", rank, (time.perf_counter() - t0) / steps))
+    del ctx
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the fused NT kernel from the committed PMC pass (profiles/*_pmc.json; collected by
-    tools/collect_profiles.sh in separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
+def cpu_baseline(n, k, m_full, steps=3):
+    """The reference's CPU path beside the GPU number: P = min(8, host cores) processes x 1 thread, each
+    holding the 1/P row slab a rank of the p_r = P grid would hold, each running the oracle's MU/FRO step; the iteration
+    time of the job is the slowest rank's (the 2 MiB allreduce the reference adds is not simulated: it only makes the
+    CPU figure slightly optimistic).  Bounded: 1 warm-up + `steps` timed steps per process."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    P = min(8, cores)
+    m_l = m_full // P
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_rank, args=(r, P, m_l, n, k, steps, q)) for r in range(P)]
+    for pr in procs:
+        pr.start()
+    import queue
+    times, deadline = {}, time.time() + 600
+    try:
+        while len(times) < P and time.time() < deadline:
+            try:
+                msg = q.get(timeout=2)
+            except queue.Empty:
+                if any(pr.exitcode not in (None, 0) for pr in procs):
+                    break                                    # a rank died: report that instead of waiting
+                continue
+            if msg[0] == "done":
+                times[msg[1]] = msg[2]
+    finally:
+        for pr in procs:
+            pr.join(timeout=5)
+            if pr.is_alive():
+                pr.kill()
+    if len(times) < P:
+        return {"value": None, "unit": "iter/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
+                "sample": "FAILED: %d of %d CPU ranks finished (exit codes %s)" % (len(times), P, [pr.exitcode for pr in procs])}
+    t = max(times.values())
+    flops = 4.0 * m_full * n * k + 4.0 * (m_full + n * P) * k * k          # every rank forms its own k x k products
+    return {"value": 1.0 / t, "unit": "iter/s", "cores": P, "kind": "port",
+            "sample": "oracle fro_mu_step_local in the reference's process model: %d processes x 1 BLAS thread, each on "
+                      "its %dx%d row slab (1/%d of X), k=%d, 1 warm-up + %d timed steps; iteration time = slowest rank "
+                      "(%.2f s; fastest %.2f s), no allreduce simulated" % (P, m_l, n, P, k, steps, t, min(times.values())),
+            "host_cores": cores, "host_cpu": model, "seconds_per_iter": t, "gflops_whole_job": flops / t / 1e9}
+
+
+def pmc_traffic(role):
+    """HBM bytes per launch of a kernel from the NEWEST committed PMC pass (profiles/*_pmc.json: separate --pmc runs of
+    tools/collect_profiles.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md) -- a constant of the committed profile, not a
+    live counter: the driver's run has no profiler attached.  Kernels are picked by role (template argument lists change
+    between rounds): 'nt' = the k = 64 NT instantiation with the most bytes (the fused A H^T + W update; the gram launch
+    only reads H), 'tn' = likewise for the TN form, otherwise a name prefix.  None if absent."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
@@ -112,11 +158,9 @@ def pmc_traffic_bytes():
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        # the k = 64 (KT = 2) NT instantiations of the step: the gram H H^T launch only reads H, the fused
-        # A H^T + W-update launch streams A -> it is the one with the most HBM bytes (template argument lists
-        # change between rounds, so the kernel is picked by role, not by its exact name)
+        prefix = {"nt": "nt_kernel<2,", "tn": "tn_kernel<2,"}.get(role, role)
         cand = [(c["hbm_bytes"], name) for name, c in d.items()
-                if name.startswith("nt_kernel<2,") and isinstance(c, dict) and "hbm_bytes" in c]
+                if name.startswith(prefix) and isinstance(c, dict) and "hbm_bytes" in c]
         if cand:
             by, name = max(cand)
             best = {"bytes": by, "source": os.path.basename(f), "kernel": name}
@@ -214,6 +258,25 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(W).all() and torch.isfinite(H).all()
 
+    def timed(nsteps):
+        """EXACTLY nsteps steps between barrier + device sync on both sides; max over ranks."""
+        if world > 1:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
     out = None
     if rank == 0:
         ms = elapsed / a.steps * 1e3
@@ -231,11 +294,22 @@ def main():
             "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
         }
 
+    # A timed region of a few tens of ms (the driver's --steps 20) shows the boost clock; the big kernels are bound by the
+    # clock the chip HOLDS under MFMA + HBM load.  Time the same step again over >= 300 steps (every rank takes part).
+    if not a.no_sustained and elapsed < 2.0:
+        ns = max(300, int(2.5 / max(elapsed / a.steps, 1e-6)))
+        ns = min(ns, 20000)
+        el = timed(ns)
+        if rank == 0:
+            out["sustained"] = {"steps": ns, "seconds": el, "ms_per_step": el / ns * 1e3, "value": ns / el,
+                                "note": "same step, longer timed region (the headline value above is the K steps asked for)"}
+
     if not a.no_kernel_timing and a.norm == "fro":
         # Per-kernel HIP-event timings IN SITU: the step is replayed primitive by primitive (same launches, same order
         # as dnmf_mu_fro_step / the 1D-row choreography) with an event pair around every library call, so each kernel
         # runs in the cache / clock state it sees inside the real step.  Events are recorded on torch's current stream,
-        # which is the stream every launch goes to.
+        # which is the stream every launch goes to.  (The event pairs cost ~2-3 %: the per-kernel times sum to slightly
+        # more than ms_per_step.)
         G = new_gram(k, dev)
         AtW = torch.empty(k, n, device=dev)
         reps = 10
@@ -253,51 +327,85 @@ def main():
                 e.record()
                 if it >= 2:
                     evs[name].append((s, e))
-            if world > 1:
-                pass  # kernels are timed on this rank's slab; the exchange is part of ms_per_step only
         torch.cuda.synchronize()
         t = {name: sum(s.elapsed_time(e) for s, e in v) / len(v) for name, v in evs.items()}
-        t3, _ = event_time_ms(lambda: ops.sqnorm(A), reps=6, warm=2)
+        t_sq, _ = event_time_ms(lambda: ops.sqnorm(A), reps=10, warm=3)
+        t_res, _ = event_time_ms(lambda: ops.resid_sqnorm(A, W, H), reps=10, warm=3)
+        # the eltwise multiply-divide kernel in isolation (measure it on a large n; k x 2^22 = 3.2 GB at
+        # k = 64): in the step itself H is 2 MiB and the kernel is a 15 us latency chain
+        n_iso = 1 << 22
+        Hi = torch.rand(k, n_iso, device=dev)
+        Si = torch.rand(k, n_iso, device=dev)
+        Gi = new_gram(k, dev)
+        Gi[:k, :k] = torch.rand(k, k, device=dev) + k
+        t_upd, _ = event_time_ms(lambda: ops.mu_update_h(Hi, Si, Gi, p.eps, False), reps=20, warm=10)
+        del Hi, Si
         fl_nt = 2.0 * m_l * n * k + 2.0 * m_l * k * k
         fl_tn = 2.0 * m_l * n * k
+        fl_res = 2.0 * m_l * n * k + 3.0 * m_l * n
+        by_upd = 12.0 * n_iso * k
+        kt = max(1, (k + 31) // 32)
+        small = k <= 16 and n % 32 == 0
+        kname_nt = "nt16_kernel<FUSED_W>" if small else "nt_kernel<KT=%d,FUSED_W>" % kt
+        kname_tn = "tn16_kernel" if (small and n % 64 == 0) else "tn_kernel<KT=%d,PARTIAL>" % kt
+
+        def mfma_entry(kernel, ms_, flops, role):
+            ach = flops / ms_ / 1e9
+            e = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops, "ms_per_launch": ms_}
+            if k in MEASURED_MFMA_WITH_STREAM_TFLOPS:       # informational: fraction of the MEASURED mixed ceiling
+                e["measured_ceiling"] = MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
+                e["frac_of_measured_ceiling"] = ach / MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
+            tr = pmc_traffic(role) if (m, n, k, world) == (262144, 8192, 64, 1) else None
+            if tr is not None:
+                e["traffic"] = tr["bytes"]
+                e["traffic_note"] = ("HBM bytes per launch from the committed PMC pass %s, kernel %s (FETCH_SIZE x2 + "
+                                     "WRITE_SIZE); a constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
+            return e
+
+        def hbm_entry(kernel, ms_, nbytes, note):
+            ach = nbytes / ms_ / 1e6
+            return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": nbytes, "ms_per_launch": ms_,
+                    "measured_ceiling": MEASURED_STREAM_GBS, "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS,
+                    "note": note}
+
         kern = {
-            "dnmf_aht_update_w = nt_kernel<FUSED_W> (A.H^T + W update, 1 launch)": {
+            "dnmf_aht_update_w = %s (A.H^T + W update, 1 launch)" % kname_nt: {
                 "ms": t["aht_update_w"], "tflops": fl_nt / t["aht_update_w"] / 1e9,
                 "frac_mfma": fl_nt / t["aht_update_w"] / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "algorithmic_gbs": (4.0 * m_l * n + 8.0 * m_l * k) / t["aht_update_w"] / 1e6},
-            "dnmf_wta = tn_kernel<PARTIAL> + reduce_partials (W^T.A)": {
+            "dnmf_wta = %s + reduce_partials (W^T.A)" % kname_tn: {
                 "ms": t["wta"], "tflops": fl_tn / t["wta"] / 1e9,
                 "frac_mfma": fl_tn / t["wta"] / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "algorithmic_gbs": (4.0 * m_l * n + 4.0 * m_l * k) / t["wta"] / 1e6},
-            "dnmf_mu_update_h = tn_kernel<UPDATE_H> (eltwise multiply-divide + k x k product)": {
+            "dnmf_mu_update_h = update_h_seq_kernel, in the step (H is %.1f MiB: latency bound)" % (4.0 * k * n / 2**20): {
                 "ms": t["mu_update_h"], "algorithmic_gbs": 12.0 * n * k / t["mu_update_h"] / 1e6},
+            "dnmf_mu_update_h = update_h_seq_kernel, isolated on %d x 2^22 (eltwise multiply-divide + k x k product)" % k: {
+                "ms": t_upd, "algorithmic_gbs": by_upd / t_upd / 1e6, "frac_hbm": by_upd / t_upd / 1e6 / PEAK_HBM_GBS},
             "dnmf_gram_wtw (tn_kernel + reduce)": {"ms": t["gram_wtw"]},
             "dnmf_gram_hht (nt_kernel split + reduce)": {"ms": t["gram_hht"]},
-            "dnmf_sqnorm = sqnorm_kernel (||A||^2; eltwise/norm class, HBM bound)": {
-                "ms": t3, "algorithmic_gbs": 4.0 * m_l * n / t3 / 1e6, "frac_hbm": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS},
+            "dnmf_sqnorm = sqnorm_kernel (||A||^2, once per fit)": {
+                "ms": t_sq, "algorithmic_gbs": 4.0 * m_l * n / t_sq / 1e6, "frac_hbm": 4.0 * m_l * n / t_sq / 1e6 / PEAK_HBM_GBS},
+            "dnmf_resid_sqnorm = resid_kernel (||A - W H||^2, once per fit)": {
+                "ms": t_res, "tflops": fl_res / t_res / 1e9, "frac_mfma": fl_res / t_res / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_gbs": 4.0 * m_l * n / t_res / 1e6},
         }
         if rank == 0:
-            ach = fl_nt / t["aht_update_w"] / 1e9
-            kname = "nt16_kernel<FUSED_W>" if (k <= 16 and n % 32 == 0) else "nt_kernel<KT=%d,FUSED_W>" % max(1, (k + 31) // 32)
-            out["roofline"] = {"kernel": kname + " (dnmf_aht_update_w)",
-                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                               "flops_per_launch": fl_nt, "ms_per_launch": t["aht_update_w"]}
-            if k in MEASURED_MFMA_WITH_STREAM_TFLOPS:       # informational: fraction of the MEASURED mixed ceiling
-                out["roofline"]["measured_ceiling"] = MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
-                out["roofline"]["frac_of_measured_ceiling"] = ach / MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
-            tr = pmc_traffic_bytes() if (m, n, k, world) == (262144, 8192, 64, 1) else None
-            if tr is not None:
-                out["roofline"]["traffic"] = tr["bytes"]
-                out["roofline"]["traffic_note"] = "HBM bytes per launch, PMC pass %s (FETCH_SIZE x2 + WRITE_SIZE)" % tr["source"]
-            out["roofline_hbm"] = {"kernel": "sqnorm_kernel", "bound": "hbm", "achieved": 4.0 * m_l * n / t3 / 1e6,
-                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 4.0 * m_l * n / t3 / 1e6 / PEAK_HBM_GBS,
-                                   "traffic": None, "measured_ceiling": MEASURED_STREAM_GBS,
-                                   "frac_of_measured_ceiling": 4.0 * m_l * n / t3 / 1e6 / MEASURED_STREAM_GBS}
+            r_nt = mfma_entry(kname_nt + " (dnmf_aht_update_w)", t["aht_update_w"], fl_nt, "nt")
+            r_tn = mfma_entry(kname_tn + " (dnmf_wta, incl. the reduction of the partial slabs)", t["wta"], fl_tn, "tn")
+            r_res = mfma_entry("resid_kernel<KT=%d> (dnmf_resid_sqnorm)" % kt, t_res, fl_res, "resid_kernel")
+            r_upd = hbm_entry("update_h_seq_kernel<KT=%d> (dnmf_mu_update_h: H *= S / (G H + eps), %d x 2^22)" % (kt, k),
+                              t_upd, by_upd, "algorithmic bytes = 12 per element of H (read H, read S, write H)")
+            r_sq = hbm_entry("sqnorm_kernel (dnmf_sqnorm on X)", t_sq, 4.0 * m_l * n, "one read of X")
+            out["roofline"] = r_nt
+            out["roofline_hbm"] = r_upd
+            out["rooflines"] = [r_nt, r_tn, r_res, r_upd, r_sq]
             out["kernels"] = kern
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
+            torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(n, k, m)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -83,6 +83,11 @@ int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, vo
 /* the whole W sweep on one rank (no allreduce of the norms): k column launches + the final scale; ss2 = k doubles */
 int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                        double* ss2, void* stream);
+/* The same W sweep in ONE launch when the rank's rows fit on the device at once (one lane per row for the whole sweep:
+ * W and AH are read once, W written once; grid-wide column norms through per-workgroup fp64 slots reduced in a fixed
+ * order -- bitwise reproducible); otherwise it runs dnmf_hals_update_w.  `ws` >= dnmf_ws_bytes(m, k, k). dist_nmf.py:884-891 */
+int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                      void* ws, size_t ws_bytes, void* stream);
 /* H sweep: for kk: H[kk,:] = max(H[kk,:] + AtW[kk,:] - G[kk,:] H, eps), rows updated in sequence (dist_nmf.py:905-909) */
 int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
                        void* stream);

@@ -290,6 +290,7 @@ size_t partial_bytes(long m, long n, int k) {
         if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
     }
     b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
+    b = std::max(b, (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long) + (size_t)kp * sizeof(double));  // HALS W sweep slots
     return b;
 }
 
@@ -816,6 +817,56 @@ int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long 
         if (rc) return rc;
     }
     return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
+}
+
+}  // extern "C"
+namespace {
+// co-residency of the persistent sweep: workgroups the device can hold at once
+template <typename K>
+long resident_workgroups(K kernel, int threads) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+    return (long)cus * per_cu;
+}
+
+template <int KP>
+int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                      unsigned long long* slab, double* ss2, hipStream_t st) {
+    const bool vec = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;
+    const long grid = cdiv(m, HALS_WG);
+    static long cap_v = -1, cap_s = -1;
+    if (cap_v < 0) { cap_v = resident_workgroups(hals_w_sweep_kernel<KP, true>, HALS_WG); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG); }
+    if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
+    if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
+        return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
+    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, true>), dim3((unsigned)grid), dim3(HALS_WG), 0, st, W, m, k, ldw, AH, ldah, G, eps, slab, ss2);
+    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), 0, st, W, m, k, ldw, AH, ldah, G, eps, slab, ss2);
+    return check_launch("hals_sweep_w");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
+                      size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
+    const int kp = 32 * kt;
+    const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
+    if (ws_bytes < slab_bytes + (size_t)kp * sizeof(double)) return fail(DNMF_EWS, "hals_sweep_w: workspace too small");
+    unsigned long long* slab = (unsigned long long*)ws;
+    double* ss2 = (double*)((char*)ws + slab_bytes);
+    static const int mode = (int)tune("DNMF_HALS_SWEEP", 1);     // 0: always the column-per-launch path (A/B runs)
+    int rc = 1;
+    if (mode) {
+        hipStream_t st = S(stream);
+        if (kt == 1) rc = launch_hals_sweep<32>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
+        else if (kt == 2) rc = launch_hals_sweep<64>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
+        else rc = launch_hals_sweep<128>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
+    }
+    if (rc != 1) return rc;
+    return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column
 }
 
 int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,

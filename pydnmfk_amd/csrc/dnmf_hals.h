@@ -110,3 +110,158 @@ __global__ __launch_bounds__(64) void hals_h_kernel_lds(float* __restrict__ H, i
 
 
 }  // namespace
+
+namespace {
+
+// =============================================================================================== persistent W sweep
+// The whole W sweep in ONE launch (a rank whose column norms are local: p_r == 1).  The per-column kernels above re-read
+// every row of W for every column (k m k 4 bytes: 4.3 GB per sweep at m = 262144, k = 64 against 67 MB of factor) and pay
+// a launch per column.  Here one lane owns one row for the whole sweep and keeps it in registers:
+//   1. load the row of W; turn it IN PLACE into t[j] = AH[i][j] - sum_{l > j} W_old[i][l] G[l][j]  (j ascending: t[j] only
+//      needs the old values at l > j, which are still in their registers);
+//   2. for kk = 0 .. k-1:  u = max(t[kk], eps);  the column's sum of squares over ALL rows (grid-wide, see below);
+//      w = u / sqrt(ss2) (if ss2 > 0);  t[kk] := w (the slot is dead: it now holds the result);  t[j] -= w G[kk][j], j > kk
+//      -- first j = kk+1 alone (the next column's critical path), the rest after the next column's partial sum is on its
+//      way, so the triangular update overlaps the wait;
+//   3. store the row.
+// This is the reference's column step with its cancelling pair removed: W[i][kk] G[kk][kk] + AH[i][kk] - (W G)[i][kk]
+// (dist_nmf.py:887) = AH[i][kk] - sum_{l != kk} W[i][l] G[l][kk]; l < kk are the new columns, l > kk the old ones.
+// G[l][j] is wave-uniform with compile-time indices: scalar loads, FMAs with an SGPR operand, no LDS.
+//
+// Grid-wide sum per column WITHOUT a separate barrier: every workgroup publishes its fp64 partial sum into its own slot
+// slab[kk][wg] (the slab is preset to all-ones bit patterns = "not there yet") with an agent-scope store; every
+// workgroup polls all slots of the column (one per thread), and reduces them in a FIXED order -- the result is
+// bitwise identical in every workgroup and from run to run (no floating-point atomics).  One memory round trip per
+// column.  All workgroups must be co-resident (the host checks the occupancy and otherwise takes the per-column path).
+constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
+constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
+constexpr unsigned long long HALS_EMPTY = ~0ull;
+
+__device__ __forceinline__ double dshfl_xor(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// sum of one value per thread over the workgroup, the same association order everywhere; result in every thread
+__device__ __forceinline__ double block_sum_fixed(double v, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += dshfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                           // red[] may still be read from the previous use
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < HALS_WG / 64; ++w) s += red[w];
+    return s;
+}
+
+template <int KP, bool VEC>
+// waves per SIMD: what the row (KP registers) + the fp64 reductions hold without spilling; 8-wave workgroups, so the device
+// keeps 6 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 393216 / 262144 / 131072 rows resident for KP = 32 / 64 / 128
+__global__ __launch_bounds__(HALS_WG, KP <= 32 ? 6 : (KP <= 64 ? 4 : 2)) void hals_w_sweep_kernel(
+    float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ AH, long ldah, const float* __restrict__ G,
+    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out) {
+    __shared__ double red[HALS_WG / 64];
+    const long i = (long)blockIdx.x * HALS_WG + threadIdx.x;
+    const bool live = i < m;
+    const long ir = live ? i : m - 1;                 // dead lanes read a valid row and contribute nothing
+    const int nwg = gridDim.x;
+    float t[KP];
+    const float* wrow = W + ir * ldw;
+    const float* arow = AH + ir * ldah;
+#pragma unroll
+    for (int j = 0; j < KP; j += 4) {
+        if constexpr (VEC) {
+            if (j < k) {                              // VEC: k % 4 == 0, 16-byte aligned rows
+                const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + j);
+                t[j] = v[0]; t[j + 1] = v[1]; t[j + 2] = v[2]; t[j + 3] = v[3];
+            } else { t[j] = t[j + 1] = t[j + 2] = t[j + 3] = 0.f; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[j + e] = (j + e < k) ? wrow[j + e] : 0.f;
+        }
+    }
+    // 1. in-place triangular transform (rows / columns >= k of the zero-padded G contribute nothing)
+#pragma unroll
+    for (int j0 = 0; j0 < KP; j0 += 4) {
+        float a[4];
+        if constexpr (VEC) {
+            if (j0 < k) { const f32x4 v = *reinterpret_cast<const f32x4*>(arow + j0); a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; }
+            else { a[0] = a[1] = a[2] = a[3] = 0.f; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (j0 + e < k) ? arow[j0 + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            float acc = a[e];
+#pragma unroll
+            for (int l = j + 1; l < KP; ++l) acc = fmaf(-t[l], G[l * KP + j], acc);
+            t[j] = acc;
+        }
+    }
+    // 2. the column sweep
+    float u = fmaxf(t[0], eps);
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+        if (kk < k) {                                 // uniform
+            const double sq = live ? (double)u * (double)u : 0.0;
+            const double part = block_sum_fixed(sq, red);
+            unsigned long long* col = slab + (long)kk * HALS_MAX_WG;
+            if (threadIdx.x == 0) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+                if (bits == HALS_EMPTY) bits = 0x7ff8000000000000ull;            // (a NaN with that payload cannot occur)
+                __hip_atomic_store(col + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // lagging part of the previous column's triangular update: overlaps the round trip of the partial sums
+            if (kk > 0) {
+                const float wp = t[kk - 1];
+#pragma unroll
+                for (int j = kk + 1; j < KP; ++j) t[j] = fmaf(-wp, G[(kk - 1) * KP + j], t[j]);
+            }
+            // the first wave of the workgroup fetches the slots of this column (lane l: slots l, l + 64, ...): one polling
+            // wave per workgroup keeps the traffic on the few cache lines of the column down (all 512 threads polling
+            // measured 10 us per column on 512 workgroups)
+            double mine = 0.0;
+            if (threadIdx.x < 64) {
+                for (int s = threadIdx.x; s < nwg; s += 64) {
+                    unsigned long long bits;
+                    do {
+                        bits = __hip_atomic_load(col + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (bits == HALS_EMPTY) __builtin_amdgcn_s_sleep(2);
+                    } while (bits == HALS_EMPTY);
+                    mine += __longlong_as_double((long long)bits);
+                }
+            }
+            const double ss2 = block_sum_fixed(mine, red);
+            if (blockIdx.x == 0 && threadIdx.x == 0 && ss2_out) ss2_out[kk] = ss2;
+            const float ss = (float)sqrt(ss2);
+            const float w = ss > 0.f ? u / ss : u;
+            t[kk] = w;
+            if (kk + 1 < KP) {
+                t[kk + 1] = fmaf(-w, G[kk * KP + kk + 1], t[kk + 1]);
+                u = fmaxf(t[kk + 1], eps);
+            }
+        }
+    }
+    // 3. store the row
+    if (live) {
+        float* orow = W + i * ldw;
+#pragma unroll
+        for (int j = 0; j < KP; j += 4) {
+            if constexpr (VEC) {
+                if (j < k) *reinterpret_cast<f32x4*>(orow + j) = f32x4{t[j], t[j + 1], t[j + 2], t[j + 3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j + e < k) orow[j + e] = t[j + e];
+            }
+        }
+    }
+}
+
+}  // namespace

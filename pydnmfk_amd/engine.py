@@ -157,6 +157,16 @@ class HipOps:
         check(lib.dnmf_hals_w_scale(W.data_ptr(), W.shape[0], _ld(W), int(col), ss2[col:].data_ptr(), _stream()))
 
     def hals_update_w(self, W, AH, G, eps):
+        """The whole W sweep of a rank with local column norms: one persistent launch when the rows fit on the device at
+        once, else one launch per column (decided inside the library)."""
+        _req(W, "W"); _req(AH, "AH"); _req(G, "G")
+        m, k = W.shape
+        ws = workspace(m, k, k, W.device)
+        check(lib.dnmf_hals_sweep_w(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), float(eps),
+                                    ws.data_ptr(), ws.numel(), _stream()))
+
+    def hals_update_w_columns(self, W, AH, G, eps):
+        """The same sweep as k column launches (what the persistent kernel falls back to; kept callable for A/B tests)."""
         _req(W, "W"); _req(AH, "AH"); _req(G, "G")
         m, k = W.shape
         ss2 = self.hals_ss2(k, W)

@@ -221,7 +221,14 @@ def test_hals_sweeps(ops, m, n, k):
     for kk in range(k):
         ops.hals_w_col(Wc, _d(AH), G, kk, ss2, EPS)
     ops.hals_w_scale(Wc, k - 1, ss2)
-    assert _rel(Wc.cpu().numpy(), Wd.cpu().numpy()) < 1e-6
+    # (the one-call form keeps the rows in registers and drops the cancelling pair W[i][kk] G[kk][kk] - W[i][kk] G[kk][kk]
+    #  of dist_nmf.py:887; the column kernels evaluate the reference's expression as written)
+    assert _rel(Wc.cpu().numpy(), Wd.cpu().numpy()) < 2e-4
+    assert _rel(Wc.cpu().numpy(), Wr) < 2e-4
+    # and the k-launch composite the persistent sweep falls back to equals the explicit column calls bit for bit
+    We = _d(W)
+    ops.hals_update_w_columns(We, _d(AH), G, EPS)
+    assert torch.equal(We, Wc)
     # H sweep alone
     W64 = Wr.astype(np.float64)
     AtW = (W64.T @ A64).astype(np.float32)
@@ -235,6 +242,36 @@ def test_hals_sweeps(ops, m, n, k):
         Hr[kk, :] = np.maximum(t, np.float32(EPS))
     assert _rel(Hd.cpu().numpy(), Hr) < 2e-4
     assert float(Hd.min()) >= EPS
+
+
+@pytest.mark.parametrize("m,k", [(70000, 64), (262144, 16), (131072, 64), (40001, 5), (9000, 128), (300000, 64)])
+def test_hals_persistent_w_sweep_large(ops, m, k):
+    """The one-launch W sweep (one lane per row, grid-wide column norms through per-workgroup slots) on grids of many
+    workgroups -- 300000 x 64 exceeds what the device keeps resident and takes the column path -- against a float64
+    evaluation of dist_nmf.py:884-891, and bit-reproducible from run to run."""
+    from pydnmfk_amd.engine import new_gram
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(k + m)
+    W = torch.rand(m, k, device=dev, generator=g)
+    H = torch.rand(k, 512, device=dev, generator=g)
+    AH = torch.rand(m, k, device=dev, generator=g) * 200.0
+    G = ops.gram_hht(H, new_gram(k, dev))
+    outs = []
+    for _ in range(2):
+        Wd = W.clone()
+        ops.hals_update_w(Wd, AH, G, EPS)
+        outs.append(Wd)
+    assert torch.equal(outs[0], outs[1])
+    Wr = W.double()
+    G64, A64 = G[:k, :k].double(), AH.double()
+    for kk in range(k):
+        t = Wr[:, kk] * G64[kk, kk] + A64[:, kk] - Wr @ G64[:, kk]
+        Wr[:, kk] = torch.clamp(t, min=EPS)
+        ss = torch.linalg.norm(Wr[:, kk])
+        if float(ss) > 0:
+            Wr[:, kk] /= ss
+    assert float((outs[0].double() - Wr).norm() / Wr.norm()) < 5e-5
+    assert torch.allclose(outs[0].double().norm(dim=0), torch.ones(k, dtype=torch.float64, device=dev), atol=1e-5)
 
 
 def test_errors_are_loud(ops):

@@ -21,3 +21,19 @@ for method in ("mu", "hals"):
     for i in range(10): nmf_algorithms_1D(A, W, H, params=p).update()
     torch.cuda.synchronize(); out[method + "_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
 print(json.dumps(out))
+# the W sweep alone: persistent launch vs one launch per column
+from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+G = ops.gram_hht(H, new_gram(k, dev)); AH = torch.rand(m, k, device=dev, generator=g) * 100
+def tm(fn, reps=10, warm=3):
+    for _ in range(warm): fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in ev:
+        s.record(); fn(); e.record()
+    torch.cuda.synchronize()
+    xs = sorted(s.elapsed_time(e) for s, e in ev)
+    return xs[len(xs) // 2]
+Wc = W.clone()
+out2 = {"w_sweep_persistent_ms": round(tm(lambda: ops.hals_update_w(Wc, AH, G, 1.19e-7)), 4),
+        "w_sweep_columns_ms": round(tm(lambda: ops.hals_update_w_columns(Wc, AH, G, 1.19e-7)), 4),
+        "stream_2mk4_ms_at_5TBs": round(2.0 * m * k * 4 / 5e9, 4)}
+print(json.dumps(out2))

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
 m, n, k = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (262144, 8192, 64)
+if "--bf16" in sys.argv: os.environ["BF16"] = "1"
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 A = torch.rand(m, n, device=dev, generator=g) if not os.environ.get("ALIAS") else torch.rand(1, n, device=dev, generator=g).expand(m, n); W = torch.rand(m, k, device=dev, generator=g); H = torch.rand(k, n, device=dev, generator=g)

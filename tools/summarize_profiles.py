@@ -6,6 +6,7 @@
 import collections, csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+what = sys.argv[3] if len(sys.argv) > 3 else "bench.py, X = 262144 x 8192 fp32, k = 64"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -20,7 +21,7 @@ rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows[:16]:
+    for r in rows[:24]:
         w.writerow([short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
 
 pmc = collections.defaultdict(dict)
@@ -58,9 +59,14 @@ for n, c in pmc.items():
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 
 with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
-    f.write("# rocprofv3 summary `%s` (bench.py, X = 262144 x 8192 fp32, k = 64, 1 MI355X)\n\n" % tag)
+    f.write("# rocprofv3 summary `%s` (`python3 %s`, 1 MI355X)\n\n" % (tag, what))
+    so = os.path.join(src, "stdout.json")
+    if os.path.exists(so):
+        lines = [l for l in open(so).read().splitlines() if l.startswith("{")]
+        if lines:
+            f.write("Program output under the profiler (timings include its overhead):\n\n```\n%s\n```\n\n" % "\n".join(l[:1500] for l in lines[-6:]))
     f.write("## kernel-trace --stats (top kernels)\n\n| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n")
-    for r in rows[:12]:
+    for r in rows[:18]:
         f.write("| `%s` | %s | %.1f | %.2f | %s |\n" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3,
                                                      float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
     f.write("\n## PMC passes (separate runs; per-dispatch averages)\n\n| kernel | us (pmc) | clock GHz | MFMA busy | HBM read GB | HBM write GB | L2 hit |\n|---|---|---|---|---|---|---|\n")
