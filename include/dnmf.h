@@ -125,6 +125,10 @@ int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* str
 /* *out (double, device) = sum (A - W H)^2 without materialising the residual (pyDNMF.py:207,215) */
 int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                       int k, double* out, void* stream);
+/* per-column pieces of PyNMF.column_err (pyDNMF.py:221-239) over this rank's rows: num[c] += sum_i (A - W H)[i][c]^2,
+ * den[c] += sum_i A[i][c]^2 (device doubles, n each, ACCUMULATED: the caller zeroes them; A - W H is never materialised) */
+int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                    int k, double* num, double* den, void* stream);
 
 /* ---- bf16 STORAGE of the data matrix (BASELINE config 5, "mixed precision"; no reference counterpart: numpy has no
  * bf16).  A is bfloat16 in device memory (pointer to 16-bit words, lda in elements, rows 8-byte aligned for the vector
@@ -141,6 +145,8 @@ int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, lo
 int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void* stream);
 int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H,
                             long ldh, int k, double* out, void* stream);
+int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                          int k, double* num, double* den, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,11 +54,13 @@ SIGNATURES = {
     "dnmf_scale_cols_div": [c_void_p, c_long, c_int, c_long, c_void_p, c_float, c_void_p],
     "dnmf_scale_rows_mul": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
     "dnmf_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p],
+    "dnmf_column_err": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_void_p,
+                        c_void_p],
     "dnmf_resid_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
                           c_void_p],
 }
 # bf16 storage of A: same argument lists as the fp32 twins (A is passed as a device pointer either way)
-for _n in ("aht", "wta", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm"):
+for _n in ("aht", "wta", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "column_err"):
     SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
 _RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t}
 

@@ -677,6 +677,41 @@ int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float
     return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream);
 }
 
+}  // extern "C"
+namespace {
+template <typename TA>
+int column_err_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                    double* num, double* den, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && num && den && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "column_err: bad arguments");
+    hipStream_t st = S(stream);
+    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
+    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
+    // about 8 waves per SIMD in flight, every wave walking a chunk of row blocks of its 128-column block
+    const long rpc = std::max<long>(1, cdiv(a.nrowblk * a.ncolblk, 8192));
+    const long waves = cdiv(a.nrowblk, rpc) * a.ncolblk;
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+#define CE_CASE(KT_)                                                                             \
+    if (kt == KT_) {                                                                             \
+        if (fast) hipLaunchKernelGGL((colerr_kernel<KT_, true, TA>), grid, block, 0, st, a, num, den, rpc); \
+        else hipLaunchKernelGGL((colerr_kernel<KT_, false, TA>), grid, block, 0, st, a, num, den, rpc);    \
+    }
+    CE_CASE(1) CE_CASE(2) CE_CASE(4)
+#undef CE_CASE
+    return check_launch("column_err");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                    double* num, double* den, void* stream) {
+    return column_err_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
+}
+int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                          double* num, double* den, void* stream) {
+    return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
+}
+
 struct UhtPlan { int nsplit; long cols_per_split; };
 
 static UhtPlan plan_uht(long m, long n) {

@@ -100,6 +100,53 @@ __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     block_atomic_sum(total, p.out);
 }
 
+// Per-column residual statistics (PyNMF.column_err, pyDNMF.py:221-239): num[c] += sum_i (A[i][c] - (W H)[i][c])^2 and
+// den[c] += sum_i A[i][c]^2 over this rank's rows -- the residual kernel's tile loop with one accumulator pair per
+// column instead of one scalar.  A wave owns a 128-column block and walks a chunk of 32-row blocks; fp32 partial sums per
+// tile (16 rows), fp64 across tiles; the two lane halves are combined with one shuffle and 32 lanes add 4 columns each to
+// the global fp64 arrays (atomics: these are statistics, like the norms of pyDNMF.py:205-218).
+template <int KT, bool FAST, typename TA = float>
+__global__ __launch_bounds__(256) void colerr_kernel(NnArgs p, double* __restrict__ num, double* __restrict__ den,
+                                                     long rowblks_per_chunk) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * 4 + wid;
+    const long nchunks = cdiv(p.nrowblk, rowblks_per_chunk);
+    if (gw >= nchunks * p.ncolblk) return;
+    const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;
+    const long col0 = colblk * 128;
+    double dn[4] = {0.0, 0.0, 0.0, 0.0}, dd[4] = {0.0, 0.0, 0.0, 0.0};
+    long rb1 = (chunk + 1) * rowblks_per_chunk;
+    if (rb1 > p.nrowblk) rb1 = p.nrowblk;
+    for (long rb = chunk * rowblks_per_chunk; rb < rb1; ++rb) {
+        const long row0 = rb * 32;
+        f32x16 acc[4];     // (one predicated tile variant: the kernel runs once per k of an NMFk sweep, not per iteration)
+        nn_tile<KT, 4, FAST, false>(acc, p.W, p.ldw, p.m, p.k, p.H, p.ldh, p.n, row0, col0, li, h);
+        float pn[4] = {0.f, 0.f, 0.f, 0.f}, pd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + crow(r, h);
+            float a[4];
+            load_tile_vec<4, FAST, false>(a, reinterpret_cast<const TA*>(p.A) + row * p.lda, col0 + 4 * li, p.n, row < p.m);
+#pragma unroll
+            for (int ne = 0; ne < 4; ++ne) {
+                const float d = a[ne] - acc[ne][r];        // rows >= m / cols >= n: a = 0 and acc = 0
+                pn[ne] = fmaf(d, d, pn[ne]);
+                pd[ne] = fmaf(a[ne], a[ne], pd[ne]);
+            }
+        }
+#pragma unroll
+        for (int ne = 0; ne < 4; ++ne) { dn[ne] += (double)pn[ne]; dd[ne] += (double)pd[ne]; }
+    }
+#pragma unroll
+    for (int ne = 0; ne < 4; ++ne) {
+        dn[ne] += __shfl_xor(dn[ne], 32, 64);
+        dd[ne] += __shfl_xor(dd[ne], 32, 64);
+        const long c = col0 + 4 * li + ne;
+        if (h == 0 && c < p.n) { atomicAdd(num + c, dn[ne]); atomicAdd(den + c, dd[ne]); }
+    }
+}
+
 // KL H-side: P[chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)          (dist_nmf.py:806,808)
 // A workgroup = 4 waves that share one block of CW = 32*NT columns and each own a chunk of 32-row blocks.  The
 // KP x CW block of H those columns need is loop invariant: it is staged ONCE per workgroup into LDS (row jj,

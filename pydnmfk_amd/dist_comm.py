@@ -134,6 +134,17 @@ class TorchComm:
                 dist.all_reduce(t, group=self.group)
         return t
 
+    def allreduce_begin(self, t):
+        """Start a SUM allreduce of `t` in place and return a handle whose wait() orders the result before whatever
+        the caller enqueues next.  Over RCCL the collective runs on the communicator's own stream (it starts when the
+        kernels enqueued so far on the current stream are done), so kernels launched between begin and wait overlap it."""
+        if self._solo():
+            return _Done()
+        if self._staged(t):
+            self.allreduce_(t)                  # staged transports (tests) exchange synchronously
+            return _Done()
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
     def allgather_blocks(self, x, shapes):
         """All-gather row-major blocks whose per-rank shapes are known (ragged allowed: padded to the largest)."""
         if self._solo():
@@ -170,6 +181,13 @@ class TorchComm:
             return
         dist.all_gather_object(counts, int(recvbuf.shape[0]), group=self.group)
         recvbuf.copy_(self.reduce_scatter_rows(sendbuf, counts))
+
+
+class _Done:
+    """Handle of an exchange that has already happened."""
+
+    def wait(self):
+        return True
 
 
 def COMM_WORLD():

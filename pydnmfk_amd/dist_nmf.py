@@ -133,16 +133,58 @@ class nmf_algorithms_1D(_Base):
                 ops.aht(A, H, AH)
                 self.comm1.allreduce_(buf[: off + kp * kp])
                 ops.mu_update_w(W, AH, G, eps)
-        off = _pad64(k * n_l)                                      # Fro_MU_update_H :736-751
-        buf = _buf(("atwg", k, n_l), off + kp * kp, A)
-        AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
-        ops.gram_wtw(W, G)
-        ops.wta(A, W, AtW)
-        if self.p_r != 1:                                          # allreduce [W^T A | W^T W] (:681,:707)
-            self.comm1.allreduce_(buf[: off + kp * kp])
-        ops.mu_update_h(H, AtW, G, eps, clamp)
+        nch = self._overlap_chunks(n_l)
+        if nch > 1:
+            self._fro_h_phase_overlapped(nch, clamp)
+        else:
+            off = _pad64(k * n_l)                                  # Fro_MU_update_H :736-751
+            buf = _buf(("atwg", k, n_l), off + kp * kp, A)
+            AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
+            ops.gram_wtw(W, G)
+            ops.wta(A, W, AtW)
+            if self.p_r != 1:                                      # allreduce [W^T A | W^T W] (:681,:707)
+                self.comm1.allreduce_(buf[: off + kp * kp])
+            ops.mu_update_h(H, AtW, G, eps, clamp)
         if clamp:
             ops.clamp_min(W, eps)
+
+    def _overlap_chunks(self, n_l):
+        """Column chunks of the H phase on a row grid of more than two ranks (the 8-GPU configuration): the exchange of
+        chunk c runs on the communicator's stream while W^T A of chunk c+1 is computed, only the last exchange is
+        exposed.  Up to two ranks the single packed allreduce stays (one latency, nothing worth hiding behind).
+        `params.overlap_chunks` (default 4) / `params.overlap_min_cols` (default 4096) tune it; 1 switches it off."""
+        if self.p_c != 1 or self.p_r <= 2:
+            return 1
+        nch = int(getattr(self.params, "overlap_chunks", 4))
+        if nch <= 1 or n_l < int(getattr(self.params, "overlap_min_cols", 4096)):
+            return 1
+        return max(1, min(nch, n_l // 64))
+
+    def _fro_h_phase_overlapped(self, nch, clamp):
+        """Fro_MU_update_H (:736-751) with the allreduce of [W^T A | W^T W] (:681,:707) cut into column chunks: chunk 0
+        carries W^T W.  Each chunk is a contiguous buffer [k x cw (| KP x KP)], W^T A of the chunk is written with
+        ld = cw, and the H update runs per chunk on column views of H -- same arithmetic, same per-element sums."""
+        ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_i, self.H_j, self.eps, self.k
+        kp = _kp(k)
+        m_l, n_l = A.shape
+        cw = -(-(-(-n_l // nch)) // 64) * 64                       # chunk width: ceil(n_l / nch) rounded up to 64 columns
+        starts = list(range(0, n_l, cw))
+        total = sum(_pad64(k * min(cw, n_l - c0)) for c0 in starts) + kp * kp
+        buf = _buf(("atwg_chunks", k, n_l), total, A)
+        G = buf[_pad64(k * min(cw, n_l)): _pad64(k * min(cw, n_l)) + kp * kp].view(kp, kp)
+        ops.gram_wtw(W, G)
+        pending, off = [], 0
+        for ci, c0 in enumerate(starts):
+            c1 = min(n_l, c0 + cw)
+            ne = _pad64(k * (c1 - c0))
+            AtW = buf[off: off + k * (c1 - c0)].view(k, c1 - c0)
+            ops.wta(A[:, c0:c1], W, AtW)
+            span = ne + (kp * kp if ci == 0 else 0)                # chunk 0: [W^T A chunk | W^T W] in one message
+            pending.append((c0, c1, AtW, self.comm1.allreduce_begin(buf[off: off + span])))
+            off += span
+        for c0, c1, AtW, work in pending:
+            work.wait()
+            ops.mu_update_h(H[:, c0:c1], AtW, G, eps, clamp)
 
     # ---- HALS / Frobenius (dist_nmf.py:873-934)
     def FRO_HALS_update(self, W_update=True, clamp=False):
@@ -236,7 +278,12 @@ class nmf_algorithms_2D(_Base):
     # ---- gathers (dist_nmf.py:163-165, :195-197, :268-291)
     def gather_W(self):
         blocks = self.cartesian1d_column.allgather_blocks(self.W_ij, [(c, self.k) for c in self.w_counts])
-        return torch.cat(blocks, dim=0) if len(blocks) > 1 else blocks[0]          # vstack -> W_i [m_l x k]
+        if len(blocks) == 1:
+            return blocks[0]
+        if len(set(self.w_counts)) == 1:       # equal row blocks: the receive buffer already IS the vstack (no copy)
+            b0 = blocks[0]
+            return torch.as_strided(b0, (sum(self.w_counts), self.k), (self.k, 1))
+        return torch.cat(blocks, dim=0)                                             # vstack -> W_i [m_l x k]
 
     def gather_H(self):
         blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
@@ -310,7 +357,9 @@ class nmf_algorithms_2D(_Base):
             ops.kl_update_w(W, sk, x, eps)                         # :369
         ops.colsum(W, x)                                           # KL_MU_update_H :371-389
         self.comm1.allreduce_(x)
-        W_i, H_j = self.gather_W(), self.gather_H()                # :387
+        W_i = self.gather_W()                                      # :387 (the W phase changed W, not H: the H_j it
+        if not W_update:                                           #  gathered is still current -- one exchange less)
+            H_j = self.gather_H()
         WTU = ops.kl_wtu(A, W_i, H_j, eps, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))      # :311-312
         ks = self._scatter_to_H(WTU)                               # :314-316
         ops.kl_update_h(H, ks, x, eps, clamp)                      # :389

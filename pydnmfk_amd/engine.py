@@ -259,6 +259,15 @@ class HipOps:
                                     _ld(H), W.shape[1], out.data_ptr(), _stream()))
         return out
 
+    def column_err_sums(self, A, W, H):
+        """(num, den): per-column sums over this rank's rows of (A - W H)^2 and A^2, fp64 device vectors of length n."""
+        sfx = _req_a(A); _req(W, "W"); _req(H, "H")
+        n = A.shape[1]
+        out = torch.zeros(2, n, dtype=torch.float64, device=A.device)
+        check(_fn("column_err", sfx)(A.data_ptr(), A.shape[0], n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H),
+                                  W.shape[1], out[0].data_ptr(), out[1].data_ptr(), _stream()))
+        return out[0], out[1]
+
     # ---- allocation helpers used by the choreography
     def empty(self, shape, like):
         return torch.empty(shape, dtype=torch.float32, device=like.device)

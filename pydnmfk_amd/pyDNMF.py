@@ -24,13 +24,15 @@ from .dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
 from .utils import data_operations, var_init
 
 
-def _to_device(x, device, dtype=torch.float32):
+def _to_device(x, device, dtype=torch.float32, what="A_ij"):
     if isinstance(x, torch.Tensor):
         t = x
     else:
         t = torch.from_numpy(np.ascontiguousarray(x))
-    if t.dtype == torch.float64:
+    if t.dtype == torch.float64 and what == "A_ij":
         raise TypeError("PyNMF: float64 input; the MI355X engine computes in float32 -- cast with .astype('float32')")
+    # factors take the data's compute dtype on entry, as in the reference (`factors[i].astype(self.A_ij.dtype)`,
+    # pyDNMF.py:92-96): NMFk hands the float64 medians / centroids of its clustering to the regression fit
     return t.to(device=device, dtype=dtype).contiguous()
 
 
@@ -95,7 +97,8 @@ class PyNMF:
         self.data_op = data_operations(self.A_ij, self.params)      # :88 -> params.m, n, m_loc, n_loc, ...
         self.params = self.data_op.params
         if factors is not None:                                     # :90-96 (copied on entry)
-            W0, H0 = _to_device(factors[0], device).clone(), _to_device(factors[1], device).clone()
+            W0 = _to_device(factors[0], device, what="factors").clone()
+            H0 = _to_device(factors[1], device, what="factors").clone()
         else:
             W0, H0 = self.init_factors()
         if self.topo == '1d':
@@ -122,7 +125,7 @@ class PyNMF:
             if self.topo != '1d':
                 raise Exception('NNSVD init only available for 1D topology, please try with 1d topo.')
             from .dist_svd import DistSVD
-            return DistSVD(self.params, self.A_ij).nnsvd(flag=1, verbose=0)
+            return DistSVD(self.params, self.A_ij, ops=self._ops()).nnsvd(flag=1, verbose=0)
         if self.init != 'rand':
             raise NotImplementedError("init='%s': 'rand', 'nnsvd' or factors=... are provided" % self.init)
         f32 = np.float32
@@ -210,8 +213,8 @@ class PyNMF:
 
     def column_err(self):
         """pyDNMF.py:221-239: per-column relative error sqrt(sum_i (A - W H)^2 / sum_i A^2) over the GLOBAL n columns
-        (each rank fills its own column range, float64 allreduce).  Used once per k by NMFk; the residual is formed in
-        row slabs so that no m_l x n_l temporary is materialised."""
+        (each rank fills its own column range, float64 allreduce).  Used once per k by NMFk; the per-column sums come
+        from one kernel pass over A (dnmf_column_err: the residual tile stays in accumulators)."""
         from .utils import determine_block_params
         blk = determine_block_params(self.comm1, (self.p_r, self.p_c), (self.params.m, self.params.n))
         c0 = blk.determine_block_index_range_asymm()[0][1]
@@ -222,14 +225,7 @@ class PyNMF:
         if W.shape[0] != self.A_ij.shape[0] or H.shape[1] != self.A_ij.shape[1]:   # factors were un-pruned by fit()
             W = W[self.params.row_zero_idx_x] if W.shape[0] != self.A_ij.shape[0] else W
             H = H[:, self.params.col_zero_idx_x] if H.shape[1] != self.A_ij.shape[1] else H
-        num = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
-        den = torch.zeros(self.n_loc, dtype=torch.float64, device=self.A_ij.device)
-        step = max(1, (1 << 26) // max(1, self.n_loc))
-        for r0 in range(0, self.m_loc, step):
-            a = self.A_ij[r0:r0 + step]
-            d = (a - W[r0:r0 + step] @ H).double()
-            num += (d * d).sum(0)
-            den += (a.double() ** 2).sum(0)
+        num, den = self._ops().column_err_sums(self.A_ij, W.contiguous(), H.contiguous())   # one pass over A, no temporaries
         col_num = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
         col_den = torch.zeros(self.params.n, dtype=torch.float64, device=num.device)
         keep = getattr(self.params, "col_zero_idx_x", None) if self.prune else None

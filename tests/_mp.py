@@ -18,7 +18,7 @@ def free_port():
     return port
 
 
-def run_case_rank(rank, world, port, name, q, use_hip):
+def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
     try:
         import torch.distributed as dist
         from oracle import nmf_oracle as orc
@@ -46,6 +46,8 @@ def run_case_rank(rank, world, port, name, q, use_hip):
             args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
             args.itr, args.init, args.verbose, args.prune = itr, "rand", False, meta.get("prune", False)
             args.norm, args.method, args.W_update = meta["norm"], meta.get("method", "mu"), meta["W_update"]
+            for key, val in (extra or {}).items():
+                setattr(args, key, val)
             s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
             assert [s[0], e[0] + 1, s[1], e[1] + 1] == list(z["r%d_A_range" % rank])
             A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1]
@@ -65,13 +67,13 @@ def run_case_rank(rank, world, port, name, q, use_hip):
         q.put((rank, None, traceback.format_exc()))
 
 
-def run_case(name, use_hip=False, timeout=240):
+def run_case(name, use_hip=False, timeout=240, extra=None):
     meta = load_case(name)[0]
     world = meta["grid"][0] * meta["grid"][1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_case_rank, args=(r, world, port, name, q, use_hip)) for r in range(world)]
+    procs = [ctx.Process(target=run_case_rank, args=(r, world, port, name, q, use_hip, extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=timeout) for _ in procs]
@@ -146,3 +148,66 @@ def run_bf16(grid, method, use_hip=False, timeout=240):
         assert err is None, "rank %d failed:\n%s" % (rank, err)
         dw, dh, de = out
         assert dw <= tol and dh <= tol and de <= 1e-5, (grid, method, rank, dw, dh, de)
+
+
+def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
+    """examples/dist_pynmfk_2d_Swim.py of the reference: swim.mat on a 2 x 2 grid, KL / MU, rand init, noise 0.016,
+    sill_thr 0.6, the default 20 perturbations; `cfg` = (start_k, end_k, itr)."""
+    try:
+        import time
+        import numpy as np
+        import torch.distributed as dist
+        from pydnmfk_amd.dist_comm import MPI_comm
+        from pydnmfk_amd.pyDNMFk import PyNMFk
+        from pydnmfk_amd.utils import determine_block_params, parse
+
+        torch.set_num_threads(1)
+        if use_hip:
+            torch.cuda.set_device(0)
+            ops = None
+        else:
+            from tests._ops_double import OracleOps
+            ops = OracleOps()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import tempfile
+        from tests._golden import GOLDEN
+        A = np.ascontiguousarray(np.load(os.path.join(GOLDEN, "data_swim.npz"))["A"].astype(np.float32))
+        p_r, p_c = 2, 2
+        comms = MPI_comm(None, p_r, p_c)
+        args = parse()
+        args.size, args.rank, args.comm, args.p_r, args.p_c = world, rank, comms, p_r, p_c
+        args.row_comm, args.col_comm, args.comm1 = comms.cart_1d_row(), comms.cart_1d_column(), comms.comm
+        args.fpath, args.fname, args.ftype = "../data/", "swim", "mat"
+        args.start_k, args.end_k, args.sill_thr, args.itr, args.init = cfg[0], cfg[1], 0.6, cfg[2], "rand"
+        args.noise_var, args.verbose, args.norm, args.method, args.checkpoint = 0.016, False, "kl", "mu", False
+        args.precision = np.float32
+        tmp = [tempfile.mkdtemp() if rank == 0 else None]
+        dist.broadcast_object_list(tmp, src=0)
+        args.results_path = tmp[0] + "/"
+        s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+        A_ij = A[s[0]:e[0] + 1, s[1]:e[1] + 1].astype(args.precision)
+        t0 = time.time()
+        nmfk = PyNMFk(A_ij, factors=None, params=args, ops=ops)
+        nopt = nmfk.fit()
+        sil = {k: float(np.min(v["clusterSilhouetteCoefficients"])) for k, v in nmfk.stats.items()}
+        q.put((rank, (int(nopt), sil, time.time() - t0), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def run_swim_nmfk(cfg, use_hip=True, timeout=3600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_swim_nmfk_rank, args=(r, 4, port, cfg, q, use_hip)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, err in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+    return [out for _, out, _ in sorted(res, key=lambda r: r[0])]

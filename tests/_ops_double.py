@@ -130,6 +130,11 @@ class OracleOps:
     def resid_sqnorm(self, A, W, H):
         return torch.tensor([float(np.linalg.norm(_n(A) - _n(W) @ _n(H))) ** 2], dtype=torch.float64)
 
+    def column_err_sums(self, A, W, H):
+        a = _n(A).astype(np.float64)
+        d = a - (_n(W) @ _n(H)).astype(np.float64)                      # pyDNMF.py:229-231 (float32 product, as numpy forms it)
+        return torch.from_numpy((d * d).sum(0)), torch.from_numpy((a * a).sum(0))
+
     def empty(self, shape, like):
         return torch.empty(shape, dtype=torch.float32)
 

@@ -40,6 +40,15 @@ def test_choreography_matches_reference(name):
     _run(name)
 
 
+@pytest.mark.parametrize("name", ["swim_4x1_fro_float32", "r25x13_3x1_fro_float32"])
+def test_overlapped_h_phase_matches_reference(name):
+    """Row grids of more than two ranks cut the allreduce of [W^T A | W^T W] into column chunks that travel while the
+    next chunk is computed (dist_nmf._fro_h_phase_overlapped).  swim on 4 x 1 (n = 256) takes 4 chunks of 64 columns,
+    25 x 13 on 3 x 1 is too narrow and keeps the single packed exchange; both must still reproduce the reference."""
+    from tests._mp import run_case
+    run_case(name, use_hip=False, extra={"overlap_min_cols": 32, "overlap_chunks": 4})
+
+
 @pytest.mark.parametrize("grid,method", [((1, 1), "mu"), ((2, 1), "mu"), ((1, 2), "hals"), ((2, 2), "hals"), ((2, 2), "mu")])
 def test_bf16_storage_precision_on_a_grid(grid, method):
     """params.precision = 'bfloat16' (config 5): the data block is held as bf16, factors and arithmetic stay float32 --

@@ -33,3 +33,9 @@ def test_multirank_hip_bf16_storage(grid, method):
     """bf16-stored data blocks on a grid, real HIP kernels (the *_bf16a entry points), gloo transport."""
     from tests._mp import run_bf16
     run_bf16(grid, method, use_hip=True)
+
+
+def test_multirank_hip_overlapped_h_phase():
+    """The chunked / overlapped H phase of row grids with more than two ranks, real kernels on column views of A and H."""
+    from tests._mp import run_case
+    run_case("swim_4x1_fro_float32", use_hip=True, timeout=400, extra={"overlap_min_cols": 32, "overlap_chunks": 4})

@@ -128,3 +128,28 @@ def test_wtsi_known_answer_with_bf16_storage(tmp_path, golden_dir):
         args.checkpoint, args.results_path = False, str(tmp_path) + "/results_%s/" % method
         args.precision = "bfloat16"
         assert PyNMFk(A, factors=None, params=args).fit() == 4, method
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("DNMF_LONG_TESTS"), reason="~15 min: 4 ranks x 105 KL fits x 5000 iterations over the host-staged test transport; set DNMF_LONG_TESTS=1 (log of a run: profiles/r02_swim_2x2_kl_known_answer.log)")
+def test_swim_2x2_kl_known_answer():
+    """The reference's second end-to-end known answer (examples/dist_pynmfk_2d_Swim.py:23-50): swim.mat on a 2 x 2 grid,
+    KL / MU, k = 14..18, 5000 iterations, rand init, noise 0.016, sill_thr 0.6 -> asserts nopt == 16.  Four ranks on the
+    one GPU, real HIP kernels, gloo transport."""
+    from tests._mp import run_swim_nmfk
+    outs = run_swim_nmfk((14, 18, 5000), use_hip=True, timeout=7000)
+    assert all(o[0] == 16 for o in outs), outs
+
+
+def test_swim_2x2_kl_nmfk_short(tmp_path):
+    """The same example cut to what fits the regular GPU tier (k = 16..17, 800 iterations): every rank of the 2 x 2 grid
+    runs the 2D KL choreography inside NMFk, the four ranks agree on the estimate and on the silhouettes, and the
+    clustering of k = 17 (one feature too many for the 16 swimmer limbs) is unstable.  The known answer itself needs the
+    reference's 5000 iterations (KL / MU converges slowly: at 1000 the k = 16 silhouette is still 0.54 < sill_thr)."""
+    from tests._mp import run_swim_nmfk
+    outs = run_swim_nmfk((16, 17, 800), use_hip=True, timeout=900)
+    assert len({o[0] for o in outs}) == 1
+    for o in outs[1:]:
+        assert o[1] == outs[0][1]
+    sil = outs[0][1]
+    assert sil[17] < 0.3 and sil[16] > sil[17], sil
+    print("swim 2x2 KL short: nopt", outs[0][0], "min silhouettes", sil, "seconds", round(outs[0][2], 1))
