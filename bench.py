@@ -189,8 +189,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.backend)      # nccl = RCCL; communicators are created lazily on the current device
         if a.backend == "nccl":
-            # one tiny collective up front: if RCCL cannot come up on this node the run continues over gloo (host staged,
-            # slower, and labelled as such in config.parallelism) instead of producing no number at all
+            # one tiny collective up front: if RCCL cannot come up the run ends here with a non-zero exit (the launcher
+            # then stops the other ranks).  There is no per-rank fallback to another transport: ranks deciding that on
+            # their own could end up in different process groups.  `--backend gloo` selects the host-staged transport
+            # explicitly (debugging only; labelled in config.parallelism).
             try:
                 t = torch.ones(1, device=dev)
                 dist.all_reduce(t)
@@ -198,13 +200,9 @@ def main():
                 if int(t.item()) != world:
                     raise RuntimeError("allreduce returned %s" % t.item())
             except Exception as exc:  # noqa: BLE001
-                sys.stderr.write("bench.py: RCCL unavailable (%s); falling back to gloo\n" % exc)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                a.backend = "gloo"
-                dist.init_process_group("gloo")
+                sys.stderr.write("bench.py: RCCL did not come up on rank %d (%s)\n" % (rank, exc))
+                sys.stderr.flush()
+                os._exit(3)
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
