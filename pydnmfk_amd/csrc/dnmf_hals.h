@@ -158,10 +158,44 @@ __device__ __forceinline__ double block_sum_fixed(double v, double* red) {
     return s;
 }
 
+// One wave collects the nwg <= 64 NQ slots of a column: every lane keeps NQ slots, ALL of them are requested back to back in
+// each polling round (independent, unconditional loads -- a loop that waits for one slot after the other pays one memory
+// round trip per slot: measured 16 us per column on 512 workgroups), slots that are still empty are asked for again.
+// Returns the lane's sum in slot order.
+template <int NQ>
+__device__ __forceinline__ double hals_poll(const unsigned long long* col, int nwg) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long bits[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bits[q] = (lane + 64 * q < nwg) ? HALS_EMPTY : 0ull;   // beyond the grid: +0.0, never awaited
+    for (;;) {
+        unsigned long long v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int s = lane + 64 * q;
+            v[q] = __hip_atomic_load(col + (s < nwg ? s : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            bits[q] = bits[q] == HALS_EMPTY ? v[q] : bits[q];
+            missing = missing || bits[q] == HALS_EMPTY;
+        }
+        if (!__any(missing)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s += __longlong_as_double((long long)bits[q]);
+    return s;
+}
+
 template <int KP, bool VEC>
-// waves per SIMD: what the row (KP registers) + the fp64 reductions hold without spilling; 8-wave workgroups, so the device
-// keeps 6 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 393216 / 262144 / 131072 rows resident for KP = 32 / 64 / 128
-__global__ __launch_bounds__(HALS_WG, KP <= 32 ? 6 : (KP <= 64 ? 4 : 2)) void hals_w_sweep_kernel(
+// waves per SIMD: what the row (KP registers) + the fp64 reductions + the slot polling hold (almost) without spilling;
+// 8-wave workgroups, so the device keeps 5 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 327680 / 262144 / 131072 rows resident
+// for KP = 32 / 64 / 128.  (hipcc register-allocates KP = 32 pathologically at 4 waves per SIMD -- the whole row goes to
+// scratch -- and cleanly at 5.)
+__global__ __launch_bounds__(HALS_WG, KP <= 32 ? 5 : (KP <= 64 ? 4 : 2)) void hals_w_sweep_kernel(
     float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ AH, long ldah, const float* __restrict__ G,
     float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out) {
     __shared__ double red[HALS_WG / 64];
@@ -223,18 +257,16 @@ __global__ __launch_bounds__(HALS_WG, KP <= 32 ? 6 : (KP <= 64 ? 4 : 2)) void ha
 #pragma unroll
                 for (int j = kk + 1; j < KP; ++j) t[j] = fmaf(-wp, G[(kk - 1) * KP + j], t[j]);
             }
-            // the first wave of the workgroup fetches the slots of this column (lane l: slots l, l + 64, ...): one polling
-            // wave per workgroup keeps the traffic on the few cache lines of the column down (all 512 threads polling
-            // measured 10 us per column on 512 workgroups)
+            // the first wave of the workgroup fetches the slots of this column (lane l: slots l, l + 64, ...); one polling
+            // wave per workgroup keeps the traffic on the few cache lines of the column down
             double mine = 0.0;
-            if (threadIdx.x < 64) {
-                for (int s = threadIdx.x; s < nwg; s += 64) {
-                    unsigned long long bits;
-                    do {
-                        bits = __hip_atomic_load(col + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (bits == HALS_EMPTY) __builtin_amdgcn_s_sleep(2);
-                    } while (bits == HALS_EMPTY);
-                    mine += __longlong_as_double((long long)bits);
+            if (threadIdx.x < 128) {                       // wave 0: slots 0..511, wave 1: slots 512..1023
+                const int base = (threadIdx.x >> 6) * 512, cnt = nwg - base;
+                if (cnt > 0) {
+                    if (cnt <= 64) mine = hals_poll<1>(col + base, cnt);
+                    else if (cnt <= 128) mine = hals_poll<2>(col + base, cnt);
+                    else if (cnt <= 256) mine = hals_poll<4>(col + base, cnt);
+                    else mine = hals_poll<8>(col + base, cnt);
                 }
             }
             const double ss2 = block_sum_fixed(mine, red);
