@@ -24,10 +24,17 @@ def _as_tensor(x):
 class custom_clustering:
     early_exit = True      # stop the 100 rounds at the first exact fixed point (False = run them all, for the tests)
 
-    def __init__(self, Wall, Hall, params):
+    def __init__(self, Wall, Hall, params, ops=None):
         self.W_all = _as_tensor(Wall).clone()          # m_loc x k x P
         self.H_all = _as_tensor(Hall).clone()          # k x n_loc x P
         self.H_all = self.H_all.to(self.W_all.device)
+        # the two contractions over the (long) row index -- similarities to the centroids, the silhouette Gram matrix --
+        # run through the update engine's W^T A kernel when the factors live on the GPU (`ops` = HipOps); a checker back
+        # end / CPU tensors take the torch expressions
+        if ops is None and self.W_all.is_cuda:
+            from .engine import HIP_OPS
+            ops = HIP_OPS
+        self.ops = ops if (ops is not None and hasattr(ops, "wta") and self.W_all.is_cuda) else None
         self.p_r, self.p_c = params.p_r, params.p_c
         self.comm1 = params.comm1
         self.eps = float(params.eps)
@@ -87,7 +94,7 @@ class custom_clustering:
         rounds = 100
         for rnd in range(rounds):
             # similarities of every group's vectors to the centroids: k x k x P, one allreduce per round
-            dist = self._allreduce(torch.einsum("mc,mfp->cfp", centroids, self.W_all)).cpu().numpy()
+            dist = self._allreduce(self._centroid_similarities(centroids)).cpu().numpy()
             orders = [self.change_order(self.greedy_lsa(dist[:, :, p])) for p in range(P)]
             permute_order.extend(orders)
             if any(j != identity for j in orders):
@@ -106,12 +113,35 @@ class custom_clustering:
             centroids = centroids / torch.sqrt(cn)
         return centroids, self.W_all, self.H_all, permute_order
 
+    def _centroid_similarities(self, centroids):
+        """sim[c][f][p] = sum_m centroids[m][c] W_all[m][f][p]  (k x k x P): `dnmf_wta` with W = centroids (m x k) and the
+        data operand = W_all seen as an m x (k P) matrix."""
+        N, k, P = self.W_all.shape
+        if self.ops is None or self.W_all.dtype != torch.float32:
+            return torch.einsum("mc,mfp->cfp", centroids, self.W_all)
+        flat = self.W_all.reshape(N, k * P)
+        out = torch.empty(k, k * P, dtype=torch.float32, device=flat.device)
+        self.ops.wta(flat, centroids.to(torch.float32).contiguous(), out)
+        return out.view(k, k, P)
+
+    def _gram_of_all_vectors(self):
+        """(k P) x (k P) Gram matrix of all column vectors, in row blocks of at most 128 (the engine's rank limit)."""
+        N, k, P = self.W_all.shape
+        flat = self.W_all.reshape(N, k * P)
+        if self.ops is None or self.W_all.dtype != torch.float32:
+            return flat.t() @ flat
+        flat = flat.contiguous()
+        out = torch.empty(k * P, k * P, dtype=torch.float32, device=flat.device)
+        for b0 in range(0, k * P, 128):
+            b1 = min(k * P, b0 + 128)
+            self.ops.wta(flat, flat[:, b0:b1].contiguous(), out[b0:b1])
+        return out
+
     def dist_silhouettes(self):
         """:130-160  k x P cosine-distance silhouettes (re-runs the clustering first, as the reference does)."""
         self.dist_custom_clustering()
         N, k, n_pert = self.W_all.shape
-        W_flat = self.W_all.reshape(N, k * n_pert)
-        gram = self._allreduce(W_flat.t() @ W_flat).reshape(k, n_pert, k, n_pert)
+        gram = self._allreduce(self._gram_of_all_vectors()).reshape(k, n_pert, k, n_pert)
         distances = torch.arccos(torch.clamp(gram, -1.0, 1.0)).cpu().numpy().astype(np.float64)
         if k == 1:
             return np.ones((k, n_pert))

@@ -18,6 +18,7 @@ def _req(t, name, ndim=2):
         raise TypeError("%s: expected a torch.Tensor on a CUDA device, got %s (no CPU fallback)" % (name, type(t)))
     if not t.is_cuda:
         raise TypeError("%s: tensor is on %s; the MU engine only runs on the GPU (no CPU fallback)" % (name, t.device))
+    _same_device(t, name)
     if t.dtype != torch.float32:
         raise TypeError("%s: dtype %s unsupported; the engine computes in float32" % (name, t.dtype))
     if t.dim() != ndim or (t.numel() and t.stride(-1) != 1):
@@ -25,9 +26,18 @@ def _req(t, name, ndim=2):
     return t
 
 
+def _same_device(t, name):
+    """Kernels are launched on the CURRENT device's current stream; a tensor of another GPU would be reached through peer
+    access without any ordering against its own stream (or fault).  One process drives one GPU: fail loudly instead."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise ValueError("%s lives on %s but the current device is cuda:%d; call torch.cuda.set_device(%d) "
+                         "(one process per GPU)" % (name, t.device, torch.cuda.current_device(), t.device.index))
+
+
 def _req_a(t, name="A"):
     """The data matrix: float32, or bfloat16 STORAGE (Frobenius paths only; arithmetic stays float32)."""
     if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16:
+        _same_device(t, name)
         if t.dim() != 2 or (t.numel() and t.stride(-1) != 1):
             raise ValueError("%s: must be 2-D row-major with unit inner stride" % name)
         return "_bf16a"

@@ -152,8 +152,16 @@ class PyNMFk:
         self.params.flag = 1
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
         # stack: W m_loc x k x P (column-major over (k, P) as the reference's order='F' reshape, :234-235), H k x n_loc x P
-        Ws = [r[0] if isinstance(r[0], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[0])) for r in results]
-        Hs = [r[1] if isinstance(r[1], torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r[1])) for r in results]
+        # numpy in / numpy out fits: the stacks still go to the GPU for the clustering (its contractions over the row index
+        # run on the update engine's kernels); with an injected checker back end they stay where they are
+        dev = torch.device("cuda", torch.cuda.current_device()) if (self.ops is None and torch.cuda.is_available()) else None
+
+        def _t(x):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            t = t.to(torch.float32) if t.dtype == torch.float64 else t      # (prune=True hands float64 back, as the reference)
+            return t.to(dev) if (dev is not None and not t.is_cuda) else t
+        Ws = [_t(r[0]) for r in results]
+        Hs = [_t(r[1]) for r in results]
         self.Wall = torch.stack(Ws, dim=-1)
         if self.hall_layout == 'reference':
             # exactly the reference's array: np.vstack(H_0 .. H_{P-1}) (P k x n) re-read in C order as (k, n, P), :236-237.
@@ -165,7 +173,7 @@ class PyNMFk:
             self.Hall = torch.stack(Hs, dim=-1)
         self.recon_err = [float(r[2]) for r in results]
         centroids, _, self.Hall, self.clusterSilhouetteCoefficients, self.avgSilhouetteCoefficients, _ = \
-            custom_clustering(self.Wall, self.Hall, self.params).fit()                                  # :239-240
+            custom_clustering(self.Wall, self.Hall, self.params, ops=self.ops).fit()                    # :239-240
         self.params.flag = 2
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
         self.AvgH = _median_np_semantics(self.Hall)                                                     # :243

@@ -40,6 +40,25 @@ def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
         p_r, p_c = meta["grid"]
         comms = MPI_comm(None, p_r, p_c)
         out = {}
+        if not meta.get("prune", False):
+            # one bare update() from the fixture's initial factors (what make_golden.py captured as step1): pins every
+            # method -- HALS included -- per step, where the fits below carry the looser multi-iteration budget
+            from pydnmfk_amd.dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
+            args = parse()
+            args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
+            args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+            args.itr, args.init, args.verbose, args.prune = 1, "rand", False, False
+            args.norm, args.method, args.W_update = meta["norm"], meta.get("method", "mu"), meta["W_update"]
+            for key, val in (extra or {}).items():
+                setattr(args, key, val)
+            s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+            (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, meta["m"], meta["n"])
+            nmf = PyNMF(A[s[0]:e[0] + 1, s[1]:e[1] + 1], factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops)
+            if nmf.topo == "2d":
+                W1, H1 = nmf_algorithms_2D(nmf.A_ij, nmf.W_ij, nmf.H_ij, params=nmf.params, ops=nmf._ops()).update()
+            else:
+                W1, H1 = nmf_algorithms_1D(nmf.A_ij, nmf.W_i, nmf.H_j, params=nmf.params, ops=nmf._ops()).update()
+            out["step1"] = (rel_fro(W1.cpu().numpy(), z["r%d_step1_W" % rank]), rel_fro(H1.cpu().numpy(), z["r%d_step1_H" % rank]), 0.0)
         for itr in meta["itrs"]:
             args = parse()
             args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
@@ -81,8 +100,12 @@ def run_case(name, use_hip=False, timeout=240, extra=None):
         p.join(timeout=60)
     for rank, out, err in res:
         assert err is None, "rank %d failed:\n%s" % (rank, err)
-        tol = 2e-3 if meta.get("method") == "hals" else 1e-4   # HALS cancels: see tests/test_oracle_golden.py::test_fit
+        hals = meta.get("method") == "hals"
         for itr, (dw, dh, de) in out.items():
+            if itr == "step1":
+                tol = 5e-5 if hals else 1e-5
+            else:
+                tol = 2e-3 if hals else 1e-4      # HALS cancels: see tests/test_oracle_golden.py::test_fit
             assert dw <= tol and dh <= tol and de <= 1e-5, (name, rank, itr, dw, dh, de)
 
 
