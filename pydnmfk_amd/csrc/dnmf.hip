@@ -290,7 +290,10 @@ size_t partial_bytes(long m, long n, int k) {
         if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
     }
     b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
-    b = std::max(b, (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long) + (size_t)kp * sizeof(double));  // HALS W sweep slots
+    // HALS W sweep: slots + norms + the m x KP block T of its first pass (only when the sweep is asked for a factor of
+    // this shape, i.e. n == k: dnmf_hals_sweep_w is called with dnmf_ws_bytes(m, k, k))
+    b = std::max(b, align256((size_t)kp * HALS_MAX_WG * sizeof(unsigned long long) + (size_t)kp * sizeof(double)) +
+                        (n == k ? (size_t)m * kp * sizeof(float) : 0));
     return b;
 }
 
@@ -858,26 +861,56 @@ int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long 
 namespace {
 // co-residency of the persistent sweep: workgroups the device can hold at once
 template <typename K>
-long resident_workgroups(K kernel, int threads) {
+long resident_workgroups(K kernel, int threads, size_t lds) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return 0;
     return (long)cus * per_cu;
 }
 
-template <int KP>
+template <int KT>
 int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                      unsigned long long* slab, double* ss2, hipStream_t st) {
-    const bool vec = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;
+                      unsigned long long* slab, double* ss2, float* T, hipStream_t st) {
+    constexpr int KP = 32 * KT;
+    const long ldt = KP;
+    const bool vecw = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;   // pass 1 reads W, AH
+    // pass 2: T rows are aligned.  (KP = 32 always takes the dword form: hipcc register-allocates its 16-byte variant
+    // pathologically -- the whole row in scratch, 20000 spills -- and the row is only loaded and stored once per sweep.)
+    const bool vec = KT > 1 && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
     const long grid = cdiv(m, HALS_WG);
+    constexpr size_t lds = (size_t)KP * KP * sizeof(float);          // G staged per workgroup
     static long cap_v = -1, cap_s = -1;
-    if (cap_v < 0) { cap_v = resident_workgroups(hals_w_sweep_kernel<KP, true>, HALS_WG); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG); }
+    if (cap_v < 0) {
+        allow_lds(hals_w_sweep_kernel<KP, KT != 1>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
+        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, KT != 1>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
+    }
     if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
+    REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "hals_sweep_w: leading dimension beyond the 32-bit tile offsets");
     if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
         return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
-    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, true>), dim3((unsigned)grid), dim3(HALS_WG), 0, st, W, m, k, ldw, AH, ldah, G, eps, slab, ss2);
-    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), 0, st, W, m, k, ldw, AH, ldah, G, eps, slab, ss2);
+    {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
+        constexpr size_t lds1 = (size_t)KP * (KP + 4) * sizeof(float);
+        constexpr int OCC = KT == 4 ? 4 : 5;
+        static bool once = false;
+        if (!once) {
+            allow_lds(update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>, lds1); allow_lds(update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>, lds1);
+            allow_lds(update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>, lds1);
+            once = true;
+        }
+        const unsigned g1 = (unsigned)cdiv(cdiv(m, 32), 4);
+        if (vecw && k == KP && m % 32 == 0)
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        else if (vecw)
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        else
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        int rc = check_launch("hals_sweep_w(transform)");
+        if (rc) return rc;
+    }
+    static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
+    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, KT != 1>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
     return check_launch("hals_sweep_w");
 }
 }  // namespace
@@ -889,16 +922,18 @@ int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long l
     REQUIRE(kt > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
     const int kp = 32 * kt;
     const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
+    const size_t t_off = align256(slab_bytes + (size_t)kp * sizeof(double));
     if (ws_bytes < slab_bytes + (size_t)kp * sizeof(double)) return fail(DNMF_EWS, "hals_sweep_w: workspace too small");
     unsigned long long* slab = (unsigned long long*)ws;
     double* ss2 = (double*)((char*)ws + slab_bytes);
+    float* T = (float*)((char*)ws + t_off);
     static const int mode = (int)tune("DNMF_HALS_SWEEP", 1);     // 0: always the column-per-launch path (A/B runs)
     int rc = 1;
-    if (mode) {
+    if (mode && ws_bytes >= t_off + (size_t)m * kp * sizeof(float)) {
         hipStream_t st = S(stream);
-        if (kt == 1) rc = launch_hals_sweep<32>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
-        else if (kt == 2) rc = launch_hals_sweep<64>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
-        else rc = launch_hals_sweep<128>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, st);
+        if (kt == 1) rc = launch_hals_sweep<1>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
+        else if (kt == 2) rc = launch_hals_sweep<2>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
+        else rc = launch_hals_sweep<4>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
     }
     if (rc != 1) return rc;
     return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column

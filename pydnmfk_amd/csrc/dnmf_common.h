@@ -2,6 +2,7 @@
 // Part of libdnmf_hip.so (single translation unit: csrc/dnmf.hip includes every header once).
 #pragma once
 #include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -103,6 +104,17 @@ __device__ __forceinline__ void buf_store(const float (&d)[V], i32x4 rsrc, int v
     if constexpr (V == 4) buf_st_f32x4(f32x4{d[0], d[1], d[2], d[3]}, rsrc, voff, soff, 0);
     else if constexpr (V == 2) buf_st_f32x2(f32x2{d[0], d[1]}, rsrc, voff, soff, 0);
     else buf_st_f32(d[0], rsrc, voff, soff, 0);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E).  `#pragma unroll` is a request hipcc drops for large
+// bodies ("loop not unrolled"), and an array indexed by a runtime loop variable then lives in scratch memory instead of
+// registers; this form cannot be left rolled.
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 
 // C/D row of accumulator register `reg` for lane-half h

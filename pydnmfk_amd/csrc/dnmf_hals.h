@@ -114,25 +114,30 @@ __global__ __launch_bounds__(64) void hals_h_kernel_lds(float* __restrict__ H, i
 namespace {
 
 // =============================================================================================== persistent W sweep
-// The whole W sweep in ONE launch (a rank whose column norms are local: p_r == 1).  The per-column kernels above re-read
-// every row of W for every column (k m k 4 bytes: 4.3 GB per sweep at m = 262144, k = 64 against 67 MB of factor) and pay
-// a launch per column.  Here one lane owns one row for the whole sweep and keeps it in registers:
-//   1. load the row of W; turn it IN PLACE into t[j] = AH[i][j] - sum_{l > j} W_old[i][l] G[l][j]  (j ascending: t[j] only
-//      needs the old values at l > j, which are still in their registers);
-//   2. for kk = 0 .. k-1:  u = max(t[kk], eps);  the column's sum of squares over ALL rows (grid-wide, see below);
-//      w = u / sqrt(ss2) (if ss2 > 0);  t[kk] := w (the slot is dead: it now holds the result);  t[j] -= w G[kk][j], j > kk
-//      -- first j = kk+1 alone (the next column's critical path), the rest after the next column's partial sum is on its
-//      way, so the triangular update overlaps the wait;
-//   3. store the row.
+// The W sweep of a rank whose column norms are local (p_r == 1) in TWO launches instead of k.  The per-column kernels above
+// re-read every row of W for every column (k m k 4 bytes: 4.3 GB per sweep at m = 262144, k = 64 against 67 MB of factor) and
+// pay a launch per column.  Here:
+//   1. an MFMA pass (update_w_seq_kernel<.., UW_HALS_T>, dnmf_update.h) forms T[i][j] = AH[i][j] - sum_{l > j} W_old[i][l] G[l][j]
+//      -- the old columns' part of every column step, a masked W G product;
+//   2. hals_w_sweep_kernel: one lane owns one row of T for the whole sweep and keeps it in registers; for kk = 0 .. k-1:
+//      u = max(t[kk], eps);  the column's sum of squares over ALL rows (grid-wide, see below);  w = u / sqrt(ss2) (if
+//      ss2 > 0);  t[kk] := w (the slot is dead: it now holds the result);  t[j] -= w G[kk][j] for j > kk -- first j = kk+1
+//      alone (the next column's critical path), the rest after the next column's partial sum is on its way, so the
+//      triangular update overlaps the wait;  finally the row (now W_new) is stored.
 // This is the reference's column step with its cancelling pair removed: W[i][kk] G[kk][kk] + AH[i][kk] - (W G)[i][kk]
 // (dist_nmf.py:887) = AH[i][kk] - sum_{l != kk} W[i][l] G[l][kk]; l < kk are the new columns, l > kk the old ones.
-// G[l][j] is wave-uniform with compile-time indices: scalar loads, FMAs with an SGPR operand, no LDS.
+// The column steps are function templates expanded by a fold expression: a `#pragma unroll` loop over the columns is NOT
+// unrolled by hipcc (body too large), the row then lives in scratch memory and every column costs 6.5 us even on a
+// single workgroup (measured).  G rows come from LDS (staged once per workgroup) as broadcast 16-byte reads.  (A first
+// version also did step 1 in this kernel, row-wise on the VALU: hipcc could not allocate registers for it -- thousands
+// of spills in every formulation tried.)
 //
 // Grid-wide sum per column WITHOUT a separate barrier: every workgroup publishes its fp64 partial sum into its own slot
-// slab[kk][wg] (the slab is preset to all-ones bit patterns = "not there yet") with an agent-scope store; every
-// workgroup polls all slots of the column (one per thread), and reduces them in a FIXED order -- the result is
-// bitwise identical in every workgroup and from run to run (no floating-point atomics).  One memory round trip per
-// column.  All workgroups must be co-resident (the host checks the occupancy and otherwise takes the per-column path).
+// slab[kk][wg] (the slab is preset to all-ones bit patterns = "not there yet") with an agent-scope store; four waves of
+// every workgroup poll the slots of the column (all of a lane's slots requested in one round), and all reduce them in a
+// FIXED order -- the result is bitwise identical in every workgroup and from run to run (no floating-point atomics).
+// One memory round trip per column.  All workgroups must be co-resident (the host checks the occupancy and otherwise
+// takes the per-column path).
 constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
 constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
 constexpr unsigned long long HALS_EMPTY = ~0ull;
@@ -144,10 +149,31 @@ __device__ __forceinline__ double dshfl_xor(double v, int mask) {
     return __hiloint2double(hi, lo);
 }
 
+// partner exchange inside a row of 16 lanes with DPP (a register-to-register move, no LDS crossbar round trip):
+// quad_perm [1,0,3,2] / [2,3,0,1] pair lanes inside a quad, row_half_mirror pairs the two quads of 8 lanes, row_mirror
+// the two halves of the row.  Every pairing is symmetric, so after the four steps all 16 lanes hold the same sum.
+template <int CTRL>
+__device__ __forceinline__ double ddpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// wave-wide sum, identical in all 64 lanes (symmetric butterfly: a + b == b + a at every step)
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v += ddpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += ddpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += ddpp<0x141>(v);     // row_half_mirror
+    v += ddpp<0x140>(v);     // row_mirror
+    v += dshfl_xor(v, 16);
+    v += dshfl_xor(v, 32);
+    return v;
+}
+
 // sum of one value per thread over the workgroup, the same association order everywhere; result in every thread
 __device__ __forceinline__ double block_sum_fixed(double v, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += dshfl_xor(v, off);
+    v = wave_sum_all(v);
     const int wave = threadIdx.x >> 6;
     __syncthreads();                           // red[] may still be read from the previous use
     if ((threadIdx.x & 63) == 0) red[wave] = v;
@@ -190,96 +216,102 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
     return s;
 }
 
+// Column KK of the sweep (see hals_w_sweep_kernel).  A function template per column, expanded by a fold expression: a
+// `#pragma unroll` loop over the columns is not unrolled by hipcc (body too large), the row then lives in scratch memory
+// and every column costs 6.5 us even on a single workgroup.
+template <int KP, int KK>
+__device__ __forceinline__ void hals_col_step(float (&t)[KP], float& u, int k, bool live, float eps, const float* gs,
+                                              unsigned long long* __restrict__ slab, double* __restrict__ ss2_out,
+                                              double* red, int nwg, int dbg) {
+    asm volatile("" ::: "memory");
+    if (KK >= k) return;                                  // uniform
+    const double sq = live ? (double)u * (double)u : 0.0;
+    const double part = block_sum_fixed(sq, red);
+    unsigned long long* col = slab + (long)KK * HALS_MAX_WG;
+    if (threadIdx.x == 0) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+        if (bits == HALS_EMPTY) bits = 0x7ff8000000000000ull;            // (a NaN with that payload cannot occur)
+        __hip_atomic_store(col + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the one entry of G on the next column's critical path is read before the wait
+    float g_next = 0.f;
+    if constexpr (KK + 1 < KP) g_next = gs[KK * KP + KK + 1];
+    // lagging part of the previous column's triangular update: overlaps the round trip of the partial sums
+    if constexpr (KK > 0) {
+        const float wp = t[KK - 1];
+#pragma unroll
+        for (int j0 = 4 * ((KK + 1) / 4); j0 < KP; j0 += 4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&gs[(KK - 1) * KP + j0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q > KK) t[j0 + q] = fmaf(-wp, g[q], t[j0 + q]);
+            if ((j0 / 4) % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // at most four pieces of the G row in flight
+        }
+    }
+    // the first four waves of the workgroup fetch the slots of this column (wave w: slots 256 w .. 256 w + 255)
+    double mine = 0.0;
+    if (dbg & 1) {                                         // tuning build only: no exchange (each workgroup on its own)
+        if (threadIdx.x == 0) mine = part;
+    } else if (threadIdx.x < 256) {
+        const int base = (threadIdx.x >> 6) * 256, cnt = nwg - base;
+        if (cnt > 0) {
+            if (cnt <= 64) mine = hals_poll<1>(col + base, cnt);
+            else if (cnt <= 128) mine = hals_poll<2>(col + base, cnt);
+            else mine = hals_poll<4>(col + base, cnt);
+        }
+    }
+    const double ss2 = block_sum_fixed(mine, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ss2_out) ss2_out[KK] = ss2;
+    const float ss = (float)sqrt(ss2);
+    const float w = ss > 0.f ? u / ss : u;
+    t[KK] = w;
+    if constexpr (KK + 1 < KP) {
+        t[KK + 1] = fmaf(-w, g_next, t[KK + 1]);
+        u = fmaxf(t[KK + 1], eps);
+    }
+}
+
+template <int KP, int... Ks>
+__device__ __forceinline__ void hals_sweep_all(float (&t)[KP], float& u, int k, bool live, float eps, const float* gs,
+                                               unsigned long long* __restrict__ slab, double* __restrict__ ss2_out,
+                                               double* red, int nwg, int dbg, std::integer_sequence<int, Ks...>) {
+    (hals_col_step<KP, Ks>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg), ...);
+}
+
+// waves per SIMD: what the row (KP registers) + the fp64 reductions + the slot polling hold; 8-wave workgroups, so the device keeps 4 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 262144 / 262144 / 131072 rows
+// resident for KP = 32 / 64 / 128
 template <int KP, bool VEC>
-// waves per SIMD: what the row (KP registers) + the fp64 reductions + the slot polling hold (almost) without spilling;
-// 8-wave workgroups, so the device keeps 5 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 327680 / 262144 / 131072 rows resident
-// for KP = 32 / 64 / 128.  (hipcc register-allocates KP = 32 pathologically at 4 waves per SIMD -- the whole row goes to
-// scratch -- and cleanly at 5.)
-__global__ __launch_bounds__(HALS_WG, KP <= 32 ? 5 : (KP <= 64 ? 4 : 2)) void hals_w_sweep_kernel(
-    float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ AH, long ldah, const float* __restrict__ G,
-    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out) {
+__global__ __launch_bounds__(HALS_WG, KP <= 64 ? 4 : 2) void hals_w_sweep_kernel(
+    float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ T, long ldt, const float* __restrict__ G,
+    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out, int dbg) {
     __shared__ double red[HALS_WG / 64];
+    // G (KP x KP, zero padded, symmetric) staged once per workgroup: every use is a row segment G[r][c0 .. c0+3] at a
+    // wave-uniform address = a broadcast ds_read_b128
+    extern __shared__ __attribute__((aligned(16))) float gs[];
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += HALS_WG)
+        *reinterpret_cast<f32x4*>(&gs[idx * 4]) = *reinterpret_cast<const f32x4*>(G + idx * 4);
+    __syncthreads();
     const long i = (long)blockIdx.x * HALS_WG + threadIdx.x;
     const bool live = i < m;
     const long ir = live ? i : m - 1;                 // dead lanes read a valid row and contribute nothing
     const int nwg = gridDim.x;
     float t[KP];
-    const float* wrow = W + ir * ldw;
-    const float* arow = AH + ir * ldah;
+    const float* trow = T + ir * ldt;                  // 1. the row of T (the transform ran as its own MFMA kernel)
 #pragma unroll
     for (int j = 0; j < KP; j += 4) {
         if constexpr (VEC) {
             if (j < k) {                              // VEC: k % 4 == 0, 16-byte aligned rows
-                const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + j);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(trow + j);
                 t[j] = v[0]; t[j + 1] = v[1]; t[j + 2] = v[2]; t[j + 3] = v[3];
             } else { t[j] = t[j + 1] = t[j + 2] = t[j + 3] = 0.f; }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[j + e] = (j + e < k) ? wrow[j + e] : 0.f;
-        }
-    }
-    // 1. in-place triangular transform (rows / columns >= k of the zero-padded G contribute nothing)
-#pragma unroll
-    for (int j0 = 0; j0 < KP; j0 += 4) {
-        float a[4];
-        if constexpr (VEC) {
-            if (j0 < k) { const f32x4 v = *reinterpret_cast<const f32x4*>(arow + j0); a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; }
-            else { a[0] = a[1] = a[2] = a[3] = 0.f; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (j0 + e < k) ? arow[j0 + e] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = j0 + e;
-            float acc = a[e];
-#pragma unroll
-            for (int l = j + 1; l < KP; ++l) acc = fmaf(-t[l], G[l * KP + j], acc);
-            t[j] = acc;
+            for (int e = 0; e < 4; ++e) t[j + e] = (j + e < k) ? trow[j + e] : 0.f;
         }
     }
     // 2. the column sweep
     float u = fmaxf(t[0], eps);
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk) {
-        if (kk < k) {                                 // uniform
-            const double sq = live ? (double)u * (double)u : 0.0;
-            const double part = block_sum_fixed(sq, red);
-            unsigned long long* col = slab + (long)kk * HALS_MAX_WG;
-            if (threadIdx.x == 0) {
-                unsigned long long bits = (unsigned long long)__double_as_longlong(part);
-                if (bits == HALS_EMPTY) bits = 0x7ff8000000000000ull;            // (a NaN with that payload cannot occur)
-                __hip_atomic_store(col + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // lagging part of the previous column's triangular update: overlaps the round trip of the partial sums
-            if (kk > 0) {
-                const float wp = t[kk - 1];
-#pragma unroll
-                for (int j = kk + 1; j < KP; ++j) t[j] = fmaf(-wp, G[(kk - 1) * KP + j], t[j]);
-            }
-            // the first wave of the workgroup fetches the slots of this column (lane l: slots l, l + 64, ...); one polling
-            // wave per workgroup keeps the traffic on the few cache lines of the column down
-            double mine = 0.0;
-            if (threadIdx.x < 128) {                       // wave 0: slots 0..511, wave 1: slots 512..1023
-                const int base = (threadIdx.x >> 6) * 512, cnt = nwg - base;
-                if (cnt > 0) {
-                    if (cnt <= 64) mine = hals_poll<1>(col + base, cnt);
-                    else if (cnt <= 128) mine = hals_poll<2>(col + base, cnt);
-                    else if (cnt <= 256) mine = hals_poll<4>(col + base, cnt);
-                    else mine = hals_poll<8>(col + base, cnt);
-                }
-            }
-            const double ss2 = block_sum_fixed(mine, red);
-            if (blockIdx.x == 0 && threadIdx.x == 0 && ss2_out) ss2_out[kk] = ss2;
-            const float ss = (float)sqrt(ss2);
-            const float w = ss > 0.f ? u / ss : u;
-            t[kk] = w;
-            if (kk + 1 < KP) {
-                t[kk + 1] = fmaf(-w, G[kk * KP + kk + 1], t[kk + 1]);
-                u = fmaxf(t[kk + 1], eps);
-            }
-        }
-    }
+    hals_sweep_all<KP>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg, std::make_integer_sequence<int, KP>{});
     // 3. store the row
     if (live) {
         float* orow = W + i * ldw;

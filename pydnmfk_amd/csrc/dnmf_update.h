@@ -135,15 +135,24 @@ __global__ __launch_bounds__(256, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_
 // descriptor is re-based to the tile's first row; the lane offset (li ldw + 4h) is shared by all pieces, the piece index
 // is an immediate.  V = 4: 16-byte pieces (aligned rows, k % 4 == 0); V = 1: the same tile with dword accesses and a
 // per-element column predicate (any k, any alignment).
-template <int KT, int V, bool INTERIOR>
+// MODE UW_MU: the multiplicative update, in place.  MODE UW_HALS_T: the first pass of the HALS W sweep (dnmf_hals.h) --
+// T[i][j] = S[i][j] - (W G')[i][j] with the staged G' = G masked to l > j, i.e. T[i][j] = AH[i][j] - sum_{l > j} W[i][l] G[l][j],
+// written to a separate buffer; W is only read.
+enum { UW_MU = 0, UW_HALS_T = 1 };
+
+template <int KT, int V, bool INTERIOR, int MODE = UW_MU>
 __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ Sm,
-                                                  long lds_, const float* gs, float eps, long row0, int li, int h) {
+                                                  long lds_, const float* gs, float eps, long row0, int li, int h,
+                                                  float* __restrict__ T = nullptr, long ldt = 0) {
     constexpr int KP = 32 * KT, GP = KP + 4;
     const i32x4 wrs = buf_rsrc(W + row0 * ldw), srs = buf_rsrc(Sm + row0 * lds_);
+    const i32x4 trs = MODE == UW_HALS_T ? buf_rsrc(T + row0 * ldt) : wrs;
     int woff = (int)(((long)li * ldw + 4 * h) * 4), soff = (int)(((long)li * lds_ + 4 * h) * 4);
+    int toff = MODE == UW_HALS_T ? (int)(((long)li * ldt + 4 * h) * 4) : woff;
     if constexpr (!INTERIOR) {
-        if (row0 + li >= m) { woff = BUF_OOB; soff = BUF_OOB; }
+        if (row0 + li >= m) { woff = BUF_OOB; soff = BUF_OOB; toff = BUF_OOB; }
     }
+    if constexpr (MODE == UW_HALS_T) asm volatile("" : "+v"(toff));
     // opaque to the optimiser: otherwise (x << 2) + 32 s is rewritten as (x + 8 s) << 2 and no longer folds into the
     // instruction's immediate offset (one address register per piece instead of one per tile)
     asm volatile("" : "+v"(woff));
@@ -191,31 +200,40 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
         for (int g = 0; g < 4; ++g) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = wreg[4 * jt + g][e] * (sreg[g][e] / (out[4 * g + e] + eps));
-            st4(o, wrs, woff, 4 * jt + g);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (MODE == UW_HALS_T) o[e] = sreg[g][e] - out[4 * g + e];
+                else o[e] = wreg[4 * jt + g][e] * (sreg[g][e] / (out[4 * g + e] + eps));
+            }
+            st4(o, trs, toff, 4 * jt + g);
         }
     }
 }
 
-template <int KT, int V, int OCC, bool EDGE>
+template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU>
 __global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) void update_w_seq_kernel(float* __restrict__ W, long m, int k, long ldw,
                                                                 const float* __restrict__ Sm, long lds_,
-                                                                const float* __restrict__ G, float eps) {
+                                                                const float* __restrict__ G, float eps,
+                                                                float* __restrict__ T = nullptr, long ldt = 0) {
     constexpr int KP = 32 * KT, GP = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float gs[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256) {
         const int gr = idx / (KP / 4), gc = (idx % (KP / 4)) * 4;
-        *reinterpret_cast<f32x4*>(&gs[gr * GP + gc]) = *reinterpret_cast<const f32x4*>(G + gr * KP + gc);
+        f32x4 g = *reinterpret_cast<const f32x4*>(G + gr * KP + gc);
+        if constexpr (MODE == UW_HALS_T) {      // gs[j][l] feeds output column j with contraction index l: keep l > j
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (gc + e > gr) ? g[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(&gs[gr * GP + gc]) = g;
     }
     __syncthreads();
     const long ntiles = cdiv(m, 32);
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
         const long row0 = t * 32;
-        if constexpr (!EDGE) update_w_seq_tile<KT, V, true>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h);
-        else if (k == KP && row0 + 32 <= m) update_w_seq_tile<KT, V, true>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h);
-        else update_w_seq_tile<KT, V, false>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h);
+        if constexpr (!EDGE) update_w_seq_tile<KT, V, true, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
+        else if (k == KP && row0 + 32 <= m) update_w_seq_tile<KT, V, true, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
+        else update_w_seq_tile<KT, V, false, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
     }
 }
 
