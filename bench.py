@@ -145,15 +145,18 @@ def cpu_baseline(n, k, m_full, steps=3):
             "host_cores": cores, "host_cpu": model, "seconds_per_iter": t, "gflops_whole_job": flops / t / 1e9}
 
 
-def pmc_traffic(role):
-    """HBM bytes per launch of a kernel from the NEWEST committed PMC pass (profiles/*_pmc.json: separate --pmc runs of
-    tools/collect_profiles.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md) -- a constant of the committed profile, not a
-    live counter: the driver's run has no profiler attached.  Kernels are picked by role (template argument lists change
-    between rounds): 'nt' = the k = 64 NT instantiation with the most bytes (the fused A H^T + W update; the gram launch
-    only reads H), 'tn' = likewise for the TN form, otherwise a name prefix.  None if absent."""
+def pmc_traffic(role, workload="bench"):
+    """HBM bytes per launch of a kernel from the NEWEST committed PMC pass of the given profiled workload
+    (profiles/<tag>_<workload>_pmc.json: separate --pmc runs of tools/collect_profiles.sh, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md; older rounds: profiles/<tag>_pmc.json) -- a constant of the committed profile, not a live counter:
+    the driver's run has no profiler attached.  Kernels are picked by role (template argument lists change between
+    rounds): 'nt' = the k = 64 NT instantiation with the most bytes (the fused A H^T + W update; the gram launch only
+    reads H), 'tn' = likewise for the TN form, otherwise a name prefix.  None if absent."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    files = [f for f in files if ("_%s_pmc" % workload) in f or os.path.basename(f).count("_") == 1]
+    for f in files:
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
@@ -361,12 +364,18 @@ def main():
                                      "WRITE_SIZE); a constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
             return e
 
-        def hbm_entry(kernel, ms_, nbytes, note):
+        def hbm_entry(kernel, ms_, nbytes, note, role=None, workload="bench"):
             ach = nbytes / ms_ / 1e6
-            return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": nbytes, "ms_per_launch": ms_,
-                    "measured_ceiling": MEASURED_STREAM_GBS, "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS,
-                    "note": note}
+            e = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": nbytes, "ms_per_launch": ms_,
+                 "measured_ceiling": MEASURED_STREAM_GBS, "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS,
+                 "note": note}
+            tr = pmc_traffic(role, workload) if (role and (m, n, k, world) == (262144, 8192, 64, 1)) else None
+            if tr is not None:
+                e["traffic"] = tr["bytes"]
+                e["traffic_note"] = ("HBM bytes per launch from the committed PMC pass %s, kernel %s (FETCH_SIZE x2 + "
+                                     "WRITE_SIZE); a constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
+            return e
 
         kern = {
             "dnmf_aht_update_w = %s (A.H^T + W update, 1 launch)" % kname_nt: {
@@ -394,8 +403,9 @@ def main():
             r_tn = mfma_entry(kname_tn + " (dnmf_wta, incl. the reduction of the partial slabs)", t["wta"], fl_tn, "tn")
             r_res = mfma_entry("resid_kernel<KT=%d> (dnmf_resid_sqnorm)" % kt, t_res, fl_res, "resid_kernel")
             r_upd = hbm_entry("update_h_seq_kernel<KT=%d> (dnmf_mu_update_h: H *= S / (G H + eps), %d x 2^22)" % (kt, k),
-                              t_upd, by_upd, "algorithmic bytes = 12 per element of H (read H, read S, write H)")
-            r_sq = hbm_entry("sqnorm_kernel (dnmf_sqnorm on X)", t_sq, 4.0 * m_l * n, "one read of X")
+                              t_upd, by_upd, "algorithmic bytes = 12 per element of H (read H, read S, write H)",
+                              role="update_h_seq_kernel<2", workload="elt")
+            r_sq = hbm_entry("sqnorm_kernel (dnmf_sqnorm on X)", t_sq, 4.0 * m_l * n, "one read of X", role="sqnorm_kernel")
             out["roofline"] = r_nt
             out["roofline_hbm"] = r_upd
             out["rooflines"] = [r_nt, r_tn, r_res, r_upd, r_sq]

@@ -294,9 +294,28 @@ class nmf_algorithms_2D(_Base):
         return self.cartesian1d_column.reduce_scatter_rows(V, self.w_counts)
 
     def _scatter_to_H(self, Y):
-        """Reduce_scatter over the row group of Y^T (n_l x k) -> (n_h x k) -> transpose (:169-171, :314-316)."""
+        """Reduce_scatter over the row group of Y^T (n_l x k) -> (n_h x k) -> transpose (:169-171, :314-316).  Only for
+        ragged column slices; equal slices take `_product_scattered_to_H` (no transposes)."""
         ks = self.cartesian1d_row.reduce_scatter_rows(Y.t().contiguous(), self.h_counts)
         return ks.t().contiguous()
+
+    def _product_scattered_to_H(self, product):
+        """The k x n_l product of the H phase, reduce-scattered over the row group into this rank's k x n_h slice.
+        `product(c0, c1, out)` writes the product restricted to the local columns [c0, c1) into the k x (c1 - c0) block
+        `out`.  The reference transposes to n_l x k so that MPI's Reduce_scatter can cut row blocks (:169-171, :314-316).
+        With equal slices the product is instead formed slice by slice straight into a [p_r][k][n_h] buffer -- member q's
+        slice is a contiguous block, which is what reduce_scatter_tensor cuts -- and nothing is transposed or copied."""
+        k, hc = self.k, self.h_counts
+        n_l = sum(hc)
+        if len(set(hc)) != 1:
+            Y = _buf(("Y", k, n_l), k * n_l, self.A_ij)[: k * n_l].view(k, n_l)
+            product(0, n_l, Y)
+            return self._scatter_to_H(Y)
+        nh, p = hc[0], len(hc)
+        buf = _buf(("Yb", k, n_l), p * k * nh, self.A_ij)[: p * k * nh]
+        for q in range(p):
+            product(q * nh, (q + 1) * nh, buf[q * k * nh: (q + 1) * k * nh].view(k, nh))
+        return self.cartesian1d_row.reduce_scatter_rows(buf.view(p * k, nh), [k] * p)
 
     # ---- Frobenius (dist_nmf.py:207-263)
     def Fro_MU_update(self, W_update=True, clamp=False):
@@ -314,8 +333,7 @@ class nmf_algorithms_2D(_Base):
         ops.gram_wtw(W, G)                                         # Fro_MU_update_H :207-225
         self.comm1.allreduce_(G)
         W_i = self.gather_W()                                      # ATW_glob :163-165
-        Y = ops.wta(A, W_i, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))       # :166
-        AtW = self._scatter_to_H(Y)                                # :169-171
+        AtW = self._product_scattered_to_H(lambda c0, c1, out: ops.wta(A[:, c0:c1], W_i, out))   # :166, :169-171
         ops.mu_update_h(H, AtW, G, eps, clamp)                     # :224-225
         if clamp:
             ops.clamp_min(W, eps)
@@ -336,8 +354,7 @@ class nmf_algorithms_2D(_Base):
         ops.gram_wtw(W, G)                                         # FRO_HALS_update_H :436-452
         self.comm1.allreduce_(G)
         W_i = self.gather_W()
-        Y = ops.wta(A, W_i, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))       # ATW_glob :448
-        AtW = self._scatter_to_H(Y)
+        AtW = self._product_scattered_to_H(lambda c0, c1, out: ops.wta(A[:, c0:c1], W_i, out))   # ATW_glob :448
         ops.hals_update_h(H, AtW, G, eps)                          # :449-452
         if clamp:
             ops.clamp_min(H, eps)
@@ -360,8 +377,8 @@ class nmf_algorithms_2D(_Base):
         W_i = self.gather_W()                                      # :387 (the W phase changed W, not H: the H_j it
         if not W_update:                                           #  gathered is still current -- one exchange less)
             H_j = self.gather_H()
-        WTU = ops.kl_wtu(A, W_i, H_j, eps, _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l))      # :311-312
-        ks = self._scatter_to_H(WTU)                               # :314-316
+        ks = self._product_scattered_to_H(                         # :311-312, :314-316
+            lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[:, c0:c1], eps, out))
         ops.kl_update_h(H, ks, x, eps, clamp)                      # :389
         if clamp:
             ops.clamp_min(W, eps)

@@ -47,7 +47,8 @@ def test_fit_matches_reference_golden(name):
     for itr in meta["itrs"]:
         W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"],
                                                              meta.get("method", "mu"), meta.get("prune", False))).fit()
-        assert isinstance(W, np.ndarray) and W.dtype == np.float32       # numpy in -> numpy out
+        # numpy in -> numpy out, in the dtype the reference hands back (float64 after unprune, utils.py:195,198)
+        assert isinstance(W, np.ndarray) and W.dtype == z["r0_fit%d_W" % itr].dtype and H.dtype == z["r0_fit%d_H" % itr].dtype
         assert rel_fro(W, z["r0_fit%d_W" % itr]) <= tol_fit, itr
         assert rel_fro(H, z["r0_fit%d_H" % itr]) <= tol_fit, itr
         ref = float(z["r0_fit%d_err" % itr])
