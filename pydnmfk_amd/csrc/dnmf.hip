@@ -289,7 +289,7 @@ size_t partial_bytes(long m, long n, int k) {
         const int nsp = (int)cdiv(n, cps);
         if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
     }
-    b = std::max(b, (size_t)cdiv(m, 1024) * kp * sizeof(float));  // colsum partials
+    b = std::max(b, (size_t)1024 * kp * sizeof(float));  // colsum partials (at most 1024 slabs)
     // HALS W sweep: slots + norms + the m x KP block T of its first pass (only when the sweep is asked for a factor of
     // this shape, i.e. n == k: dnmf_hals_sweep_w is called with dnmf_ws_bytes(m, k, k))
     b = std::max(b, align256((size_t)kp * HALS_MAX_WG * sizeof(unsigned long long) + (size_t)kp * sizeof(double)) +
@@ -794,7 +794,7 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
 
 int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {
     REQUIRE(H && x && k >= 1 && n >= 1 && ldh >= n, "rowsum: bad arguments");
-    hipLaunchKernelGGL(rowsum_kernel, dim3(k), dim3(256), 0, S(stream), H, n, ldh, x);
+    hipLaunchKernelGGL(rowsum_kernel, dim3(k), dim3(1024), 0, S(stream), H, n, ldh, x);
     return check_launch("rowsum");
 }
 
@@ -802,7 +802,9 @@ int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, siz
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && x && ws && m >= 1 && ldw >= k, "colsum: bad arguments");
     const int kp = 32 * kt;
-    const long rows_per_blk = 1024;
+    // slabs of 128 rows (a 32768-row shard gives 256 workgroups; 1024-row slabs left it on 32 CUs: 116 us for 16 MiB),
+    // at most 1024 slabs; the partials are summed in slab order by one small launch
+    const long rows_per_blk = std::max<long>(128, round_up(cdiv(m, 1024), 8));
     const int nblk = (int)cdiv(m, rows_per_blk);
     if (ws_bytes < (size_t)nblk * kp * sizeof(float)) return fail(DNMF_EWS, "colsum: workspace too small");
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, S(stream), W, m, k, ldw, rows_per_blk, (float*)ws, kp);

@@ -139,16 +139,27 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, l
     block_atomic_sum(acc, out);
 }
 
-// x[j] = sum_c H[j][c]  -- one workgroup per row
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ H, long n, long ldh, float* x) {
+// x[j] = sum_c H[j][c]  -- one 16-wave workgroup per row, 16-byte loads where the row allows, fp64 accumulation in a fixed
+// order (per-thread stride, wave butterfly, waves in order)
+__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ H, long n, long ldh, float* x) {
     const float* row = H + (long)blockIdx.x * ldh;
     double acc = 0.0;
-    for (long c = threadIdx.x; c < n; c += blockDim.x) acc += (double)row[c];
-    __shared__ double red[4];
+    const bool vec = ((uintptr_t)row & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    for (long c = threadIdx.x; c < n4; c += blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c);
+        acc += (double)((v[0] + v[1]) + (v[2] + v[3]));
+    }
+    for (long c = 4 * n4 + threadIdx.x; c < n; c += blockDim.x) acc += (double)row[c];
+    __shared__ double red[16];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) x[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        x[blockIdx.x] = (float)s;
+    }
 }
 
 // stage 1 of x[j] = sum_i W[i][j]: partial[blk][j] over a slab of rows (coalesced along j)
