@@ -106,3 +106,88 @@ def test_random_shapes_kl_and_hals(m, n, k, seed):
     Wr, Hr = W.copy(), H.copy()
     orc.fro_hals_step_local(A, Wr, Hr, np.float32(EPS), W_update=True)
     assert _rel(Wd.cpu().numpy(), Wr) < 5e-5 and _rel(Hd.cpu().numpy(), Hr) < 5e-5
+
+
+def _shapes_upd(seed, count):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        k = int(rs.choice([1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 32, 33, 40, 63, 64, 65, 96, 100, 127, 128]))
+        r = int(rs.choice([1, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 1000, 1024, 2049, 4100, 70000]))
+        pad = int(rs.choice([0, 0, 1, 3, 4, 8]))          # leading-dimension padding (elements)
+        off = int(rs.choice([0, 0, 1, 2, 4]))             # start offset into the allocation (elements): alignment
+        out.append((r, k, pad, off, int(rs.randint(1 << 30))))
+    return out
+
+
+def _view(rows, cols, pad, off, rs, dev, scale=1.0):
+    """A rows x cols float32 view with leading dimension cols + pad, starting `off` elements into its buffer."""
+    buf = torch.from_numpy((rs.rand(rows * (cols + pad) + off + 8) * scale).astype(np.float32)).to(dev)
+    return torch.as_strided(buf, (rows, cols), (cols + pad, 1), off)
+
+
+@pytest.mark.parametrize("r,k,pad,off,seed", _shapes_upd(_SEED + 7, max(60, _COUNT // 2)))
+def test_random_shapes_update_kernels(r, k, pad, off, seed):
+    """The stand-alone update / element-wise / statistics entry points (the ones multi-rank and 2D runs use) on views with
+    padded leading dimensions and unaligned starts: dnmf_mu_update_w / _h (buffer-addressed MFMA kernels, vector and
+    dword forms, interior and edge tiles), clamp / scale / KL updates (ew_kernel), column_err, the HALS W sweep."""
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    rs = np.random.RandomState(seed)
+    dev = torch.device("cuda")
+    G = new_gram(k, dev)
+    g = rs.rand(k, k)
+    G[:k, :k] = torch.from_numpy((g @ g.T + k).astype(np.float32)).to(dev)
+    G64 = G[:k, :k].double().cpu().numpy()
+    # W-type (r x k) and H-type (k x r)
+    W, S = _view(r, k, pad, off, rs, dev), _view(r, k, pad, off, rs, dev, 20.0)
+    W64, S64 = W.double().cpu().numpy(), S.double().cpu().numpy()
+    Wd = W.clone() if pad == 0 and off == 0 else W        # views are updated in place
+    ops.mu_update_w(Wd, S, G, EPS)
+    assert _rel(Wd.cpu().numpy(), W64 * (S64 / (W64 @ G64 + EPS))) < 1e-5
+    H, T = _view(k, r, pad, off, rs, dev), _view(k, r, pad, off, rs, dev, 20.0)
+    H64, T64 = H.double().cpu().numpy(), T.double().cpu().numpy()
+    ops.mu_update_h(H, T, G, EPS, True)
+    assert _rel(H.cpu().numpy(), np.maximum(H64 * (T64 / (G64 @ H64 + EPS)), EPS)) < 1e-5
+    # element-wise passes
+    x = torch.from_numpy((rs.rand(k) + 0.5).astype(np.float32)).to(dev)
+    x64 = x.double().cpu().numpy()
+    W2, S2 = _view(r, k, pad, off, rs, dev), _view(r, k, pad, off, rs, dev)
+    W264, S264 = W2.double().cpu().numpy(), S2.double().cpu().numpy()
+    ops.kl_update_w(W2, S2, x, EPS)
+    assert _rel(W2.cpu().numpy(), W264 * (S264 / (x64[None, :] + EPS))) < 1e-6
+    H2, T2 = _view(k, r, pad, off, rs, dev), _view(k, r, pad, off, rs, dev)
+    H264, T264 = H2.double().cpu().numpy(), T2.double().cpu().numpy()
+    ops.kl_update_h(H2, T2, x, EPS, False)
+    assert _rel(H2.cpu().numpy(), H264 * (T264 / (x64[:, None] + EPS))) < 1e-6
+    W3 = _view(r, k, pad, off, rs, dev)
+    W3[W3 < 0.3] = 0.0
+    W364 = W3.double().cpu().numpy()
+    ops.clamp_min(W3, EPS)
+    assert np.array_equal(W3.cpu().numpy(), np.maximum(W364, EPS).astype(np.float32))
+    ops.scale_cols_div(W3, x, EPS)
+    assert _rel(W3.cpu().numpy(), np.maximum(W364, EPS) / (x64[None, :] + EPS)) < 1e-6
+    H3 = _view(k, r, pad, off, rs, dev)
+    H364 = H3.double().cpu().numpy()
+    ops.scale_rows_mul(H3, x)
+    assert _rel(H3.cpu().numpy(), H364 * x64[:, None]) < 1e-6
+    # column_err sums on an r x n block
+    n = int(rs.choice([4, 33, 128, 200]))
+    A = _view(r, n, pad, off, rs, dev)
+    Wc = torch.from_numpy(rs.rand(r, k).astype(np.float32)).to(dev)
+    Hc = torch.from_numpy(rs.rand(k, n).astype(np.float32)).to(dev)
+    num, den = ops.column_err_sums(A, Wc, Hc)
+    A64 = A.double().cpu().numpy()
+    R = A64 - Wc.double().cpu().numpy() @ Hc.double().cpu().numpy()
+    assert _rel(num.cpu().numpy(), (R * R).sum(0)) < 2e-5 and _rel(den.cpu().numpy(), (A64 * A64).sum(0)) < 1e-6
+    # HALS W sweep (persistent form) vs the float64 recursion
+    if r >= 8:
+        W4, AH = _view(r, k, pad, off, rs, dev), _view(r, k, pad, off, rs, dev, 300.0)
+        Wr, A4 = W4.double().cpu().numpy(), AH.double().cpu().numpy()
+        ops.hals_update_w(W4, AH, G, EPS)
+        for kk in range(k):
+            t = Wr[:, kk] * G64[kk, kk] + A4[:, kk] - Wr @ G64[:, kk]
+            Wr[:, kk] = np.maximum(t, EPS)
+            ss = np.linalg.norm(Wr[:, kk])
+            if ss > 0:
+                Wr[:, kk] /= ss
+        assert _rel(W4.cpu().numpy(), Wr) < 1e-4
