@@ -92,6 +92,27 @@ def _child(port, q):
             TorchComm.always_collective = True
             nmf_algorithms_2D(Ad, W2, H2, params=args).update()
             log["2d_%s" % norm] = (float((W1 - W2).norm() / W1.norm()), float((H1 - H2).norm() / H1.norm()))
+        # --- the overlapped H phase of row grids with more than two ranks: column chunks whose allreduce is started with
+        #     async_op=True on RCCL's stream while the next chunk is computed.  One rank pretending to be row 0 of a 4 x 1
+        #     grid: the sums over a one-rank group are identities, so the step must equal the plain single-rank step.
+        args4 = parse()
+        args4.comm1, args4.comm, args4.p_r, args4.p_c, args4.k, args4.m, args4.n = world, comms, 4, 1, k, m, n
+        args4.eps, args4.W_update, args4.norm, args4.method = eps, True, "fro", "mu"
+        args4.overlap_min_cols, args4.overlap_chunks = 128, 4
+        W5, H5 = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+        alg = nmf_algorithms_1D(Ad, W5, H5, params=args4)
+        assert alg._overlap_chunks(n) == 4
+        for i in range(3):
+            nmf_algorithms_1D(Ad, W5, H5, params=args4).update(clamp=(i == 0))
+        W6, H6 = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+        args1 = parse()
+        args1.comm1, args1.comm, args1.p_r, args1.p_c, args1.k, args1.m, args1.n = world, comms, 1, 1, k, m, n
+        args1.eps, args1.W_update, args1.norm, args1.method = eps, True, "fro", "mu"
+        TorchComm.always_collective = False
+        for i in range(3):
+            nmf_algorithms_1D(Ad, W6, H6, params=args1).update(clamp=(i == 0))
+        TorchComm.always_collective = True
+        log["overlap"] = (float((W5 - W6).norm() / W6.norm()), float((H5 - H6).norm() / H6.norm()))
         # --- a whole fit with the nccl group up (relative_err allreduces a float64 pair on the device)
         args2 = parse()
         args2.comm1, args2.comm, args2.p_r, args2.p_c, args2.k = world, comms, 1, 1, k
@@ -121,4 +142,5 @@ def test_rccl_code_path_on_one_gpu():
     assert log["dW"] <= 1e-5 and log["dH"] <= 1e-5, log
     for norm in ("fro", "kl"):
         assert max(log["2d_%s" % norm]) <= 1e-6, log
+    assert max(log["overlap"]) <= 2e-6, log
     assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log
