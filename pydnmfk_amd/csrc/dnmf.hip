@@ -111,6 +111,9 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
                 : launch_nt_inst<KT_, MT_, NW_, KS_, false, MODE, TX>(a, nsplit, st);
     // 128-row tiles for every rank.  (k <= 32 used 256-row tiles, MT = 2, in an earlier version: equal at 262144 rows,
     // 1.8x slower at 32768 rows where it left half the CUs without a workgroup.)
+#ifdef DNMF_TUNING
+    if (kt == 2 && tune("DNMF_NT_MT", 1) == 2) { NT_CASE(2, 2, 4, 1) }     // 256-row tiles at k = 64 (A/B runs)
+#endif
     if (kt == 1) { NT_CASE(1, 1, 4, 1) }
     if (kt == 2) { NT_CASE(2, 1, 4, 1) }
     if (kt == 4) { NT_CASE(4, 1, 4, 1) }
