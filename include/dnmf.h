@@ -8,7 +8,9 @@
  *   - every matrix is dense row-major fp32 in DEVICE memory, given as pointer + leading
  *     dimension (elements); the caller owns every buffer, nothing is retained;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
- *     stream-ordered, no entry point synchronises the device or allocates memory;
+ *     stream-ordered, no entry point synchronises the device or allocates memory; the library
+ *     reads no environment variables;
+ *   - every leading dimension must be >= the logical row length (lda >= n, ...);
  *   - `ws` is caller-provided device scratch of at least dnmf_ws_bytes(m, n, k) bytes;
  *   - return value: 0 on success, negative DNMF_E* on error (dnmf_last_error() has text);
  *   - k <= DNMF_MAX_K.  Internally k is padded to KP = 32/64/128; "gram" buffers G are
@@ -53,7 +55,9 @@ int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, lo
 int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw,
              float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
 
-/* ---- Multiplicative updates (element-wise multiply/divide with the small k x k product) ---- */
+/* ---- Multiplicative updates (element-wise multiply/divide with the small k x k product) ----
+ * G must be symmetric (the Gram matrices are).  These two kernels address a tile through 32-bit offsets: leading
+ * dimensions up to 2^23 (W side) / 2^24 (H side) elements, DNMF_EINVAL beyond. */
 /* W *= AH / (W G + eps), G = H H^T       (dist_nmf.py:731-732, :244-245) */
 int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G,
                      float eps, void* stream);
