@@ -89,7 +89,10 @@ int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long 
                        double* ss2, void* stream);
 /* The same W sweep in ONE launch when the rank's rows fit on the device at once (one lane per row for the whole sweep:
  * W and AH are read once, W written once; grid-wide column norms through per-workgroup fp64 slots reduced in a fixed
- * order -- bitwise reproducible); otherwise it runs dnmf_hals_update_w.  `ws` >= dnmf_ws_bytes(m, k, k). dist_nmf.py:884-891 */
+ * order -- bitwise reproducible); otherwise it runs dnmf_hals_update_w.  `ws` >= dnmf_ws_bytes(m, k, k). dist_nmf.py:884-891
+ * The persistent kernel's workgroups wait for each other: do not run two of these sweeps concurrently on one device
+ * (two streams, or two processes sharing a GPU with factors of tens of thousands of rows) -- each could hold the
+ * resources the other's remaining workgroups need.  One process per GPU and one stream, the product's model, is safe. */
 int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                       void* ws, size_t ws_bytes, void* stream);
 /* H sweep: for kk: H[kk,:] = max(H[kk,:] + AtW[kk,:] - G[kk,:] H, eps), rows updated in sequence (dist_nmf.py:905-909) */
