@@ -194,7 +194,11 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
     unsigned long long bits[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bits[q] = (lane + 64 * q < nwg) ? HALS_EMPTY : 0ull;   // beyond the grid: +0.0, never awaited
-    for (;;) {
+    // Safety valve: a sweep whose workgroups are not all resident (two sweeps sharing the device, which the host-side
+    // occupancy check cannot see) would wait forever.  After ~2^21 polling rounds (about a second) the wave gives up; the
+    // missing slots keep their "empty" pattern, which is a NaN, so the column norm -- and with it W -- turns NaN instead
+    // of the GPU hanging.
+    for (unsigned spins = 0; spins < (1u << 21); ++spins) {
         unsigned long long v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
