@@ -880,15 +880,17 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
     constexpr int KP = 32 * KT;
     const long ldt = KP;
     const bool vecw = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;   // pass 1 reads W, AH
-    // pass 2: T rows are aligned.  (KP = 32 always takes the dword form: hipcc register-allocates its 16-byte variant
-    // pathologically -- the whole row in scratch, 20000 spills -- and the row is only loaded and stored once per sweep.)
-    const bool vec = KT > 1 && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    // pass 2: T rows are aligned.  Only KP = 64 has a 16-byte variant of the row load / store (once per sweep): hipcc
+    // register-allocates the KP = 32 one pathologically (the whole row in scratch, 20000 spills), and every variant of the
+    // fully expanded KP = 128 sweep costs a minute of build time.
+    constexpr bool HASVEC = KT == 2;
+    const bool vec = HASVEC && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
     const long grid = cdiv(m, HALS_WG);
     constexpr size_t lds = (size_t)KP * KP * sizeof(float);          // G staged per workgroup
     static long cap_v = -1, cap_s = -1;
     if (cap_v < 0) {
-        allow_lds(hals_w_sweep_kernel<KP, KT != 1>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
-        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, KT != 1>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
+        allow_lds(hals_w_sweep_kernel<KP, HASVEC>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
+        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, HASVEC>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
     }
     if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
     REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "hals_sweep_w: leading dimension beyond the 32-bit tile offsets");
@@ -914,7 +916,7 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
         if (rc) return rc;
     }
     static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
-    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, KT != 1>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
     else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
     return check_launch("hals_sweep_w");
 }
