@@ -98,7 +98,7 @@ def main():
     else:
         raise SystemExit("--process must be pyDNMF or pyDNMFk")
     if world > 1:
-        dist.barrier()
+        comms.comm.barrier()
         dist.destroy_process_group()
 
 

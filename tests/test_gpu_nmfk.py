@@ -55,6 +55,27 @@ def test_cli_end_to_end(tmp_path, golden_dir):
     assert abs(np.linalg.norm(A - W @ H) / np.linalg.norm(A) - err) < 1e-4
 
 
+def test_cli_nmfk_end_to_end(tmp_path, golden_dir):
+    """main.py --process=pyDNMFk (reference main.py:13-88 flags): rank estimation from the command line on the synthetic
+    3-feature problem of the NMFk golden (the reference's own run estimates 3), results layout per k on disk."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(golden_dir + "/nmfk_1x1.npz")
+    np.save(tmp_path / "synth.npy", z["A"].astype(np.float32))
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--process=pyDNMFk", "--p_r=1", "--p_c=1",
+           "--fpath=%s/" % tmp_path, "--fname=synth", "--ftype=npy", "--itr=300", "--norm=fro", "--method=mu",
+           "--start_k=1", "--end_k=5", "--perturbations=6", "--noise_var=0.03", "--sill_thr=0.8", "--init=rand",
+           "--results_path=%s/res/" % tmp_path]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Estimated k with NMFk is  3" in out.stdout or "Estimated k with NMFk is 3" in out.stdout, out.stdout[-500:]
+    for k in range(1, 6):
+        base = tmp_path / "res" / "synth" / str(k)
+        assert (base / "W_reg_factors" / "W_0.npy").exists() and (base / "H_reg_factors" / "H_0.npy").exists()
+
+
 def test_cli_bf16_precision(tmp_path, golden_dir):
     """main.py --precision bfloat16 --method hals (BASELINE config 5 flags): X is held as bf16 on the GPU, the factors
     come back float32 and reproduce the rounded matrix as well as the reported error says."""
