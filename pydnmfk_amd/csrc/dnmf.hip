@@ -86,9 +86,12 @@ int launch_nt_inst(const NtArgs& a, int nsplit, hipStream_t st) {
     // 2.2-2.4 GHz without), i.e. power, not the instruction schedule (measured ceilings).
     static const int pf = (int)tune("DNMF_NT_PF", 10);
     if constexpr (FAST && KS == 1) if (MODE == NT_FUSED_W || !a.store_all) {
+#ifdef DNMF_TUNING      // the A/B variants are only instantiated in the tuning build
         if (pf == 5) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 5, TX>(a, nsplit, st);
-        if constexpr (std::is_same<TX, float>::value) {
+        if constexpr (std::is_same<TX, float>::value)
             if (pf == 7) return launch_nt_pf<KT, MT, NW, KS, FAST, MODE, 7, TX>(a, nsplit, st);
+#endif
+        if constexpr (std::is_same<TX, float>::value) {
             // 13 = 10 with three tiles in flight: chosen when the grid has at most one workgroup per CU (a 32768-row
             // shard = the per-GPU work of the 8-GPU configuration), where a single wave per SIMD has to cover the HBM latency
             constexpr int BM = 32 * MT * (NW / KS);
