@@ -228,6 +228,14 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
     constexpr int U = 4;
     if (cvecs > 256 && rows <= 65535) {                       // long rows
         const dim3 grid((unsigned)cdiv(cvecs, 256 * U), (unsigned)rows);
+        // a matrix that cannot stay in the caches until it is touched again (>= 256 MiB) is streamed with nontemporal
+        // loads and stores: 5.5 -> 6.1 TB/s on the 1 GiB operands of the isolation pass; smaller factors (the W and H of a
+        // step are re-read by the next kernel) keep the default policy.  DNMF_EW_NT = 0 / 1 forces it in the tuning build.
+        const long ntp_dflt = (double)rows * cols * sizeof(float) >= 256.0 * (1 << 20);
+        if (vec && tune("DNMF_EW_NT", ntp_dflt)) {
+            hipLaunchKernelGGL((ew_kernel<OP, 4, true, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+            return check_launch(what);
+        }
         if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
         else hipLaunchKernelGGL((ew_kernel<OP, 1, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
         return check_launch(what);
@@ -237,6 +245,10 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
     while (txs < 8 && (1L << txs) < cvecs) ++txs;
     const long TY = 256 >> txs;
     const dim3 grid((unsigned)cdiv(rows, TY * U));
+    if (vec && tune("DNMF_EW_NT", (double)rows * cols * sizeof(float) >= 256.0 * (1 << 20))) {
+        hipLaunchKernelGGL((ew_kernel<OP, 4, false, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+        return check_launch(what);
+    }
     if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
     else hipLaunchKernelGGL((ew_kernel<OP, 1, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
     return check_launch(what);
@@ -487,6 +499,13 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
                     : launch_update_w_seq<KT_, 1, OCC_>(W, m, k, ldw, AH, ldah, G, eps, st);
     UWS(1, 5) UWS(2, 5) UWS(4, 4)
 #ifdef DNMF_TUNING
+    if (var == 35 && kt == 2 && fast && k == 64 && m % 32 == 0) {      // nontemporal loads and stores (A/B)
+        constexpr size_t lds = 64 * 68 * sizeof(float);
+        static bool once = false;
+        if (!once) { allow_lds(update_w_seq_kernel<2, 4, 5, false, UW_MU, 2>, lds); once = true; }
+        hipLaunchKernelGGL((update_w_seq_kernel<2, 4, 5, false, UW_MU, 2>), dim3((unsigned)cdiv(cdiv(m, 32), 4)), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        return check_launch("mu_update_w(nt)");
+    }
     UWS(1, 3) UWS(2, 3) UWS(4, 3) UWS(1, 4) UWS(2, 4) UWS(4, 5) UWS(1, 6) UWS(2, 6) UWS(1, 8) UWS(2, 2) UWS(4, 2)
 #endif
 #undef UWS
@@ -556,6 +575,17 @@ int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, lon
     static bool once = false;
     if (!once) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false>, lds); allow_lds(update_h_seq_kernel<KT, NT, OCC, true>, lds); once = true; }
     const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32 * NT), 4), tune("DNMF_UPD_GRID", 1L << 30));
+    if constexpr (NT == 2 && KT <= 2) {
+        // a long H that cannot stay cached (>= 64 MiB) streams with nontemporal loads and stores: 4.87 -> 5.07 TB/s at
+        // 64 x 2^22 (each line is touched by exactly one instruction here; the W-side kernel touches a line four times
+        // and loses a factor of two with the same hint, so it keeps the default policy)
+        if (k == 32 * KT && n % (32 * NT) == 0 && (double)k * n * sizeof(float) >= 64.0 * (1 << 20)) {
+            static bool once2 = false;
+            if (!once2) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>, lds); once2 = true; }
+            hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+            return check_launch("mu_update_h");
+        }
+    }
     if (k == 32 * KT && n % (32 * NT) == 0)
         hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     else
@@ -585,6 +615,14 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
         return launch_update_h_seq<KT_, NT_, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st);
     UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4) UHS(1, 2, 3) UHS(2, 2, 3)
 #ifdef DNMF_TUNING
+    if (var >= 91 && var <= 93 && kt == 2 && k == 64 && n % 64 == 0 && even) {   // cache-policy variants of the k = 64, NT = 2 kernel
+        constexpr size_t lds = 64 * 68 * sizeof(float);
+        const unsigned grid = (unsigned)cdiv(cdiv(n, 64), 4);
+        if (var == 91) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 2, 0>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        if (var == 92) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 0, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        if (var == 93) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 2, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        return check_launch("mu_update_h(aux)");
+    }
     if (var == 99 && kt == 2 && k == 64 && n % 32 == 0) {   // memory pattern of the k = 64 kernel without its matrix work
         constexpr size_t lds = 64 * 68 * sizeof(float);
         const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32), 4), tune("DNMF_UPD_GRID", 1024L));

@@ -92,18 +92,19 @@ __device__ __forceinline__ i32x4 buf_rsrc(const void* base) {
     return r;
 }
 
-template <int V>
+// AUX = the instruction's cache-policy bits (0 = default, 2 = nontemporal / streaming)
+template <int V, int AUX = 0>
 __device__ __forceinline__ void buf_load(float (&d)[V], i32x4 rsrc, int voff, int soff) {
-    if constexpr (V == 4) { const f32x4 v = buf_ld_f32x4(rsrc, voff, soff, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
-    else if constexpr (V == 2) { const f32x2 v = buf_ld_f32x2(rsrc, voff, soff, 0); d[0] = v[0]; d[1] = v[1]; }
-    else d[0] = buf_ld_f32(rsrc, voff, soff, 0);
+    if constexpr (V == 4) { const f32x4 v = buf_ld_f32x4(rsrc, voff, soff, AUX); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+    else if constexpr (V == 2) { const f32x2 v = buf_ld_f32x2(rsrc, voff, soff, AUX); d[0] = v[0]; d[1] = v[1]; }
+    else d[0] = buf_ld_f32(rsrc, voff, soff, AUX);
 }
 
-template <int V>
+template <int V, int AUX = 0>
 __device__ __forceinline__ void buf_store(const float (&d)[V], i32x4 rsrc, int voff, int soff) {
-    if constexpr (V == 4) buf_st_f32x4(f32x4{d[0], d[1], d[2], d[3]}, rsrc, voff, soff, 0);
-    else if constexpr (V == 2) buf_st_f32x2(f32x2{d[0], d[1]}, rsrc, voff, soff, 0);
-    else buf_st_f32(d[0], rsrc, voff, soff, 0);
+    if constexpr (V == 4) buf_st_f32x4(f32x4{d[0], d[1], d[2], d[3]}, rsrc, voff, soff, AUX);
+    else if constexpr (V == 2) buf_st_f32x2(f32x2{d[0], d[1]}, rsrc, voff, soff, AUX);
+    else buf_st_f32(d[0], rsrc, voff, soff, AUX);
 }
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E).  `#pragma unroll` is a request hipcc drops for large

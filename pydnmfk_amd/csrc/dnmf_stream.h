@@ -17,7 +17,7 @@ namespace {
 //          operand stays in registers.
 enum { EW_CLAMP = 0, EW_COLS_DIV = 1, EW_ROWS_MUL = 2, EW_KL_BYROW = 3, EW_KL_BYCOL = 4 };
 
-template <int OP, int V, bool LONG>
+template <int OP, int V, bool LONG, bool NTP = false>
 __global__ __launch_bounds__(256) void ew_kernel(float* __restrict__ X, long rows, long cols, long ldx,
                                                  const float* __restrict__ Sm, long lds_, const float* __restrict__ x,
                                                  float eps, int clamp, int txs) {
@@ -56,8 +56,13 @@ __global__ __launch_bounds__(256) void ew_kernel(float* __restrict__ X, long row
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (IN || ok[u]) {
-                load_vec_raw<V>(v[u], X + r[u] * ldx + cv[u] * V);
-                if constexpr (HAS_S) load_vec_raw<V>(sv[u], Sm + r[u] * lds_ + cv[u] * V);
+                if constexpr (NTP) {
+                    load_vec_raw_nt<V>(v[u], X + r[u] * ldx + cv[u] * V);
+                    if constexpr (HAS_S) load_vec_raw_nt<V>(sv[u], Sm + r[u] * lds_ + cv[u] * V);
+                } else {
+                    load_vec_raw<V>(v[u], X + r[u] * ldx + cv[u] * V);
+                    if constexpr (HAS_S) load_vec_raw<V>(sv[u], Sm + r[u] * lds_ + cv[u] * V);
+                }
                 if constexpr (BYCOL) {
                     if (LONG || u == 0) load_vec_raw<V>(colv[u], x + cv[u] * V);
                 }
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(256) void ew_kernel(float* __restrict__ X, long row
                     if (clamp) v[u][e] = fmaxf(v[u][e], eps);
                 }
             }
-            store_tile_vec<V, true, true>(v[u], X + r[u] * ldx, cv[u] * V, cols, true);
+            if constexpr (NTP && V == 4) __builtin_nontemporal_store(f32x4{v[u][0], v[u][1], v[u][2], v[u][3]}, reinterpret_cast<f32x4*>(X + r[u] * ldx + cv[u] * V));
+            else store_tile_vec<V, true, true>(v[u], X + r[u] * ldx, cv[u] * V, cols, true);
         }
     };
     if (full) body(std::true_type{});

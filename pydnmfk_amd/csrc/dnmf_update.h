@@ -34,7 +34,7 @@ constexpr int edge_occ(int kt, int occ) { return kt == 4 ? 2 : (occ < 4 ? occ : 
 // Step (jb, r) of output block ob: A operand lane (li, h) = G[32 ob + li][32 jb + crow(r, h)], read four at a time
 // (r = 4g .. 4g+3 are four consecutive columns of G starting at 32 jb + 8g + 4h).
 // NT = 1 needs no alignment at all (dword accesses); NT = 2 needs 8-byte aligned rows and an even n.
-template <int KT, int NT, bool INTERIOR, bool MMA = true>
+template <int KT, int NT, bool INTERIOR, bool MMA = true, int AUXL = 0, int AUXS = 0>
 __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, long n, long ldh, const float* __restrict__ Sm,
                                                   long lds_, const float* gs, float eps, int clamp, long col0, int li, int h) {
     constexpr int KP = 32 * KT, GP = KP + 4;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ju = (r & 3) + 8 * (r >> 2);
-            buf_load<NT>(hreg[jb][r], hrs[jb], vo(hoff, 32 * jb + ju), ju * ldh4);
+            buf_load<NT, AUXL>(hreg[jb][r], hrs[jb], vo(hoff, 32 * jb + ju), ju * ldh4);
         }
 #pragma unroll
     for (int ob = 0; ob < KT; ++ob) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ju = (r & 3) + 8 * (r >> 2);
-            buf_load<NT>(sreg[r], srs[ob], vo(soff, 32 * ob + ju), ju * lds4);
+            buf_load<NT, AUXL>(sreg[r], srs[ob], vo(soff, 32 * ob + ju), ju * lds4);
         }
         f32x16 acc[NT];
 #pragma unroll
@@ -101,7 +101,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
                 if (clamp) v = fmaxf(v, eps);
                 o[ne] = v;
             }
-            buf_store<NT>(o, hrs[ob], vo(hoff, 32 * ob + ju), ju * ldh4);
+            buf_store<NT, AUXS>(o, hrs[ob], vo(hoff, 32 * ob + ju), ju * ldh4);
         }
     }
 }
@@ -109,7 +109,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
 // Workgroups walk the column tiles grid-stride (G is staged once per workgroup, not once per tile).  EDGE = false is the
 // kernel for k == KP and n a whole number of tiles: it contains the interior tile code only (the edge tile's per-row offset
 // selects cost ~40 registers, i.e. one to two waves per SIMD).
-template <int KT, int NT, int OCC, bool EDGE, bool MMA = true>
+template <int KT, int NT, int OCC, bool EDGE, bool MMA = true, int AUXL = 0, int AUXS = 0>
 __global__ __launch_bounds__(256, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_seq_kernel(float* __restrict__ H, int k, long n, long ldh,
                                                                 const float* __restrict__ Sm, long lds_,
                                                                 const float* __restrict__ G, float eps, int clamp) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_
     const long ntiles = cdiv(n, 32 * NT);
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
         const long col0 = t * 32 * NT;
-        if constexpr (!EDGE) update_h_seq_tile<KT, NT, true, MMA>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
+        if constexpr (!EDGE) update_h_seq_tile<KT, NT, true, MMA, AUXL, AUXS>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
         else if (k == KP && col0 + 32 * NT <= n) update_h_seq_tile<KT, NT, true>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
         else update_h_seq_tile<KT, NT, false>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_
 // written to a separate buffer; W is only read.
 enum { UW_MU = 0, UW_HALS_T = 1 };
 
-template <int KT, int V, bool INTERIOR, int MODE = UW_MU>
+template <int KT, int V, bool INTERIOR, int MODE = UW_MU, int AUX = 0>
 __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ Sm,
                                                   long lds_, const float* gs, float eps, long row0, int li, int h,
                                                   float* __restrict__ T = nullptr, long ldt = 0) {
@@ -164,7 +164,7 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
     // (measured: lanes 12-15 / 28-31 of a store picked up the following group's denominators).
     auto ld4 = [&](float (&d)[4], i32x4 rs, int off, int s) {
         if constexpr (V == 4) {
-            buf_load<4>(d, rs, ((INTERIOR || 8 * s + 4 * h < k) ? off : BUF_OOB) + 32 * s, 0);
+            buf_load<4, AUX>(d, rs, ((INTERIOR || 8 * s + 4 * h < k) ? off : BUF_OOB) + 32 * s, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = buf_ld_f32(rs, ((8 * s + 4 * h + e < k) ? off : BUF_OOB) + 32 * s + 4 * e, 0, 0);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
     };
     auto st4 = [&](const float (&d)[4], i32x4 rs, int off, int s) {
         if constexpr (V == 4) {
-            buf_store<4>(d, rs, ((INTERIOR || 8 * s + 4 * h < k) ? off : BUF_OOB) + 32 * s, 0);
+            buf_store<4, AUX>(d, rs, ((INTERIOR || 8 * s + 4 * h < k) ? off : BUF_OOB) + 32 * s, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) buf_st_f32(d[e], rs, ((8 * s + 4 * h + e < k) ? off : BUF_OOB) + 32 * s + 4 * e, 0, 0);
@@ -209,7 +209,7 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
     }
 }
 
-template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU>
+template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU, int AUX = 0>
 __global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) void update_w_seq_kernel(float* __restrict__ W, long m, int k, long ldw,
                                                                 const float* __restrict__ Sm, long lds_,
                                                                 const float* __restrict__ G, float eps,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) vo
     const long ntiles = cdiv(m, 32);
     for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
         const long row0 = t * 32;
-        if constexpr (!EDGE) update_w_seq_tile<KT, V, true, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
+        if constexpr (!EDGE) update_w_seq_tile<KT, V, true, MODE, AUX>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
         else if (k == KP && row0 + 32 <= m) update_w_seq_tile<KT, V, true, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
         else update_w_seq_tile<KT, V, false, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
     }
