@@ -148,15 +148,16 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
     const i32x4 wrs = buf_rsrc(W + row0 * ldw), srs = buf_rsrc(Sm + row0 * lds_);
     const i32x4 trs = MODE == UW_HALS_T ? buf_rsrc(T + row0 * ldt) : wrs;
     int woff = (int)(((long)li * ldw + 4 * h) * 4), soff = (int)(((long)li * lds_ + 4 * h) * 4);
-    int toff = MODE == UW_HALS_T ? (int)(((long)li * ldt + 4 * h) * 4) : woff;
+    int toff = MODE == UW_HALS_T ? (int)(((long)li * ldt + 4 * h) * 4) : 0;
     if constexpr (!INTERIOR) {
         if (row0 + li >= m) { woff = BUF_OOB; soff = BUF_OOB; toff = BUF_OOB; }
     }
-    if constexpr (MODE == UW_HALS_T) asm volatile("" : "+v"(toff));
     // opaque to the optimiser: otherwise (x << 2) + 32 s is rewritten as (x + 8 s) << 2 and no longer folds into the
     // instruction's immediate offset (one address register per piece instead of one per tile)
     asm volatile("" : "+v"(woff));
     asm volatile("" : "+v"(soff));
+    if constexpr (MODE == UW_HALS_T) asm volatile("" : "+v"(toff));
+    else toff = woff;                        // (the laundered value: the stores fold their piece offsets like the loads)
     // piece (s, h) = columns 8s + 4h .. +3; the edge variant switches off columns >= k
     // The piece offset 32 s goes into the instruction's IMMEDIATE offset (a constant added to the lane offset), never into
     // the SGPR offset: on gfx950 a 16-byte buffer store with an SGPR offset can still be reading its data registers when
