@@ -275,6 +275,11 @@ Tn16Plan plan_tn16(long m, long n, int v) {
     return p;
 }
 
+// zero-padded factor images of the KL products (see pad_factors)
+size_t pad_bytes(long m, long n, int kp) {
+    return align256((size_t)m * kp * sizeof(float)) + align256((size_t)kp * round_up(n, 4) * sizeof(float));
+}
+
 size_t partial_bytes(long m, long n, int k) {
     const int kt = kt_of(k), kp = 32 * kt;
     size_t b = 0;
@@ -323,7 +328,8 @@ WsLayout ws_layout(long m, long n, int k) {
     const size_t s_elems = std::max((size_t)k * round_up(n, 4), (size_t)m * round_up(k, 4));
     w.x_off = w.s_off + align256(s_elems * sizeof(float));
     w.part_off = w.x_off + align256((size_t)kp * sizeof(float));
-    w.total = w.part_off + align256(partial_bytes(m, n, k));
+    // + room for the zero-padded factor images of the KL products (pad_factors) at the end of the partial area
+    w.total = w.part_off + align256(partial_bytes(m, n, k)) + pad_bytes(m, n, kp);
     return w;
 }
 
@@ -759,6 +765,33 @@ int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* 
     return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
 }
 
+// Factors whose rank is not a whole number of 32-wide tiles, or whose rows are not 16-byte aligned -- an NMFk sweep visits
+// k = 2, 3, 5, ... -- send the NN-form kernels (S = W H in accumulators) down their predicated paths: per-element loads
+// behind exec-masked branches, at which hipcc drains vmcnt.  Measured on 32768 x 16384 (tools/klbench.py): a KL step takes
+// 1.78 ms at k = 32, 1.90 ms at k = 8 / 16 / 20 and 2.56-2.61 ms at k = 3 / 5 / 13.  Instead the factors are copied into
+// zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
+// A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
+// outputs beyond k are never stored.
+static bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
+                        size_t ws_bytes, size_t own_need, hipStream_t st) {
+    const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
+    if (friendly || tune("DNMF_KL_PAD", 1) == 0) return false;
+    const size_t pb = pad_bytes(m, n, kp);
+    if (!ws || ws_bytes < align256(own_need) + pb) return false;
+    char* base = (char*)ws + align256(own_need);
+    float* Wp = (float*)base;
+    const long ldhp = round_up(n, 4);
+    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
+    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
+    return true;
+}
+
 struct UhtPlan { int nsplit; long cols_per_split; };
 
 static UhtPlan plan_uht(long m, long n) {
@@ -772,19 +805,22 @@ static UhtPlan plan_uht(long m, long n) {
 }
 
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
+                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
     const int kp = 32 * kt;
-    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
     const UhtPlan u = plan_uht(m, n);
     const size_t pbytes = u.nsplit > 1 ? (size_t)u.nsplit * m * kp * sizeof(float) : 0;
     const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
     if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
+    const int k_out = k;                                   // columns of UHT the caller gets
+    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
+        pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
     const bool split = u.nsplit > 1;
     float* out = split ? (float*)ws : UHT;
     const long ldout = split ? kp : ldo;
-    const int out_cols = split ? kp : k;
+    const int out_cols = split ? kp : k_out;
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(out) && ldout % 4 == 0;
     const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
     const size_t lds = 2ul * kp * BK * sizeof(float);
@@ -800,7 +836,7 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
 #undef UH_CASE
     int rc = check_launch("kl_uht");
     if (rc || !split) return rc;
-    return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k, (int)m, k,
+    return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
                          (float*)((char*)ws + pbytes), st);
 }
 
@@ -809,16 +845,18 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
     const int kp = 32 * kt;
-    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
     const int nt = kl_nt(kt);
     TnPlan p = plan_tn(m, n, kt, nt);
-    a.ncolblk = p.ncolblk;
     const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
-    const long nchunks = cdiv(a.nrowblk, rowblks_per_chunk);
-    a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
-    const size_t pbytes = (size_t)nchunks * a.chunk_stride * sizeof(float);
+    const long nchunks = cdiv(cdiv(m, 32), rowblks_per_chunk);
+    const size_t pbytes = (size_t)nchunks * p.ldp * kp * sizeof(float);
     const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
+    const int k_out = k;                                   // rows of WTU the caller gets
+    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    a.ncolblk = p.ncolblk;
+    a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
     const dim3 grid((unsigned)(cdiv(nchunks, 4) * a.ncolblk)), block(256);   // 4 row chunks (waves) per workgroup
     const size_t lds = (size_t)kp * 32 * nt * sizeof(float);                   // the H block of the workgroup's columns
@@ -832,7 +870,7 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
 #undef WU_CASE
     int rc = check_launch("kl_wtu");
     if (rc) return rc;
-    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k, n, k, n,
+    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k_out, n, k_out, n,
                          (float*)((char*)ws + pbytes), st);
 }
 
