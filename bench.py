@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x6"],
+                    help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
+                         "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
+    ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
     return ap.parse_args()
 
 
@@ -209,7 +213,7 @@ def main():
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
-    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    from pydnmfk_amd.engine import new_gram, ops_for
     from pydnmfk_amd.utils import determine_block_params, parse
 
     m, n, k = a.m, a.n, a.k
@@ -218,6 +222,8 @@ def main():
     p.comm1, p.comm, p.p_r, p.p_c, p.k, p.m, p.n = comms.comm, comms, world, 1, k, m, n
     p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
     p.norm, p.method, p.W_update, p.eps = a.norm, "mu", True, 1.1920929e-07
+    p.gemm = a.gemm
+    ops = ops_for(p)
     m_l = determine_block_params(rank, (world, 1), (m, n)).determine_block_shape_asymm()[0]
 
     # synthetic data, generated on device: X ~ U[0,1), W0 per rank, H0 from rank 0
@@ -240,6 +246,13 @@ def main():
     def step(i):
         nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
 
+    p6 = parse()
+    p6.__dict__.update(vars(p))
+    p6.gemm = "bf16x6"
+
+    def step_x6(i):
+        nmf_algorithms_1D(A, W, H, params=p6).update(clamp=(i % 10 == 0))
+
     for i in range(a.warmup):
         step(i)
     if world > 1:
@@ -259,7 +272,7 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(W).all() and torch.isfinite(H).all()
 
-    def timed(nsteps):
+    def timed(nsteps, step=step):
         """EXACTLY nsteps steps between barrier + device sync on both sides; max over ranks."""
         if world > 1:
             barrier()
@@ -285,13 +298,14 @@ def main():
         out = {
             "metric": "mu_iterations_per_sec", "value": a.steps / elapsed, "unit": "iter/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if a.gemm == "fp32" else "f32 operands as 3 bf16 pieces, 6 bf16 MFMA products per fp32 product, fp32 accumulation",
             "data": "synthetic",
             "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)" % (
-                a.norm.upper(), m, n, k, world), "m": m, "n": n, "k": k, "rows_per_gpu": m_l,
+                a.norm.upper(), m, n, k, world), "m": m, "n": n, "k": k, "rows_per_gpu": m_l, "gemm": a.gemm,
                 "parallelism": ("row-sharded X, allreduce[W^T A | W^T W] over %s" % ("RCCL" if a.backend == "nccl" else a.backend + " (host staged)")) if world > 1 else "single GPU"},
             "step_tflops_per_gpu": flops_iter / world / (ms * 1e-3) / 1e12,
-            "step_mfma_frac": flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "step_mfma_frac": (flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if a.gemm == "fp32" else None,
             "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
         }
 
@@ -304,6 +318,22 @@ def main():
         if rank == 0:
             out["sustained"] = {"steps": ns, "seconds": el, "ms_per_step": el / ns * 1e3, "value": ns / el,
                                 "note": "same step, longer timed region (the headline value above is the K steps asked for)"}
+
+    # The same step with the two big contractions as six bf16 piece products per fp32 product (opt-in, params.gemm =
+    # 'bf16x6'): reported NEXT TO the fp32-MFMA headline, never as it.  Same factors, same data, every rank takes part.
+    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 64 and n % 128 == 0:
+        for i in range(5):
+            step_x6(i)
+        ns6 = max(100, int(1.5 / max(elapsed / a.steps, 1e-6)))
+        el6 = timed(ns6, step_x6)
+        if rank == 0:
+            out["bf16x6"] = {
+                "value": ns6 / el6, "unit": "iter/s", "ms_per_step": el6 / ns6 * 1e3, "steps": ns6,
+                "speedup_vs_fp32_mfma": (ns6 / el6) / (out["sustained"]["value"] if "sustained" in out else out["value"]),
+                "step_algorithmic_hbm_gbs_per_gpu": (8.0 * m_l * n + 12.0 * (m_l + n) * k) / (el6 / ns6) / 1e9,   # X is read twice per step
+                "note": "opt-in arithmetic (params.gemm='bf16x6', bench.py --gemm bf16x6): fp32 operands cut into three bf16 "
+                        "pieces, six bf16 MFMA products per fp32 product, fp32 accumulation; as close to float64 as the fp32 "
+                        "MFMA path (tests/test_gpu_split.py); the two passes over X become HBM bound"}
 
     if not a.no_kernel_timing and a.norm == "fro":
         # Per-kernel HIP-event timings IN SITU: the step is replayed primitive by primitive (same launches, same order
@@ -330,6 +360,11 @@ def main():
                     evs[name].append((s, e))
         torch.cuda.synchronize()
         t = {name: sum(s.elapsed_time(e) for s, e in v) / len(v) for name, v in evs.items()}
+        x6_t = None
+        if 32 < k <= 64 and n % 128 == 0:
+            ops6 = ops_for(p6)
+            x6_t = {"aht_update_w": event_time_ms(lambda: ops6.aht_update_w(A, H, G, W, p.eps), reps=10, warm=3)[0],
+                    "wta": event_time_ms(lambda: ops6.wta(A, W, AtW), reps=10, warm=3)[0]}
         t_sq, _ = event_time_ms(lambda: ops.sqnorm(A), reps=10, warm=3)
         t_res, _ = event_time_ms(lambda: ops.resid_sqnorm(A, W, H), reps=10, warm=3)
         # the eltwise multiply-divide kernel in isolation (measure it on a large n; k x 2^22 = 3.2 GB at
@@ -409,6 +444,15 @@ def main():
             out["roofline"] = r_nt
             out["roofline_hbm"] = r_upd
             out["rooflines"] = [r_nt, r_tn, r_res, r_upd, r_sq]
+            if x6_t is not None:
+                by_nt, by_tn = 4.0 * m_l * n + 8.0 * m_l * k, 4.0 * m_l * n + 4.0 * m_l * k + 4.0 * k * n
+                out["rooflines"] += [
+                    hbm_entry("ntx_kernel<KT=2,FUSED_W> (dnmf_aht_update_w_bf16x6; incl. cutting H)", x6_t["aht_update_w"], by_nt,
+                              "bf16x6 arithmetic; algorithmic bytes = X once + W read and written", role="ntx_kernel<2, 1", workload="split"),
+                    hbm_entry("tnx_kernel<KT=2> (dnmf_wta_bf16x6; incl. cutting W^T and the reduction of the partial slabs)", x6_t["wta"], by_tn,
+                              "bf16x6 arithmetic; algorithmic bytes = X once + W once + the k x n result", role="tnx_kernel<2", workload="split")]
+                if a.gemm == "bf16x6":
+                    out["roofline"] = out["rooflines"][-2]
             out["kernels"] = kern
 
     if rank == 0:

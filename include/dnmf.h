@@ -155,6 +155,24 @@ int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float
 int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                           int k, double* num, double* den, void* stream);
 
+/* ---- bf16x6: the two big contractions on the bf16 matrix cores with fp32-grade products (no reference counterpart; an
+ * alternative arithmetic for global_mm, dist_nmf.py:705).  Every fp32 operand is cut into three bf16 pieces (x = x1 + x2 + x3
+ * to 2^-24 |x|) and a product is the sum of the six largest piece products, each exact in the fp32 accumulator; the dropped
+ * terms are below one fp32 rounding of the product (csrc/dnmf_split.h has the bound, tests/test_gpu_split.py the measurement
+ * against float64).  Opt-in: the fp32-MFMA entry points above stay the default and the reference for parity.
+ * Kernels exist for 32 < k <= 64, 16-byte aligned rows of A and n % 128 == 0; any other shape is forwarded to the fp32
+ * entry point of the same name.  Same arguments as the fp32 twins plus a workspace of dnmf_ws_bytes_bf16x6(m, n, k) bytes
+ * (the bf16 images of H and W^T, partial sums). ---- */
+size_t dnmf_ws_bytes_bf16x6(long m, long n, int k);
+int dnmf_aht_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh,
+                    float* AH, long ldah, void* ws, size_t ws_bytes, void* stream);
+int dnmf_wta_bf16x6(const float* A, long m, long n, long lda, const float* W, int k, long ldw,
+                    float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh,
+                             const float* G, float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream);
+int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
+                            int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

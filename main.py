@@ -48,6 +48,7 @@ FLAGS = [
     ('timing_stats', _flag, False, False, 'accepted for compatibility; ignored'),
     ('prune', _flag, False, False, 'drop all-zero rows / columns before factorising'),
     ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
+    ('gemm', str, 'fp32', False, 'arithmetic of the two big Frobenius contractions: fp32 (fp32 MFMA) or bf16x6 (six bf16 piece products, fp32-grade)'),
     # NMFk
     ('perturbations', int, 20, False, 'perturbed copies per rank'),
     ('noise_var', float, 0.015, False, 'perturbation amplitude'),

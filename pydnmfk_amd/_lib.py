@@ -62,7 +62,13 @@ SIGNATURES = {
 # bf16 storage of A: same argument lists as the fp32 twins (A is passed as a device pointer either way)
 for _n in ("aht", "wta", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "column_err"):
     SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
-_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t}
+# bf16x6 contractions: the fp32 argument lists, aht / aht_update_w with a workspace added
+SIGNATURES["dnmf_ws_bytes_bf16x6"] = SIGNATURES["dnmf_ws_bytes"]
+SIGNATURES["dnmf_aht_bf16x6"] = SIGNATURES["dnmf_aht"][:-1] + [c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_wta_bf16x6"] = SIGNATURES["dnmf_wta"]
+SIGNATURES["dnmf_aht_update_w_bf16x6"] = SIGNATURES["dnmf_aht_update_w"][:-1] + [c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_mu_fro_step_bf16x6"] = SIGNATURES["dnmf_mu_fro_step"]
+_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t}
 
 
 def load():

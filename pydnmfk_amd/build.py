@@ -10,7 +10,6 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "dnmf.hip")
 LIB = os.path.join(HERE, "libdnmf_hip.so")
 TUNE_LIB = os.path.join(ROOT, "tools", "_build", "libdnmf_hip_tune.so")   # -DDNMF_TUNING: experiment switches (tools only)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -25,27 +24,47 @@ def _stale():
 
 
 def build_lib(force=False, report=False, tuning=False):
-    """Compile csrc/dnmf.hip (one translation unit, kernels in csrc/dnmf_*.h) -> libdnmf_hip.so.  Returns the library path.
-    `tuning=True` builds tools/_build/libdnmf_hip_tune.so instead: the same source with -DDNMF_TUNING, in which the
+    """Compile the translation units csrc/*.hip (kernels in csrc/dnmf_*.h) side by side and link them into
+    libdnmf_hip.so.  Returns the library path.
+    `tuning=True` builds tools/_build/libdnmf_hip_tune.so instead: the same sources with -DDNMF_TUNING, in which the
     DNMF_* environment switches and the extra kernel variants of the A/B runs exist (tools/README.md); the shipped
     library reads no environment."""
+    import glob
+    from concurrent.futures import ThreadPoolExecutor
     out = TUNE_LIB if tuning else LIB
     if not tuning and not force and not report and not _stale():
         return LIB
+    objdir = os.path.join(ROOT, "tools", "_build", "obj_tune" if tuning else "obj")
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(HERE, "csrc"),
-           "-shared", "-fPIC", "-o", out, SRC]
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+             "-I" + os.path.join(HERE, "csrc")]
     if tuning:
-        cmd.insert(1, "-DDNMF_TUNING")
+        flags.append("-DDNMF_TUNING")
     if report:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    srcs = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
+    only = os.environ.get("DNMF_BUILD_ONLY")          # development: recompile just this unit (e.g. dnmf_split), reuse the other objects
+    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if only and only not in os.path.basename(src) and os.path.exists(obj):
+            return ""
+        res = subprocess.run([HIPCC] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stderr)
+            raise RuntimeError("hipcc failed on %s (%d)" % (os.path.basename(src), res.returncode))
+        return res.stderr
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        logs = list(ex.map(compile_one, zip(srcs, objs)))
+    res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stderr)
-        raise RuntimeError("hipcc failed (%d)" % res.returncode)
+        raise RuntimeError("hipcc link failed (%d)" % res.returncode)
     if report:
-        print(resource_report(res.stderr))
+        print(resource_report("".join(logs)))
     return out
 
 

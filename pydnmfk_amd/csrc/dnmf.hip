@@ -17,6 +17,7 @@
 // The contraction order inside a tile and the output row/column order inside a tile are permuted freely
 // (sums are order-agnostic up to fp32 rounding; outputs are written to their true addresses).
 #include "dnmf_common.h"
+#include "dnmf_host.h"
 #include "dnmf_nt.h"
 #include "dnmf_tn.h"
 #include "dnmf_stream.h"
@@ -25,27 +26,12 @@
 #include "dnmf_nn.h"
 #include "dnmf_k16.h"
 
+char* dnmf_errbuf_() {
+    static thread_local char buf[DNMF_ERRBUF] = "";
+    return buf;
+}
+
 namespace {
-
-// =============================================================================================== host side
-int kt_of(int k) {
-    if (k < 1 || k > DNMF_MAX_K) return -1;
-    return k <= 32 ? 1 : (k <= 64 ? 2 : 4);
-}
-
-// lda == 0 (every row of A aliases one row: A becomes cache resident) is an experiment of the tuning build only
-// (tools/kbench.py ALIAS=1); the shipped library requires lda >= n everywhere, as include/dnmf.h says
-inline bool alias_ok(long lda) { return lda == 0 && tune("DNMF_ALLOW_ALIAS", 0) != 0; }
-
-hipStream_t S(void* s) {
-    clear_hip_error();
-    return reinterpret_cast<hipStream_t>(s);
-}
-
-template <typename K>
-void allow_lds(K kernel, size_t bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF, typename TX>
 int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
@@ -149,40 +135,6 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
 }
 
-// two-stage when there are many partials per output (gram of a tall W): slices of 32 splits, then one more pass
-constexpr int REDUCE_SLICE = 32;
-inline int reduce_slices(int nsplit) { return nsplit > 2 * REDUCE_SLICE ? (int)cdiv(nsplit, REDUCE_SLICE) : 1; }
-inline size_t reduce_scratch_bytes(int nsplit, int rows_out, long cols_out) {
-    const int y = reduce_slices(nsplit);
-    return y > 1 ? (size_t)y * rows_out * round_up(cols_out, 4) * sizeof(float) : 0;
-}
-
-// `scratch` must hold reduce_scratch_bytes(nsplit, rows_out, cols_out)
-int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out, long ldo, int rows, long cols,
-                  int rows_out, long cols_out, float* scratch, hipStream_t st) {
-    const long total = (long)rows_out * cdiv(cols_out, 4);
-    const unsigned gx = (unsigned)cdiv(total, 64);
-    const int ny = reduce_slices(nsplit);
-    static const bool wide = tune("DNMF_REDUCE_WIDE", 1) != 0;
-    if (wide && ny == 1 && rows == rows_out && cols == cols_out && cols % 4 == 0 && cols >= 4096 && ldo % 4 == 0 &&
-        aligned16(out) && aligned16(P) && ldp % 4 == 0 && stride % 4 == 0) {
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, P, stride, ldp,
-                           nsplit, out, ldo, rows, cols);
-        return check_launch("reduce_partials_wide");
-    }
-    if (ny == 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
-                           0L, rows, cols, rows_out, cols_out);
-    } else {
-        const long ld2 = round_up(cols_out, 4), ys = (long)rows_out * ld2;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, ny), dim3(256), 0, st, P, stride, ldp, nsplit, REDUCE_SLICE,
-                           scratch, ld2, ys, rows, cols, rows_out, cols_out);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, ys, ld2, ny, ny, out,
-                           ldo, 0L, rows_out, cols_out, rows_out, cols_out);
-    }
-    return check_launch("reduce_partials");
-}
-
 // ---- chunking heuristics (shared by the ws-size query and the launches)
 struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
 
@@ -216,7 +168,6 @@ SplitPlan plan_gram_nt(long n) {
     return s;
 }
 
-size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 // element-wise pass (dnmf_stream.h): 16-byte vectors when X (and S) allow it; a long-row or a patch launch
 template <int OP>
@@ -336,9 +287,15 @@ WsLayout ws_layout(long m, long n, int k) {
 }  // namespace
 
 // =============================================================================================== C ABI
+__attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]);
+void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]) {   // library-internal (csrc/dnmf_split.hip)
+    const WsLayout L = ws_layout(m, n, k);
+    out[0] = L.g_off; out[1] = L.s_off; out[2] = L.x_off; out[3] = L.part_off; out[4] = L.total;
+}
+
 extern "C" {
 
-const char* dnmf_last_error(void) { return g_err; }
+const char* dnmf_last_error(void) { return dnmf_errbuf_(); }
 int dnmf_version(void) { return 100; }
 int dnmf_kp(int k) { const int kt = kt_of(k); return kt < 0 ? -1 : 32 * kt; }
 
@@ -347,8 +304,6 @@ size_t dnmf_ws_bytes(long m, long n, int k) {
     return ws_layout(m, n, k).total;
 }
 
-#define REQUIRE(cond, ...) \
-    do { if (!(cond)) return fail(DNMF_EINVAL, __VA_ARGS__); } while (0)
 
 int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, size_t ws_bytes, void* stream) {
     const int kt = kt_of(k);

@@ -1,5 +1,5 @@
 // dnmf_common.h -- types, error plumbing and the element loaders shared by every kernel family.
-// Part of libdnmf_hip.so (single translation unit: csrc/dnmf.hip includes every header once).
+// Part of libdnmf_hip.so (included by every translation unit csrc/*.hip).
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -28,15 +28,18 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
-namespace {
-
 // ----------------------------------------------------------------------------------------------- errors
-thread_local char g_err[512] = "";
+// One thread-local message buffer for the whole library (csrc/dnmf.hip owns it; dnmf_last_error returns it); the other
+// translation units reach it through this library-internal accessor.
+constexpr int DNMF_ERRBUF = 512;
+__attribute__((visibility("hidden"))) char* dnmf_errbuf_();
+
+namespace {
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    vsnprintf(dnmf_errbuf_(), DNMF_ERRBUF, fmt, ap);
     va_end(ap);
     return code;
 }

@@ -1,0 +1,379 @@
+// dnmf_split.h -- the two big contractions (A H^T, W^T A) on the bf16 matrix cores with fp32-grade products ("bf16x6").
+// Part of libdnmf_hip.so (translation unit csrc/dnmf_split.hip).
+//
+// Why: at the headline rank the fp32 kernels of dnmf_nt.h / dnmf_tn.h are bound by v_mfma_f32_32x32x2_f32 (256 flop per CU
+// and clock, 85-88 % busy: 2.3 ms per pass over the 8.6 GB of A, where the HBM alone would need 1.1-1.4 ms).
+// v_mfma_f32_32x32x16_bf16 does 16x the work per clock, so even six of them per fp32 product leave the pass memory bound.
+//
+// Arithmetic: every fp32 operand x is cut into three bf16 pieces x = x1 + x2 + x3, x1 = rne_bf16(x), x2 = rne_bf16(x - x1),
+// x3 = rne_bf16(x - x1 - x2); both subtractions are exact in fp32 and |x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|, |x - x1 - x2 - x3|
+// <= 2^-24 |x| (three 8-bit significands cover the 24 bits of fp32 unless x is within 2^16 of the smallest normal number).
+// A product is taken as  x y ~ x1 y1 + (x1 y2 + x2 y1) + (x1 y3 + x2 y2 + x3 y1): every piece product is exact in the fp32
+// accumulator (8 x 8 significant bits), the three dropped terms are bounded by (2^-24 + 2^-24 + 2^-32) |x y| and have random
+// sign (round-to-nearest residuals), i.e. the product is as good as ONE fp32 rounding of x y, which is what the fp32 MFMA
+// chain commits per term as well.  Accumulation is fp32 in both; the 32x32x16 instruction adds 16 products per accumulator
+// update where the fp32 one adds 2, so six updates per 16 contraction indices stand against eight.  Measured against a
+// float64 product the two paths are equally close (tests/test_gpu_split.py).
+//
+// Layout: the streamed operand A is read ONCE from HBM as fp32 and cut in registers; its operand fragments are formed without
+// LDS -- for A H^T a lane reads 16 consecutive floats of its row (the contraction index may be permuted freely as long as both
+// operands agree, so the lane pair (li, 0), (li, 1) consumes one whole 128-B line), for W^T A a lane reads an 8-row x 4-column
+// block and the four columns become its fragments of four column-interleaved output tiles.  The small operand (H, or W
+// transposed) is cut once per call into a bf16 image [piece][k][index] in the workspace and staged through LDS.
+#pragma once
+#include "dnmf_common.h"
+#include "dnmf_nt.h"
+#include "dnmf_tn.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// (lo, hi) -> packed round-to-nearest-even bf16 pair
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// two floats -> their three bf16 pieces, packed pairwise (11 VALU instructions)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned int& s1, unsigned int& s2, unsigned int& s3) {
+    s1 = cvt_pk_bf16(a, b);
+    float ra = a - __uint_as_float(s1 << 16), rb = b - __uint_as_float(s1 & 0xffff0000u);
+    s2 = cvt_pk_bf16(ra, rb);
+    ra -= __uint_as_float(s2 << 16);
+    rb -= __uint_as_float(s2 & 0xffff0000u);
+    s3 = cvt_pk_bf16(ra, rb);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& s1, u32x4& s2, u32x4& s3) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned int a, b, c;
+        split_pair(v[2 * p], v[2 * p + 1], a, b, c);
+        s1[p] = a; s2[p] = b; s3[p] = c;
+    }
+}
+
+// the six piece products of one 32 x 32 x 16 tile step, small terms first
+__device__ __forceinline__ void mfma_x6(f32x16& acc, const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b1,
+                                        const u32x4& b2, const u32x4& b3) {
+    acc = mfma_bf16(a3, b1, acc);
+    acc = mfma_bf16(a2, b2, acc);
+    acc = mfma_bf16(a1, b3, acc);
+    acc = mfma_bf16(a2, b1, acc);
+    acc = mfma_bf16(a1, b2, acc);
+    acc = mfma_bf16(a1, b1, acc);
+}
+
+// ---------------------------------------------------------------------------------------------- cutting the small operand
+// S[s][r][c] = piece s of Y[r][c] for r < rows_pad, c < ld_s (bf16; zero outside [yrows x ycols]).  One thread = 8 columns.
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ Y, long ldy, int yrows, long ycols,
+                                                          bf16_t* __restrict__ S, long ld_s, long split_stride, int rows_pad) {
+    const long c8 = ld_s / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows_pad * c8) return;
+    const int r = (int)(idx / c8);
+    const long c = (idx % c8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r < yrows && c + e < ycols) ? Y[r * ldy + c + e] : 0.f;
+    u32x4 s1, s2, s3;
+    split8(v, s1, s2, s3);
+    bf16_t* dst = S + r * ld_s + c;
+    *reinterpret_cast<u32x4*>(dst) = s1;
+    *reinterpret_cast<u32x4*>(dst + split_stride) = s2;
+    *reinterpret_cast<u32x4*>(dst + 2 * split_stride) = s3;
+}
+
+// S[s][c][r] = piece s of W[r][c] (the image is W TRANSPOSED) for c < 32 * gridDim.y, r < ld_s; zero outside [m x k].
+// A wave takes 64 rows x 8 columns: lane (cb = l & 7, rb = l >> 3) reads W[r0 + 8 rb + i][c0 + cb], i = 0..7, and stores the
+// eight row pieces of its column as 16 bytes; the lanes rb = 0..7 of one column fill one whole 128-B line.
+__global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restrict__ W, long ldw, long m, int k,
+                                                          bf16_t* __restrict__ S, long ld_s, long split_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cb = lane & 7, rb = lane >> 3;
+    const long r0 = (long)blockIdx.x * 64 + 8 * rb;
+    const int c = blockIdx.y * 32 + wave * 8 + cb;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (r0 + i < m && c < k) ? W[(r0 + i) * ldw + c] : 0.f;
+    u32x4 s1, s2, s3;
+    split8(v, s1, s2, s3);
+    bf16_t* dst = S + c * ld_s + r0;
+    *reinterpret_cast<u32x4*>(dst) = s1;
+    *reinterpret_cast<u32x4*>(dst + split_stride) = s2;
+    *reinterpret_cast<u32x4*>(dst + 2 * split_stride) = s3;
+}
+
+// ---------------------------------------------------------------------------------------------- small-operand tile in LDS
+// [piece 3][row 32*KT][64 contraction indices = 128 B]; the eight 16-B chunks of a row are XOR-swizzled with (row >> 1) & 7,
+// which makes the ds_read_b128 of lanes (row = li, same chunk) conflict free (as lds_idx of dnmf_nt.h).
+constexpr int XK = 64;
+struct SplitOperand { const bf16_t* S; long split_stride; long ld; };   // S[piece][row][index]
+
+template <int KT>
+__device__ __forceinline__ void tile_load(u32x4 (&v)[3 * KT], const SplitOperand& o, long k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 3 * KT; ++i) {
+        const int p = tid + 256 * i, s = p / (256 * KT), row = (p >> 3) % (32 * KT), ch = p & 7;
+        v[i] = *reinterpret_cast<const u32x4*>(o.S + s * o.split_stride + row * o.ld + k0 + ch * 8);
+    }
+}
+
+template <int KT>
+__device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT], int tid) {
+#pragma unroll
+    for (int i = 0; i < 3 * KT; ++i) {
+        const int p = tid + 256 * i, s = p / (256 * KT), row = (p >> 3) % (32 * KT), ch = p & 7;
+        *reinterpret_cast<u32x4*>(tile + (s * 32 * KT + row) * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A H^T (+ fused W update)
+// Workgroup = 4 waves x 32 rows of A; wave tile 32 x KP.  A is staged through LDS as fp32 tiles of 128 rows x 32 columns with
+// the coalesced loads and the swizzled image of dnmf_nt.h (a lane per row reading its own 64 bytes was measured first: 2.9
+// TB/s, the texture path then sees 64 separate lines per load instruction).  A tile is two MFMA steps: step u, lane (li, h)
+// contracts over columns 16 u + 8 h + [0, 8) of the tile = 16-B chunks 4 u + 2 h, + 1 of its fp32 row = chunk 2 u + h of the
+// H tile [piece 3][row 32*KT][32 indices = 64 B], whose four chunks are swizzled with (row >> 2) & 3.
+// NSET tiles are in flight: the loads of tile t + NSET are issued at the top of tile t into the register set that tile t left
+// free, tile t + 1 (loaded NSET - 1 tiles ago) goes to the other LDS stage after the MFMAs of tile t.
+constexpr int XT = 32;                                                   // contraction indices per NT tile
+
+template <int KT>
+__device__ __forceinline__ void htile_load(u32x4 (&v)[3], const SplitOperand& o, long k0, int tid) {
+    static_assert(KT == 2, "64 rows x 4 chunks = one piece image per pass of 256 threads");
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        v[s] = *reinterpret_cast<const u32x4*>(o.S + s * o.split_stride + (tid >> 2) * o.ld + k0 + (tid & 3) * 8);
+}
+
+template <int KT>
+__device__ __forceinline__ void htile_store(char* tile, const u32x4 (&v)[3], int tid) {
+    const int row = tid >> 2, ch = tid & 3;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        *reinterpret_cast<u32x4*>(tile + (s * 32 * KT + row) * 64 + ((ch ^ ((row >> 2) & 3)) << 4)) = v[s];
+}
+
+template <int KT, bool INTERIOR, bool NTX, int NSET>
+__device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* __restrict__ X, long ldx, long nrows, long row0,
+                                             const SplitOperand& ys, long cbeg, long cend, float* smem) {
+    constexpr int XB = 128 * XT * 4, HB = 3 * 32 * KT * 64, STAGE = XB + HB;      // bytes
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = (int)((cend - cbeg) / XT);
+    if (nk <= 0) return;
+    // rotated tile order per workgroup: row tiles are a power-of-two pitch apart (see nt_mainloop_)
+    const int kshift = (int)((blockIdx.x * 37u) % (unsigned)nk);
+    auto col_of = [&](int t) {
+        t = t < nk ? t : nk - 1;                         // past the end: the last tile again (never used)
+        t += kshift;
+        t = t >= nk ? t - nk : t;
+        return cbeg + (long)t * XT;
+    };
+    f32x4 xv[NSET][4];
+    u32x4 hv[NSET][3];
+    auto load = [&](f32x4 (&x)[4], u32x4 (&hh)[3], int t) {
+        const long c0 = col_of(t);
+        stage_load<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
+        htile_load<KT>(hh, ys, c0, tid);
+    };
+    auto store = [&](char* st, const f32x4 (&x)[4], const u32x4 (&hh)[3]) {
+        stage_store<128, 256>(reinterpret_cast<float*>(st), x, tid);
+        htile_store<KT>(st + XB, hh, tid);
+    };
+    const int xrow = wave * 32 + li;
+    const int hsw = (li >> 2) & 3;
+    auto compute = [&](const char* st) {
+        const float* xc = reinterpret_cast<const float*>(st);
+        const char* hc = st + XB;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h)]);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h + 1)]);
+            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            u32x4 a1, a2, a3;
+            split8(v, a1, a2, a3);
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) {
+                const char* f = hc + (jt * 32 + li) * 64 + (((2 * u + h) ^ hsw) << 4);
+                const u32x4 b1 = *reinterpret_cast<const u32x4*>(f);
+                const u32x4 b2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * 64);
+                const u32x4 b3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * 64);
+                mfma_x6(acc[0][jt], a1, a2, a3, b1, b2, b3);
+            }
+        }
+    };
+    static_for<0, NSET>([&](auto i_) { constexpr int i = decltype(i_)::value; load(xv[i], hv[i], i); });
+    store(lds, xv[0], hv[0]);
+    __syncthreads();
+    // tile t: set t % NSET (already in LDS stage t & 1) is refilled with tile t + NSET; set (t + 1) % NSET = tile t + 1 goes to
+    // the other stage after the MFMAs.  NSET tiles per trip (nk % NSET == 0: n % 128 == 0).
+    for (int t = 0; t < nk; t += NSET) {
+        static_for<0, NSET>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            load(xv[i], hv[i], t + i + NSET);
+            compute(lds + (i & 1) * STAGE);
+            store(lds + ((i + 1) & 1) * STAGE, xv[(i + 1) % NSET], hv[(i + 1) % NSET]);
+            __syncthreads();
+        });
+    }
+}
+
+template <int KT, int MODE, int AUX, int NSET = 4>
+__global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long row0 = (long)blockIdx.x * 128;
+    const long cbeg = (long)blockIdx.y * p.cols_per_split;
+    long cend = cbeg + p.cols_per_split;
+    if (cend > p.ncols) cend = p.ncols;
+
+    f32x16 acc[1][KT];
+#pragma unroll
+    for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][jt][r] = 0.f;
+
+    const float* X = static_cast<const float*>(p.X);
+    if (row0 + 128 <= p.nrows) ntx_mainloop<KT, true, AUX != 0, NSET>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+    else ntx_mainloop<KT, false, false, 2>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+
+    if constexpr (MODE == NT_STORE) {
+        float* out = p.out + (long)blockIdx.y * p.split_stride;
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + wave * 32 + crow(r, h);
+                const int col = jt * 32 + li;
+                if (p.store_all || (row < p.nrows && col < p.yrows)) out[row * p.ldo + col] = acc[0][jt][r];
+            }
+    } else {
+        // W[rows] *= acc / (W[rows] G + eps): the k x k product stays on the fp32 path of dnmf_nt.h (dist_nmf.py:731-732)
+        f32x16 acc2[1][KT];
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][jt][r] = 0.f;
+        if (p.wfast) nt_mainloop<KT, 1, 4, 1, true>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        else nt_mainloop<KT, 1, 4, 1, false>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+#pragma unroll
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + wave * 32 + crow(r, h);
+                const int col = jt * 32 + li;
+                if (row < p.nrows && col < p.k) {
+                    const float w = p.W[row * p.ldw + col];
+                    p.W[row * p.ldw + col] = w * (acc[0][jt][r] / (acc2[0][jt][r] + p.eps));
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- W^T A (partial sums per row chunk)
+// Workgroup = 4 waves on 4 adjacent 128-column blocks of one row chunk, sharing the staged W^T tiles.  MFMA step = 16 rows:
+// lane (g = l & 31, h = l >> 5) reads rows r + 8 h + i (i = 0..7), columns col0 + 4 g + [0, 4) -- 512 contiguous bytes per row
+// and half wave -- and column j of that block is its B fragment (k = 8 h + i) of output tile j, whose 32 columns are
+// col0 + 4 g' + j.  acc[kt][j] (reg, lane) = C[kt * 32 + crow(reg, h)][col0 + 4 li + j]: the four tiles of a lane store as one
+// float4.
+template <int KT, int AUX>
+__global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    constexpr int TB = 3 * 32 * KT * 128;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb4 = (p.ncolblk + 3) / 4;
+    const long chunk = blockIdx.x / cb4;
+    int colblk = (int)(blockIdx.x % cb4) * 4 + wave;
+    const bool live = colblk < p.ncolblk;
+    colblk = live ? colblk : p.ncolblk - 1;
+    const long col0 = (long)colblk * 128;
+    const long rbeg = chunk * p.rows_per_chunk;
+    long rend = rbeg + p.rows_per_chunk;
+    if (rend > p.nrows) rend = p.nrows;
+    const int nch = (int)((rend - rbeg + XK - 1) / XK);
+    const float* A = static_cast<const float*>(p.Y) + rbeg * p.ldy + col0;
+    const long left = ((p.nrows - rbeg) * p.ldy - col0) * 4;          // rows past the end of A read as zeros
+    i32x4 rs = buf_rsrc(A);
+    rs[2] = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffL ? left : 0x7fffffffL));
+    const int voff = (int)((8 * h * p.ldy + 4 * li) * 4);
+    const int rowb = (int)(p.ldy * 4);
+
+    f32x16 acc[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kt][j][r] = 0.f;
+
+    f32x4 xr[8];
+    u32x4 wv[3 * KT];
+    static_for<0, 8>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        xr[i] = buf_ld_f32x4(rs, voff, i * rowb, AUX);
+    });
+    tile_load<KT>(wv, ws, rbeg, tid);
+    tile_store<KT>(lds, wv, tid);
+    __syncthreads();
+    int fo[4];               // fragment of step st: row li, chunk 2 st + h
+#pragma unroll
+    for (int st = 0; st < 4; ++st) fo[st] = li * 128 + (((2 * st + h) ^ ((li >> 1) & 7)) << 4);
+    const int nsteps = 4 * nch;
+    for (int c = 0; c < nch; ++c) {
+        const int cn = c + 1 < nch ? c + 1 : c;
+        const char* cur = lds + (c & 1) * TB;
+        tile_load<KT>(wv, ws, rbeg + (long)cn * XK, tid);
+        static_for<0, 4>([&](auto st_) {
+            constexpr int st = decltype(st_)::value;
+            u32x4 b[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v[8] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], xr[6][j], xr[7][j]};
+                split8(v, b[j][0], b[j][1], b[j][2]);
+            }
+            int nx = 4 * c + st + 1;                              // next step's rows (past the end: the last step again)
+            nx = nx < nsteps ? nx : nsteps - 1;
+            const int sbase = nx * 16 * rowb;
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                xr[i] = buf_ld_f32x4(rs, voff, sbase + i * rowb, AUX);
+            });
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const char* f = cur + fo[st] + kt * 32 * 128;
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(f);
+                const u32x4 a2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * 128);
+                const u32x4 a3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
+            }
+        });
+        tile_store<KT>(lds + ((c + 1) & 1) * TB, wv, tid);
+        __syncthreads();
+    }
+
+    if (live) {
+        float* Pc = p.P + chunk * p.chunk_stride;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = kt * 32 + crow(r, h);
+                *reinterpret_cast<f32x4*>(Pc + (long)j * p.ldp + col0 + 4 * li) =
+                    f32x4{acc[kt][0][r], acc[kt][1][r], acc[kt][2][r], acc[kt][3][r]};
+            }
+    }
+}
+
+}  // namespace

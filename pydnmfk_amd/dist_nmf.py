@@ -37,9 +37,9 @@ def release_buffers():
     engine._ws_cache.clear()
 
 
-def _default_ops():
-    from .engine import HIP_OPS
-    return HIP_OPS
+def _default_ops(params=None):
+    from .engine import ops_for
+    return ops_for(params)
 
 
 def _kp(k):
@@ -104,7 +104,7 @@ class nmf_algorithms_1D(_Base):
         self.rank = self.comm1.rank
         self.local_W_m = self.W_i.shape[0]
         self.local_H_n = self.H_j.shape[1]
-        self.ops = ops if ops is not None else _default_ops()
+        self.ops = ops if ops is not None else _default_ops(params)
 
     def update(self, clamp=False):
         """One step; `clamp=True` additionally applies H = max(H, eps), W = max(W, eps) after it
@@ -260,7 +260,7 @@ class nmf_algorithms_2D(_Base):
         self.rank = self.comm1.rank
         self.local_W_m = self.W_ij.shape[0]
         self.local_H_n = self.H_ij.shape[1]
-        self.ops = ops if ops is not None else _default_ops()
+        self.ops = ops if ops is not None else _default_ops(params)
         # per-member slice sizes inside the sub-communicators: the partition rule (utils.py:99-103), unless pruning
         # changed them (then PyNMF has exchanged the actual sizes once and left them on params)
         from .utils import determine_block_params

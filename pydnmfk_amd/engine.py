@@ -287,3 +287,83 @@ class HipOps:
 
 
 HIP_OPS = HipOps()
+
+
+class HipOpsBf16x6(HipOps):
+    """The same operator set with the two big contractions A H^T and W^T A of an fp32 data matrix taken on the bf16 matrix
+    cores as sums of six bf16 piece products (`dnmf_*_bf16x6`, csrc/dnmf_split.h): fp32-grade products at a rate the HBM,
+    not the fp32 MFMA, bounds.  Opt-in (`params.gemm = 'bf16x6'`); shapes without a split kernel and bf16-stored A run the
+    fp32 kernels, everything else of a step is the fp32 code either way."""
+
+    name = "hip-bf16x6"
+
+    @staticmethod
+    def _ws6(m, n, k, device):
+        nbytes = lib.dnmf_ws_bytes_bf16x6(int(m), int(n), int(k))
+        if nbytes == 0:
+            raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+        key = ("x6", device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _ws_cache[key] = ws
+        return ws
+
+    def aht(self, A, H, out):
+        if _req_a(A):
+            return super().aht(A, H, out)
+        _req(H, "H"); _req(out, "AH")
+        m, n = A.shape
+        k = H.shape[0]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_aht_bf16x6(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out),
+                                  ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def wta(self, A, W, out):
+        if _req_a(A):
+            return super().wta(A, W, out)
+        _req(W, "W"); _req(out, "AtW")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_wta_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
+                                  ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def aht_update_w(self, A, H, G, W, eps):
+        if _req_a(A):
+            return super().aht_update_w(A, H, G, W, eps)
+        _req(H, "H"); _req(G, "G"); _req(W, "W")
+        m, n = A.shape
+        k = H.shape[0]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_aht_update_w_bf16x6(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
+                                           _ld(W), float(eps), ws.data_ptr(), ws.numel(), _stream()))
+
+    def mu_fro_step(self, A, W, H, eps, w_update=True, clamp=False):
+        if _req_a(A):
+            return super().mu_fro_step(A, W, H, eps, w_update, clamp)
+        _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_mu_fro_step_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+                                          float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
+                                          _stream()))
+
+
+HIP_OPS_BF16X6 = HipOpsBf16x6()
+
+
+
+def ops_for(params=None):
+    """The operator set `params` asks for: `params.gemm` = 'fp32' (default: the fp32-MFMA contractions, the parity
+    reference) or 'bf16x6' (HipOpsBf16x6)."""
+    mode = getattr(params, "gemm", None) or "fp32"
+    if mode == "fp32":
+        return HIP_OPS
+    if mode == "bf16x6":
+        return HIP_OPS_BF16X6
+    raise ValueError("params.gemm = %r: expected 'fp32' or 'bf16x6'" % (mode,))

@@ -144,8 +144,8 @@ class PyNMF:
 
     def _ops(self):
         if self.ops is None:
-            from .engine import HIP_OPS
-            self.ops = HIP_OPS
+            from .engine import ops_for
+            self.ops = ops_for(self.params)
         return self.ops
 
     def _out(self, t):

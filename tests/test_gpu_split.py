@@ -1,0 +1,154 @@
+"""bf16x6: the contractions A H^T and W^T A as six bf16 piece products per fp32 product (csrc/dnmf_split.h).  The claim
+tested here is "fp32 grade": against a float64 product the split path is as close as the fp32-MFMA path, the updates built
+on it follow the fp32 ones to rounding level, the goldens of the fp32 path pass at the same tolerances, and shapes without a
+split kernel run the fp32 kernels bit for bit."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def _ops():
+    from pydnmfk_amd.engine import HIP_OPS, HIP_OPS_BF16X6, new_gram
+    return HIP_OPS, HIP_OPS_BF16X6, new_gram
+
+
+def _rand(m, n, k, seed, scale=None):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A = torch.rand(m, n, device=dev, generator=g)
+    W = torch.rand(m, k, device=dev, generator=g)
+    H = torch.rand(k, n, device=dev, generator=g)
+    if scale == "wide":           # entries over 12 decades, both signs of the exponent: the pieces of tiny and huge values
+        A = A * torch.exp(14.0 * (torch.rand(m, n, device=dev, generator=g) - 0.5))
+        H = H * torch.exp(14.0 * (torch.rand(k, n, device=dev, generator=g) - 0.5))
+        W = W * torch.exp(14.0 * (torch.rand(m, k, device=dev, generator=g) - 0.5))
+    return A, W, H
+
+
+@pytest.mark.parametrize("m,n,k,scale", [(4096, 1024, 64, None), (5000, 2048, 40, None), (100, 128, 33, None),
+                                         (777, 384, 64, None), (4096, 1024, 64, "wide"), (16384, 8192, 64, None)])
+def test_products_are_fp32_grade(m, n, k, scale):
+    """max and rms relative error against float64: the split path is within 1.25x of the fp32-MFMA path (it is usually the
+    closer one: 16 products per accumulator update instead of 2), and both are at rounding level."""
+    f32, x6, _ = _ops()
+    A, W, H = _rand(m, n, k, 11, scale)
+    dev = A.device
+    AH0, AH1 = torch.empty(m, k, device=dev), torch.empty(m, k, device=dev)
+    AtW0, AtW1 = torch.empty(k, n, device=dev), torch.empty(k, n, device=dev)
+    f32.aht(A, H, AH0); x6.aht(A, H, AH1)
+    f32.wta(A, W, AtW0); x6.wta(A, W, AtW1)
+    ref_ah = A.double() @ H.double().t()
+    ref_wa = W.double().t() @ A.double()
+    for got0, got1, ref, depth in ((AH0, AH1, ref_ah, n), (AtW0, AtW1, ref_wa, m)):
+        e0 = ((got0.double() - ref) / ref).abs()
+        e1 = ((got1.double() - ref) / ref).abs()
+        assert float(e1.max()) <= max(1.25 * float(e0.max()), 8 * EPS)
+        assert float(e1.pow(2).mean().sqrt()) <= max(1.25 * float(e0.pow(2).mean().sqrt()), 2 * EPS)
+        assert float(e1.max()) <= 4 * EPS * np.sqrt(depth)          # rounding level for a sum of `depth` positive terms
+
+
+@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 40), (300, 256, 50)])
+def test_fused_w_update_and_step_follow_fp32(m, n, k):
+    f32, x6, new_gram = _ops()
+    A, W, H = _rand(m, n, k, 5)
+    G = f32.gram_hht(H, new_gram(k, A.device))
+    Wa, Wb = W.clone(), W.clone()
+    f32.aht_update_w(A, H, G, Wa, EPS)
+    x6.aht_update_w(A, H, G, Wb, EPS)
+    assert float((Wa - Wb).abs().max() / Wa.abs().max()) < 5e-6       # both are ~3e-6 from the float64 result at this depth
+    Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+    for i in range(10):
+        f32.mu_fro_step(A, Wa, Ha, EPS, True, i % 10 == 0)
+        x6.mu_fro_step(A, Wb, Hb, EPS, True, i % 10 == 0)
+    assert float((Wa - Wb).norm() / Wa.norm()) < 1e-5 and float((Ha - Hb).norm() / Ha.norm()) < 1e-5
+    assert torch.isfinite(Wb).all() and torch.isfinite(Hb).all()
+
+
+def test_step_matches_oracle_at_fp32_tolerance():
+    """The fp32 path's own parity bar (tests/test_gpu_parity.py: one MU step against the numpy restatement, 1e-5)."""
+    from oracle import nmf_oracle as orc
+    _, x6, _ = _ops()
+    rs = np.random.RandomState(3)
+    m, n, k = 2048, 512, 48
+    A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.01 * rs.randn(m, n)).astype(np.float32)
+    W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+    Wr, Hr = orc.fro_mu_step_local(A, W0.copy(), H0.copy(), np.float32(EPS))
+    dev = torch.device("cuda")
+    Ad, Wd, Hd = (torch.from_numpy(v).to(dev) for v in (A, W0, H0))
+    x6.mu_fro_step(Ad, Wd, Hd, EPS, True, False)
+    assert np.linalg.norm(Wd.cpu().numpy() - Wr) / np.linalg.norm(Wr) < 1e-5
+    assert np.linalg.norm(Hd.cpu().numpy() - Hr) / np.linalg.norm(Hr) < 1e-5
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 700, 40), (4096, 1024, 16), (2048, 512, 128), (512, 1000, 64)])
+def test_shapes_without_a_split_kernel_run_the_fp32_kernels(m, n, k):
+    f32, x6, _ = _ops()
+    A, W, H = _rand(m, n, k, 9)
+    Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+    for _ in range(3):
+        f32.mu_fro_step(A, Wa, Ha, EPS)
+        x6.mu_fro_step(A, Wb, Hb, EPS)
+    assert torch.equal(Wa, Wb) and torch.equal(Ha, Hb)
+    out0, out1 = torch.empty(k, n, device=A.device), torch.empty(k, n, device=A.device)
+    assert torch.equal(f32.wta(A, W, out0), x6.wta(A, W, out1))
+
+
+def test_split_steps_are_bitwise_reproducible():
+    _, x6, _ = _ops()
+    A, W, H = _rand(8192, 1024, 64, 21)
+    outs = []
+    for _ in range(2):
+        Wc, Hc = W.clone(), H.clone()
+        for i in range(6):
+            x6.mu_fro_step(A, Wc, Hc, EPS, True, i % 10 == 0)
+        outs.append((Wc, Hc))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_views_with_a_row_pitch_and_zero_rows():
+    """A as a column slice of a wider matrix (lda > n) and all-zero rows / columns (0 * pieces stay 0, no NaN)."""
+    f32, x6, _ = _ops()
+    m, n, k = 1024, 512, 64
+    big, W, H = _rand(m, 768, k, 4)
+    A = big[:, 128:128 + n]
+    A[17] = 0
+    A[:, 5] = 0
+    H = H[:, :n].contiguous()
+    o0, o1 = torch.empty(m, k, device=A.device), torch.empty(m, k, device=A.device)
+    f32.aht(A, H, o0); x6.aht(A, H, o1)
+    assert float(o1[17].abs().max()) == 0.0
+    assert float((o0 - o1).abs().max() / o0.abs().max()) < 5e-6
+    t0, t1 = torch.empty(k, n, device=A.device), torch.empty(k, n, device=A.device)
+    f32.wta(A, W, t0); x6.wta(A, W, t1)
+    assert float(t1[:, 5].abs().max()) == 0.0
+    assert float((t0 - t1).abs().max() / t0.abs().max()) < 5e-6
+
+
+def test_pynmf_with_gemm_option_matches_default():
+    """params.gemm = 'bf16x6' through the reference-shaped entry point: same factors as the default to rounding level."""
+    from pydnmfk_amd.pyDNMF import PyNMF
+    from pydnmfk_amd.utils import parse
+    from pydnmfk_amd.dist_comm import MPI_comm
+    rs = np.random.RandomState(0)
+    m, n, k = 1024, 512, 40
+    A = np.abs(rs.rand(m, k) @ rs.rand(k, n)).astype(np.float32)
+    W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+    res = []
+    for gemm in ("fp32", "bf16x6"):
+        comms = MPI_comm(None, 1, 1)
+        p = parse()
+        p.comm1, p.comm, p.p_r, p.p_c, p.k = comms.comm, comms, 1, 1, k
+        p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        p.norm, p.method, p.itr, p.init, p.verbose, p.prune, p.W_update, p.gemm = "fro", "mu", 30, "rand", False, False, True, gemm
+        W, H, err = PyNMF(A, factors=[W0.copy(), H0.copy()], params=p).fit()
+        res.append((np.asarray(W), np.asarray(H), err))
+    assert np.linalg.norm(res[0][0] - res[1][0]) / np.linalg.norm(res[0][0]) < 1e-4
+    assert np.linalg.norm(res[0][1] - res[1][1]) / np.linalg.norm(res[0][1]) < 1e-4
+    with pytest.raises(ValueError):
+        from pydnmfk_amd.engine import ops_for
+        bad = parse(); bad.gemm = "fp8"
+        ops_for(bad)
