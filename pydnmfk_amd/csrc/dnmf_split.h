@@ -63,6 +63,12 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& s1, u32x4& s2
 // the six piece products of one 32 x 32 x 16 tile step, small terms first
 __device__ __forceinline__ void mfma_x6(f32x16& acc, const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b1,
                                         const u32x4& b2, const u32x4& b3) {
+#ifdef DNMF_TUNING_3PROD      // timing experiment only (wrong results): how much of the pass is the matrix pipe?
+    acc = mfma_bf16(a2, b1, acc);
+    acc = mfma_bf16(a1, b2, acc);
+    acc = mfma_bf16(a1, b1, acc);
+    return;
+#endif
     acc = mfma_bf16(a3, b1, acc);
     acc = mfma_bf16(a2, b2, acc);
     acc = mfma_bf16(a1, b3, acc);

@@ -109,8 +109,9 @@ def run_case(name, use_hip=False, timeout=240, extra=None):
             assert dw <= tol and dh <= tol and de <= 1e-5, (name, rank, itr, dw, dh, de)
 
 
-def run_bf16_rank(rank, world, port, grid, method, q, use_hip):
-    """PyNMF with params.precision = 'bfloat16' on a p_r x p_c grid == the oracle's grid simulation on float(bf16(A))."""
+def run_bf16_rank(rank, world, port, grid, method, q, use_hip, cfg=None):
+    """PyNMF with params.precision = 'bfloat16' on a p_r x p_c grid == the oracle's grid simulation on float(bf16(A)).
+    `cfg` = {"shape": (m, n, k, itr), "precision": ..., "gemm": ...} varies the problem (default: the bf16 case)."""
     try:
         import numpy as np
         import torch.distributed as dist
@@ -130,22 +131,30 @@ def run_bf16_rank(rank, world, port, grid, method, q, use_hip):
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         p_r, p_c = grid
-        m, n, k, itr = 50, 38, 4, 12
+        cfg = cfg or {}
+        m, n, k, itr = cfg.get("shape", (50, 38, 4, 12))
+        precision = cfg.get("precision", "bfloat16")
         rs = np.random.RandomState(11)
         A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.05 * rs.randn(m, n)).astype(np.float32)
         W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
-        Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy()
+        Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy() if precision == "bfloat16" else A
         Wr, Hr, err_r = orc.SimGrid(Ar, W0, H0, p_r, p_c, norm="fro", W_update=True, method=method).fit(itr)
         comms = MPI_comm(None, p_r, p_c)
         args = parse()
         args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, k
         args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
         args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
-        args.norm, args.method, args.W_update, args.precision = "fro", method, True, "bfloat16"
+        args.norm, args.method, args.W_update, args.precision = "fro", method, True, precision
+        if cfg.get("gemm"):
+            args.gemm = cfg["gemm"]
+        if cfg.get("overlap_min_cols"):
+            args.overlap_min_cols = cfg["overlap_min_cols"]
         s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
         (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, m, n)
         nmf = PyNMF(A[s[0]:e[0] + 1, s[1]:e[1] + 1], factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops)
-        assert nmf.A_ij.dtype == torch.bfloat16
+        assert nmf.A_ij.dtype == (torch.bfloat16 if precision == "bfloat16" else torch.float32)
+        if cfg.get("gemm") and use_hip:
+            assert nmf._ops().name == "hip-" + cfg["gemm"]
         W, H, err = nmf.fit()
         q.put((rank, (rel_fro(W, Wr[rank]), rel_fro(H, Hr[rank]), abs(err - err_r)), None))
         if world > 1:
@@ -155,12 +164,12 @@ def run_bf16_rank(rank, world, port, grid, method, q, use_hip):
         q.put((rank, None, traceback.format_exc()))
 
 
-def run_bf16(grid, method, use_hip=False, timeout=240):
+def run_bf16(grid, method, use_hip=False, timeout=240, cfg=None):
     world = grid[0] * grid[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_bf16_rank, args=(r, world, port, grid, method, q, use_hip)) for r in range(world)]
+    procs = [ctx.Process(target=run_bf16_rank, args=(r, world, port, grid, method, q, use_hip, cfg)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=timeout) for _ in procs]

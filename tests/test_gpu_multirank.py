@@ -35,6 +35,16 @@ def test_multirank_hip_bf16_storage(grid, method):
     run_bf16(grid, method, use_hip=True)
 
 
+@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), ((1, 2), "mu"), ((2, 2), "mu"), ((2, 1), "hals"), ((4, 1), "mu")])
+def test_multirank_hip_bf16x6_gemm(grid, method):
+    """params.gemm = 'bf16x6' on a grid: the split kernels on every rank's block (k = 40, local n a multiple of 128; the
+    4 x 1 grid takes the overlapped H phase on column halves of A), checked against the oracle's grid simulation at the fp32
+    path's tolerances."""
+    from tests._mp import run_bf16
+    run_bf16(grid, method, use_hip=True, cfg={"shape": (512, 512, 40, 8), "precision": "float32", "gemm": "bf16x6",
+                                              "overlap_min_cols": 128})
+
+
 def test_multirank_hip_overlapped_h_phase():
     """The chunked / overlapped H phase of row grids with more than two ranks, real kernels on column views of A and H."""
     from tests._mp import run_case
