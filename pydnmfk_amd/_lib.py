@@ -68,6 +68,9 @@ SIGNATURES["dnmf_aht_bf16x6"] = SIGNATURES["dnmf_aht"][:-1] + [c_void_p, c_size_
 SIGNATURES["dnmf_wta_bf16x6"] = SIGNATURES["dnmf_wta"]
 SIGNATURES["dnmf_aht_update_w_bf16x6"] = SIGNATURES["dnmf_aht_update_w"][:-1] + [c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_mu_fro_step_bf16x6"] = SIGNATURES["dnmf_mu_fro_step"]
+SIGNATURES["dnmf_kl_uht_bf16x6"] = SIGNATURES["dnmf_kl_uht"]
+SIGNATURES["dnmf_kl_wtu_bf16x6"] = SIGNATURES["dnmf_kl_wtu"]
+SIGNATURES["dnmf_mu_kl_step_bf16x6"] = SIGNATURES["dnmf_mu_kl_step"]
 _RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t}
 
 

@@ -845,7 +845,7 @@ int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, siz
     const int nblk = (int)cdiv(m, rows_per_blk);
     if (ws_bytes < (size_t)nblk * kp * sizeof(float)) return fail(DNMF_EWS, "colsum: workspace too small");
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, S(stream), W, m, k, ldw, rows_per_blk, (float*)ws, kp);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(kp), 0, S(stream), (const float*)ws, nblk, kp, k, x);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, S(stream), (const float*)ws, nblk, kp, k, x);
     return check_launch("colsum");
 }
 

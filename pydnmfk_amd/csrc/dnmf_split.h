@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
     *reinterpret_cast<u32x4*>(dst + 2 * split_stride) = s3;
 }
 
-// S[s][c][r] = piece s of W[r][c] (the image is W TRANSPOSED) for c < 32 * gridDim.y, r < ld_s; zero outside [m x k].
+// S[s][c][r] = piece s of W[r][c] (the image is W TRANSPOSED) for c < 32 * gridDim.y, r < min(ld_s, 64 * gridDim.x); zero
+// outside [m x k].
 // A wave takes 64 rows x 8 columns: lane (cb = l & 7, rb = l >> 3) reads W[r0 + 8 rb + i][c0 + cb], i = 0..7, and stores the
 // eight row pieces of its column as 16 bytes; the lanes rb = 0..7 of one column fill one whole 128-B line.
 __global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restrict__ W, long ldw, long m, int k,
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restric
     for (int i = 0; i < 8; ++i) v[i] = (r0 + i < m && c < k) ? W[(r0 + i) * ldw + c] : 0.f;
     u32x4 s1, s2, s3;
     split8(v, s1, s2, s3);
+    if (r0 >= ld_s) return;                                         // images narrower than 64 rows (H^T with KP = 32)
     bf16_t* dst = S + c * ld_s + r0;
     *reinterpret_cast<u32x4*>(dst) = s1;
     *reinterpret_cast<u32x4*>(dst + split_stride) = s2;

@@ -3,6 +3,7 @@
 #include "dnmf_common.h"
 #include "dnmf_host.h"
 #include "dnmf_split.h"
+#include "dnmf_split_kl.h"
 
 // workspace layout of the fused steps, owned by dnmf.hip: {g_off, s_off, x_off, part_off, total}
 __attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]);
@@ -85,6 +86,72 @@ int launch_ntx(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
     return check_launch("ntx_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------- KL products
+// k <= 64 (KT = 1, 2), whole 128-column blocks, 16-byte aligned rows of A; other shapes run the fp32 kernels.
+bool klx_shape(const float* A, long m, long n, long lda, int k) {
+    return k >= 1 && k <= 64 && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+           n < (1L << 19) && tune("DNMF_SPLIT_KL", 1) != 0;
+}
+
+struct KlxImages { SplitOperand wp, ht; };
+long klx_mpad(long m) { return round_up(m, 128); }
+size_t klx_w_bytes(long m, int kp) { return align256((size_t)3 * klx_mpad(m) * kp * sizeof(bf16_t)); }
+size_t klx_h_bytes(long n, int kp) { return align256((size_t)3 * n * kp * sizeof(bf16_t)); }
+
+struct WtuxPlan { int nt, ncolblk; long rowblks_per_chunk, nchunks, ldp; };
+WtuxPlan plan_wtux(long m, long n, int kt) {
+    WtuxPlan p;
+    p.nt = 2;
+    p.ncolblk = (int)(n / (32 * p.nt));
+    const long nrowblk = cdiv(m, 32);
+    const long target = kt == 1 ? 3072 : 2048;                        // waves: one resident round
+    long nchunks = std::max<long>(1, target / p.ncolblk);
+    nchunks = std::min<long>(nchunks, std::max<long>(1, nrowblk / 4));
+    nchunks = std::max<long>(nchunks, cdiv(m * n * 16, 1L << 30));   // 32-bit offsets inside a chunk, lda <= 4 n
+    p.rowblks_per_chunk = cdiv(nrowblk, nchunks);
+    p.nchunks = cdiv(nrowblk, p.rowblks_per_chunk);
+    p.ldp = n;
+    return p;
+}
+size_t wtux_need(long m, long n, int k) {
+    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const WtuxPlan p = plan_wtux(m, n, kt);
+    return align256((size_t)p.nchunks * kp * p.ldp * sizeof(float)) + reduce_scratch_bytes((int)p.nchunks, k, n);
+}
+
+struct UhtxPlan { int nsplit; long cols_per_split; };
+UhtxPlan plan_uhtx(long m, long n) {
+    UhtxPlan u;
+    const long rowtiles = cdiv(m, 128);
+    long ns = std::max<long>(1, cdiv(1024, rowtiles));
+    ns = std::min<long>(ns, std::max<long>(1, n / 256));
+    u.cols_per_split = round_up(cdiv(n, ns), 32);
+    u.nsplit = (int)cdiv(n, u.cols_per_split);
+    return u;
+}
+size_t uhtx_need(long m, long n, int k) {
+    const int kp = k <= 32 ? 32 : 64;
+    const UhtxPlan u = plan_uhtx(m, n);
+    return u.nsplit > 1 ? align256((size_t)u.nsplit * m * kp * sizeof(float)) + reduce_scratch_bytes(u.nsplit, (int)m, k) : 0;
+}
+size_t klx_need(long m, long n, int k) {                              // images + the larger of the two partial areas
+    const int kp = k <= 32 ? 32 : 64;
+    return klx_w_bytes(m, kp) + klx_h_bytes(n, kp) + std::max(wtux_need(m, n, k), uhtx_need(m, n, k));
+}
+
+// wp [piece][m_pad][kp] = pieces of W as it lies in memory; ht [piece][n][kp] = pieces of H transposed
+int klx_images(const float* W, long m, long ldw, const float* H, long n, long ldh, int k, int kp, char* base, KlxImages& im,
+               hipStream_t st) {
+    const long mp = klx_mpad(m);
+    im.wp.S = (bf16_t*)base; im.wp.ld = kp; im.wp.split_stride = mp * kp;
+    im.ht.S = (bf16_t*)(base + klx_w_bytes(m, kp)); im.ht.ld = kp; im.ht.split_stride = n * kp;
+    hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)cdiv(mp * (kp / 8), 256)), dim3(256), 0, st, W, ldw,
+                       (int)std::min<long>(m, INT32_MAX), (long)k, const_cast<bf16_t*>(im.wp.S), (long)kp, im.wp.split_stride, (int)mp);
+    hipLaunchKernelGGL(split3_cols_kernel, dim3(1, (unsigned)(n / 32)), dim3(256), 0, st, H, ldh, (long)k, (int)n,
+                       const_cast<bf16_t*>(im.ht.S), (long)kp, im.ht.split_stride);
+    return check_launch("split3 (KL images)");
+}
+
 }  // namespace
 
 extern "C" {
@@ -92,8 +159,10 @@ extern "C" {
 size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
     const size_t base = dnmf_ws_bytes(m, n, k);
     if (!base) return 0;
-    if (!(k > 32 && k <= 64 && n % 128 == 0)) return base;
-    return align256(base) + h_image_bytes(n) + wta_need(m, n, k);
+    size_t extra = 0;
+    if (k > 32 && k <= 64 && n % 128 == 0) extra = h_image_bytes(n) + wta_need(m, n, k);
+    if (k <= 64 && n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));
+    return align256(base) + extra;
 }
 
 int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
@@ -180,6 +249,92 @@ int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, 
     if ((rc = dnmf_wta_bf16x6(A, m, n, lda, W, k, ldw, Sb, ldatw, img + h_image_bytes(n), img_bytes - h_image_bytes(n), stream))) return rc;
     if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
+    return DNMF_OK;
+}
+
+int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                       float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    if (!klx_shape(A, m, n, lda, k)) return dnmf_kl_wtu(A, m, n, lda, W, ldw, H, ldh, k, eps, WTU, ldo, ws, ws_bytes, stream);
+    REQUIRE(W && H && WTU && ws && ldw >= k && ldh >= n && ldo >= n, "kl_wtu_bf16x6: bad arguments");
+    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const size_t img = klx_w_bytes(m, kp) + klx_h_bytes(n, kp), need = img + wtux_need(m, n, k);
+    if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu_bf16x6: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t st = S(stream);
+    KlxArgs a{};
+    KlxImages im;
+    int rc = klx_images(W, m, ldw, H, n, ldh, k, kp, (char*)ws, im, st);
+    if (rc) return rc;
+    const WtuxPlan p = plan_wtux(m, n, kt);
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps;
+    a.wp = im.wp; a.ht = im.ht;
+    a.P = (float*)((char*)ws + img); a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
+    a.nrowblk = cdiv(m, 32); a.ncolblk = p.ncolblk; a.rowblks_per_chunk = p.rowblks_per_chunk; a.nchunks = p.nchunks;
+    const dim3 grid((unsigned)(cdiv(p.nchunks, 4) * p.ncolblk)), block(256);
+    const size_t lds = (size_t)3 * 32 * p.nt * kp * sizeof(bf16_t) + 4ul * 3 * 32 * kp * sizeof(bf16_t);   // H^T tile + 4 W block images
+    static bool once = false;
+    if (!once) { allow_lds(klx_wtu_kernel<1, 2>, 3 * 64 * 32 * 2 + 12 * 32 * 32 * 2); allow_lds(klx_wtu_kernel<2, 2>, 3 * 64 * 64 * 2 + 12 * 32 * 64 * 2); once = true; }
+    if (kt == 1) hipLaunchKernelGGL((klx_wtu_kernel<1, 2>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((klx_wtu_kernel<2, 2>), grid, block, lds, st, a);
+    if ((rc = check_launch("klx_wtu_kernel"))) return rc;
+    const size_t pbytes = align256((size_t)p.nchunks * kp * p.ldp * sizeof(float));
+    return launch_reduce(a.P, a.chunk_stride, a.ldp, (int)p.nchunks, WTU, ldo, k, n, k, n, (float*)((char*)a.P + pbytes), st);
+}
+
+int dnmf_kl_uht_bf16x6(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                       float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    if (!klx_shape(A, m, n, lda, k)) return dnmf_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, UHT, ldo, ws, ws_bytes, stream);
+    REQUIRE(W && H && UHT && ws && ldw >= k && ldh >= n && ldo >= k, "kl_uht_bf16x6: bad arguments");
+    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const size_t img = klx_w_bytes(m, kp) + klx_h_bytes(n, kp), need = img + uhtx_need(m, n, k);
+    if (ws_bytes < need) return fail(DNMF_EWS, "kl_uht_bf16x6: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t st = S(stream);
+    KlxArgs a{};
+    KlxImages im;
+    int rc = klx_images(W, m, ldw, H, n, ldh, k, kp, (char*)ws, im, st);
+    if (rc) return rc;
+    const UhtxPlan u = plan_uhtx(m, n);
+    const bool split = u.nsplit > 1;
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps;
+    a.wp = im.wp; a.ht = im.ht;
+    a.out = split ? (float*)((char*)ws + img) : UHT;
+    a.ldo = split ? kp : ldo; a.split_stride = (long)m * kp; a.cols_per_split = u.cols_per_split; a.out_cols = split ? kp : k;
+    const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
+    static bool once = false;
+    if (!once) { allow_lds(klx_uht_kernel<1>, 2 * UhtStage<1>::BYTES); allow_lds(klx_uht_kernel<2>, 2 * UhtStage<2>::BYTES); once = true; }
+    if (kt == 1) hipLaunchKernelGGL((klx_uht_kernel<1>), grid, block, 2 * UhtStage<1>::BYTES, st, a);
+    else hipLaunchKernelGGL((klx_uht_kernel<2>), grid, block, 2 * UhtStage<2>::BYTES, st, a);
+    if ((rc = check_launch("klx_uht_kernel")) || !split) return rc;
+    const size_t pbytes = align256((size_t)u.nsplit * m * kp * sizeof(float));
+    return launch_reduce(a.out, a.split_stride, kp, u.nsplit, UHT, ldo, (int)m, k, (int)m, k, (float*)((char*)a.out + pbytes), st);
+}
+
+int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                           int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    if (!klx_shape(A, m, n, lda, k)) return dnmf_mu_kl_step(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
+    REQUIRE(W && H && ws, "mu_kl_step_bf16x6: bad arguments");
+    const size_t total = dnmf_ws_bytes_bf16x6(m, n, k);
+    if (ws_bytes < total) return fail(DNMF_EWS, "mu_kl_step_bf16x6: workspace %zu < %zu", ws_bytes, total);
+    size_t off[5];
+    dnmf_ws_offsets_(m, n, k, off);
+    char* base = (char*)ws;
+    float* Sb = (float*)(base + off[1]);
+    float* x = (float*)(base + off[2]);
+    void* part = base + off[3];
+    const size_t part_bytes = off[4] - off[3];
+    char* img = base + align256(off[4]);
+    const size_t img_bytes = total - align256(off[4]);
+    int rc;
+    if (w_update) {                                                                   // dist_nmf.py:813-830
+        const long ldu = round_up(k, 4);
+        if ((rc = dnmf_rowsum(H, k, n, ldh, x, stream))) return rc;
+        if ((rc = dnmf_kl_uht_bf16x6(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldu, img, img_bytes, stream))) return rc;
+        if ((rc = dnmf_kl_update_w(W, m, k, ldw, Sb, ldu, x, eps, stream))) return rc;
+    }
+    const long ldo = round_up(n, 4);                                                  // dist_nmf.py:832-849
+    if ((rc = dnmf_colsum(W, m, k, ldw, x, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_kl_wtu_bf16x6(A, m, n, lda, W, ldw, H, ldh, k, eps, Sb, ldo, img, img_bytes, stream))) return rc;
+    if ((rc = dnmf_kl_update_h(H, k, n, ldh, Sb, ldo, x, eps, clamp, stream))) return rc;
+    if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);
     return DNMF_OK;
 }
 

@@ -187,12 +187,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-__global__ void colsum_final_kernel(const float* partial, int nblk, int kp, int k, float* x) {
-    const int j = threadIdx.x;
-    if (j >= k) return;
+// x[j] = sum over the slab partials, fp64.  One workgroup of 1024 threads: thread (j, g) adds slabs g, g + G, ... (G = 1024 / kp)
+// in order, the G sums of a column are combined in fixed order through LDS -> deterministic.  (One thread per column walking
+// all slabs was a 60 us latency chain at 256 slabs: 4 % of a KL step.)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int kp, int k,
+                                                            float* __restrict__ x) {
+    __shared__ double red[1024];
+    const int j = threadIdx.x % kp, g = threadIdx.x / kp, G = 1024 / kp;
     double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)partial[(long)b * kp + j];
-    x[j] = (float)acc;
+    for (int b = g; b < nblk; b += G) acc += (double)partial[(long)b * kp + j];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && j < k) {
+        for (int q = 1; q < G; ++q) acc += red[q * kp + j];
+        x[j] = (float)acc;
+    }
 }
 
 

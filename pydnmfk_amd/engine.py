@@ -354,6 +354,34 @@ class HipOpsBf16x6(HipOps):
                                           _stream()))
 
 
+    def kl_uht(self, A, W, H, eps, out):
+        _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "UHT")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_kl_uht_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                                     out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def kl_wtu(self, A, W, H, eps, out):
+        _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "WTU")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_kl_wtu_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                                     out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def mu_kl_step(self, A, W, H, eps, w_update=True, clamp=False):
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws6(m, n, k, A.device)
+        check(lib.dnmf_mu_kl_step_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+                                         float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
+                                         _stream()))
+
+
 HIP_OPS_BF16X6 = HipOpsBf16x6()
 
 

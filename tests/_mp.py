@@ -138,13 +138,14 @@ def run_bf16_rank(rank, world, port, grid, method, q, use_hip, cfg=None):
         A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.05 * rs.randn(m, n)).astype(np.float32)
         W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
         Ar = torch.from_numpy(A).to(torch.bfloat16).float().numpy() if precision == "bfloat16" else A
-        Wr, Hr, err_r = orc.SimGrid(Ar, W0, H0, p_r, p_c, norm="fro", W_update=True, method=method).fit(itr)
+        norm = cfg.get("norm", "fro")
+        Wr, Hr, err_r = orc.SimGrid(Ar, W0, H0, p_r, p_c, norm=norm, W_update=True, method=method).fit(itr)
         comms = MPI_comm(None, p_r, p_c)
         args = parse()
         args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, k
         args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
         args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
-        args.norm, args.method, args.W_update, args.precision = "fro", method, True, precision
+        args.norm, args.method, args.W_update, args.precision = norm, method, True, precision
         if cfg.get("gemm"):
             args.gemm = cfg["gemm"]
         if cfg.get("overlap_min_cols"):

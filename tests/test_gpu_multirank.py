@@ -45,6 +45,13 @@ def test_multirank_hip_bf16x6_gemm(grid, method):
                                               "overlap_min_cols": 128})
 
 
+@pytest.mark.parametrize("grid", [(2, 1), (1, 2), (2, 2)])
+def test_multirank_hip_bf16x6_kl(grid):
+    """KL updates with params.gemm = 'bf16x6' on a grid (k = 12: the split KL kernels on every block, 2D slices included)."""
+    from tests._mp import run_bf16
+    run_bf16(grid, "mu", use_hip=True, cfg={"shape": (512, 512, 12, 8), "precision": "float32", "gemm": "bf16x6", "norm": "kl"})
+
+
 def test_multirank_hip_overlapped_h_phase():
     """The chunked / overlapped H phase of row grids with more than two ranks, real kernels on column views of A and H."""
     from tests._mp import run_case

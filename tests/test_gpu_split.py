@@ -152,3 +152,89 @@ def test_pynmf_with_gemm_option_matches_default():
         from pydnmfk_amd.engine import ops_for
         bad = parse(); bad.gemm = "fp8"
         ops_for(bad)
+
+
+# ---------------------------------------------------------------------------------------------- KL products
+def _kl_ref(A, W, H, eps):
+    U = A.double() / (W.double() @ H.double() + eps)
+    return U @ H.double().t(), W.double().t() @ U
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 512, 16), (1000, 384, 40), (333, 128, 5), (4096, 1024, 64), (130, 256, 1),
+                                   (2048, 2048, 32), (5000, 1280, 33)])
+def test_kl_products_are_fp32_grade(m, n, k):
+    """U H^T and W^T U with U = A / (W H + eps): the split path against float64, next to the fp32-MFMA path."""
+    f32, x6, _ = _ops()
+    A, W, H = _rand(m, n, k, 13)
+    dev = A.device
+    ref_u, ref_t = _kl_ref(A, W, H, EPS)
+    for name, ref, shape in (("kl_uht", ref_u, (m, k)), ("kl_wtu", ref_t, (k, n))):
+        o0, o1 = torch.empty(*shape, device=dev), torch.empty(*shape, device=dev)
+        getattr(f32, name)(A, W, H, EPS, o0)
+        getattr(x6, name)(A, W, H, EPS, o1)
+        e0 = ((o0.double() - ref) / ref).abs()
+        e1 = ((o1.double() - ref) / ref).abs()
+        assert float(e1.max()) <= max(1.25 * float(e0.max()), 8 * EPS), name
+        assert float(e1.pow(2).mean().sqrt()) <= max(1.25 * float(e0.pow(2).mean().sqrt()), 2 * EPS), name
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 384, 40), (2048, 512, 8), (4096, 1024, 64)])
+def test_kl_step_follows_fp32_and_oracle(m, n, k):
+    from oracle import nmf_oracle as orc
+    f32, x6, _ = _ops()
+    rs = np.random.RandomState(8)
+    A = np.abs(rs.rand(m, k) @ rs.rand(k, n) + 0.01 * rs.randn(m, n)).astype(np.float32)
+    W0, H0 = rs.rand(m, k).astype(np.float32), rs.rand(k, n).astype(np.float32)
+    Wr, Hr = orc.kl_mu_step_local(A, W0.copy(), H0.copy(), np.float32(EPS))
+    dev = torch.device("cuda")
+    Ad = torch.from_numpy(A).to(dev)
+    Wb, Hb = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+    x6.mu_kl_step(Ad, Wb, Hb, EPS, True, False)
+    assert np.linalg.norm(Wb.cpu().numpy() - Wr) / np.linalg.norm(Wr) < 1e-5      # the fp32 path's bar for one step
+    assert np.linalg.norm(Hb.cpu().numpy() - Hr) / np.linalg.norm(Hr) < 1e-5
+    Wa, Ha = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+    Wb, Hb = Wa.clone(), Ha.clone()
+    for i in range(10):
+        f32.mu_kl_step(Ad, Wa, Ha, EPS, True, i % 10 == 0)
+        x6.mu_kl_step(Ad, Wb, Hb, EPS, True, i % 10 == 0)
+    assert float((Wa - Wb).norm() / Wa.norm()) < 1e-5 and float((Ha - Hb).norm() / Ha.norm()) < 1e-5
+
+
+def test_kl_zero_rows_and_views():
+    """All-zero rows / columns of A give exact zeros (U = 0 / (S + eps)), A as a column view of a wider matrix."""
+    f32, x6, _ = _ops()
+    m, n, k = 777, 256, 12
+    big, W, H = _rand(m, 512, k, 17)
+    A = big[:, 128:128 + n]
+    A[5] = 0
+    A[:, 9] = 0
+    H = H[:, :n].contiguous()
+    u0, u1 = torch.empty(m, k, device=A.device), torch.empty(m, k, device=A.device)
+    f32.kl_uht(A, W, H, EPS, u0); x6.kl_uht(A, W, H, EPS, u1)
+    assert float(u1[5].abs().max()) == 0.0 and float((u0 - u1).abs().max() / u0.abs().max()) < 5e-6
+    t0, t1 = torch.empty(k, n, device=A.device), torch.empty(k, n, device=A.device)
+    f32.kl_wtu(A, W, H, EPS, t0); x6.kl_wtu(A, W, H, EPS, t1)
+    assert float(t1[:, 9].abs().max()) == 0.0 and float((t0 - t1).abs().max() / t0.abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 700, 40), (2048, 512, 128)])
+def test_kl_shapes_without_a_split_kernel_run_the_fp32_kernels(m, n, k):
+    f32, x6, _ = _ops()
+    A, W, H = _rand(m, n, k, 19)
+    Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+    for _ in range(2):
+        f32.mu_kl_step(A, Wa, Ha, EPS)
+        x6.mu_kl_step(A, Wb, Hb, EPS)
+    assert torch.equal(Wa, Wb) and torch.equal(Ha, Hb)
+
+
+def test_kl_split_steps_are_bitwise_reproducible():
+    _, x6, _ = _ops()
+    A, W, H = _rand(4096, 1024, 20, 23)
+    outs = []
+    for _ in range(2):
+        Wc, Hc = W.clone(), H.clone()
+        for i in range(5):
+            x6.mu_kl_step(A, Wc, Hc, EPS, True, i % 10 == 0)
+        outs.append((Wc, Hc))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
