@@ -185,7 +185,7 @@ def run_bf16(grid, method, use_hip=False, timeout=240, cfg=None):
 
 def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
     """examples/dist_pynmfk_2d_Swim.py of the reference: swim.mat on a 2 x 2 grid, KL / MU, rand init, noise 0.016,
-    sill_thr 0.6, the default 20 perturbations; `cfg` = (start_k, end_k, itr)."""
+    sill_thr 0.6, the default 20 perturbations; `cfg` = (start_k, end_k, itr[, gemm])."""
     try:
         import time
         import numpy as np
@@ -215,6 +215,8 @@ def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
         args.start_k, args.end_k, args.sill_thr, args.itr, args.init = cfg[0], cfg[1], 0.6, cfg[2], "rand"
         args.noise_var, args.verbose, args.norm, args.method, args.checkpoint = 0.016, False, "kl", "mu", False
         args.precision = np.float32
+        if len(cfg) > 3:
+            args.gemm = cfg[3]
         tmp = [tempfile.mkdtemp() if rank == 0 else None]
         dist.broadcast_object_list(tmp, src=0)
         args.results_path = tmp[0] + "/"

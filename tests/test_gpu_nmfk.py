@@ -161,16 +161,17 @@ def test_swim_2x2_kl_known_answer():
     assert all(o[0] == 16 for o in outs), outs
 
 
-def test_swim_2x2_kl_nmfk_short(tmp_path):
+@pytest.mark.parametrize("gemm", ["fp32", "bf16x6"])
+def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):
     """The same example cut to what fits the regular GPU tier (k = 16..17, 800 iterations): every rank of the 2 x 2 grid
     runs the 2D KL choreography inside NMFk, the four ranks agree on the estimate and on the silhouettes, and the
     clustering of k = 17 (one feature too many for the 16 swimmer limbs) is unstable.  The known answer itself needs the
     reference's 5000 iterations (KL / MU converges slowly: at 1000 the k = 16 silhouette is still 0.54 < sill_thr)."""
     from tests._mp import run_swim_nmfk
-    outs = run_swim_nmfk((16, 17, 800), use_hip=True, timeout=900)
+    outs = run_swim_nmfk((16, 17, 800, gemm), use_hip=True, timeout=900)        # bf16x6: the split KL kernels on every block
     assert len({o[0] for o in outs}) == 1
     for o in outs[1:]:
         assert o[1] == outs[0][1]
     sil = outs[0][1]
     assert sil[17] < 0.3 and sil[16] > sil[17], sil
-    print("swim 2x2 KL short: nopt", outs[0][0], "min silhouettes", sil, "seconds", round(outs[0][2], 1))
+    print("swim 2x2 KL short (%s): nopt" % gemm, outs[0][0], "min silhouettes", sil, "seconds", round(outs[0][2], 1))
