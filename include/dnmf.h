@@ -173,7 +173,7 @@ int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const flo
 int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
                             int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
 /* The two KL products (dist_nmf.py:806-810) in the same arithmetic: S = W H, U H^T and W^T U as bf16 piece products, U = A / (S
- * + eps) in fp32 between them.  Kernels for k <= 64, n % 128 == 0, 16-byte aligned rows of A; other shapes are forwarded to
+ * + eps) in fp32 between them.  Kernels for every k <= 128 with n % 128 == 0 and 16-byte aligned rows of A; other shapes are forwarded to
  * dnmf_kl_uht / dnmf_kl_wtu / dnmf_mu_kl_step.  Workspace: dnmf_ws_bytes_bf16x6(m, n, k). */
 int dnmf_kl_uht_bf16x6(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                        int k, float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream);

@@ -87,9 +87,9 @@ int launch_ntx(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------- KL products
-// k <= 64 (KT = 1, 2), whole 128-column blocks, 16-byte aligned rows of A; other shapes run the fp32 kernels.
+// whole 128-column blocks, 16-byte aligned rows of A; other shapes run the fp32 kernels.
 bool klx_shape(const float* A, long m, long n, long lda, int k) {
-    return k >= 1 && k <= 64 && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+    return k >= 1 && k <= DNMF_MAX_K && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT_KL", 1) != 0;
 }
 
@@ -104,7 +104,7 @@ WtuxPlan plan_wtux(long m, long n, int kt) {
     p.nt = 2;
     p.ncolblk = (int)(n / (32 * p.nt));
     const long nrowblk = cdiv(m, 32);
-    const long target = kt == 1 ? 3072 : 2048;                        // waves: one resident round
+    const long target = kt == 1 ? 3072 : (kt == 2 ? 2048 : 1024);      // waves: one resident round
     long nchunks = std::max<long>(1, target / p.ncolblk);
     nchunks = std::min<long>(nchunks, std::max<long>(1, nrowblk / 4));
     nchunks = std::max<long>(nchunks, cdiv(m * n * 16, 1L << 30));   // 32-bit offsets inside a chunk, lda <= 4 n
@@ -114,7 +114,7 @@ WtuxPlan plan_wtux(long m, long n, int kt) {
     return p;
 }
 size_t wtux_need(long m, long n, int k) {
-    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const int kt = kt_of(k), kp = 32 * kt;
     const WtuxPlan p = plan_wtux(m, n, kt);
     return align256((size_t)p.nchunks * kp * p.ldp * sizeof(float)) + reduce_scratch_bytes((int)p.nchunks, k, n);
 }
@@ -130,12 +130,12 @@ UhtxPlan plan_uhtx(long m, long n) {
     return u;
 }
 size_t uhtx_need(long m, long n, int k) {
-    const int kp = k <= 32 ? 32 : 64;
+    const int kp = 32 * kt_of(k);
     const UhtxPlan u = plan_uhtx(m, n);
     return u.nsplit > 1 ? align256((size_t)u.nsplit * m * kp * sizeof(float)) + reduce_scratch_bytes(u.nsplit, (int)m, k) : 0;
 }
 size_t klx_need(long m, long n, int k) {                              // images + the larger of the two partial areas
-    const int kp = k <= 32 ? 32 : 64;
+    const int kp = 32 * kt_of(k);
     return klx_w_bytes(m, kp) + klx_h_bytes(n, kp) + std::max(wtux_need(m, n, k), uhtx_need(m, n, k));
 }
 
@@ -147,7 +147,7 @@ int klx_images(const float* W, long m, long ldw, const float* H, long n, long ld
     im.ht.S = (bf16_t*)(base + klx_w_bytes(m, kp)); im.ht.ld = kp; im.ht.split_stride = n * kp;
     hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)cdiv(mp * (kp / 8), 256)), dim3(256), 0, st, W, ldw,
                        (int)std::min<long>(m, INT32_MAX), (long)k, const_cast<bf16_t*>(im.wp.S), (long)kp, im.wp.split_stride, (int)mp);
-    hipLaunchKernelGGL(split3_cols_kernel, dim3(1, (unsigned)(n / 32)), dim3(256), 0, st, H, ldh, (long)k, (int)n,
+    hipLaunchKernelGGL(split3_cols_kernel, dim3((unsigned)cdiv(kp, 64), (unsigned)(n / 32)), dim3(256), 0, st, H, ldh, (long)k, (int)n,
                        const_cast<bf16_t*>(im.ht.S), (long)kp, im.ht.split_stride);
     return check_launch("split3 (KL images)");
 }
@@ -161,7 +161,7 @@ size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
     if (!base) return 0;
     size_t extra = 0;
     if (k > 32 && k <= 64 && n % 128 == 0) extra = h_image_bytes(n) + wta_need(m, n, k);
-    if (k <= 64 && n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));
+    if (n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));
     return align256(base) + extra;
 }
 
@@ -256,7 +256,7 @@ int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W,
                        float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
     if (!klx_shape(A, m, n, lda, k)) return dnmf_kl_wtu(A, m, n, lda, W, ldw, H, ldh, k, eps, WTU, ldo, ws, ws_bytes, stream);
     REQUIRE(W && H && WTU && ws && ldw >= k && ldh >= n && ldo >= n, "kl_wtu_bf16x6: bad arguments");
-    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const int kt = kt_of(k), kp = 32 * kt;
     const size_t img = klx_w_bytes(m, kp) + klx_h_bytes(n, kp), need = img + wtux_need(m, n, k);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu_bf16x6: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = S(stream);
@@ -272,9 +272,14 @@ int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W,
     const dim3 grid((unsigned)(cdiv(p.nchunks, 4) * p.ncolblk)), block(256);
     const size_t lds = (size_t)3 * 32 * p.nt * kp * sizeof(bf16_t) + 4ul * 3 * 32 * kp * sizeof(bf16_t);   // H^T tile + 4 W block images
     static bool once = false;
-    if (!once) { allow_lds(klx_wtu_kernel<1, 2>, 3 * 64 * 32 * 2 + 12 * 32 * 32 * 2); allow_lds(klx_wtu_kernel<2, 2>, 3 * 64 * 64 * 2 + 12 * 32 * 64 * 2); once = true; }
+    if (!once) {
+        allow_lds(klx_wtu_kernel<1, 2>, 3 * 64 * 32 * 2 + 12 * 32 * 32 * 2); allow_lds(klx_wtu_kernel<2, 2>, 3 * 64 * 64 * 2 + 12 * 32 * 64 * 2);
+        allow_lds(klx_wtu_kernel<4, 2>, 3 * 64 * 128 * 2 + 12 * 32 * 128 * 2);
+        once = true;
+    }
     if (kt == 1) hipLaunchKernelGGL((klx_wtu_kernel<1, 2>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((klx_wtu_kernel<2, 2>), grid, block, lds, st, a);
+    else if (kt == 2) hipLaunchKernelGGL((klx_wtu_kernel<2, 2>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((klx_wtu_kernel<4, 2>), grid, block, lds, st, a);
     if ((rc = check_launch("klx_wtu_kernel"))) return rc;
     const size_t pbytes = align256((size_t)p.nchunks * kp * p.ldp * sizeof(float));
     return launch_reduce(a.P, a.chunk_stride, a.ldp, (int)p.nchunks, WTU, ldo, k, n, k, n, (float*)((char*)a.P + pbytes), st);
@@ -284,7 +289,7 @@ int dnmf_kl_uht_bf16x6(const float* A, long m, long n, long lda, const float* W,
                        float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
     if (!klx_shape(A, m, n, lda, k)) return dnmf_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, UHT, ldo, ws, ws_bytes, stream);
     REQUIRE(W && H && UHT && ws && ldw >= k && ldh >= n && ldo >= k, "kl_uht_bf16x6: bad arguments");
-    const int kt = k <= 32 ? 1 : 2, kp = 32 * kt;
+    const int kt = kt_of(k), kp = 32 * kt;
     const size_t img = klx_w_bytes(m, kp) + klx_h_bytes(n, kp), need = img + uhtx_need(m, n, k);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_uht_bf16x6: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = S(stream);
@@ -300,9 +305,14 @@ int dnmf_kl_uht_bf16x6(const float* A, long m, long n, long lda, const float* W,
     a.ldo = split ? kp : ldo; a.split_stride = (long)m * kp; a.cols_per_split = u.cols_per_split; a.out_cols = split ? kp : k;
     const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
     static bool once = false;
-    if (!once) { allow_lds(klx_uht_kernel<1>, 2 * UhtStage<1>::BYTES); allow_lds(klx_uht_kernel<2>, 2 * UhtStage<2>::BYTES); once = true; }
+    if (!once) {
+        allow_lds(klx_uht_kernel<1>, 2 * UhtStage<1>::BYTES); allow_lds(klx_uht_kernel<2>, 2 * UhtStage<2>::BYTES);
+        allow_lds(klx_uht_kernel<4>, 2 * UhtStage<4>::BYTES);
+        once = true;
+    }
     if (kt == 1) hipLaunchKernelGGL((klx_uht_kernel<1>), grid, block, 2 * UhtStage<1>::BYTES, st, a);
-    else hipLaunchKernelGGL((klx_uht_kernel<2>), grid, block, 2 * UhtStage<2>::BYTES, st, a);
+    else if (kt == 2) hipLaunchKernelGGL((klx_uht_kernel<2>), grid, block, 2 * UhtStage<2>::BYTES, st, a);
+    else hipLaunchKernelGGL((klx_uht_kernel<4>), grid, block, 2 * UhtStage<4>::BYTES, st, a);
     if ((rc = check_launch("klx_uht_kernel")) || !split) return rc;
     const size_t pbytes = align256((size_t)u.nsplit * m * kp * sizeof(float));
     return launch_reduce(a.out, a.split_stride, kp, u.nsplit, UHT, ldo, (int)m, k, (int)m, k, (float*)((char*)a.out + pbytes), st);

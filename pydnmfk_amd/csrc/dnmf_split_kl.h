@@ -64,7 +64,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int KT>
 __device__ __forceinline__ int wblk_off(int row, int chunk) {       // byte offset of 16-byte chunk `chunk` of row `row`
     if constexpr (KT == 1) return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4);
-    else return row * 128 + ((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+    else if constexpr (KT == 2) return row * 128 + ((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+    else return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);   // cdna_hip_programming.md T10, image (b)
 }
 
 __device__ __forceinline__ u32x2 lds_tr16(const char* p) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ u32x2 lds_tr16(const char* p) {
 }
 
 template <int KT, int NT>
-__global__ __launch_bounds__(256, 2) void klx_wtu_kernel(KlxArgs p) {
+__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void klx_wtu_kernel(KlxArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     constexpr int KP = 32 * KT, CW = 32 * NT, CR = 4 * KT;           // CR chunks of 8 k per row
@@ -356,7 +357,7 @@ __device__ __forceinline__ void klx_uht_body(const KlxArgs& p, float* smem) {
 }
 
 template <int KT>
-__global__ __launch_bounds__(256, 2) void klx_uht_kernel(KlxArgs p) {
+__global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void klx_uht_kernel(KlxArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (((long)blockIdx.x + 1) * 128 <= p.m) klx_uht_body<KT, true, 2>(p, smem);
     else klx_uht_body<KT, false, 2>(p, smem);
