@@ -63,7 +63,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int KT>
 __device__ __forceinline__ int wblk_off(int row, int chunk) {       // byte offset of 16-byte chunk `chunk` of row `row`
-    if constexpr (KT == 1) return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4);
+    if constexpr (KT == 1) return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);      // (row reads go in the lane groups of MI355X_MICROARCH.md, LDS table)
     else if constexpr (KT == 2) return row * 128 + ((chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
     else return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);   // cdna_hip_programming.md T10, image (b)
 }
@@ -359,7 +359,8 @@ __device__ __forceinline__ void klx_uht_body(const KlxArgs& p, float* smem) {
 template <int KT>
 __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void klx_uht_kernel(KlxArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (((long)blockIdx.x + 1) * 128 <= p.m) klx_uht_body<KT, true, 2>(p, smem);
+    constexpr int NSET = 2;      // (4 sets at KT = 1: 229 registers, two waves per SIMD instead of three, no faster)
+    if (((long)blockIdx.x + 1) * 128 <= p.m) klx_uht_body<KT, true, NSET>(p, smem);
     else klx_uht_body<KT, false, 2>(p, smem);
 }
 
