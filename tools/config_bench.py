@@ -24,11 +24,13 @@ def params(k, norm, method, m, n):
     return p
 
 
-def step_ms(A, k, norm, method, steps=20, warm=3):
+def step_ms(A, k, norm, method, steps=20, warm=3, gemm=None):
     m, n = A.shape
     g = torch.Generator(device=dev); g.manual_seed(2)
     W = torch.rand(m, k, device=dev, generator=g); H = torch.rand(k, n, device=dev, generator=g)
     p = params(k, norm, method, m, n)
+    if gemm:
+        p.gemm = gemm
     for i in range(warm): nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(steps): nmf_algorithms_1D(A, W, H, params=p).update(clamp=(i % 10 == 0))
@@ -42,6 +44,8 @@ if "c2" in which:
     ms = step_ms(A, 32, "fro", "mu", steps=50)
     print(json.dumps({"config": "c2: MU/FRO 65536x4096 fp32 k=32, 1 GPU", "ms_per_iter": round(ms, 4), "iter_per_s": round(1e3 / ms, 1),
                       "algorithmic_hbm_gbs": round(2 * A.numel() * 4 / ms / 1e6, 1)}))
+    ms6 = step_ms(A, 32, "fro", "mu", steps=50, gemm="bf16x6")      # k <= 32: no split kernel, forwarded to the fp32 ones
+    print(json.dumps({"config": "c2 with params.gemm = 'bf16x6' (k <= 32 runs the fp32 kernels)", "ms_per_iter": round(ms6, 4)}))
     ms16 = step_ms(A.to(torch.bfloat16), 32, "fro", "mu", steps=50)
     print(json.dumps({"config": "c2 with bf16-stored X", "ms_per_iter": round(ms16, 4), "iter_per_s": round(1e3 / ms16, 1)}))
     del A
@@ -51,6 +55,8 @@ if "c4" in which:
     fl = 8.0 * 32768 * 32768 * 128
     print(json.dumps({"config": "c4 per-rank proxy: MU/KL 32768x32768 fp32 k=128 (one block of 131072x65536 on 4x2)", "ms_per_iter": round(ms, 3),
                       "tflops": round(fl / ms / 1e9, 1)}))
+    ms6 = step_ms(A, 128, "kl", "mu", steps=10, gemm="bf16x6")
+    print(json.dumps({"config": "c4 per-rank proxy with params.gemm = 'bf16x6'", "ms_per_iter": round(ms6, 3), "speedup": round(ms / ms6, 2)}))
     del A
 if "c5k" in which:
     A = torch.rand(65536, 4096, device=dev, generator=g)
