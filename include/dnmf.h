@@ -160,7 +160,7 @@ int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* 
  * to 2^-24 |x|) and a product is the sum of the six largest piece products, each exact in the fp32 accumulator; the dropped
  * terms are below one fp32 rounding of the product (csrc/dnmf_split.h has the bound, tests/test_gpu_split.py the measurement
  * against float64).  Opt-in: the fp32-MFMA entry points above stay the default and the reference for parity.
- * Kernels exist for 32 < k <= 64, 16-byte aligned rows of A and n % 128 == 0; any other shape is forwarded to the fp32
+ * Kernels exist for 32 < k <= 128, 16-byte aligned rows of A and n % 128 == 0; any other shape is forwarded to the fp32
  * entry point of the same name.  Same arguments as the fp32 twins plus a workspace of dnmf_ws_bytes_bf16x6(m, n, k) bytes
  * (the bf16 images of H and W^T, partial sums). ---- */
 size_t dnmf_ws_bytes_bf16x6(long m, long n, int k);

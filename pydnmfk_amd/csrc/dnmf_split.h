@@ -119,26 +119,30 @@ __global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- small-operand tile in LDS
-// [piece 3][row 32*KT][64 contraction indices = 128 B]; the eight 16-B chunks of a row are XOR-swizzled with (row >> 1) & 7,
-// which makes the ds_read_b128 of lanes (row = li, same chunk) conflict free (as lds_idx of dnmf_nt.h).
+// [piece 3][row 32*KT][XKT contraction indices = CR 16-byte chunks]; the chunks of a row are XOR-swizzled (128-byte rows:
+// (row >> 1) & 7, 64-byte rows: (row >> 2) & 3), which makes the ds_read_b128 of lanes (row = li, same chunk) conflict free
+// (as lds_idx of dnmf_nt.h).
 constexpr int XK = 64;
 struct SplitOperand { const bf16_t* S; long split_stride; long ld; };   // S[piece][row][index]
 
-template <int KT>
-__device__ __forceinline__ void tile_load(u32x4 (&v)[3 * KT], const SplitOperand& o, long k0, int tid) {
+template <int CR>
+__device__ __forceinline__ int tile_swz(int row) { return (row / (16 / CR)) & (CR - 1); }
+
+template <int KT, int CR>
+__device__ __forceinline__ void tile_load(u32x4 (&v)[3 * KT * CR / 8], const SplitOperand& o, long k0, int tid) {
 #pragma unroll
-    for (int i = 0; i < 3 * KT; ++i) {
-        const int p = tid + 256 * i, s = p / (256 * KT), row = (p >> 3) % (32 * KT), ch = p & 7;
+    for (int i = 0; i < 3 * KT * CR / 8; ++i) {
+        const int p = tid + 256 * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
         v[i] = *reinterpret_cast<const u32x4*>(o.S + s * o.split_stride + row * o.ld + k0 + ch * 8);
     }
 }
 
-template <int KT>
-__device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT], int tid) {
+template <int KT, int CR>
+__device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT * CR / 8], int tid) {
 #pragma unroll
-    for (int i = 0; i < 3 * KT; ++i) {
-        const int p = tid + 256 * i, s = p / (256 * KT), row = (p >> 3) % (32 * KT), ch = p & 7;
-        *reinterpret_cast<u32x4*>(tile + (s * 32 * KT + row) * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v[i];
+    for (int i = 0; i < 3 * KT * CR / 8; ++i) {
+        const int p = tid + 256 * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
+        *reinterpret_cast<u32x4*>(tile + ((s * 32 * KT + row) * CR + (ch ^ tile_swz<CR>(row))) * 16) = v[i];
     }
 }
 
@@ -151,22 +155,6 @@ __device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT],
 // NSET tiles are in flight: the loads of tile t + NSET are issued at the top of tile t into the register set that tile t left
 // free, tile t + 1 (loaded NSET - 1 tiles ago) goes to the other LDS stage after the MFMAs of tile t.
 constexpr int XT = 32;                                                   // contraction indices per NT tile
-
-template <int KT>
-__device__ __forceinline__ void htile_load(u32x4 (&v)[3], const SplitOperand& o, long k0, int tid) {
-    static_assert(KT == 2, "64 rows x 4 chunks = one piece image per pass of 256 threads");
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        v[s] = *reinterpret_cast<const u32x4*>(o.S + s * o.split_stride + (tid >> 2) * o.ld + k0 + (tid & 3) * 8);
-}
-
-template <int KT>
-__device__ __forceinline__ void htile_store(char* tile, const u32x4 (&v)[3], int tid) {
-    const int row = tid >> 2, ch = tid & 3;
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        *reinterpret_cast<u32x4*>(tile + (s * 32 * KT + row) * 64 + ((ch ^ ((row >> 2) & 3)) << 4)) = v[s];
-}
 
 template <int KT, bool INTERIOR, bool NTX, int NSET>
 __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* __restrict__ X, long ldx, long nrows, long row0,
@@ -186,18 +174,19 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* 
         return cbeg + (long)t * XT;
     };
     f32x4 xv[NSET][4];
-    u32x4 hv[NSET][3];
-    auto load = [&](f32x4 (&x)[4], u32x4 (&hh)[3], int t) {
+    constexpr int NH = 3 * KT / 2;                                    // 16-byte pieces of the H tile per thread
+    u32x4 hv[NSET][NH];
+    auto load = [&](f32x4 (&x)[4], u32x4 (&hh)[NH], int t) {
         const long c0 = col_of(t);
         stage_load<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
-        htile_load<KT>(hh, ys, c0, tid);
+        tile_load<KT, 4>(hh, ys, c0, tid);
     };
-    auto store = [&](char* st, const f32x4 (&x)[4], const u32x4 (&hh)[3]) {
+    auto store = [&](char* st, const f32x4 (&x)[4], const u32x4 (&hh)[NH]) {
         stage_store<128, 256>(reinterpret_cast<float*>(st), x, tid);
-        htile_store<KT>(st + XB, hh, tid);
+        tile_store<KT, 4>(st + XB, hh, tid);
     };
     const int xrow = wave * 32 + li;
-    const int hsw = (li >> 2) & 3;
+    const int hsw = tile_swz<4>(li);
     auto compute = [&](const char* st) {
         const float* xc = reinterpret_cast<const float*>(st);
         const char* hc = st + XB;
@@ -234,7 +223,7 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* 
     }
 }
 
-template <int KT, int MODE, int AUX, int NSET = 4>
+template <int KT, int MODE, int AUX, int NSET = (KT == 2 ? 4 : 2)>
 __global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -288,16 +277,17 @@ __global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) 
 }
 
 // ---------------------------------------------------------------------------------------------- W^T A (partial sums per row chunk)
-// Workgroup = 4 waves on 4 adjacent 128-column blocks of one row chunk, sharing the staged W^T tiles.  MFMA step = 16 rows:
-// lane (g = l & 31, h = l >> 5) reads rows r + 8 h + i (i = 0..7), columns col0 + 4 g + [0, 4) -- 512 contiguous bytes per row
-// and half wave -- and column j of that block is its B fragment (k = 8 h + i) of output tile j, whose 32 columns are
-// col0 + 4 g' + j.  acc[kt][j] (reg, lane) = C[kt * 32 + crow(reg, h)][col0 + 4 li + j]: the four tiles of a lane store as one
-// float4.
-template <int KT, int AUX>
+// Workgroup = 4 waves on 4 adjacent blocks of 32 NT columns of one row chunk, sharing the staged W^T tiles (XKT rows of A per
+// tile).  MFMA step = 16 rows: lane (g = l & 31, h = l >> 5) reads rows r + 8 h + i (i = 0..7), columns col0 + NT g + [0, NT)
+// -- contiguous per row and half wave -- and column j of that block is its B fragment (k = 8 h + i) of output tile j, whose 32
+// columns are col0 + NT g' + j.  acc[kt][j] (reg, lane) = C[kt * 32 + crow(reg, h)][col0 + NT li + j]: the NT tiles of a lane
+// store as one vector.  NT = 4, XKT = 64 at KP = 64; KP = 128 has 4 x NT accumulator tiles, so NT = 2 there, and 32-row
+// tiles keep two workgroups per CU.
+template <int KT, int NT, int XKT, int AUX>
 __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
-    constexpr int TB = 3 * 32 * KT * 128;
+    constexpr int CR = XKT / 8, NST = XKT / 16, TB = 3 * 32 * KT * CR * 16, CW = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb4 = (p.ncolblk + 3) / 4;
@@ -305,69 +295,69 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
     int colblk = (int)(blockIdx.x % cb4) * 4 + wave;
     const bool live = colblk < p.ncolblk;
     colblk = live ? colblk : p.ncolblk - 1;
-    const long col0 = (long)colblk * 128;
+    const long col0 = (long)colblk * CW;
     const long rbeg = chunk * p.rows_per_chunk;
     long rend = rbeg + p.rows_per_chunk;
     if (rend > p.nrows) rend = p.nrows;
-    const int nch = (int)((rend - rbeg + XK - 1) / XK);
+    const int nch = (int)((rend - rbeg + XKT - 1) / XKT);
     const float* A = static_cast<const float*>(p.Y) + rbeg * p.ldy + col0;
     const long left = ((p.nrows - rbeg) * p.ldy - col0) * 4;          // rows past the end of A read as zeros
     i32x4 rs = buf_rsrc(A);
     rs[2] = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffL ? left : 0x7fffffffL));
-    const int voff = (int)((8 * h * p.ldy + 4 * li) * 4);
+    const int voff = (int)((8 * h * p.ldy + NT * li) * 4);
     const int rowb = (int)(p.ldy * 4);
 
-    f32x16 acc[KT][4];
+    f32x16 acc[KT][NT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[kt][j][r] = 0.f;
 
-    f32x4 xr[8];
-    u32x4 wv[3 * KT];
+    float xr[8][NT];
+    u32x4 wv[3 * KT * CR / 8];
     static_for<0, 8>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
-        xr[i] = buf_ld_f32x4(rs, voff, i * rowb, AUX);
+        buf_load<NT, AUX>(xr[i], rs, voff, i * rowb);
     });
-    tile_load<KT>(wv, ws, rbeg, tid);
-    tile_store<KT>(lds, wv, tid);
+    tile_load<KT, CR>(wv, ws, rbeg, tid);
+    tile_store<KT, CR>(lds, wv, tid);
     __syncthreads();
-    int fo[4];               // fragment of step st: row li, chunk 2 st + h
+    int fo[NST];             // fragment of step st: row li, chunk 2 st + h
 #pragma unroll
-    for (int st = 0; st < 4; ++st) fo[st] = li * 128 + (((2 * st + h) ^ ((li >> 1) & 7)) << 4);
-    const int nsteps = 4 * nch;
+    for (int st = 0; st < NST; ++st) fo[st] = (li * CR + ((2 * st + h) ^ tile_swz<CR>(li))) * 16;
+    const int nsteps = NST * nch;
     for (int c = 0; c < nch; ++c) {
         const int cn = c + 1 < nch ? c + 1 : c;
         const char* cur = lds + (c & 1) * TB;
-        tile_load<KT>(wv, ws, rbeg + (long)cn * XK, tid);
-        static_for<0, 4>([&](auto st_) {
+        tile_load<KT, CR>(wv, ws, rbeg + (long)cn * XKT, tid);
+        static_for<0, NST>([&](auto st_) {
             constexpr int st = decltype(st_)::value;
-            u32x4 b[4][3];
+            u32x4 b[NT][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 const float v[8] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], xr[6][j], xr[7][j]};
                 split8(v, b[j][0], b[j][1], b[j][2]);
             }
-            int nx = 4 * c + st + 1;                              // next step's rows (past the end: the last step again)
+            int nx = NST * c + st + 1;                            // next step's rows (past the end: the last step again)
             nx = nx < nsteps ? nx : nsteps - 1;
             const int sbase = nx * 16 * rowb;
             static_for<0, 8>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                xr[i] = buf_ld_f32x4(rs, voff, sbase + i * rowb, AUX);
+                buf_load<NT, AUX>(xr[i], rs, voff, sbase + i * rowb);
             });
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
-                const char* f = cur + fo[st] + kt * 32 * 128;
+                const char* f = cur + fo[st] + kt * 32 * CR * 16;
                 const u32x4 a1 = *reinterpret_cast<const u32x4*>(f);
-                const u32x4 a2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * 128);
-                const u32x4 a3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * 128);
+                const u32x4 a2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
+                const u32x4 a3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
+                for (int j = 0; j < NT; ++j) mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
             }
         });
-        tile_store<KT>(lds + ((c + 1) & 1) * TB, wv, tid);
+        tile_store<KT, CR>(lds + ((c + 1) & 1) * TB, wv, tid);
         __syncthreads();
     }
 
@@ -377,9 +367,10 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = kt * 32 + crow(r, h);
-                *reinterpret_cast<f32x4*>(Pc + (long)j * p.ldp + col0 + 4 * li) =
-                    f32x4{acc[kt][0][r], acc[kt][1][r], acc[kt][2][r], acc[kt][3][r]};
+                float d[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) d[j] = acc[kt][j][r];
+                store_vec<NT, true>(d, Pc + (long)(kt * 32 + crow(r, h)) * p.ldp, col0 + (long)NT * li, p.ldp, true);
             }
     }
 }

@@ -10,19 +10,20 @@ __attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int 
 
 namespace {
 
-// The split kernels exist for 32 < k <= 64 (below that the fp32 kernels are already bound by the HBM, not by the matrix
+// The split kernels exist for 32 < k <= 128 (below that the fp32 kernels are already bound by the HBM, not by the matrix
 // cores) and take A in whole 128-byte lines: 16-byte aligned rows, n a multiple of 128.  Every other shape runs the fp32
 // kernels of dnmf.hip -- the caller gets the exact products instead.
 bool split_shape(const float* A, long m, long n, long lda, int k) {
-    return k > 32 && k <= 64 && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+    return k > 32 && k <= DNMF_MAX_K && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT", 1) != 0;
 }
 
-struct TnxPlan { int ncolblk, nchunks; long rows_per_chunk, ldp, chunk_stride; };
+struct TnxPlan { int nt, ncolblk, nchunks; long rows_per_chunk, ldp, chunk_stride; };
 
-TnxPlan plan_tnx(long m, long n) {
+TnxPlan plan_tnx(long m, long n, int kt) {
     TnxPlan p;
-    p.ncolblk = (int)(n / 128);
+    p.nt = kt == 4 ? 2 : 4;
+    p.ncolblk = (int)(n / (32 * p.nt));
     const long cb4 = cdiv(p.ncolblk, 4);
     static const long target = tune("DNMF_TNX_WGS", 512);           // one resident round: 256 CUs x 2 workgroups
     long nchunks = std::max<long>(1, target / cb4);
@@ -33,57 +34,65 @@ TnxPlan plan_tnx(long m, long n) {
     p.rows_per_chunk = round_up(cdiv(m, nchunks), XK);
     p.nchunks = (int)cdiv(m, p.rows_per_chunk);
     p.ldp = n;
-    p.chunk_stride = 64 * n;
+    p.chunk_stride = 32L * kt * n;
     return p;
 }
 
-size_t h_image_bytes(long n) { return align256((size_t)3 * 64 * round_up(n, XK) * sizeof(bf16_t)); }
-size_t w_image_bytes(long m) { return align256((size_t)3 * 64 * round_up(m, XK) * sizeof(bf16_t)); }
+size_t h_image_bytes(long n, int kp) { return align256((size_t)3 * kp * round_up(n, XK) * sizeof(bf16_t)); }
+size_t w_image_bytes(long m, int kp) { return align256((size_t)3 * kp * round_up(m, XK) * sizeof(bf16_t)); }
 
 size_t wta_need(long m, long n, int k) {
-    const TnxPlan p = plan_tnx(m, n);
-    return w_image_bytes(m) + align256((size_t)p.nchunks * p.chunk_stride * sizeof(float)) + reduce_scratch_bytes(p.nchunks, k, n);
+    const int kt = kt_of(k), kp = 32 * kt;
+    const TnxPlan p = plan_tnx(m, n, kt);
+    return w_image_bytes(m, kp) + align256((size_t)p.nchunks * p.chunk_stride * sizeof(float)) + reduce_scratch_bytes(p.nchunks, k, n);
 }
 
-int cut_h(const float* H, int k, long n, long ldh, bf16_t* img, SplitOperand& o, hipStream_t st) {
+int cut_h(const float* H, int k, int kp, long n, long ldh, bf16_t* img, SplitOperand& o, hipStream_t st) {
     o.ld = round_up(n, XK);
-    o.split_stride = 64 * o.ld;
+    o.split_stride = kp * o.ld;
     o.S = img;
-    const long threads = 64 * (o.ld / 8);
+    const long threads = kp * (o.ld / 8);
     hipLaunchKernelGGL(split3_rows_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, H, ldh, k, n, img, o.ld,
-                       o.split_stride, 64);
+                       o.split_stride, kp);
     return check_launch("split3_rows");
 }
 
-int cut_wt(const float* W, long m, int k, long ldw, bf16_t* img, SplitOperand& o, hipStream_t st) {
+int cut_wt(const float* W, long m, int k, int kp, long ldw, bf16_t* img, SplitOperand& o, hipStream_t st) {
     o.ld = round_up(m, XK);
-    o.split_stride = 64 * o.ld;
+    o.split_stride = kp * o.ld;
     o.S = img;
-    hipLaunchKernelGGL(split3_cols_kernel, dim3((unsigned)(o.ld / 64), 2), dim3(256), 0, st, W, ldw, m, k, img, o.ld, o.split_stride);
+    hipLaunchKernelGGL(split3_cols_kernel, dim3((unsigned)(o.ld / 64), (unsigned)(kp / 32)), dim3(256), 0, st, W, ldw, m, k, img, o.ld, o.split_stride);
     return check_launch("split3_cols");
 }
 
-template <int MODE>
-int launch_ntx(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
-    constexpr size_t lds = 2 * (128 * 32 * 4 + 3 * 64 * 64);      // two stages [A tile fp32 | H tile bf16 pieces]; >= the W.G loop's 49152 B
+template <int KT, int MODE>
+int launch_ntx_kt(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
+    constexpr size_t lds = 2 * (128 * 32 * 4 + 3 * 32 * KT * 64);      // two stages [A tile fp32 | H tile bf16 pieces]; >= the W.G loop's LDS
     static bool once = false;
     // A is touched once: stream it past the caches when it cannot stay in them anyway
     const bool nt = (double)a.nrows * a.ncols * 4 >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
-    static const int nset = (int)tune("DNMF_SPLIT_NSET", 4);
-    if (!once) {
-        allow_lds(ntx_kernel<2, MODE, 0, 4>, lds); allow_lds(ntx_kernel<2, MODE, 2, 4>, lds);
-        allow_lds(ntx_kernel<2, MODE, 0, 2>, lds); allow_lds(ntx_kernel<2, MODE, 2, 2>, lds);
-        once = true;
-    }
+    if (!once) { allow_lds(ntx_kernel<KT, MODE, 0>, lds); allow_lds(ntx_kernel<KT, MODE, 2>, lds); once = true; }
     const dim3 grid((unsigned)cdiv(a.nrows, 128), 1);
-    if (nset == 2) {
-        if (nt) hipLaunchKernelGGL((ntx_kernel<2, MODE, 2, 2>), grid, dim3(256), lds, st, a, ys);
-        else hipLaunchKernelGGL((ntx_kernel<2, MODE, 0, 2>), grid, dim3(256), lds, st, a, ys);
-    } else {
-        if (nt) hipLaunchKernelGGL((ntx_kernel<2, MODE, 2, 4>), grid, dim3(256), lds, st, a, ys);
-        else hipLaunchKernelGGL((ntx_kernel<2, MODE, 0, 4>), grid, dim3(256), lds, st, a, ys);
-    }
+    if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2>), grid, dim3(256), lds, st, a, ys);
+    else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0>), grid, dim3(256), lds, st, a, ys);
     return check_launch("ntx_kernel");
+}
+
+template <int MODE>
+int launch_ntx(const NtArgs& a, const SplitOperand& ys, int kt, hipStream_t st) {
+    return kt == 2 ? launch_ntx_kt<2, MODE>(a, ys, st) : launch_ntx_kt<4, MODE>(a, ys, st);
+}
+
+template <int KT, int NT, int XKT>
+int launch_tnx(const TnArgs& a, const SplitOperand& wsplit, const TnxPlan& p, long m, long n, hipStream_t st) {
+    constexpr size_t lds = 2 * 3 * 32 * KT * (XKT / 8) * 16;
+    static bool once = false;
+    if (!once) { allow_lds(tnx_kernel<KT, NT, XKT, 0>, lds); allow_lds(tnx_kernel<KT, NT, XKT, 2>, lds); once = true; }
+    const bool nt = (double)m * n * 4 >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
+    const dim3 grid((unsigned)(cdiv(p.ncolblk, 4) * p.nchunks));
+    if (nt) hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 2>), grid, dim3(256), lds, st, a, wsplit);
+    else hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 0>), grid, dim3(256), lds, st, a, wsplit);
+    return check_launch("tnx_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------- KL products
@@ -160,7 +169,7 @@ size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
     const size_t base = dnmf_ws_bytes(m, n, k);
     if (!base) return 0;
     size_t extra = 0;
-    if (k > 32 && k <= 64 && n % 128 == 0) extra = h_image_bytes(n) + wta_need(m, n, k);
+    if (k > 32 && n % 128 == 0) extra = h_image_bytes(n, 32 * kt_of(k)) + wta_need(m, n, k);
     if (n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));
     return align256(base) + extra;
 }
@@ -169,31 +178,33 @@ int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const flo
                              float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream) {
     if (!split_shape(A, m, n, lda, k)) return dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
     REQUIRE(H && G && W && ws && ldh >= n && ldw >= k, "aht_update_w_bf16x6: bad arguments");
-    if (ws_bytes < h_image_bytes(n)) return fail(DNMF_EWS, "aht_update_w_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n));
+    const int kt = kt_of(k), kp = 32 * kt;
+    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_update_w_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
     hipStream_t st = S(stream);
     SplitOperand ys;
-    int rc = cut_h(H, k, n, ldh, (bf16_t*)ws, ys, st);
+    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
     if (rc) return rc;
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
     a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
     a.wfast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
-    return launch_ntx<NT_FUSED_W>(a, ys, st);
+    return launch_ntx<NT_FUSED_W>(a, ys, kt, st);
 }
 
 int dnmf_aht_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
                     void* ws, size_t ws_bytes, void* stream) {
     if (!split_shape(A, m, n, lda, k)) return dnmf_aht(A, m, n, lda, H, k, ldh, AH, ldah, stream);
     REQUIRE(H && AH && ws && ldh >= n && ldah >= k, "aht_bf16x6: bad arguments");
-    if (ws_bytes < h_image_bytes(n)) return fail(DNMF_EWS, "aht_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n));
+    const int kt = kt_of(k), kp = 32 * kt;
+    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
     hipStream_t st = S(stream);
     SplitOperand ys;
-    int rc = cut_h(H, k, n, ldh, (bf16_t*)ws, ys, st);
+    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
     if (rc) return rc;
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
     a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
-    return launch_ntx<NT_STORE>(a, ys, st);
+    return launch_ntx<NT_STORE>(a, ys, kt, st);
 }
 
 int dnmf_wta_bf16x6(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
@@ -202,25 +213,20 @@ int dnmf_wta_bf16x6(const float* A, long m, long n, long lda, const float* W, in
     REQUIRE(W && AtW && ws && ldw >= k && ldatw >= n, "wta_bf16x6: bad arguments");
     const size_t need = wta_need(m, n, k);
     if (ws_bytes < need) return fail(DNMF_EWS, "wta_bf16x6: workspace %zu < %zu", ws_bytes, need);
+    const int kt = kt_of(k), kp = 32 * kt;
     hipStream_t st = S(stream);
     SplitOperand wsplit;
-    int rc = cut_wt(W, m, k, ldw, (bf16_t*)ws, wsplit, st);
+    int rc = cut_wt(W, m, k, kp, ldw, (bf16_t*)ws, wsplit, st);
     if (rc) return rc;
-    const TnxPlan p = plan_tnx(m, n);
-    float* P = (float*)((char*)ws + w_image_bytes(m));
+    const TnxPlan p = plan_tnx(m, n, kt);
+    float* P = (float*)((char*)ws + w_image_bytes(m, kp));
     const size_t pbytes = align256((size_t)p.nchunks * p.chunk_stride * sizeof(float));
     TnArgs a{};
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
     a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
     a.P = P; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
-    constexpr size_t lds = 2 * 3 * 64 * 128;
-    static bool once = false;
-    if (!once) { allow_lds(tnx_kernel<2, 0>, lds); allow_lds(tnx_kernel<2, 2>, lds); once = true; }
-    const bool nt = (double)m * n * 4 >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
-    const dim3 grid((unsigned)(cdiv(p.ncolblk, 4) * p.nchunks));
-    if (nt) hipLaunchKernelGGL((tnx_kernel<2, 2>), grid, dim3(256), lds, st, a, wsplit);
-    else hipLaunchKernelGGL((tnx_kernel<2, 0>), grid, dim3(256), lds, st, a, wsplit);
-    if ((rc = check_launch("tnx_kernel"))) return rc;
+    rc = kt == 2 ? launch_tnx<2, 4, 64>(a, wsplit, p, m, n, st) : launch_tnx<4, 2, 32>(a, wsplit, p, m, n, st);
+    if (rc) return rc;
     return launch_reduce(P, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)P + pbytes), st);
 }
 
@@ -246,7 +252,7 @@ int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, 
     }
     const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
     if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
-    if ((rc = dnmf_wta_bf16x6(A, m, n, lda, W, k, ldw, Sb, ldatw, img + h_image_bytes(n), img_bytes - h_image_bytes(n), stream))) return rc;
+    if ((rc = dnmf_wta_bf16x6(A, m, n, lda, W, k, ldw, Sb, ldatw, img + h_image_bytes(n, 32 * kt_of(k)), img_bytes - h_image_bytes(n, 32 * kt_of(k)), stream))) return rc;
     if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
     return DNMF_OK;

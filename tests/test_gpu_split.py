@@ -30,7 +30,8 @@ def _rand(m, n, k, seed, scale=None):
 
 
 @pytest.mark.parametrize("m,n,k,scale", [(4096, 1024, 64, None), (5000, 2048, 40, None), (100, 128, 33, None),
-                                         (777, 384, 64, None), (4096, 1024, 64, "wide"), (16384, 8192, 64, None)])
+                                         (777, 384, 64, None), (4096, 1024, 64, "wide"), (16384, 8192, 64, None),
+                                         (4096, 1024, 128, None), (5000, 2048, 100, None), (300, 256, 65, "wide")])
 def test_products_are_fp32_grade(m, n, k, scale):
     """max and rms relative error against float64: the split path is within 1.25x of the fp32-MFMA path (it is usually the
     closer one: 16 products per accumulator update instead of 2), and both are at rounding level."""
@@ -51,7 +52,7 @@ def test_products_are_fp32_grade(m, n, k, scale):
         assert float(e1.max()) <= 4 * EPS * np.sqrt(depth)          # rounding level for a sum of `depth` positive terms
 
 
-@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 40), (300, 256, 50)])
+@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 40), (300, 256, 50), (2048, 1024, 128), (1000, 384, 97)])
 def test_fused_w_update_and_step_follow_fp32(m, n, k):
     f32, x6, new_gram = _ops()
     A, W, H = _rand(m, n, k, 5)
@@ -84,7 +85,7 @@ def test_step_matches_oracle_at_fp32_tolerance():
     assert np.linalg.norm(Hd.cpu().numpy() - Hr) / np.linalg.norm(Hr) < 1e-5
 
 
-@pytest.mark.parametrize("m,n,k", [(1000, 700, 40), (4096, 1024, 16), (2048, 512, 128), (512, 1000, 64)])
+@pytest.mark.parametrize("m,n,k", [(1000, 700, 40), (4096, 1024, 16), (2048, 520, 128), (512, 1000, 64)])
 def test_shapes_without_a_split_kernel_run_the_fp32_kernels(m, n, k):
     f32, x6, _ = _ops()
     A, W, H = _rand(m, n, k, 9)
