@@ -321,7 +321,7 @@ def main():
 
     # The same step with the two big contractions as six bf16 piece products per fp32 product (opt-in, params.gemm =
     # 'bf16x6'): reported NEXT TO the fp32-MFMA headline, never as it.  Same factors, same data, every rank takes part.
-    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 64 and n % 128 == 0:
+    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
         for i in range(5):
             step_x6(i)
         ns6 = max(100, int(1.5 / max(elapsed / a.steps, 1e-6)))
@@ -361,7 +361,7 @@ def main():
         torch.cuda.synchronize()
         t = {name: sum(s.elapsed_time(e) for s, e in v) / len(v) for name, v in evs.items()}
         x6_t = None
-        if 32 < k <= 64 and n % 128 == 0:
+        if 32 < k <= 128 and n % 128 == 0:
             ops6 = ops_for(p6)
             x6_t = {"aht_update_w": event_time_ms(lambda: ops6.aht_update_w(A, H, G, W, p.eps), reps=10, warm=3)[0],
                     "wta": event_time_ms(lambda: ops6.wta(A, W, AtW), reps=10, warm=3)[0]}
@@ -447,9 +447,9 @@ def main():
             if x6_t is not None:
                 by_nt, by_tn = 4.0 * m_l * n + 8.0 * m_l * k, 4.0 * m_l * n + 4.0 * m_l * k + 4.0 * k * n
                 out["rooflines"] += [
-                    hbm_entry("ntx_kernel<KT=2,FUSED_W> (dnmf_aht_update_w_bf16x6; incl. cutting H)", x6_t["aht_update_w"], by_nt,
+                    hbm_entry("ntx_kernel<KT=%d,FUSED_W> (dnmf_aht_update_w_bf16x6; incl. cutting H)" % kt, x6_t["aht_update_w"], by_nt,
                               "bf16x6 arithmetic; algorithmic bytes = X once + W read and written", role="ntx_kernel<2, 1", workload="split"),
-                    hbm_entry("tnx_kernel<KT=2> (dnmf_wta_bf16x6; incl. cutting W^T and the reduction of the partial slabs)", x6_t["wta"], by_tn,
+                    hbm_entry("tnx_kernel<KT=%d> (dnmf_wta_bf16x6; incl. cutting W^T and the reduction of the partial slabs)" % kt, x6_t["wta"], by_tn,
                               "bf16x6 arithmetic; algorithmic bytes = X once + W once + the k x n result", role="tnx_kernel<2", workload="split")]
                 if a.gemm == "bf16x6":
                     out["roofline"] = out["rooflines"][-2]
