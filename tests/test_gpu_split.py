@@ -239,3 +239,40 @@ def test_kl_split_steps_are_bitwise_reproducible():
             x6.mu_kl_step(A, Wc, Hc, EPS, True, i % 10 == 0)
         outs.append((Wc, Hc))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_split_vs_fp32(seed):
+    """Ragged row counts, every rank tile, column views with a pitch: each split product against its fp32 twin (both within
+    rounding of the exact result, so they agree to a few 1e-6 of the largest entry)."""
+    f32, x6, new_gram = _ops()
+    rs = np.random.RandomState(1000 + seed)
+    dev = torch.device("cuda")
+    for _ in range(12):
+        m = int(rs.choice([1, 7, 31, 32, 33, 100, 129, 500, 1023, 2500]))
+        n = 128 * int(rs.randint(1, 9))
+        k = int(rs.choice([1, 2, 5, 16, 17, 32, 33, 40, 64, 65, 96, 127, 128]))
+        pitch = n + 4 * int(rs.randint(0, 3)) * int(rs.randint(0, 2))
+        g = torch.Generator(device="cuda").manual_seed(int(rs.randint(1 << 30)))
+        big = torch.rand(m, pitch, device=dev, generator=g) + 0.01
+        A = big[:, :n]
+        W = torch.rand(m, k, device=dev, generator=g) + 0.01
+        H = torch.rand(k, n, device=dev, generator=g) + 0.01
+        tag = (m, n, k, pitch)
+        for name, shape in (("aht", (m, k)), ("wta", (k, n))):
+            o0, o1 = torch.empty(*shape, device=dev), torch.empty(*shape, device=dev)
+            args = (A, H) if name == "aht" else (A, W)
+            getattr(f32, name)(*args, o0)
+            getattr(x6, name)(*args, o1)
+            assert float((o0 - o1).abs().max() / o0.abs().max()) < 5e-6, (name, tag)
+        for name, shape in (("kl_uht", (m, k)), ("kl_wtu", (k, n))):
+            o0, o1 = torch.empty(*shape, device=dev), torch.empty(*shape, device=dev)
+            getattr(f32, name)(A, W, H, EPS, o0)
+            getattr(x6, name)(A, W, H, EPS, o1)
+            assert float((o0 - o1).abs().max() / o0.abs().max()) < 5e-6, (name, tag)
+        Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+        f32.mu_fro_step(A, Wa, Ha, EPS); x6.mu_fro_step(A, Wb, Hb, EPS)
+        assert float((Wa - Wb).abs().max() / Wa.abs().max()) < 2e-5 and float((Ha - Hb).abs().max() / Ha.abs().max()) < 2e-5, tag
+        Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+        f32.mu_kl_step(A, Wa, Ha, EPS); x6.mu_kl_step(A, Wb, Hb, EPS)
+        assert float((Wa - Wb).abs().max() / Wa.abs().max()) < 2e-5 and float((Ha - Hb).abs().max() / Ha.abs().max()) < 2e-5, tag
