@@ -172,6 +172,17 @@ int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const flo
                              const float* G, float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream);
 int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
                             int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+/* The same four with A STORED as bfloat16 (dnmf_*_bf16a above): A is then its own single piece, a product is the sum of three
+ * bf16 piece products (A times the three pieces of the fp32 factor), each exact in the fp32 accumulator -- the result equals
+ * the fp32-MFMA twin on float(A) to fp32 rounding, at half the HBM bytes and a quarter of the matrix work of the fp32 A case. */
+int dnmf_aht_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
+                          float* AH, long ldah, void* ws, size_t ws_bytes, void* stream);
+int dnmf_wta_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* W, int k, long ldw,
+                          float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+int dnmf_aht_update_w_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
+                                   const float* G, float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream);
+int dnmf_mu_fro_step_bf16a_bf16x6(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
+                                  int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
 /* The two KL products (dist_nmf.py:806-810) in the same arithmetic: S = W H, U H^T and W^T U as bf16 piece products, U = A / (S
  * + eps) in fp32 between them.  Kernels for every k <= 128 with n % 128 == 0 and 16-byte aligned rows of A; other shapes are forwarded to
  * dnmf_kl_uht / dnmf_kl_wtu / dnmf_mu_kl_step.  Workspace: dnmf_ws_bytes_bf16x6(m, n, k). */

@@ -68,6 +68,8 @@ SIGNATURES["dnmf_aht_bf16x6"] = SIGNATURES["dnmf_aht"][:-1] + [c_void_p, c_size_
 SIGNATURES["dnmf_wta_bf16x6"] = SIGNATURES["dnmf_wta"]
 SIGNATURES["dnmf_aht_update_w_bf16x6"] = SIGNATURES["dnmf_aht_update_w"][:-1] + [c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_mu_fro_step_bf16x6"] = SIGNATURES["dnmf_mu_fro_step"]
+for _n in ("aht", "wta", "aht_update_w", "mu_fro_step"):
+    SIGNATURES["dnmf_%s_bf16a_bf16x6" % _n] = SIGNATURES["dnmf_%s_bf16x6" % _n]
 SIGNATURES["dnmf_kl_uht_bf16x6"] = SIGNATURES["dnmf_kl_uht"]
 SIGNATURES["dnmf_kl_wtu_bf16x6"] = SIGNATURES["dnmf_kl_wtu"]
 SIGNATURES["dnmf_mu_kl_step_bf16x6"] = SIGNATURES["dnmf_mu_kl_step"]

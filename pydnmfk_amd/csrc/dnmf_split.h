@@ -77,6 +77,19 @@ __device__ __forceinline__ void mfma_x6(f32x16& acc, const u32x4& a1, const u32x
     acc = mfma_bf16(a1, b1, acc);
 }
 
+// bf16-STORED streamed operand: x is its own (only) piece, so a product needs the three pieces of the other factor only
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const u32x4& x, const u32x4& y1, const u32x4& y2, const u32x4& y3, bool x_is_a) {
+    if (x_is_a) {
+        acc = mfma_bf16(x, y3, acc);
+        acc = mfma_bf16(x, y2, acc);
+        acc = mfma_bf16(x, y1, acc);
+    } else {
+        acc = mfma_bf16(y3, x, acc);
+        acc = mfma_bf16(y2, x, acc);
+        acc = mfma_bf16(y1, x, acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- cutting the small operand
 // S[s][r][c] = piece s of Y[r][c] for r < rows_pad, c < ld_s (bf16; zero outside [yrows x ycols]).  One thread = 8 columns.
 __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ Y, long ldy, int yrows, long ycols,
@@ -156,14 +169,18 @@ __device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT *
 // free, tile t + 1 (loaded NSET - 1 tiles ago) goes to the other LDS stage after the MFMAs of tile t.
 constexpr int XT = 32;                                                   // contraction indices per NT tile
 
-template <int KT, bool INTERIOR, bool NTX, int NSET>
-__device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* __restrict__ X, long ldx, long nrows, long row0,
+template <int KT, bool INTERIOR, bool NTX, int NSET, typename TX>
+__device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __restrict__ X, long ldx, long nrows, long row0,
                                              const SplitOperand& ys, long cbeg, long cend, float* smem) {
-    constexpr int XB = 128 * XT * 4, HB = 3 * 32 * KT * 64, STAGE = XB + HB;      // bytes
+    // bf16-stored X: a tile is the same 128 bytes of every row = 64 contraction indices, kept in LDS as it lies in HBM; a
+    // fragment read IS the MFMA operand (no cutting), and a product is three MFMAs (the pieces of H only).
+    constexpr bool B16 = std::is_same<TX, bf16_t>::value;
+    constexpr int XTI = B16 ? 64 : XT, CR = XTI / 8;                 // indices per tile, 16-byte chunks per H-tile row
+    constexpr int XB = 128 * 128, HB = 3 * 32 * KT * CR * 16, STAGE = XB + HB;      // bytes
     char* lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = (int)((cend - cbeg) / XT);
+    const int nk = (int)((cend - cbeg) / XTI);
     if (nk <= 0) return;
     // rotated tile order per workgroup: row tiles are a power-of-two pitch apart (see nt_mainloop_)
     const int kshift = (int)((blockIdx.x * 37u) % (unsigned)nk);
@@ -171,39 +188,45 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* 
         t = t < nk ? t : nk - 1;                         // past the end: the last tile again (never used)
         t += kshift;
         t = t >= nk ? t - nk : t;
-        return cbeg + (long)t * XT;
+        return cbeg + (long)t * XTI;
     };
     f32x4 xv[NSET][4];
-    constexpr int NH = 3 * KT / 2;                                    // 16-byte pieces of the H tile per thread
+    constexpr int NH = 3 * KT * CR / 8;                               // 16-byte pieces of the H tile per thread
     u32x4 hv[NSET][NH];
     auto load = [&](f32x4 (&x)[4], u32x4 (&hh)[NH], int t) {
         const long c0 = col_of(t);
-        stage_load<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
-        tile_load<KT, 4>(hh, ys, c0, tid);
+        if constexpr (B16) stage_load_xb<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
+        else stage_load<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
+        tile_load<KT, CR>(hh, ys, c0, tid);
     };
     auto store = [&](char* st, const f32x4 (&x)[4], const u32x4 (&hh)[NH]) {
         stage_store<128, 256>(reinterpret_cast<float*>(st), x, tid);
-        tile_store<KT, 4>(st + XB, hh, tid);
+        tile_store<KT, CR>(st + XB, hh, tid);
     };
     const int xrow = wave * 32 + li;
-    const int hsw = tile_swz<4>(li);
+    const int hsw = tile_swz<CR>(li);
     auto compute = [&](const char* st) {
         const float* xc = reinterpret_cast<const float*>(st);
         const char* hc = st + XB;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h)]);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h + 1)]);
-            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int u = 0; u < XTI / 16; ++u) {
             u32x4 a1, a2, a3;
-            split8(v, a1, a2, a3);
+            if constexpr (B16) {
+                a1 = *reinterpret_cast<const u32x4*>(&xc[lds_idx(xrow, 2 * u + h)]);
+            } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h)]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h + 1)]);
+                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                split8(v, a1, a2, a3);
+            }
 #pragma unroll
             for (int jt = 0; jt < KT; ++jt) {
-                const char* f = hc + (jt * 32 + li) * 64 + (((2 * u + h) ^ hsw) << 4);
+                const char* f = hc + ((jt * 32 + li) * CR + ((2 * u + h) ^ hsw)) * 16;
                 const u32x4 b1 = *reinterpret_cast<const u32x4*>(f);
-                const u32x4 b2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * 64);
-                const u32x4 b3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * 64);
-                mfma_x6(acc[0][jt], a1, a2, a3, b1, b2, b3);
+                const u32x4 b2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
+                const u32x4 b3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
+                if constexpr (B16) mfma_x3(acc[0][jt], a1, b1, b2, b3, true);
+                else mfma_x6(acc[0][jt], a1, a2, a3, b1, b2, b3);
             }
         }
     };
@@ -211,20 +234,22 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const float* 
     store(lds, xv[0], hv[0]);
     __syncthreads();
     // tile t: set t % NSET (already in LDS stage t & 1) is refilled with tile t + NSET; set (t + 1) % NSET = tile t + 1 goes to
-    // the other stage after the MFMAs.  NSET tiles per trip (nk % NSET == 0: n % 128 == 0).
+    // the other stage after the MFMAs.  NSET tiles per trip; a trip past the end re-reads the last tile and skips its MFMAs.
     for (int t = 0; t < nk; t += NSET) {
         static_for<0, NSET>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             load(xv[i], hv[i], t + i + NSET);
-            compute(lds + (i & 1) * STAGE);
+            if (t + i < nk) compute(lds + (i & 1) * STAGE);
             store(lds + ((i + 1) & 1) * STAGE, xv[(i + 1) % NSET], hv[(i + 1) % NSET]);
             __syncthreads();
         });
     }
 }
 
-template <int KT, int MODE, int AUX, int NSET = (KT == 2 ? 4 : 2)>
-__global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
+// tiles in flight: 4 register sets at KP = 64 with fp32 A (28 registers a set), 2 where a set is 40-64 registers (KP = 128, or
+// bf16 A with its 64-index H tiles); bf16 A at KP = 128 stages 128 KiB, i.e. one workgroup per CU, and may use its registers
+template <int KT, int MODE, int AUX, typename TX = float, int NSET = ((KT == 2 && std::is_same<TX, float>::value) ? 4 : 2)>
+__global__ __launch_bounds__(256, (KT == 4 && std::is_same<TX, bf16_t>::value) ? 1 : 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -239,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][jt][r] = 0.f;
 
-    const float* X = static_cast<const float*>(p.X);
-    if (row0 + 128 <= p.nrows) ntx_mainloop<KT, true, AUX != 0, NSET>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
-    else ntx_mainloop<KT, false, false, 2>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+    const TX* X = static_cast<const TX*>(p.X);
+    if (row0 + 128 <= p.nrows) ntx_mainloop<KT, true, AUX != 0, NSET, TX>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+    else ntx_mainloop<KT, false, false, 2, TX>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
 
     if constexpr (MODE == NT_STORE) {
         float* out = p.out + (long)blockIdx.y * p.split_stride;
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void ntx_kernel(NtArgs p, SplitOperand ys) 
 // columns are col0 + NT g' + j.  acc[kt][j] (reg, lane) = C[kt * 32 + crow(reg, h)][col0 + NT li + j]: the NT tiles of a lane
 // store as one vector.  NT = 4, XKT = 64 at KP = 64; KP = 128 has 4 x NT accumulator tiles, so NT = 2 there, and 32-row
 // tiles keep two workgroups per CU.
-template <int KT, int NT, int XKT, int AUX>
+template <int KT, int NT, int XKT, int AUX, typename TX = float>
 __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
@@ -300,12 +325,16 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
     long rend = rbeg + p.rows_per_chunk;
     if (rend > p.nrows) rend = p.nrows;
     const int nch = (int)((rend - rbeg + XKT - 1) / XKT);
-    const float* A = static_cast<const float*>(p.Y) + rbeg * p.ldy + col0;
-    const long left = ((p.nrows - rbeg) * p.ldy - col0) * 4;          // rows past the end of A read as zeros
+    // bf16-stored A: the lane's 8 x NT block arrives as NT / 2 dwords per row; column j of it, packed pairwise over the
+    // rows, IS the B fragment (no cutting), and a product is three MFMAs (the pieces of W^T only)
+    constexpr bool B16 = std::is_same<TX, bf16_t>::value;
+    constexpr int EB = B16 ? 2 : 4, XW = B16 ? NT / 2 : NT;           // bytes per element, dwords per row and lane
+    const TX* A = static_cast<const TX*>(p.Y) + rbeg * p.ldy + col0;
+    const long left = ((p.nrows - rbeg) * p.ldy - col0) * EB;         // rows past the end of A read as zeros
     i32x4 rs = buf_rsrc(A);
     rs[2] = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffL ? left : 0x7fffffffL));
-    const int voff = (int)((8 * h * p.ldy + NT * li) * 4);
-    const int rowb = (int)(p.ldy * 4);
+    const int voff = (int)((8 * h * p.ldy + NT * li) * EB);
+    const int rowb = (int)(p.ldy * EB);
 
     f32x16 acc[KT][NT];
 #pragma unroll
@@ -315,11 +344,11 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[kt][j][r] = 0.f;
 
-    float xr[8][NT];
+    float xr[8][XW];
     u32x4 wv[3 * KT * CR / 8];
     static_for<0, 8>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
-        buf_load<NT, AUX>(xr[i], rs, voff, i * rowb);
+        buf_load<XW, AUX>(xr[i], rs, voff, i * rowb);
     });
     tile_load<KT, CR>(wv, ws, rbeg, tid);
     tile_store<KT, CR>(lds, wv, tid);
@@ -334,18 +363,25 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
         tile_load<KT, CR>(wv, ws, rbeg + (long)cn * XKT, tid);
         static_for<0, NST>([&](auto st_) {
             constexpr int st = decltype(st_)::value;
-            u32x4 b[NT][3];
+            u32x4 b[NT][B16 ? 1 : 3];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const float v[8] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], xr[6][j], xr[7][j]};
-                split8(v, b[j][0], b[j][1], b[j][2]);
+                if constexpr (B16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        b[j][0][q] = __builtin_amdgcn_perm(__float_as_uint(xr[2 * q + 1][j >> 1]), __float_as_uint(xr[2 * q][j >> 1]),
+                                                           (j & 1) ? 0x07060302u : 0x05040100u);
+                } else {
+                    const float v[8] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], xr[6][j], xr[7][j]};
+                    split8(v, b[j][0], b[j][1], b[j][2]);
+                }
             }
             int nx = NST * c + st + 1;                            // next step's rows (past the end: the last step again)
             nx = nx < nsteps ? nx : nsteps - 1;
             const int sbase = nx * 16 * rowb;
             static_for<0, 8>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                buf_load<NT, AUX>(xr[i], rs, voff, sbase + i * rowb);
+                buf_load<XW, AUX>(xr[i], rs, voff, sbase + i * rowb);
             });
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
@@ -354,7 +390,10 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
                 const u32x4 a2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
                 const u32x4 a3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (B16) mfma_x3(acc[kt][j], b[j][0], a1, a2, a3, false);
+                    else mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
+                }
             }
         });
         tile_store<KT, CR>(lds + ((c + 1) & 1) * TB, wv, tid);

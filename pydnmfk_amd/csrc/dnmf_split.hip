@@ -13,8 +13,10 @@ namespace {
 // The split kernels exist for 32 < k <= 128 (below that the fp32 kernels are already bound by the HBM, not by the matrix
 // cores) and take A in whole 128-byte lines: 16-byte aligned rows, n a multiple of 128.  Every other shape runs the fp32
 // kernels of dnmf.hip -- the caller gets the exact products instead.
-bool split_shape(const float* A, long m, long n, long lda, int k) {
-    return k > 32 && k <= DNMF_MAX_K && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+template <typename TA>
+bool split_shape(const TA* A, long m, long n, long lda, int k) {
+    constexpr long V = 16 / sizeof(TA);                              // elements per 16 bytes
+    return k > 32 && k <= DNMF_MAX_K && n % 128 == 0 && lda % V == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT", 1) != 0;
 }
 
@@ -65,34 +67,109 @@ int cut_wt(const float* W, long m, int k, int kp, long ldw, bf16_t* img, SplitOp
     return check_launch("split3_cols");
 }
 
-template <int KT, int MODE>
+template <int KT, int MODE, typename TX>
 int launch_ntx_kt(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
-    constexpr size_t lds = 2 * (128 * 32 * 4 + 3 * 32 * KT * 64);      // two stages [A tile fp32 | H tile bf16 pieces]; >= the W.G loop's LDS
+    // two stages [A tile, 128 rows x 128 bytes | H tile bf16 pieces (32 indices per row for fp32 A, 64 for bf16 A)]; >= the W.G loop's LDS
+    constexpr size_t lds = 2 * (128 * 128 + 3 * 32 * KT * (std::is_same<TX, bf16_t>::value ? 128 : 64));
     static bool once = false;
     // A is touched once: stream it past the caches when it cannot stay in them anyway
-    const bool nt = (double)a.nrows * a.ncols * 4 >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
-    if (!once) { allow_lds(ntx_kernel<KT, MODE, 0>, lds); allow_lds(ntx_kernel<KT, MODE, 2>, lds); once = true; }
+    const bool nt = (double)a.nrows * a.ncols * sizeof(TX) >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
+    if (!once) { allow_lds(ntx_kernel<KT, MODE, 0, TX>, lds); allow_lds(ntx_kernel<KT, MODE, 2, TX>, lds); once = true; }
     const dim3 grid((unsigned)cdiv(a.nrows, 128), 1);
-    if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2>), grid, dim3(256), lds, st, a, ys);
-    else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0>), grid, dim3(256), lds, st, a, ys);
+    if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2, TX>), grid, dim3(256), lds, st, a, ys);
+    else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0, TX>), grid, dim3(256), lds, st, a, ys);
     return check_launch("ntx_kernel");
 }
 
-template <int MODE>
+template <int MODE, typename TX>
 int launch_ntx(const NtArgs& a, const SplitOperand& ys, int kt, hipStream_t st) {
-    return kt == 2 ? launch_ntx_kt<2, MODE>(a, ys, st) : launch_ntx_kt<4, MODE>(a, ys, st);
+    return kt == 2 ? launch_ntx_kt<2, MODE, TX>(a, ys, st) : launch_ntx_kt<4, MODE, TX>(a, ys, st);
 }
 
-template <int KT, int NT, int XKT>
+template <int KT, int NT, int XKT, typename TX>
 int launch_tnx(const TnArgs& a, const SplitOperand& wsplit, const TnxPlan& p, long m, long n, hipStream_t st) {
     constexpr size_t lds = 2 * 3 * 32 * KT * (XKT / 8) * 16;
     static bool once = false;
-    if (!once) { allow_lds(tnx_kernel<KT, NT, XKT, 0>, lds); allow_lds(tnx_kernel<KT, NT, XKT, 2>, lds); once = true; }
-    const bool nt = (double)m * n * 4 >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
+    if (!once) { allow_lds(tnx_kernel<KT, NT, XKT, 0, TX>, lds); allow_lds(tnx_kernel<KT, NT, XKT, 2, TX>, lds); once = true; }
+    const bool nt = (double)m * n * sizeof(TX) >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
     const dim3 grid((unsigned)(cdiv(p.ncolblk, 4) * p.nchunks));
-    if (nt) hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 2>), grid, dim3(256), lds, st, a, wsplit);
-    else hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 0>), grid, dim3(256), lds, st, a, wsplit);
+    if (nt) hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 2, TX>), grid, dim3(256), lds, st, a, wsplit);
+    else hipLaunchKernelGGL((tnx_kernel<KT, NT, XKT, 0, TX>), grid, dim3(256), lds, st, a, wsplit);
     return check_launch("tnx_kernel");
+}
+
+// ---- the four Frobenius entry points, for fp32 and for bf16-stored A (fallbacks: the fp32-MFMA entry points of dnmf.hip)
+template <typename TA> struct Fp32Twin;
+template <> struct Fp32Twin<float> {
+    static int aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah, void* s) { return dnmf_aht(A, m, n, lda, H, k, ldh, AH, ldah, s); }
+    static int wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, void* ws, size_t wb, void* s) { return dnmf_wta(A, m, n, lda, W, k, ldw, o, ldo, ws, wb, s); }
+    static int ahtw(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G, float* W, long ldw, float eps, void* s) { return dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, s); }
+    static int step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int wu, int cl, void* ws, size_t wb, void* s) { return dnmf_mu_fro_step(A, m, n, lda, W, ldw, H, ldh, k, eps, wu, cl, ws, wb, s); }
+};
+template <> struct Fp32Twin<bf16_t> {
+    static int aht(const bf16_t* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah, void* s) { return dnmf_aht_bf16a(A, m, n, lda, H, k, ldh, AH, ldah, s); }
+    static int wta(const bf16_t* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, void* ws, size_t wb, void* s) { return dnmf_wta_bf16a(A, m, n, lda, W, k, ldw, o, ldo, ws, wb, s); }
+    static int ahtw(const bf16_t* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G, float* W, long ldw, float eps, void* s) { return dnmf_aht_update_w_bf16a(A, m, n, lda, H, k, ldh, G, W, ldw, eps, s); }
+    static int step(const bf16_t* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int wu, int cl, void* ws, size_t wb, void* s) { return dnmf_mu_fro_step_bf16a(A, m, n, lda, W, ldw, H, ldh, k, eps, wu, cl, ws, wb, s); }
+};
+
+template <typename TA>
+int ahtw_x6(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G, float* W, long ldw, float eps,
+            void* ws, size_t ws_bytes, void* stream) {
+    if (!split_shape(A, m, n, lda, k)) return Fp32Twin<TA>::ahtw(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
+    REQUIRE(H && G && W && ws && ldh >= n && ldw >= k, "aht_update_w_bf16x6: bad arguments");
+    const int kt = kt_of(k), kp = 32 * kt;
+    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_update_w_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
+    hipStream_t st = S(stream);
+    SplitOperand ys;
+    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
+    if (rc) return rc;
+    NtArgs a{};
+    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
+    a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
+    a.wfast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    return launch_ntx<NT_FUSED_W, TA>(a, ys, kt, st);
+}
+
+template <typename TA>
+int aht_x6(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah, void* ws, size_t ws_bytes,
+           void* stream) {
+    if (!split_shape(A, m, n, lda, k)) return Fp32Twin<TA>::aht(A, m, n, lda, H, k, ldh, AH, ldah, stream);
+    REQUIRE(H && AH && ws && ldh >= n && ldah >= k, "aht_bf16x6: bad arguments");
+    const int kt = kt_of(k), kp = 32 * kt;
+    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
+    hipStream_t st = S(stream);
+    SplitOperand ys;
+    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
+    if (rc) return rc;
+    NtArgs a{};
+    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
+    a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
+    return launch_ntx<NT_STORE, TA>(a, ys, kt, st);
+}
+
+template <typename TA>
+int wta_x6(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw, void* ws, size_t ws_bytes,
+           void* stream) {
+    if (!split_shape(A, m, n, lda, k)) return Fp32Twin<TA>::wta(A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
+    REQUIRE(W && AtW && ws && ldw >= k && ldatw >= n, "wta_bf16x6: bad arguments");
+    const size_t need = wta_need(m, n, k);
+    if (ws_bytes < need) return fail(DNMF_EWS, "wta_bf16x6: workspace %zu < %zu", ws_bytes, need);
+    const int kt = kt_of(k), kp = 32 * kt;
+    hipStream_t st = S(stream);
+    SplitOperand wsplit;
+    int rc = cut_wt(W, m, k, kp, ldw, (bf16_t*)ws, wsplit, st);
+    if (rc) return rc;
+    const TnxPlan p = plan_tnx(m, n, kt);
+    float* P = (float*)((char*)ws + w_image_bytes(m, kp));
+    const size_t pbytes = align256((size_t)p.nchunks * p.chunk_stride * sizeof(float));
+    TnArgs a{};
+    a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
+    a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
+    a.P = P; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
+    rc = kt == 2 ? launch_tnx<2, 4, 64, TA>(a, wsplit, p, m, n, st) : launch_tnx<4, 2, 32, TA>(a, wsplit, p, m, n, st);
+    if (rc) return rc;
+    return launch_reduce(P, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)P + pbytes), st);
 }
 
 // ---------------------------------------------------------------------------------------------- KL products
@@ -176,63 +253,37 @@ size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
 
 int dnmf_aht_update_w_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
                              float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream) {
-    if (!split_shape(A, m, n, lda, k)) return dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream);
-    REQUIRE(H && G && W && ws && ldh >= n && ldw >= k, "aht_update_w_bf16x6: bad arguments");
-    const int kt = kt_of(k), kp = 32 * kt;
-    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_update_w_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
-    hipStream_t st = S(stream);
-    SplitOperand ys;
-    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
-    if (rc) return rc;
-    NtArgs a{};
-    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
-    a.W = W; a.ldw = ldw; a.G = G; a.eps = eps; a.k = k;
-    a.wfast = aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
-    return launch_ntx<NT_FUSED_W>(a, ys, kt, st);
+    return ahtw_x6<float>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, ws, ws_bytes, stream);
+}
+int dnmf_aht_update_w_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
+                                   float* W, long ldw, float eps, void* ws, size_t ws_bytes, void* stream) {
+    return ahtw_x6<bf16_t>((const bf16_t*)A, m, n, lda, H, k, ldh, G, W, ldw, eps, ws, ws_bytes, stream);
 }
 
 int dnmf_aht_bf16x6(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
                     void* ws, size_t ws_bytes, void* stream) {
-    if (!split_shape(A, m, n, lda, k)) return dnmf_aht(A, m, n, lda, H, k, ldh, AH, ldah, stream);
-    REQUIRE(H && AH && ws && ldh >= n && ldah >= k, "aht_bf16x6: bad arguments");
-    const int kt = kt_of(k), kp = 32 * kt;
-    if (ws_bytes < h_image_bytes(n, kp)) return fail(DNMF_EWS, "aht_bf16x6: workspace %zu < %zu", ws_bytes, h_image_bytes(n, kp));
-    hipStream_t st = S(stream);
-    SplitOperand ys;
-    int rc = cut_h(H, k, kp, n, ldh, (bf16_t*)ws, ys, st);
-    if (rc) return rc;
-    NtArgs a{};
-    a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n; a.Y = H; a.ldy = ldh; a.yrows = k; a.cols_per_split = n;
-    a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
-    return launch_ntx<NT_STORE>(a, ys, kt, st);
+    return aht_x6<float>(A, m, n, lda, H, k, ldh, AH, ldah, ws, ws_bytes, stream);
+}
+int dnmf_aht_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
+                          void* ws, size_t ws_bytes, void* stream) {
+    return aht_x6<bf16_t>((const bf16_t*)A, m, n, lda, H, k, ldh, AH, ldah, ws, ws_bytes, stream);
 }
 
 int dnmf_wta_bf16x6(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
                     void* ws, size_t ws_bytes, void* stream) {
-    if (!split_shape(A, m, n, lda, k)) return dnmf_wta(A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
-    REQUIRE(W && AtW && ws && ldw >= k && ldatw >= n, "wta_bf16x6: bad arguments");
-    const size_t need = wta_need(m, n, k);
-    if (ws_bytes < need) return fail(DNMF_EWS, "wta_bf16x6: workspace %zu < %zu", ws_bytes, need);
-    const int kt = kt_of(k), kp = 32 * kt;
-    hipStream_t st = S(stream);
-    SplitOperand wsplit;
-    int rc = cut_wt(W, m, k, kp, ldw, (bf16_t*)ws, wsplit, st);
-    if (rc) return rc;
-    const TnxPlan p = plan_tnx(m, n, kt);
-    float* P = (float*)((char*)ws + w_image_bytes(m, kp));
-    const size_t pbytes = align256((size_t)p.nchunks * p.chunk_stride * sizeof(float));
-    TnArgs a{};
-    a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
-    a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
-    a.P = P; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
-    rc = kt == 2 ? launch_tnx<2, 4, 64>(a, wsplit, p, m, n, st) : launch_tnx<4, 2, 32>(a, wsplit, p, m, n, st);
-    if (rc) return rc;
-    return launch_reduce(P, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)P + pbytes), st);
+    return wta_x6<float>(A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
+}
+int dnmf_wta_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+                          void* ws, size_t ws_bytes, void* stream) {
+    return wta_x6<bf16_t>((const bf16_t*)A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
 }
 
-int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
-                            float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
-    if (!split_shape(A, m, n, lda, k)) return dnmf_mu_fro_step(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
+}  // extern "C"
+namespace {
+template <typename TA>
+int step_x6(const TA* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+            float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    if (!split_shape(A, m, n, lda, k)) return Fp32Twin<TA>::step(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
     REQUIRE(W && H && ws, "mu_fro_step_bf16x6: bad arguments");
     const size_t total = dnmf_ws_bytes_bf16x6(m, n, k);
     if (ws_bytes < total) return fail(DNMF_EWS, "mu_fro_step_bf16x6: workspace %zu < %zu", ws_bytes, total);
@@ -248,14 +299,26 @@ int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, 
     int rc;
     if (w_update) {                                                                   // dist_nmf.py:716-732
         if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
-        if ((rc = dnmf_aht_update_w_bf16x6(A, m, n, lda, H, k, ldh, G, W, ldw, eps, img, img_bytes, stream))) return rc;
+        if ((rc = ahtw_x6<TA>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, img, img_bytes, stream))) return rc;
     }
     const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
     if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
-    if ((rc = dnmf_wta_bf16x6(A, m, n, lda, W, k, ldw, Sb, ldatw, img + h_image_bytes(n, 32 * kt_of(k)), img_bytes - h_image_bytes(n, 32 * kt_of(k)), stream))) return rc;
+    if ((rc = wta_x6<TA>(A, m, n, lda, W, k, ldw, Sb, ldatw, img + h_image_bytes(n, 32 * kt_of(k)), img_bytes - h_image_bytes(n, 32 * kt_of(k)), stream))) return rc;
     if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
     return DNMF_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+                            float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    return step_x6<float>(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
+}
+int dnmf_mu_fro_step_bf16a_bf16x6(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
+                                  float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
+    return step_x6<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, stream);
 }
 
 int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,

@@ -292,8 +292,9 @@ HIP_OPS = HipOps()
 class HipOpsBf16x6(HipOps):
     """The same operator set with the two big contractions A H^T and W^T A of an fp32 data matrix taken on the bf16 matrix
     cores as sums of six bf16 piece products (`dnmf_*_bf16x6`, csrc/dnmf_split.h): fp32-grade products at a rate the HBM,
-    not the fp32 MFMA, bounds.  Opt-in (`params.gemm = 'bf16x6'`); shapes without a split kernel and bf16-stored A run the
-    fp32 kernels, everything else of a step is the fp32 code either way."""
+    not the fp32 MFMA, bounds; with bf16-STORED A (`*_bf16a_bf16x6`) A is its own single piece and a product is three MFMAs.
+    Opt-in (`params.gemm = 'bf16x6'`); shapes without a split kernel run the fp32 kernels, everything else of a step is the
+    fp32 code either way."""
 
     name = "hip-bf16x6"
 
@@ -311,45 +312,37 @@ class HipOpsBf16x6(HipOps):
         return ws
 
     def aht(self, A, H, out):
-        if _req_a(A):
-            return super().aht(A, H, out)
-        _req(H, "H"); _req(out, "AH")
+        sfx = _req_a(A); _req(H, "H"); _req(out, "AH")
         m, n = A.shape
         k = H.shape[0]
         ws = self._ws6(m, n, k, A.device)
-        check(lib.dnmf_aht_bf16x6(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out),
+        check(_fn("aht", sfx + "_bf16x6")(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out),
                                   ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def wta(self, A, W, out):
-        if _req_a(A):
-            return super().wta(A, W, out)
-        _req(W, "W"); _req(out, "AtW")
+        sfx = _req_a(A); _req(W, "W"); _req(out, "AtW")
         m, n = A.shape
         k = W.shape[1]
         ws = self._ws6(m, n, k, A.device)
-        check(lib.dnmf_wta_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
+        check(_fn("wta", sfx + "_bf16x6")(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out),
                                   ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def aht_update_w(self, A, H, G, W, eps):
-        if _req_a(A):
-            return super().aht_update_w(A, H, G, W, eps)
-        _req(H, "H"); _req(G, "G"); _req(W, "W")
+        sfx = _req_a(A); _req(H, "H"); _req(G, "G"); _req(W, "W")
         m, n = A.shape
         k = H.shape[0]
         ws = self._ws6(m, n, k, A.device)
-        check(lib.dnmf_aht_update_w_bf16x6(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
+        check(_fn("aht_update_w", sfx + "_bf16x6")(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
                                            _ld(W), float(eps), ws.data_ptr(), ws.numel(), _stream()))
 
     def mu_fro_step(self, A, W, H, eps, w_update=True, clamp=False):
-        if _req_a(A):
-            return super().mu_fro_step(A, W, H, eps, w_update, clamp)
-        _req(W, "W"); _req(H, "H")
+        sfx = _req_a(A); _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
         ws = self._ws6(m, n, k, A.device)
-        check(lib.dnmf_mu_fro_step_bf16x6(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
+        check(_fn("mu_fro_step", sfx + "_bf16x6")(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k,
                                           float(eps), int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(),
                                           _stream()))
 

@@ -52,6 +52,13 @@ def test_multirank_hip_bf16x6_kl(grid):
     run_bf16(grid, "mu", use_hip=True, cfg={"shape": (512, 512, 12, 8), "precision": "float32", "gemm": "bf16x6", "norm": "kl"})
 
 
+@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), ((2, 2), "hals")])
+def test_multirank_hip_bf16_storage_with_bf16x6(grid, method):
+    """bf16-stored blocks AND params.gemm = 'bf16x6' on a grid: the three-product kernels against the oracle on float(bf16(A))."""
+    from tests._mp import run_bf16
+    run_bf16(grid, method, use_hip=True, cfg={"shape": (512, 512, 40, 8), "precision": "bfloat16", "gemm": "bf16x6"})
+
+
 def test_multirank_hip_overlapped_h_phase():
     """The chunked / overlapped H phase of row grids with more than two ranks, real kernels on column views of A and H."""
     from tests._mp import run_case

@@ -276,3 +276,47 @@ def test_random_shapes_split_vs_fp32(seed):
         Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
         f32.mu_kl_step(A, Wa, Ha, EPS); x6.mu_kl_step(A, Wb, Hb, EPS)
         assert float((Wa - Wb).abs().max() / Wa.abs().max()) < 2e-5 and float((Ha - Hb).abs().max() / Ha.abs().max()) < 2e-5, tag
+
+
+# ---------------------------------------------------------------------------------------------- bf16-stored A: three products
+@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 100), (333, 256, 128), (100, 128, 33), (2048, 512, 40)])
+def test_bf16_stored_a_products_are_fp32_grade(m, n, k):
+    """A stored as bfloat16 is its own single piece: A times the three pieces of the fp32 factor.  Reference = float64 product of
+    float(A); the fp32-MFMA bf16a kernels are the yardstick."""
+    f32, x6, _ = _ops()
+    A, W, H = _rand(m, n, k, 31)
+    Ab = A.to(torch.bfloat16)
+    dev = A.device
+    ref_ah = Ab.double() @ H.double().t()
+    ref_wa = W.double().t() @ Ab.double()
+    for name, ref, args, shape in (("aht", ref_ah, (Ab, H), (m, k)), ("wta", ref_wa, (Ab, W), (k, n))):
+        o0, o1 = torch.empty(*shape, device=dev), torch.empty(*shape, device=dev)
+        getattr(f32, name)(*args, o0)
+        getattr(x6, name)(*args, o1)
+        e0 = ((o0.double() - ref) / ref).abs()
+        e1 = ((o1.double() - ref) / ref).abs()
+        assert float(e1.max()) <= max(1.25 * float(e0.max()), 8 * EPS), name
+        assert float(e1.pow(2).mean().sqrt()) <= max(1.25 * float(e0.pow(2).mean().sqrt()), 2 * EPS), name
+    Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+    for i in range(6):
+        f32.mu_fro_step(Ab, Wa, Ha, EPS, True, i % 10 == 0)
+        x6.mu_fro_step(Ab, Wb, Hb, EPS, True, i % 10 == 0)
+    assert float((Wa - Wb).norm() / Wa.norm()) < 1e-5 and float((Ha - Hb).norm() / Ha.norm()) < 1e-5
+
+
+def test_bf16_stored_a_fallback_shapes_and_reproducibility():
+    f32, x6, _ = _ops()
+    A, W, H = _rand(1000, 700, 40, 37)                 # n % 128 != 0: the fp32-MFMA bf16a kernels, bit for bit
+    Ab = A.to(torch.bfloat16)
+    Wa, Ha, Wb, Hb = W.clone(), H.clone(), W.clone(), H.clone()
+    f32.mu_fro_step(Ab, Wa, Ha, EPS); x6.mu_fro_step(Ab, Wb, Hb, EPS)
+    assert torch.equal(Wa, Wb) and torch.equal(Ha, Hb)
+    A, W, H = _rand(4096, 1024, 64, 41)
+    Ab = A.to(torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        Wc, Hc = W.clone(), H.clone()
+        for i in range(5):
+            x6.mu_fro_step(Ab, Wc, Hc, EPS, True, False)
+        outs.append((Wc, Hc))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -9,6 +9,8 @@ check = os.environ.get("CHECK", "1") != "0" and "--nocheck" not in sys.argv
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 A = torch.rand(m, n, device=dev, generator=g)
+if "--bf16" in sys.argv:
+    A = A.to(torch.bfloat16)          # bf16-stored X: fp32-MFMA bf16a kernels vs three bf16 piece products
 W = torch.rand(m, k, device=dev, generator=g)
 H = torch.rand(k, n, device=dev, generator=g)
 
