@@ -335,6 +335,26 @@ def main():
                         "pieces, six bf16 MFMA products per fp32 product, fp32 accumulation; as close to float64 as the fp32 "
                         "MFMA path (tests/test_gpu_split.py); the two passes over X become HBM bound"}
 
+    # Informational: the same problem with X STORED as bfloat16 (params.precision = 'bfloat16': X is rounded once, arithmetic and
+    # factors stay fp32) -- with the fp32-MFMA kernels (no gain at this rank: they are matrix-pipe bound) and with bf16x6, where
+    # X is its own single piece and a product is three bf16 MFMAs.  A different X than the headline's, hence its own key.
+    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
+        A_f32 = A
+        A = A_f32.to(torch.bfloat16)
+        res16 = {}
+        for name, fn in (("fp32_mfma", step), ("bf16x6", step_x6)):
+            for i in range(3):
+                fn(i)
+            nsb = max(50, int(0.7 / max(elapsed / a.steps, 1e-6)))
+            elb = timed(nsb, fn)
+            res16[name] = {"value": nsb / elb, "unit": "iter/s", "ms_per_step": elb / nsb * 1e3, "steps": nsb}
+        A = A_f32
+        del A_f32
+        if rank == 0:
+            res16["note"] = ("X stored as bfloat16 (half the HBM bytes; a rounded X, not the headline's fp32 X); fp32 factors and "
+                             "accumulation; bf16x6 = X times the three bf16 pieces of the fp32 factor")
+            out["bf16_stored_x"] = res16
+
     if not a.no_kernel_timing and a.norm == "fro":
         # Per-kernel HIP-event timings IN SITU: the step is replayed primitive by primitive (same launches, same order
         # as dnmf_mu_fro_step / the 1D-row choreography) with an event pair around every library call, so each kernel
