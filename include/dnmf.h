@@ -174,7 +174,8 @@ int dnmf_mu_fro_step_bf16x6(const float* A, long m, long n, long lda, float* W, 
                             int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
 /* The same four with A STORED as bfloat16 (dnmf_*_bf16a above): A is then its own single piece, a product is the sum of three
  * bf16 piece products (A times the three pieces of the fp32 factor), each exact in the fp32 accumulator -- the result equals
- * the fp32-MFMA twin on float(A) to fp32 rounding, at half the HBM bytes and a quarter of the matrix work of the fp32 A case. */
+ * the fp32-MFMA twin on float(A) to fp32 rounding, at half the HBM bytes and a quarter of the matrix work of the fp32 A case.
+ * Kernels for 16 < k <= 128 (k <= 16: the 16-wide fp32 kernels of the bf16a entry points are as fast). */
 int dnmf_aht_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
                           float* AH, long ldah, void* ws, size_t ws_bytes, void* stream);
 int dnmf_wta_bf16a_bf16x6(const void* A, long m, long n, long lda, const float* W, int k, long ldw,

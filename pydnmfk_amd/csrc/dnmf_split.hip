@@ -16,7 +16,11 @@ namespace {
 template <typename TA>
 bool split_shape(const TA* A, long m, long n, long lda, int k) {
     constexpr long V = 16 / sizeof(TA);                              // elements per 16 bytes
-    return k > 32 && k <= DNMF_MAX_K && n % 128 == 0 && lda % V == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+    // fp32 A at k <= 32 streams at the HBM rate on the fp32 kernels already.  bf16-stored A is matrix-pipe bound on them from
+    // k = 17 on (the 32-wide kernels; iteration at 262144 x 8192, k = 32: 2.39 ms, three-product kernels 1.48 ms); at k <= 16 the
+    // 16-wide fp32 kernels are as fast (1.39-1.43 ms vs 1.43-1.46 ms) and stay.
+    const int kmin = std::is_same<TA, bf16_t>::value ? 17 : 33;
+    return k >= kmin && k <= DNMF_MAX_K && n % 128 == 0 && lda % V == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT", 1) != 0;
 }
 
@@ -83,6 +87,9 @@ int launch_ntx_kt(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
 
 template <int MODE, typename TX>
 int launch_ntx(const NtArgs& a, const SplitOperand& ys, int kt, hipStream_t st) {
+    if constexpr (std::is_same<TX, bf16_t>::value) {
+        if (kt == 1) return launch_ntx_kt<1, MODE, TX>(a, ys, st);
+    }
     return kt == 2 ? launch_ntx_kt<2, MODE, TX>(a, ys, st) : launch_ntx_kt<4, MODE, TX>(a, ys, st);
 }
 
@@ -167,7 +174,10 @@ int wta_x6(const TA* A, long m, long n, long lda, const float* W, int k, long ld
     a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
     a.nrows = m; a.rows_per_chunk = p.rows_per_chunk; a.nchunks = p.nchunks; a.ncolblk = p.ncolblk;
     a.P = P; a.chunk_stride = p.chunk_stride; a.ldp = p.ldp;
-    rc = kt == 2 ? launch_tnx<2, 4, 64, TA>(a, wsplit, p, m, n, st) : launch_tnx<4, 2, 32, TA>(a, wsplit, p, m, n, st);
+    if constexpr (std::is_same<TA, bf16_t>::value) {
+        if (kt == 1) rc = launch_tnx<1, 4, 64, TA>(a, wsplit, p, m, n, st);
+    }
+    if (kt != 1) rc = kt == 2 ? launch_tnx<2, 4, 64, TA>(a, wsplit, p, m, n, st) : launch_tnx<4, 2, 32, TA>(a, wsplit, p, m, n, st);
     if (rc) return rc;
     return launch_reduce(P, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)P + pbytes), st);
 }
@@ -246,7 +256,7 @@ size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
     const size_t base = dnmf_ws_bytes(m, n, k);
     if (!base) return 0;
     size_t extra = 0;
-    if (k > 32 && n % 128 == 0) extra = h_image_bytes(n, 32 * kt_of(k)) + wta_need(m, n, k);
+    if (n % 128 == 0) extra = h_image_bytes(n, 32 * kt_of(k)) + wta_need(m, n, k);      // (k <= 32: bf16-stored A only)
     if (n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));
     return align256(base) + extra;
 }

@@ -279,7 +279,8 @@ def test_random_shapes_split_vs_fp32(seed):
 
 
 # ---------------------------------------------------------------------------------------------- bf16-stored A: three products
-@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 100), (333, 256, 128), (100, 128, 33), (2048, 512, 40)])
+@pytest.mark.parametrize("m,n,k", [(4096, 1024, 64), (5000, 2048, 100), (333, 256, 128), (100, 128, 33), (2048, 512, 40),
+                                   (4096, 1024, 32), (1000, 384, 17), (2048, 256, 24)])
 def test_bf16_stored_a_products_are_fp32_grade(m, n, k):
     """A stored as bfloat16 is its own single piece: A times the three pieces of the fp32 factor.  Reference = float64 product of
     float(A); the fp32-MFMA bf16a kernels are the yardstick."""
