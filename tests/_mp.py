@@ -185,7 +185,7 @@ def run_bf16(grid, method, use_hip=False, timeout=240, cfg=None):
 
 def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
     """examples/dist_pynmfk_2d_Swim.py of the reference: swim.mat on a 2 x 2 grid, KL / MU, rand init, noise 0.016,
-    sill_thr 0.6, the default 20 perturbations; `cfg` = (start_k, end_k, itr[, gemm])."""
+    sill_thr 0.6, the default 20 perturbations; `cfg` = (start_k, end_k, itr[, gemm[, perturbations]])."""
     try:
         import time
         import numpy as np
@@ -217,6 +217,8 @@ def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
         args.precision = np.float32
         if len(cfg) > 3:
             args.gemm = cfg[3]
+        if len(cfg) > 4:
+            args.perturbations = cfg[4]
         tmp = [tempfile.mkdtemp() if rank == 0 else None]
         dist.broadcast_object_list(tmp, src=0)
         args.results_path = tmp[0] + "/"

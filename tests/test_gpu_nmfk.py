@@ -168,7 +168,8 @@ def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):
     clustering of k = 17 (one feature too many for the 16 swimmer limbs) is unstable.  The known answer itself needs the
     reference's 5000 iterations (KL / MU converges slowly: at 1000 the k = 16 silhouette is still 0.54 < sill_thr)."""
     from tests._mp import run_swim_nmfk
-    outs = run_swim_nmfk((16, 17, 800, gemm), use_hip=True, timeout=900)        # bf16x6: the split KL kernels on every block
+    # bf16x6: the split KL kernels on every block (8 perturbations instead of 20: the check is the same, the tier stays short)
+    outs = run_swim_nmfk((16, 17, 800, gemm) + ((8,) if gemm == "bf16x6" else ()), use_hip=True, timeout=900)
     assert len({o[0] for o in outs}) == 1
     for o in outs[1:]:
         assert o[1] == outs[0][1]
