@@ -34,6 +34,15 @@ __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_floa
 constexpr int DNMF_ERRBUF = 512;
 __attribute__((visibility("hidden"))) char* dnmf_errbuf_();
 
+// MUBUF intrinsics (see "buffer addressing" below): external declarations bound to the LLVM intrinsics, no definition
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ float buf_ld_f32(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x2 buf_ld_f32x2(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ f32x4 buf_ld_f32x4(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void buf_st_f32(float v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void buf_st_f32x2(f32x2 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
 namespace {
 
 int fail(int code, const char* fmt, ...) {
@@ -75,14 +84,7 @@ inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 // RULE: a store of more than 8 bytes must not use the SGPR offset (pass 0 and add constants to the VGPR offset, they
 // fold into the immediate): with an SGPR offset the gfx950 hardware may still be reading the data registers when the
 // next VALU write hits them, and hipcc pads that hazard only for the immediate form (see update_w_seq_tile).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int BUF_OOB = (int)0x80000000u;
-__device__ float buf_ld_f32(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ f32x2 buf_ld_f32x2(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
-__device__ f32x4 buf_ld_f32x4(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ void buf_st_f32(float v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
-__device__ void buf_st_f32x2(f32x2 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
-__device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
 // descriptor for `base` (wave-uniform): raw buffer (stride 0), 2 GiB window, gfx9 data format word
 __device__ __forceinline__ i32x4 buf_rsrc(const void* base) {

@@ -1,8 +1,8 @@
 // dnmf_split.h -- the two big contractions (A H^T, W^T A) on the bf16 matrix cores with fp32-grade products ("bf16x6").
 // Part of libdnmf_hip.so (translation unit csrc/dnmf_split.hip).
 //
-// Why: at the headline rank the fp32 kernels of dnmf_nt.h / dnmf_tn.h are bound by v_mfma_f32_32x32x2_f32 (256 flop per CU
-// and clock, 85-88 % busy: 2.3 ms per pass over the 8.6 GB of A, where the HBM alone would need 1.1-1.4 ms).
+// Why: from k = 33 on the fp32 kernels of dnmf_nt.h / dnmf_tn.h are bound by v_mfma_f32_32x32x2_f32 (256 flop per CU
+// and clock, 85-88 % busy: at k = 64 2.3 ms per pass over the 8.6 GB of A, where the HBM alone would need 1.1-1.4 ms).
 // v_mfma_f32_32x32x16_bf16 does 16x the work per clock, so even six of them per fp32 product leave the pass memory bound.
 //
 // Arithmetic: every fp32 operand x is cut into three bf16 pieces x = x1 + x2 + x3, x1 = rne_bf16(x), x2 = rne_bf16(x - x1),
@@ -15,11 +15,11 @@
 // update where the fp32 one adds 2, so six updates per 16 contraction indices stand against eight.  Measured against a
 // float64 product the two paths are equally close (tests/test_gpu_split.py).
 //
-// Layout: the streamed operand A is read ONCE from HBM as fp32 and cut in registers; its operand fragments are formed without
-// LDS -- for A H^T a lane reads 16 consecutive floats of its row (the contraction index may be permuted freely as long as both
-// operands agree, so the lane pair (li, 0), (li, 1) consumes one whole 128-B line), for W^T A a lane reads an 8-row x 4-column
-// block and the four columns become its fragments of four column-interleaved output tiles.  The small operand (H, or W
-// transposed) is cut once per call into a bf16 image [piece][k][index] in the workspace and staged through LDS.
+// Layout: the streamed operand A is read ONCE from HBM (fp32, cut in registers right before its MFMAs; or bf16-stored, then it
+// is its own single piece and nothing is cut).  For W^T A the contraction runs over the rows of A, so a lane's 8-row x NT-column
+// block already holds its fragments (of NT column-interleaved output tiles) and A never touches LDS; for A H^T the MFMA wants
+// a row of A per lane, and A goes through LDS with coalesced loads.  The small operand (H, or W transposed) is cut once per
+// call into a bf16 image [piece][k][index] in the workspace and staged through LDS.
 #pragma once
 #include "dnmf_common.h"
 #include "dnmf_nt.h"
