@@ -641,6 +641,7 @@ static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, 
     NnArgs a{};
     a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
     a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
+    a.kreal = k;
     static const int kl_pipe = (int)tune("DNMF_KL_PIPE", 1);
     a.pipe = kl_pipe;
     return a;
@@ -772,6 +773,7 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
     if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
         pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    a.kreal = k_out;                                       // (k may be the padded rank by now)
     const bool split = u.nsplit > 1;
     float* out = split ? (float*)ws : UHT;
     const long ldout = split ? kp : ldo;
@@ -810,6 +812,7 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const int k_out = k;                                   // rows of WTU the caller gets
     if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    a.kreal = k_out;
     a.ncolblk = p.ncolblk;
     a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);

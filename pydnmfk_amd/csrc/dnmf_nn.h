@@ -20,6 +20,8 @@ struct NnArgs {
     float* P; long chunk_stride; long ldp;           // NN_KL_WTU partials [rowblk][KP][ldp]
     long nrowblk; int ncolblk;
     int pipe;                                        // NN_KL_*: software-pipelined interior path (DNMF_KL_PIPE=0 switches it off)
+    int kreal;                                       // NN_KL_*: the rank before zero padding to KP: S = W H skips the MFMA steps whose 8
+                                                     // contraction indices are all padding (k <= 16: half of that product's matrix work)
 };
 
 // S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
@@ -249,10 +251,13 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
                 for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[(s + 1) & 1][e], &smem[(8 * (s + 1) + 4 * h + e) * CW + NT * li]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (KT > 1 || 8 * s < p.kreal) {                     // wave uniform; the loads above stay unconditional (pipeline).  KT = 1 only:
+                                                                 // at KT = 2 the branches cost the kernel its register allocation (104 spills)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wfrag[s][e], hb[s & 1][e][ne], acc[ne]);
+                    for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wfrag[s][e], hb[s & 1][e][ne], acc[ne]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -392,8 +397,10 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
                     for (int e = 0; e < 4; ++e) hv[(s + 1) & 1][e] = Hs[lds_idx(8 * (s + 1) + 4 * h + e, li >> 2) + (li & 3)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (KT > 1 || 8 * s < p.kreal) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) st = MFMA32(hv[s & 1][e], wreg[s][e], st);
+                    for (int e = 0; e < 4; ++e) st = MFMA32(hv[s & 1][e], wreg[s][e], st);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -344,7 +344,7 @@ int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W,
     int rc = klx_images(W, m, ldw, H, n, ldh, k, kp, (char*)ws, im, st);
     if (rc) return rc;
     const WtuxPlan p = plan_wtux(m, n, kt);
-    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps;
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps; a.k = k;
     a.wp = im.wp; a.ht = im.ht;
     a.P = (float*)((char*)ws + img); a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
     a.nrowblk = cdiv(m, 32); a.ncolblk = p.ncolblk; a.rowblks_per_chunk = p.rowblks_per_chunk; a.nchunks = p.nchunks;
@@ -378,7 +378,7 @@ int dnmf_kl_uht_bf16x6(const float* A, long m, long n, long lda, const float* W,
     if (rc) return rc;
     const UhtxPlan u = plan_uhtx(m, n);
     const bool split = u.nsplit > 1;
-    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps;
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.eps = eps; a.k = k;
     a.wp = im.wp; a.ht = im.ht;
     a.out = split ? (float*)((char*)ws + img) : UHT;
     a.ldo = split ? kp : ldo; a.split_stride = (long)m * kp; a.cols_per_split = u.cols_per_split; a.out_cols = split ? kp : k;

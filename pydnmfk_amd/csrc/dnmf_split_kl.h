@@ -22,6 +22,7 @@ namespace {
 
 struct KlxArgs {
     const float* A; long lda; long m; long n; float eps;
+    int k;                                          // rank before padding: S = W H skips the steps whose 16 indices are all padding
     SplitOperand wp, ht;
     float* P; long chunk_stride; long ldp;          // W^T U partial slabs [chunk][KP][ldp]
     long nrowblk; int ncolblk; long rowblks_per_chunk; long nchunks;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void klx_wtu_kernel(KlxArgs p
             for (int r = 0; r < 16; ++r) S[ne][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2 * KT; ++s) {                          // phase 1: S = W H
+            if (16 * s >= p.k) break;                               // (uniform; the loop is unrolled: a forward branch per step)
             const u32x4 a1 = *reinterpret_cast<const u32x4*>(wb + rd[s]);
             const u32x4 a2 = *reinterpret_cast<const u32x4*>(wb + WB_PIECE + rd[s]);
             const u32x4 a3 = *reinterpret_cast<const u32x4*>(wb + 2 * WB_PIECE + rd[s]);
@@ -294,6 +296,7 @@ __device__ __forceinline__ void klx_uht_body(const KlxArgs& p, float* smem) {
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2 * KT; ++s) {
+            if (16 * s >= p.k) break;                               // steps of pure padding (uniform)
             const u32x4 a1 = *reinterpret_cast<const u32x4*>(htc + rd[s]);
             const u32x4 a2 = *reinterpret_cast<const u32x4*>(htc + St::HT_PIECE + rd[s]);
             const u32x4 a3 = *reinterpret_cast<const u32x4*>(htc + 2 * St::HT_PIECE + rd[s]);
