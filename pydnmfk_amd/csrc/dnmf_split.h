@@ -344,57 +344,62 @@ __global__ __launch_bounds__(256, 2) void tnx_kernel(TnArgs p, SplitOperand ws) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[kt][j][r] = 0.f;
 
-    float xr[8][XW];
+    // two MFMA steps of A in flight per wave (the loads of step g + 2 are issued when step g has been consumed): with one, a
+    // wave computes 48 MFMAs (0.8 us) and then waits out the rest of an HBM latency -- SQ_WAIT_ANY 46 % of the wave cycles
+    float xr[2][8][XW];
     u32x4 wv[3 * KT * CR / 8];
-    static_for<0, 8>([&](auto i_) {
-        constexpr int i = decltype(i_)::value;
-        buf_load<XW, AUX>(xr[i], rs, voff, i * rowb);
-    });
+    const int nsteps = NST * nch;
+    auto issue = [&](float (&x)[8][XW], int g) {                   // rows of step g (past the end: the last step again, unused)
+        g = g < nsteps ? g : nsteps - 1;
+        const int sbase = g * 16 * rowb;
+        static_for<0, 8>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            buf_load<XW, AUX>(x[i], rs, voff, sbase + i * rowb);
+        });
+    };
+    issue(xr[0], 0);
+    issue(xr[1], 1);
     tile_load<KT, CR>(wv, ws, rbeg, tid);
     tile_store<KT, CR>(lds, wv, tid);
     __syncthreads();
     int fo[NST];             // fragment of step st: row li, chunk 2 st + h
 #pragma unroll
     for (int st = 0; st < NST; ++st) fo[st] = (li * CR + ((2 * st + h) ^ tile_swz<CR>(li))) * 16;
-    const int nsteps = NST * nch;
+    static_assert(NST % 2 == 0, "the two register sets alternate with the step parity");
     for (int c = 0; c < nch; ++c) {
         const int cn = c + 1 < nch ? c + 1 : c;
         const char* cur = lds + (c & 1) * TB;
         tile_load<KT, CR>(wv, ws, rbeg + (long)cn * XKT, tid);
         static_for<0, NST>([&](auto st_) {
             constexpr int st = decltype(st_)::value;
-            u32x4 b[NT][B16 ? 1 : 3];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if constexpr (B16) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        b[j][0][q] = __builtin_amdgcn_perm(__float_as_uint(xr[2 * q + 1][j >> 1]), __float_as_uint(xr[2 * q][j >> 1]),
-                                                           (j & 1) ? 0x07060302u : 0x05040100u);
-                } else {
-                    const float v[8] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], xr[6][j], xr[7][j]};
-                    split8(v, b[j][0], b[j][1], b[j][2]);
-                }
-            }
-            int nx = NST * c + st + 1;                            // next step's rows (past the end: the last step again)
-            nx = nx < nsteps ? nx : nsteps - 1;
-            const int sbase = nx * 16 * rowb;
-            static_for<0, 8>([&](auto i_) {
-                constexpr int i = decltype(i_)::value;
-                buf_load<XW, AUX>(xr[i], rs, voff, sbase + i * rowb);
-            });
+            float (&x)[8][XW] = xr[st & 1];
+            u32x4 a[KT][3];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const char* f = cur + fo[st] + kt * 32 * CR * 16;
-                const u32x4 a1 = *reinterpret_cast<const u32x4*>(f);
-                const u32x4 a2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
-                const u32x4 a3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
+                a[kt][0] = *reinterpret_cast<const u32x4*>(f);
+                a[kt][1] = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
+                a[kt][2] = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
+            }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if constexpr (B16) mfma_x3(acc[kt][j], b[j][0], a1, a2, a3, false);
-                    else mfma_x6(acc[kt][j], a1, a2, a3, b[j][0], b[j][1], b[j][2]);
+            for (int j = 0; j < NT; ++j) {
+                u32x4 b[B16 ? 1 : 3];
+                if constexpr (B16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        b[0][q] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q + 1][j >> 1]), __float_as_uint(x[2 * q][j >> 1]),
+                                                        (j & 1) ? 0x07060302u : 0x05040100u);
+                } else {
+                    const float v[8] = {x[0][j], x[1][j], x[2][j], x[3][j], x[4][j], x[5][j], x[6][j], x[7][j]};
+                    split8(v, b[0], b[1], b[2]);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    if constexpr (B16) mfma_x3(acc[kt][j], b[0], a[kt][0], a[kt][1], a[kt][2], false);
+                    else mfma_x6(acc[kt][j], a[kt][0], a[kt][1], a[kt][2], b[0], b[1], b[2]);
                 }
             }
+            issue(x, NST * c + st + 2);
         });
         tile_store<KT, CR>(lds + ((c + 1) & 1) * TB, wv, tid);
         __syncthreads();
