@@ -34,11 +34,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// (lo, hi) -> packed round-to-nearest-even bf16 pair
+// (lo, hi) -> packed round-to-nearest-even bf16 pair: v_cvt_pk_bf16_f32, through the compiler (a vector fptrunc), NOT inline
+// asm: hipcc's hazard recognizer does not see inside an asm statement, and a cvt that overwrites a register an in-flight MFMA
+// still reads as its operand was scheduled without the wait states -- run-to-run different bits in tnx_kernel once its
+// cuts were interleaved with the MFMAs of the previous column.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
-    unsigned int r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 // two floats -> their three bf16 pieces, packed pairwise (11 VALU instructions)
