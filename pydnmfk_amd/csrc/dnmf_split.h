@@ -208,29 +208,74 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
     };
     const int xrow = wave * 32 + li;
     const int hsw = tile_swz<CR>(li);
+    // B fragments of step u, tile jt
+    auto hfrag = [&](const char* hc, int u, int jt, u32x4& b1, u32x4& b2, u32x4& b3) {
+        const char* f = hc + ((jt * 32 + li) * CR + ((2 * u + h) ^ hsw)) * 16;
+        b1 = *reinterpret_cast<const u32x4*>(f);
+        b2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
+        b3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
+    };
     auto compute = [&](const char* st) {
         const float* xc = reinterpret_cast<const float*>(st);
         const char* hc = st + XB;
+        if constexpr (B16) {
 #pragma unroll
-        for (int u = 0; u < XTI / 16; ++u) {
-            u32x4 a1, a2, a3;
-            if constexpr (B16) {
-                a1 = *reinterpret_cast<const u32x4*>(&xc[lds_idx(xrow, 2 * u + h)]);
-            } else {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h)]);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 * u + 2 * h + 1)]);
-                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                split8(v, a1, a2, a3);
-            }
+            for (int u = 0; u < XTI / 16; ++u) {
+                const u32x4 a1 = *reinterpret_cast<const u32x4*>(&xc[lds_idx(xrow, 2 * u + h)]);
 #pragma unroll
-            for (int jt = 0; jt < KT; ++jt) {
-                const char* f = hc + ((jt * 32 + li) * CR + ((2 * u + h) ^ hsw)) * 16;
-                const u32x4 b1 = *reinterpret_cast<const u32x4*>(f);
-                const u32x4 b2 = *reinterpret_cast<const u32x4*>(f + 32 * KT * CR * 16);
-                const u32x4 b3 = *reinterpret_cast<const u32x4*>(f + 2 * 32 * KT * CR * 16);
-                if constexpr (B16) mfma_x3(acc[0][jt], a1, b1, b2, b3, true);
-                else mfma_x6(acc[0][jt], a1, a2, a3, b1, b2, b3);
+                for (int jt = 0; jt < KT; ++jt) {
+                    u32x4 b1, b2, b3;
+                    hfrag(hc, u, jt, b1, b2, b3);
+                    mfma_x3(acc[0][jt], a1, b1, b2, b3, true);
+                }
             }
+        } else {
+            // fp32 A: two steps per tile.  The cut of step 1 (4 pairs x 11 VALU instructions) is issued in four pieces between
+            // the MFMAs of step 0, whose products alternate between the KT accumulators; the order is pinned with
+            // sched_barrier -- left alone, hipcc emits a step's cut as one block in front of its MFMA chain and the wave's
+            // matrix pipe idles through it (MFMA busy 41 %).
+            float v0[8], v1[8];
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 2 * h)]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 2 * h + 1)]);
+                const f32x4 lo1 = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 + 2 * h)]);
+                const f32x4 hi1 = *reinterpret_cast<const f32x4*>(&xc[lds_idx(xrow, 4 + 2 * h + 1)]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = lo[e]; v0[4 + e] = hi[e]; v1[e] = lo1[e]; v1[4 + e] = hi1[e]; }
+            }
+            u32x4 a1, a2, a3, n1, n2, n3;
+            split8(v0, a1, a2, a3);
+            u32x4 b[KT][3];
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) hfrag(hc, 0, jt, b[jt][0], b[jt][1], b[jt][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            // step 0: products p = 0..5 in the order of mfma_x6 (small terms first), round robin over the accumulators
+            static_for<0, 6>([&](auto p_) {
+                constexpr int pr = decltype(p_)::value;
+#pragma unroll
+                for (int jt = 0; jt < KT; ++jt) {
+                    const u32x4& xa = pr == 0 ? a3 : (pr == 1 || pr == 3) ? a2 : a1;
+                    const u32x4& xb = (pr == 0 || pr == 3 || pr == 5) ? b[jt][0] : (pr == 1 || pr == 4) ? b[jt][1] : b[jt][2];
+                    acc[0][jt] = mfma_bf16(xa, xb, acc[0][jt]);
+                }
+                if constexpr (pr < 4) {                              // one pair of step 1 after each of the first four rounds
+                    unsigned int s1, s2, s3;
+                    split_pair(v1[2 * pr], v1[2 * pr + 1], s1, s2, s3);
+                    n1[pr] = s1; n2[pr] = s2; n3[pr] = s3;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int jt = 0; jt < KT; ++jt) hfrag(hc, 1, jt, b[jt][0], b[jt][1], b[jt][2]);
+            static_for<0, 6>([&](auto p_) {
+                constexpr int pr = decltype(p_)::value;
+#pragma unroll
+                for (int jt = 0; jt < KT; ++jt) {
+                    const u32x4& xa = pr == 0 ? n3 : (pr == 1 || pr == 3) ? n2 : n1;
+                    const u32x4& xb = (pr == 0 || pr == 3 || pr == 5) ? b[jt][0] : (pr == 1 || pr == 4) ? b[jt][1] : b[jt][2];
+                    acc[0][jt] = mfma_bf16(xa, xb, acc[0][jt]);
+                }
+            });
         }
     };
     static_for<0, NSET>([&](auto i_) { constexpr int i = decltype(i_)::value; load(xv[i], hv[i], i); });
