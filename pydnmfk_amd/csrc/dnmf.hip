@@ -102,6 +102,10 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
     // 1.8x slower at 32768 rows where it left half the CUs without a workgroup.)
 #ifdef DNMF_TUNING
     if (kt == 2 && tune("DNMF_NT_MT", 1) == 2) { NT_CASE(2, 2, 4, 1) }     // 256-row tiles at k = 64 (A/B runs)
+    // 32-row workgroups (4 waves = 4 contraction slices of one row group): fills the GPU on an 8192-row slab, for the
+    // slab-wise one-pass experiment of tools/onepass.py
+    if constexpr (std::is_same<TX, float>::value)
+        if (kt == 1 && tune("DNMF_NT_KS4", 0) != 0) { NT_CASE(1, 1, 4, 4) }
 #endif
     if (kt == 1) { NT_CASE(1, 1, 4, 1) }
     if (kt == 2) { NT_CASE(2, 1, 4, 1) }
