@@ -157,8 +157,10 @@ def test_swim_2x2_kl_known_answer():
     KL / MU, k = 14..18, 5000 iterations, rand init, noise 0.016, sill_thr 0.6 -> asserts nopt == 16.  Four ranks on the
     one GPU, real HIP kernels, gloo transport."""
     from tests._mp import run_swim_nmfk
-    outs = run_swim_nmfk((14, 18, 5000), use_hip=True, timeout=7000)
+    gemm = __import__("os").environ.get("DNMF_LONG_TESTS_GEMM")      # 'bf16x6': the same known answer on the split KL kernels
+    outs = run_swim_nmfk((14, 18, 5000) + ((gemm,) if gemm else ()), use_hip=True, timeout=7000)
     assert all(o[0] == 16 for o in outs), outs
+    print("swim 2x2 KL known answer (%s): nopt" % (gemm or "fp32"), outs[0][0], "min silhouettes", outs[0][1], "seconds", round(outs[0][2], 1))
 
 
 @pytest.mark.parametrize("gemm", ["fp32", "bf16x6"])
