@@ -261,6 +261,7 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
                 if constexpr (pr < 4) {                              // one pair of step 1 after each of the first four rounds
                     unsigned int s1, s2, s3;
                     split_pair(v1[2 * pr], v1[2 * pr + 1], s1, s2, s3);
+                    asm volatile("" : "+v"(s1), "+v"(s2), "+v"(s3));   // (no instruction: keeps LLVM from sinking the cut to its use)
                     n1[pr] = s1; n2[pr] = s2; n3[pr] = s3;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -282,12 +283,14 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
     store(lds, xv[0], hv[0]);
     __syncthreads();
     // tile t: set t % NSET (already in LDS stage t & 1) is refilled with tile t + NSET; set (t + 1) % NSET = tile t + 1 goes to
-    // the other stage after the MFMAs.  NSET tiles per trip; a trip past the end re-reads the last tile and skips its MFMAs.
+    // the other stage after the MFMAs.  NSET tiles per trip, nk % NSET == 0 (n % 128 == 0 and one column split: 4 | n / 32,
+    // 2 | n / 64).  No `if (t + i < nk)` around the MFMAs: a conditional there makes hipcc keep the accumulators in two
+    // register sets and merge them with 32 v_mov per tile behind an MFMA-drain s_nop.
     for (int t = 0; t < nk; t += NSET) {
         static_for<0, NSET>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             load(xv[i], hv[i], t + i + NSET);
-            if (t + i < nk) compute(lds + (i & 1) * STAGE);
+            compute(lds + (i & 1) * STAGE);
             store(lds + ((i + 1) & 1) * STAGE, xv[(i + 1) % NSET], hv[(i + 1) % NSET]);
             __syncthreads();
         });

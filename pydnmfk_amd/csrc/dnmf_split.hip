@@ -221,7 +221,7 @@ UhtxPlan plan_uhtx(long m, long n) {
     const long rowtiles = cdiv(m, 128);
     long ns = std::max<long>(1, cdiv(1024, rowtiles));
     ns = std::min<long>(ns, std::max<long>(1, n / 256));
-    u.cols_per_split = round_up(cdiv(n, ns), 32);
+    u.cols_per_split = round_up(cdiv(n, ns), 64);                    // two 32-column tiles per trip of klx_uht_kernel
     u.nsplit = (int)cdiv(n, u.cols_per_split);
     return u;
 }

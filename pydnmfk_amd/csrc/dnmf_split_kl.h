@@ -331,13 +331,13 @@ __device__ __forceinline__ void klx_uht_body(const KlxArgs& p, float* smem) {
     store(lds, xv[0], hv[0]);
     __syncthreads();
     // tile t: register set t % NSET (already in LDS stage t & 1) is refilled with tile t + NSET, set (t + 1) % NSET = tile t + 1
-    // goes to the other stage after the MFMAs.  The trip count is rounded up: the extra tiles are clamped re-reads whose results
-    // must not be added, so the loop body checks t < nt (block uniform).
+    // goes to the other stage after the MFMAs.  nt % NSET == 0: the host cuts the columns into multiples of 64 (plan_uhtx); a
+    // conditional around the MFMAs would cost an accumulator copy per tile (see ntx_mainloop).
     for (int t0 = 0; t0 < nt; t0 += NSET) {
         static_for<0, NSET>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
             load(xv[i], hv[i], t0 + i + NSET);
-            if (t0 + i < nt) compute(lds + (i & 1) * St::BYTES);
+            compute(lds + (i & 1) * St::BYTES);
             store(lds + ((i + 1) & 1) * St::BYTES, xv[(i + 1) % NSET], hv[(i + 1) % NSET]);
             __syncthreads();
         });
