@@ -321,3 +321,20 @@ def test_bf16_stored_a_fallback_shapes_and_reproducibility():
             x6.mu_fro_step(Ab, Wc, Hc, EPS, True, False)
         outs.append((Wc, Hc))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_wide_pitch_views_fall_back():
+    """A column view whose row pitch exceeds 4 n is outside the split kernels' 32-bit tile addressing: forwarded to the fp32
+    kernels (bit-identical results), for the Frobenius and the KL entry points alike."""
+    f32, x6, _ = _ops()
+    big, W, H = _rand(2048, 1024, 40, 43)
+    A = big[:, :128]                                    # lda = 1024 = 8 n
+    H = H[:, :128].contiguous()
+    for name, args, shape in (("aht", (A, H), (2048, 40)), ("wta", (A, W), (40, 128))):
+        o0, o1 = torch.empty(*shape, device=A.device), torch.empty(*shape, device=A.device)
+        getattr(f32, name)(*args, o0); getattr(x6, name)(*args, o1)
+        assert torch.equal(o0, o1), name
+    for name, shape in (("kl_uht", (2048, 40)), ("kl_wtu", (40, 128))):
+        o0, o1 = torch.empty(*shape, device=A.device), torch.empty(*shape, device=A.device)
+        getattr(f32, name)(A, W, H, EPS, o0); getattr(x6, name)(A, W, H, EPS, o1)
+        assert torch.equal(o0, o1), name
