@@ -24,7 +24,7 @@ def _stale():
 
 
 def build_lib(force=False, report=False, tuning=False):
-    """Compile the translation units csrc/*.hip (kernels in csrc/dnmf_*.h) side by side and link them into
+    """Compile the translation units csrc/*.hip (dnmf, dnmf_kl, dnmf_hals, dnmf_split; kernels in csrc/dnmf_*.h) side by side and link them into
     libdnmf_hip.so.  Returns the library path.
     `tuning=True` builds tools/_build/libdnmf_hip_tune.so instead: the same sources with -DDNMF_TUNING, in which the
     DNMF_* environment switches and the extra kernel variants of the A/B runs exist (tools/README.md); the shipped

@@ -115,8 +115,6 @@ int launch_nt(int kt, bool fast, const NtArgs& a, int nsplit, hipStream_t st) {
 }
 
 inline int nt_rows_per_tile(int) { return 128; }
-inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
-inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
 
 template <int MODE, typename TY = float>
 int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
@@ -137,22 +135,6 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     TN_CASE(4, 2)
 #undef TN_CASE
     return fail(DNMF_EINVAL, "unsupported k tile %d", kt);
-}
-
-// ---- chunking heuristics (shared by the ws-size query and the launches)
-struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
-
-TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
-    TnPlan p;
-    p.ncolblk = (int)cdiv(ycols, 32 * nt);
-    static const long target_waves = tune("DNMF_TN_WAVES", 2048);  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
-    long nchunks = std::max<long>(1, target_waves / p.ncolblk);
-    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, min_rows)));
-    p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
-    p.nchunks = (int)cdiv(nrows, p.rows_per_chunk);
-    p.ldp = (long)p.ncolblk * 32 * nt;
-    p.chunk_stride = p.ldp * 32 * kt;
-    return p;
 }
 
 // W^T W streams only W (m x k): with 256-row chunks a 32768-row shard gives 128 waves on 32 CUs and the launch is one long
@@ -228,11 +210,6 @@ Tn16Plan plan_tn16(long m, long n, int v) {
     p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
     p.nchunks = (int)cdiv(m, p.rows_per_chunk);
     return p;
-}
-
-// zero-padded factor images of the KL products (see pad_factors)
-size_t pad_bytes(long m, long n, int kp) {
-    return align256((size_t)m * kp * sizeof(float)) + align256((size_t)kp * round_up(n, 4) * sizeof(float));
 }
 
 size_t partial_bytes(long m, long n, int k) {
@@ -364,9 +341,6 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
 }  // extern "C"  (typed implementations shared by the fp32 and the bf16-A entry points)
 namespace {
 // alignment the vector path needs from A: 16 B for fp32 rows, 8 B for bf16 rows (4 elements per lane either way)
-template <typename TA> bool a_aligned(const TA* A) { return ((uintptr_t)A % (4 * sizeof(TA))) == 0; }
-// the NT form reads 16 B per lane from A whatever its type: bf16 rows need lda % 8 == 0 and a 16-byte aligned base
-template <typename TA> bool a_rows16(const TA* A, long lda) { return aligned16(A) && (lda * sizeof(TA)) % 16 == 0; }
 
 // rank k <= 16 with aligned operands and a column count that is a whole number of k-tiles: the 16-wide kernel.
 // Returns 1 when not applicable (caller falls through to the 32-wide kernels), else the launch status.
@@ -640,202 +614,6 @@ int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void
     return sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, out, stream);
 }
 
-static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                      int k, float eps) {
-    NnArgs a{};
-    a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
-    a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
-    a.kreal = k;
-    static const int kl_pipe = (int)tune("DNMF_KL_PIPE", 1);
-    a.pipe = kl_pipe;
-    return a;
-}
-
-static bool nn_fast(const float* A, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k) {
-    return aligned16(A) && aligned16(W) && aligned16(H) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0 &&
-           ldh % 4 == 0;
-}
-
-}  // extern "C"
-namespace {
-template <typename TA>
-int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                      int k, double* out, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
-    hipStream_t st = S(stream);
-    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
-    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
-    a.out = out;
-    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
-    const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
-#define RS_CASE(KT_)                                                                   \
-    if (kt == KT_) {                                                                   \
-        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true, TA>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((resid_kernel<KT_, false, TA>), grid, block, 0, st, a);    \
-    }
-    RS_CASE(1) RS_CASE(2) RS_CASE(4)
-#undef RS_CASE
-    return check_launch("resid_sqnorm");
-}
-}  // namespace
-extern "C" {
-
-int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                      int k, double* out, void* stream) {
-    return resid_sqnorm_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, out, stream);
-}
-int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                            int k, double* out, void* stream) {
-    return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream);
-}
-
-}  // extern "C"
-namespace {
-template <typename TA>
-int column_err_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                    double* num, double* den, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && num && den && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "column_err: bad arguments");
-    hipStream_t st = S(stream);
-    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
-    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
-    // about 8 waves per SIMD in flight, every wave walking a chunk of row blocks of its 128-column block
-    const long rpc = std::max<long>(1, cdiv(a.nrowblk * a.ncolblk, 8192));
-    const long waves = cdiv(a.nrowblk, rpc) * a.ncolblk;
-    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
-#define CE_CASE(KT_)                                                                             \
-    if (kt == KT_) {                                                                             \
-        if (fast) hipLaunchKernelGGL((colerr_kernel<KT_, true, TA>), grid, block, 0, st, a, num, den, rpc); \
-        else hipLaunchKernelGGL((colerr_kernel<KT_, false, TA>), grid, block, 0, st, a, num, den, rpc);    \
-    }
-    CE_CASE(1) CE_CASE(2) CE_CASE(4)
-#undef CE_CASE
-    return check_launch("column_err");
-}
-}  // namespace
-extern "C" {
-
-int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                    double* num, double* den, void* stream) {
-    return column_err_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
-}
-int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                          double* num, double* den, void* stream) {
-    return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
-}
-
-// Factors whose rank is not a whole number of 32-wide tiles, or whose rows are not 16-byte aligned -- an NMFk sweep visits
-// k = 2, 3, 5, ... -- send the NN-form kernels (S = W H in accumulators) down their predicated paths: per-element loads
-// behind exec-masked branches, at which hipcc drains vmcnt.  Measured on 32768 x 16384 (tools/klbench.py): a KL step takes
-// 1.78 ms at k = 32, 1.90 ms at k = 8 / 16 / 20 and 2.56-2.61 ms at k = 3 / 5 / 13.  Instead the factors are copied into
-// zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
-// A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
-// outputs beyond k are never stored.
-static bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
-                        size_t ws_bytes, size_t own_need, hipStream_t st) {
-    const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
-    if (friendly || tune("DNMF_KL_PAD", 1) == 0) return false;
-    const size_t pb = pad_bytes(m, n, kp);
-    if (!ws || ws_bytes < align256(own_need) + pb) return false;
-    char* base = (char*)ws + align256(own_need);
-    float* Wp = (float*)base;
-    const long ldhp = round_up(n, 4);
-    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
-    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
-    return true;
-}
-
-struct UhtPlan { int nsplit; long cols_per_split; };
-
-static UhtPlan plan_uht(long m, long n) {
-    UhtPlan u;
-    const long rowtiles = cdiv(m, 128);
-    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
-    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
-    u.cols_per_split = round_up(cdiv(n, ns), BK);
-    u.nsplit = (int)cdiv(n, u.cols_per_split);
-    return u;
-}
-
-int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
-    const int kp = 32 * kt;
-    const UhtPlan u = plan_uht(m, n);
-    const size_t pbytes = u.nsplit > 1 ? (size_t)u.nsplit * m * kp * sizeof(float) : 0;
-    const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
-    if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
-    const int k_out = k;                                   // columns of UHT the caller gets
-    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
-        pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
-    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
-    a.kreal = k_out;                                       // (k may be the padded rank by now)
-    const bool split = u.nsplit > 1;
-    float* out = split ? (float*)ws : UHT;
-    const long ldout = split ? kp : ldo;
-    const int out_cols = split ? kp : k_out;
-    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(out) && ldout % 4 == 0;
-    const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
-    const size_t lds = 2ul * kp * BK * sizeof(float);
-    hipStream_t st = S(stream);
-#define UH_CASE(KT_)                                                                                                  \
-    if (kt == KT_) {                                                                                                  \
-        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
-                                     u.cols_per_split, out_cols);                                                     \
-        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, lds, st, a, out, ldout, (long)m * kp,        \
-                                u.cols_per_split, out_cols);                                                          \
-    }
-    UH_CASE(1) UH_CASE(2) UH_CASE(4)
-#undef UH_CASE
-    int rc = check_launch("kl_uht");
-    if (rc || !split) return rc;
-    return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
-                         (float*)((char*)ws + pbytes), st);
-}
-
-int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
-                float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
-    const int kp = 32 * kt;
-    const int nt = kl_nt(kt);
-    TnPlan p = plan_tn(m, n, kt, nt);
-    const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
-    const long nchunks = cdiv(cdiv(m, 32), rowblks_per_chunk);
-    const size_t pbytes = (size_t)nchunks * p.ldp * kp * sizeof(float);
-    const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
-    if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
-    const int k_out = k;                                   // rows of WTU the caller gets
-    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
-    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
-    a.kreal = k_out;
-    a.ncolblk = p.ncolblk;
-    a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
-    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
-    const dim3 grid((unsigned)(cdiv(nchunks, 4) * a.ncolblk)), block(256);   // 4 row chunks (waves) per workgroup
-    const size_t lds = (size_t)kp * 32 * nt * sizeof(float);                   // the H block of the workgroup's columns
-    hipStream_t st = S(stream);
-#define WU_CASE(KT_, NT_)                                                                                         \
-    if (kt == KT_) {                                                                                              \
-        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
-        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
-    }
-    WU_CASE(1, 4) WU_CASE(2, 2) WU_CASE(4, 2)
-#undef WU_CASE
-    int rc = check_launch("kl_wtu");
-    if (rc) return rc;
-    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k_out, n, k_out, n,
-                         (float*)((char*)ws + pbytes), st);
-}
-
 int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {
     REQUIRE(H && x && k >= 1 && n >= 1 && ldh >= n, "rowsum: bad arguments");
     hipLaunchKernelGGL(rowsum_kernel, dim3(k), dim3(1024), 0, S(stream), H, n, ldh, x);
@@ -866,148 +644,6 @@ int dnmf_kl_update_h(float* H, int k, long n, long ldh, const float* Sm, long ld
                      int clamp, void* stream) {
     REQUIRE(H && Sm && x && n >= 1 && k >= 1 && ldh >= n && lds_ >= n, "kl_update_h: bad arguments");
     return launch_ew<EW_KL_BYROW>(H, k, n, ldh, Sm, lds_, x, eps, clamp, "kl_update_h", S(stream));
-}
-
-static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
-                             const double* prev_ss2, float eps, double* ss2_out, bool zero, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
-    hipStream_t st = S(stream);
-    if (zero && hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
-    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
-    hipLaunchKernelGGL(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
-                       eps, ss2_out);
-    return check_launch("hals_w_col");
-}
-
-int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
-                    const double* prev_ss2, float eps, double* ss2_out, void* stream) {
-    return hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, prev_ss2, eps, ss2_out, true, stream);
-}
-
-int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream) {
-    REQUIRE(W && ss2 && m >= 1 && col >= 0 && ldw > col, "hals_w_scale: bad arguments");
-    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
-    hipLaunchKernelGGL(hals_w_scale_kernel, dim3(grid), dim3(256), 0, S(stream), W, m, ldw, col, ss2);
-    return check_launch("hals_w_scale");
-}
-
-int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                       double* ss2, void* stream) {
-    REQUIRE(ss2 != nullptr && k >= 1, "hals_update_w: ss2 scratch (k doubles) required");
-    if (hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "hals_update_w: memset failed");
-    for (int kk = 0; kk < k; ++kk) {   // one launch per column: the column norm is a grid-wide dependency
-        int rc = hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, false, stream);
-        if (rc) return rc;
-    }
-    return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
-}
-
-}  // extern "C"
-namespace {
-// co-residency of the persistent sweep: workgroups the device can hold at once
-template <typename K>
-long resident_workgroups(K kernel, int threads, size_t lds) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return 0;
-    return (long)cus * per_cu;
-}
-
-template <int KT>
-int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                      unsigned long long* slab, double* ss2, float* T, hipStream_t st) {
-    constexpr int KP = 32 * KT;
-    const long ldt = KP;
-    const bool vecw = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;   // pass 1 reads W, AH
-    // pass 2: T rows are aligned.  Only KP = 64 has a 16-byte variant of the row load / store (once per sweep): hipcc
-    // register-allocates the KP = 32 one pathologically (the whole row in scratch, 20000 spills), and every variant of the
-    // fully expanded KP = 128 sweep costs a minute of build time.
-    constexpr bool HASVEC = KT == 2;
-    const bool vec = HASVEC && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
-    const long grid = cdiv(m, HALS_WG);
-    constexpr size_t lds = (size_t)KP * KP * sizeof(float);          // G staged per workgroup
-    static long cap_v = -1, cap_s = -1;
-    if (cap_v < 0) {
-        allow_lds(hals_w_sweep_kernel<KP, HASVEC>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
-        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, HASVEC>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
-    }
-    if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
-    REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "hals_sweep_w: leading dimension beyond the 32-bit tile offsets");
-    if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
-        return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
-    {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
-        constexpr size_t lds1 = (size_t)KP * (KP + 4) * sizeof(float);
-        constexpr int OCC = KT == 4 ? 4 : 5;
-        static bool once = false;
-        if (!once) {
-            allow_lds(update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>, lds1); allow_lds(update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>, lds1);
-            allow_lds(update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>, lds1);
-            once = true;
-        }
-        const unsigned g1 = (unsigned)cdiv(cdiv(m, 32), 4);
-        if (vecw && k == KP && m % 32 == 0)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
-        else if (vecw)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
-        else
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
-        int rc = check_launch("hals_sweep_w(transform)");
-        if (rc) return rc;
-    }
-    static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
-    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
-    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
-    return check_launch("hals_sweep_w");
-}
-}  // namespace
-extern "C" {
-
-int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
-                      size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
-    const int kp = 32 * kt;
-    const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
-    const size_t t_off = align256(slab_bytes + (size_t)kp * sizeof(double));
-    if (ws_bytes < slab_bytes + (size_t)kp * sizeof(double)) return fail(DNMF_EWS, "hals_sweep_w: workspace too small");
-    unsigned long long* slab = (unsigned long long*)ws;
-    double* ss2 = (double*)((char*)ws + slab_bytes);
-    float* T = (float*)((char*)ws + t_off);
-    static const int mode = (int)tune("DNMF_HALS_SWEEP", 1);     // 0: always the column-per-launch path (A/B runs)
-    int rc = 1;
-    if (mode && ws_bytes >= t_off + (size_t)m * kp * sizeof(float)) {
-        hipStream_t st = S(stream);
-        if (kt == 1) rc = launch_hals_sweep<1>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
-        else if (kt == 2) rc = launch_hals_sweep<2>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
-        else rc = launch_hals_sweep<4>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
-    }
-    if (rc != 1) return rc;
-    return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column
-}
-
-int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
-                       void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "hals_update_h: bad arguments");
-    const dim3 grid((unsigned)cdiv(n, 256)), block(256);
-    hipStream_t st = S(stream);
-#define HH_CASE(KT_)                                                                                              \
-    if (kt == KT_) {                                                                                              \
-        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
-        hipLaunchKernelGGL((hals_h_kernel<32 * KT_>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps);     \
-    }
-    HH_CASE(1) HH_CASE(2)
-#undef HH_CASE
-    if (kt == 4) {
-        const int kp = 128;
-        const size_t lds = (size_t)(kp * kp + kp * 64) * sizeof(float);   // 96 KiB
-        static bool once = false;
-        if (!once) { allow_lds(hals_h_kernel_lds, lds); once = true; }
-        hipLaunchKernelGGL(hals_h_kernel_lds, dim3((unsigned)cdiv(n, 64)), dim3(64), lds, st, H, k, n, ldh, AtW, ldatw, G, kp, eps);
-    }
-    return check_launch("hals_update_h");
 }
 
 }  // extern "C"

@@ -1,0 +1,152 @@
+// dnmf_hals.hip -- C ABI of the HALS sweeps (csrc/dnmf_hals.h).  A translation unit of its own (see csrc/dnmf_kl.hip).
+#include "dnmf_common.h"
+#include "dnmf_host.h"
+#include "dnmf_stream.h"
+#include "dnmf_update.h"
+#include "dnmf_hals.h"
+
+extern "C" {
+
+static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                             const double* prev_ss2, float eps, double* ss2_out, bool zero, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
+    hipStream_t st = S(stream);
+    if (zero && hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
+    hipLaunchKernelGGL(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
+                       eps, ss2_out);
+    return check_launch("hals_w_col");
+}
+
+int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
+                    const double* prev_ss2, float eps, double* ss2_out, void* stream) {
+    return hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, prev_ss2, eps, ss2_out, true, stream);
+}
+
+int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream) {
+    REQUIRE(W && ss2 && m >= 1 && col >= 0 && ldw > col, "hals_w_scale: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
+    hipLaunchKernelGGL(hals_w_scale_kernel, dim3(grid), dim3(256), 0, S(stream), W, m, ldw, col, ss2);
+    return check_launch("hals_w_scale");
+}
+
+int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                       double* ss2, void* stream) {
+    REQUIRE(ss2 != nullptr && k >= 1, "hals_update_w: ss2 scratch (k doubles) required");
+    if (hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "hals_update_w: memset failed");
+    for (int kk = 0; kk < k; ++kk) {   // one launch per column: the column norm is a grid-wide dependency
+        int rc = hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, false, stream);
+        if (rc) return rc;
+    }
+    return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
+}
+
+}  // extern "C"
+namespace {
+// co-residency of the persistent sweep: workgroups the device can hold at once
+template <typename K>
+long resident_workgroups(K kernel, int threads, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return 0;
+    return (long)cus * per_cu;
+}
+
+template <int KT>
+int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                      unsigned long long* slab, double* ss2, float* T, hipStream_t st) {
+    constexpr int KP = 32 * KT;
+    const long ldt = KP;
+    const bool vecw = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;   // pass 1 reads W, AH
+    // pass 2: T rows are aligned.  Only KP = 64 has a 16-byte variant of the row load / store (once per sweep): hipcc
+    // register-allocates the KP = 32 one pathologically (the whole row in scratch, 20000 spills), and every variant of the
+    // fully expanded KP = 128 sweep costs a minute of build time.
+    constexpr bool HASVEC = KT == 2;
+    const bool vec = HASVEC && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
+    const long grid = cdiv(m, HALS_WG);
+    constexpr size_t lds = (size_t)KP * KP * sizeof(float);          // G staged per workgroup
+    static long cap_v = -1, cap_s = -1;
+    if (cap_v < 0) {
+        allow_lds(hals_w_sweep_kernel<KP, HASVEC>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
+        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, HASVEC>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
+    }
+    if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
+    REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "hals_sweep_w: leading dimension beyond the 32-bit tile offsets");
+    if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
+        return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
+    {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
+        constexpr size_t lds1 = (size_t)KP * (KP + 4) * sizeof(float);
+        constexpr int OCC = KT == 4 ? 4 : 5;
+        static bool once = false;
+        if (!once) {
+            allow_lds(update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>, lds1); allow_lds(update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>, lds1);
+            allow_lds(update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>, lds1);
+            once = true;
+        }
+        const unsigned g1 = (unsigned)cdiv(cdiv(m, 32), 4);
+        if (vecw && k == KP && m % 32 == 0)
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        else if (vecw)
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        else
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+        int rc = check_launch("hals_sweep_w(transform)");
+        if (rc) return rc;
+    }
+    static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
+    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    return check_launch("hals_sweep_w");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
+                      size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
+    const int kp = 32 * kt;
+    const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
+    const size_t t_off = align256(slab_bytes + (size_t)kp * sizeof(double));
+    if (ws_bytes < slab_bytes + (size_t)kp * sizeof(double)) return fail(DNMF_EWS, "hals_sweep_w: workspace too small");
+    unsigned long long* slab = (unsigned long long*)ws;
+    double* ss2 = (double*)((char*)ws + slab_bytes);
+    float* T = (float*)((char*)ws + t_off);
+    static const int mode = (int)tune("DNMF_HALS_SWEEP", 1);     // 0: always the column-per-launch path (A/B runs)
+    int rc = 1;
+    if (mode && ws_bytes >= t_off + (size_t)m * kp * sizeof(float)) {
+        hipStream_t st = S(stream);
+        if (kt == 1) rc = launch_hals_sweep<1>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
+        else if (kt == 2) rc = launch_hals_sweep<2>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
+        else rc = launch_hals_sweep<4>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
+    }
+    if (rc != 1) return rc;
+    return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column
+}
+
+int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
+                       void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "hals_update_h: bad arguments");
+    const dim3 grid((unsigned)cdiv(n, 256)), block(256);
+    hipStream_t st = S(stream);
+#define HH_CASE(KT_)                                                                                              \
+    if (kt == KT_) {                                                                                              \
+        const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
+        hipLaunchKernelGGL((hals_h_kernel<32 * KT_>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps);     \
+    }
+    HH_CASE(1) HH_CASE(2)
+#undef HH_CASE
+    if (kt == 4) {
+        const int kp = 128;
+        const size_t lds = (size_t)(kp * kp + kp * 64) * sizeof(float);   // 96 KiB
+        static bool once = false;
+        if (!once) { allow_lds(hals_h_kernel_lds, lds); once = true; }
+        hipLaunchKernelGGL(hals_h_kernel_lds, dim3((unsigned)cdiv(n, 64)), dim3(64), lds, st, H, k, n, ldh, AtW, ldatw, G, kp, eps);
+    }
+    return check_launch("hals_update_h");
+}
+
+}  // extern "C"

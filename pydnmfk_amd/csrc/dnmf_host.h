@@ -65,4 +65,35 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
     return check_launch("reduce_partials");
 }
 
+// ---- plans and predicates shared by csrc/dnmf.hip and csrc/dnmf_kl.hip
+// ---- chunking heuristics (shared by the ws-size query and the launches)
+struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
+
+TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
+    TnPlan p;
+    p.ncolblk = (int)cdiv(ycols, 32 * nt);
+    static const long target_waves = tune("DNMF_TN_WAVES", 2048);  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
+    long nchunks = std::max<long>(1, target_waves / p.ncolblk);
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, min_rows)));
+    p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
+    p.nchunks = (int)cdiv(nrows, p.rows_per_chunk);
+    p.ldp = (long)p.ncolblk * 32 * nt;
+    p.chunk_stride = p.ldp * 32 * kt;
+    return p;
+}
+
+inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
+
+inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
+
+// zero-padded factor images of the KL products (see pad_factors)
+size_t pad_bytes(long m, long n, int kp) {
+    return align256((size_t)m * kp * sizeof(float)) + align256((size_t)kp * round_up(n, 4) * sizeof(float));
+}
+
+template <typename TA> bool a_aligned(const TA* A) { return ((uintptr_t)A % (4 * sizeof(TA))) == 0; }
+
+// the NT form reads 16 B per lane from A whatever its type: bf16 rows need lda % 8 == 0 and a 16-byte aligned base
+template <typename TA> bool a_rows16(const TA* A, long lda) { return aligned16(A) && (lda * sizeof(TA)) % 16 == 0; }
+
 }  // namespace

@@ -1,5 +1,5 @@
 // dnmf_k16.h -- the two big contractions for rank k <= 16 on v_mfma_f32_16x16x4_f32.
-// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf.hip and csrc/dnmf_split.hip include what they launch).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; the translation units csrc/*.hip include what they launch).
 //
 // The 32x32x2 kernels pad the rank to 32, so an NMFk sweep over k = 2..16 pays twice the matrix work it needs; with
 // bf16-stored X (half the HBM bytes) that padded work, not the memory, sets the pace.  The 16x16x4 instruction has

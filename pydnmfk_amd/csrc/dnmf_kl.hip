@@ -1,0 +1,207 @@
+// dnmf_kl.hip -- C ABI of the NN-form kernels (residual / per-column error, the two KL products: csrc/dnmf_nn.h).  A translation
+// unit of its own: this kernel family compiles as long as the rest together, so it builds side by side with csrc/dnmf.hip.
+#include "dnmf_common.h"
+#include "dnmf_host.h"
+#include "dnmf_nt.h"
+#include "dnmf_stream.h"
+#include "dnmf_nn.h"
+
+extern "C" {
+
+static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, float eps) {
+    NnArgs a{};
+    a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.k = k; a.eps = eps;
+    a.nrowblk = cdiv(m, 32); a.ncolblk = (int)cdiv(n, 128);
+    a.kreal = k;
+    static const int kl_pipe = (int)tune("DNMF_KL_PIPE", 1);
+    a.pipe = kl_pipe;
+    return a;
+}
+
+static bool nn_fast(const float* A, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k) {
+    return aligned16(A) && aligned16(W) && aligned16(H) && lda % 4 == 0 && n % 4 == 0 && ldw % 4 == 0 && k % 4 == 0 &&
+           ldh % 4 == 0;
+}
+
+}  // extern "C"
+namespace {
+template <typename TA>
+int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, double* out, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
+    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
+    a.out = out;
+    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
+    const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
+#define RS_CASE(KT_)                                                                   \
+    if (kt == KT_) {                                                                   \
+        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true, TA>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((resid_kernel<KT_, false, TA>), grid, block, 0, st, a);    \
+    }
+    RS_CASE(1) RS_CASE(2) RS_CASE(4)
+#undef RS_CASE
+    return check_launch("resid_sqnorm");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                      int k, double* out, void* stream) {
+    return resid_sqnorm_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, out, stream);
+}
+int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                            int k, double* out, void* stream) {
+    return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream);
+}
+
+}  // extern "C"
+namespace {
+template <typename TA>
+int column_err_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                    double* num, double* den, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && num && den && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "column_err: bad arguments");
+    hipStream_t st = S(stream);
+    NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
+    const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
+    // about 8 waves per SIMD in flight, every wave walking a chunk of row blocks of its 128-column block
+    const long rpc = std::max<long>(1, cdiv(a.nrowblk * a.ncolblk, 8192));
+    const long waves = cdiv(a.nrowblk, rpc) * a.ncolblk;
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+#define CE_CASE(KT_)                                                                             \
+    if (kt == KT_) {                                                                             \
+        if (fast) hipLaunchKernelGGL((colerr_kernel<KT_, true, TA>), grid, block, 0, st, a, num, den, rpc); \
+        else hipLaunchKernelGGL((colerr_kernel<KT_, false, TA>), grid, block, 0, st, a, num, den, rpc);    \
+    }
+    CE_CASE(1) CE_CASE(2) CE_CASE(4)
+#undef CE_CASE
+    return check_launch("column_err");
+}
+}  // namespace
+extern "C" {
+
+int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                    double* num, double* den, void* stream) {
+    return column_err_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
+}
+int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                          double* num, double* den, void* stream) {
+    return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
+}
+
+// Factors whose rank is not a whole number of 32-wide tiles, or whose rows are not 16-byte aligned -- an NMFk sweep visits
+// k = 2, 3, 5, ... -- send the NN-form kernels (S = W H in accumulators) down their predicated paths: per-element loads
+// behind exec-masked branches, at which hipcc drains vmcnt.  Measured on 32768 x 16384 (tools/klbench.py): a KL step takes
+// 1.78 ms at k = 32, 1.90 ms at k = 8 / 16 / 20 and 2.56-2.61 ms at k = 3 / 5 / 13.  Instead the factors are copied into
+// zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
+// A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
+// outputs beyond k are never stored.
+static bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
+                        size_t ws_bytes, size_t own_need, hipStream_t st) {
+    const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
+    if (friendly || tune("DNMF_KL_PAD", 1) == 0) return false;
+    const size_t pb = pad_bytes(m, n, kp);
+    if (!ws || ws_bytes < align256(own_need) + pb) return false;
+    char* base = (char*)ws + align256(own_need);
+    float* Wp = (float*)base;
+    const long ldhp = round_up(n, 4);
+    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
+    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
+    return true;
+}
+
+struct UhtPlan { int nsplit; long cols_per_split; };
+
+static UhtPlan plan_uht(long m, long n) {
+    UhtPlan u;
+    const long rowtiles = cdiv(m, 128);
+    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
+    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
+    u.cols_per_split = round_up(cdiv(n, ns), BK);
+    u.nsplit = (int)cdiv(n, u.cols_per_split);
+    return u;
+}
+
+int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
+    const int kp = 32 * kt;
+    const UhtPlan u = plan_uht(m, n);
+    const size_t pbytes = u.nsplit > 1 ? (size_t)u.nsplit * m * kp * sizeof(float) : 0;
+    const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
+    if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
+    const int k_out = k;                                   // columns of UHT the caller gets
+    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
+        pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    a.kreal = k_out;                                       // (k may be the padded rank by now)
+    const bool split = u.nsplit > 1;
+    float* out = split ? (float*)ws : UHT;
+    const long ldout = split ? kp : ldo;
+    const int out_cols = split ? kp : k_out;
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(out) && ldout % 4 == 0;
+    const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
+    const size_t lds = 2ul * kp * BK * sizeof(float);
+    hipStream_t st = S(stream);
+#define UH_CASE(KT_)                                                                                                  \
+    if (kt == KT_) {                                                                                                  \
+        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
+                                     u.cols_per_split, out_cols);                                                     \
+        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, lds, st, a, out, ldout, (long)m * kp,        \
+                                u.cols_per_split, out_cols);                                                          \
+    }
+    UH_CASE(1) UH_CASE(2) UH_CASE(4)
+#undef UH_CASE
+    int rc = check_launch("kl_uht");
+    if (rc || !split) return rc;
+    return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
+                         (float*)((char*)ws + pbytes), st);
+}
+
+int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
+    const int kp = 32 * kt;
+    const int nt = kl_nt(kt);
+    TnPlan p = plan_tn(m, n, kt, nt);
+    const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
+    const long nchunks = cdiv(cdiv(m, 32), rowblks_per_chunk);
+    const size_t pbytes = (size_t)nchunks * p.ldp * kp * sizeof(float);
+    const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
+    if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
+    const int k_out = k;                                   // rows of WTU the caller gets
+    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+    NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
+    a.kreal = k_out;
+    a.ncolblk = p.ncolblk;
+    a.P = (float*)ws; a.ldp = p.ldp; a.chunk_stride = p.ldp * kp;
+    const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k);
+    const dim3 grid((unsigned)(cdiv(nchunks, 4) * a.ncolblk)), block(256);   // 4 row chunks (waves) per workgroup
+    const size_t lds = (size_t)kp * 32 * nt * sizeof(float);                   // the H block of the workgroup's columns
+    hipStream_t st = S(stream);
+#define WU_CASE(KT_, NT_)                                                                                         \
+    if (kt == KT_) {                                                                                              \
+        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
+        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
+    }
+    WU_CASE(1, 4) WU_CASE(2, 2) WU_CASE(4, 2)
+#undef WU_CASE
+    int rc = check_launch("kl_wtu");
+    if (rc) return rc;
+    return launch_reduce((const float*)ws, a.chunk_stride, a.ldp, (int)nchunks, WTU, ldo, k_out, n, k_out, n,
+                         (float*)((char*)ws + pbytes), st);
+}
+
+}  // extern "C"

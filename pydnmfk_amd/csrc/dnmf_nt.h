@@ -1,5 +1,5 @@
 // dnmf_nt.h -- NT form: C[i][j] = sum_c X[i][c] Y[j][c] through LDS (A H^T, H H^T, W (H H^T); fp32 and bf16-stored X).
-// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf.hip and csrc/dnmf_split.hip include what they launch).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; the translation units csrc/*.hip include what they launch).
 #pragma once
 #include "dnmf_common.h"
 

@@ -1,5 +1,5 @@
 // dnmf_stream.h -- streaming kernels: clamp, scale, KL element-wise update, norms, row / column sums.
-// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf.hip and csrc/dnmf_split.hip include what they launch).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; the translation units csrc/*.hip include what they launch).
 #pragma once
 #include "dnmf_common.h"
 

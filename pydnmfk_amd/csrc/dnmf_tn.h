@@ -1,5 +1,5 @@
 // dnmf_tn.h -- TN form: C[j][c] = sum_i X[i][j] Y[i][c] straight from global memory (W^T A, W^T W) + the partial-sum reduction.
-// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf.hip and csrc/dnmf_split.hip include what they launch).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; the translation units csrc/*.hip include what they launch).
 #pragma once
 #include "dnmf_common.h"
 
