@@ -144,20 +144,21 @@ struct SplitOperand { const bf16_t* S; long split_stride; long ld; };   // S[pie
 template <int CR>
 __device__ __forceinline__ int tile_swz(int row) { return (row / (16 / CR)) & (CR - 1); }
 
-template <int KT, int CR>
-__device__ __forceinline__ void tile_load(u32x4 (&v)[3 * KT * CR / 8], const SplitOperand& o, long k0, int tid) {
+template <int KT, int CR, int T = 256>
+__device__ __forceinline__ void tile_load(u32x4 (&v)[3 * 32 * KT * CR / T], const SplitOperand& o, long k0, int tid) {
+    static_assert(3 * 32 * KT * CR % T == 0, "whole 16-byte pieces per thread");
 #pragma unroll
-    for (int i = 0; i < 3 * KT * CR / 8; ++i) {
-        const int p = tid + 256 * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
+    for (int i = 0; i < 3 * 32 * KT * CR / T; ++i) {
+        const int p = tid + T * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
         v[i] = *reinterpret_cast<const u32x4*>(o.S + s * o.split_stride + row * o.ld + k0 + ch * 8);
     }
 }
 
-template <int KT, int CR>
-__device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT * CR / 8], int tid) {
+template <int KT, int CR, int T = 256>
+__device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * 32 * KT * CR / T], int tid) {
 #pragma unroll
-    for (int i = 0; i < 3 * KT * CR / 8; ++i) {
-        const int p = tid + 256 * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
+    for (int i = 0; i < 3 * 32 * KT * CR / T; ++i) {
+        const int p = tid + T * i, s = p / (32 * KT * CR), row = (p / CR) % (32 * KT), ch = p % CR;
         *reinterpret_cast<u32x4*>(tile + ((s * 32 * KT + row) * CR + (ch ^ tile_swz<CR>(row))) * 16) = v[i];
     }
 }
@@ -172,14 +173,15 @@ __device__ __forceinline__ void tile_store(char* tile, const u32x4 (&v)[3 * KT *
 // free, tile t + 1 (loaded NSET - 1 tiles ago) goes to the other LDS stage after the MFMAs of tile t.
 constexpr int XT = 32;                                                   // contraction indices per NT tile
 
-template <int KT, bool INTERIOR, bool NTX, int NSET, typename TX>
+template <int KT, bool INTERIOR, bool NTX, int NSET, typename TX, int NW = 4>
 __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __restrict__ X, long ldx, long nrows, long row0,
                                              const SplitOperand& ys, long cbeg, long cend, float* smem) {
     // bf16-stored X: a tile is the same 128 bytes of every row = 64 contraction indices, kept in LDS as it lies in HBM; a
     // fragment read IS the MFMA operand (no cutting), and a product is three MFMAs (the pieces of H only).
     constexpr bool B16 = std::is_same<TX, bf16_t>::value;
     constexpr int XTI = B16 ? 64 : XT, CR = XTI / 8;                 // indices per tile, 16-byte chunks per H-tile row
-    constexpr int XB = 128 * 128, HB = 3 * 32 * KT * CR * 16, STAGE = XB + HB;      // bytes
+    constexpr int BM = 32 * NW, T = 64 * NW;                       // rows and threads of the workgroup
+    constexpr int XB = BM * 128, HB = 3 * 32 * KT * CR * 16, STAGE = XB + HB;      // bytes
     char* lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,18 +195,18 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
         t = t >= nk ? t - nk : t;
         return cbeg + (long)t * XTI;
     };
-    f32x4 xv[NSET][4];
-    constexpr int NH = 3 * KT * CR / 8;                               // 16-byte pieces of the H tile per thread
+    f32x4 xv[NSET][4];                                                // BM * 8 chunks / T threads = 4
+    constexpr int NH = 3 * 32 * KT * CR / T;                          // 16-byte pieces of the H tile per thread
     u32x4 hv[NSET][NH];
     auto load = [&](f32x4 (&x)[4], u32x4 (&hh)[NH], int t) {
         const long c0 = col_of(t);
-        if constexpr (B16) stage_load_xb<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
-        else stage_load<128, 256, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
-        tile_load<KT, CR>(hh, ys, c0, tid);
+        if constexpr (B16) stage_load_xb<BM, T, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
+        else stage_load<BM, T, true, INTERIOR, NTX>(x, X, ldx, nrows, cend, row0, c0, tid);
+        tile_load<KT, CR, T>(hh, ys, c0, tid);
     };
     auto store = [&](char* st, const f32x4 (&x)[4], const u32x4 (&hh)[NH]) {
-        stage_store<128, 256>(reinterpret_cast<float*>(st), x, tid);
-        tile_store<KT, CR>(st + XB, hh, tid);
+        stage_store<BM, T>(reinterpret_cast<float*>(st), x, tid);
+        tile_store<KT, CR, T>(st + XB, hh, tid);
     };
     const int xrow = wave * 32 + li;
     const int hsw = tile_swz<CR>(li);
@@ -299,12 +301,16 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
 
 // tiles in flight: 4 register sets at KP = 64 with fp32 A (28 registers a set), 2 where a set is 40-64 registers (KP = 128, or
 // bf16 A with its 64-index H tiles); bf16 A at KP = 128 stages 128 KiB, i.e. one workgroup per CU, and may use its registers
-template <int KT, int MODE, int AUX, typename TX = float, int NSET = ((KT == 2 && std::is_same<TX, float>::value) ? 4 : 2)>
-__global__ __launch_bounds__(256, (KT == 4 && std::is_same<TX, bf16_t>::value) ? 1 : 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
+// NW = waves (32-row groups) per workgroup: 4 in the shipped library.  NW = 6 (192 rows, 166 registers with two register sets
+// in flight, three waves per SIMD) exists for A/B runs: it is slower (2.16 vs 1.91 ms at the headline shape).
+template <int KT, int MODE, int AUX, typename TX = float, int NW = 4,
+          int NSET = ((KT == 2 && std::is_same<TX, float>::value && NW == 4) ? 4 : 2)>
+__global__ __launch_bounds__(64 * NW, (KT == 4 && std::is_same<TX, bf16_t>::value) ? 1 : 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = 32 * NW;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long row0 = (long)blockIdx.x * 128;
+    const long row0 = (long)blockIdx.x * BM;
     const long cbeg = (long)blockIdx.y * p.cols_per_split;
     long cend = cbeg + p.cols_per_split;
     if (cend > p.ncols) cend = p.ncols;
@@ -316,8 +322,8 @@ __global__ __launch_bounds__(256, (KT == 4 && std::is_same<TX, bf16_t>::value) ?
         for (int r = 0; r < 16; ++r) acc[0][jt][r] = 0.f;
 
     const TX* X = static_cast<const TX*>(p.X);
-    if (row0 + 128 <= p.nrows) ntx_mainloop<KT, true, AUX != 0, NSET, TX>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
-    else ntx_mainloop<KT, false, false, 2, TX>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+    if (row0 + BM <= p.nrows) ntx_mainloop<KT, true, AUX != 0, NSET, TX, NW>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
+    else ntx_mainloop<KT, false, false, 2, TX, NW>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
 
     if constexpr (MODE == NT_STORE) {
         float* out = p.out + (long)blockIdx.y * p.split_stride;
@@ -336,8 +342,8 @@ __global__ __launch_bounds__(256, (KT == 4 && std::is_same<TX, bf16_t>::value) ?
         for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[0][jt][r] = 0.f;
-        if (p.wfast) nt_mainloop<KT, 1, 4, 1, true>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
-        else nt_mainloop<KT, 1, 4, 1, false>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        if (p.wfast) nt_mainloop<KT, 1, NW, 1, true>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
+        else nt_mainloop<KT, 1, NW, 1, false>(acc2, p.W, p.ldw, p.nrows, row0, p.G, 32 * KT, 32 * KT, 0, p.k, smem);
 #pragma unroll
         for (int jt = 0; jt < KT; ++jt)
 #pragma unroll

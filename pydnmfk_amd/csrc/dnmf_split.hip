@@ -71,17 +71,17 @@ int cut_wt(const float* W, long m, int k, int kp, long ldw, bf16_t* img, SplitOp
     return check_launch("split3_cols");
 }
 
-template <int KT, int MODE, typename TX>
+template <int KT, int MODE, typename TX, int NW = 4>
 int launch_ntx_kt(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
-    // two stages [A tile, 128 rows x 128 bytes | H tile bf16 pieces (32 indices per row for fp32 A, 64 for bf16 A)]; >= the W.G loop's LDS
-    constexpr size_t lds = 2 * (128 * 128 + 3 * 32 * KT * (std::is_same<TX, bf16_t>::value ? 128 : 64));
+    // two stages [A tile, 32 NW rows x 128 bytes | H tile bf16 pieces (32 indices per row for fp32 A, 64 for bf16 A)]; >= the W.G loop's LDS
+    constexpr size_t lds = 2 * (32 * NW * 128 + 3 * 32 * KT * (std::is_same<TX, bf16_t>::value ? 128 : 64));
     static bool once = false;
     // A is touched once: stream it past the caches when it cannot stay in them anyway
     const bool nt = (double)a.nrows * a.ncols * sizeof(TX) >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
-    if (!once) { allow_lds(ntx_kernel<KT, MODE, 0, TX>, lds); allow_lds(ntx_kernel<KT, MODE, 2, TX>, lds); once = true; }
-    const dim3 grid((unsigned)cdiv(a.nrows, 128), 1);
-    if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2, TX>), grid, dim3(256), lds, st, a, ys);
-    else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0, TX>), grid, dim3(256), lds, st, a, ys);
+    if (!once) { allow_lds(ntx_kernel<KT, MODE, 0, TX, NW>, lds); allow_lds(ntx_kernel<KT, MODE, 2, TX, NW>, lds); once = true; }
+    const dim3 grid((unsigned)cdiv(a.nrows, 32 * NW), 1);
+    if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2, TX, NW>), grid, dim3(64 * NW), lds, st, a, ys);
+    else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0, TX, NW>), grid, dim3(64 * NW), lds, st, a, ys);
     return check_launch("ntx_kernel");
 }
 
@@ -90,6 +90,12 @@ int launch_ntx(const NtArgs& a, const SplitOperand& ys, int kt, hipStream_t st) 
     if constexpr (std::is_same<TX, bf16_t>::value) {
         if (kt == 1) return launch_ntx_kt<1, MODE, TX>(a, ys, st);
     }
+#ifdef DNMF_TUNING
+    // 192-row workgroups = three waves per SIMD (166 registers, two register sets in flight): measured 2.16 ms against 1.91 ms
+    // for the 128-row form on 262144 x 8192 -- more resident waves do not fill the idle issue slots.  A/B runs only.
+    if constexpr (std::is_same<TX, float>::value)
+        if (kt == 2 && tune("DNMF_SPLIT_NW6", 0) != 0) return launch_ntx_kt<2, MODE, TX, 6>(a, ys, st);
+#endif
     return kt == 2 ? launch_ntx_kt<2, MODE, TX>(a, ys, st) : launch_ntx_kt<4, MODE, TX>(a, ys, st);
 }
 
