@@ -7,8 +7,10 @@ A "step" is one full MU iteration exactly as PyNMF.fit runs it (W update, H upda
 allreduce of [W^T A | W^T W] when N > 1, and the clamp on every 10th step), X already resident in HBM.
 
   python bench.py                      # N=1
+  python bench.py --gpus N             # N>1 typed by hand: starts its own N ranks (fresh child processes) and relays
+                                       # rank 0's JSON line and exit code
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W        # what the driver runs
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     : the dominant kernel (fused A H^T + W update, one launch), algorithmic flops / HIP-event time
@@ -18,6 +20,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   kernels      : per-kernel HIP-event times measured in situ (the step replayed primitive by primitive)
   sustained    : when the timed region asked for is shorter than 2 s, the same step timed again over >= 300 steps
                  (its own ms/step: shows the clock the chip HOLDS under the load, not its boost)
+  multi_gpu    : (N > 1) rccl_ranks_seen, per-rank compute-only ms (the same step with the exchange stubbed out) next to
+                 the full step -> exposed_comm_ms, the packed allreduce timed alone, and an A/B of the H phase's overlap
+                 chunking (overlap_chunks 1 / 2 / 4) measured in the warm-up; the fastest is used for the timed region
   cpu_baseline : the numpy oracle (port of the reference's path) in the reference's process model -- P = min(8, cores)
                  single-thread processes, each on its 1/P row slab of X -- timed on the host (N=1 only)
 With no flags: N = 1 and 500 timed steps (about 2.3 s of GPU time).
@@ -56,6 +61,9 @@ def parse_args():
                     help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
                          "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
+    ap.add_argument("--overlap-chunks", default="auto",
+                    help="N > 1: column chunks of the H phase's overlapped exchange; 'auto' (default) times 1 / 2 / 4 in "
+                         "the warm-up and uses the fastest")
     return ap.parse_args()
 
 
@@ -174,8 +182,64 @@ def pmc_traffic(role, workload="bench"):
     return best
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` typed by hand (no launcher environment): start N fresh ranks as CHILD processes through
+    torch.distributed.run, relay rank 0's JSON line and the exit code.  Nothing in this parent touches the GPU: the device
+    count comes from the KFD topology in sysfs (no HIP call), and the parent never re-executes itself."""
+    import socket
+    import subprocess
+    ndev = count_gpus()
+    oversub = bool(os.environ.get("DNMF_BENCH_OVERSUBSCRIBE")) and a.backend != "nccl"
+    if ndev < a.gpus and not oversub:
+        sys.stderr.write("bench.py: --gpus %d but this node has %d GPU(s) (DNMF_BENCH_OVERSUBSCRIBE=1 with --backend gloo "
+                         "stacks ranks on one device for debugging)\n" % (a.gpus, ndev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env)                    # stdout / stderr are inherited: rank 0's line goes straight out
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = 130
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch exited with code %d\n" % (a.gpus, rc))
+    return rc
+
+
+def count_gpus():
+    """GPUs of this node without initialising HIP: KFD topology nodes with SIMDs (CPUs have simd_count 0); falls back to
+    torch.cuda.device_count() (which does not create a context on this stack) when sysfs is not readable."""
+    import glob
+    n, seen = 0, False
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                if line.startswith("simd_count"):
+                    seen = True
+                    n += int(line.split()[1]) > 0
+        except (OSError, ValueError):
+            pass
+    if seen:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis:
+            n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+        return n
+    import torch
+    return torch.cuda.device_count()
+
+
 def main():
     a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
 
@@ -183,33 +247,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks" % a.gpus)
-        a.gpus = world
+        a.gpus = world                          # the launcher's rank count is authoritative
     ndev = torch.cuda.device_count()
-    if world > ndev and a.backend == "nccl" and not os.environ.get("DNMF_BENCH_OVERSUBSCRIBE"):   # (the override exercises the fallback below)
-        sys.exit("bench.py: %d ranks but %d GPUs" % (world, ndev))
+    if world > ndev and not (a.backend != "nccl" and os.environ.get("DNMF_BENCH_OVERSUBSCRIBE")):
+        sys.exit("bench.py: %d ranks but %d GPUs (RCCL needs one GPU per rank)" % (world, ndev))
     local = local % max(1, ndev)            # gloo debugging runs may stack ranks on one device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ctl = dev if a.backend == "nccl" else torch.device("cpu")      # where control-plane scalars of this bench are reduced
+    rccl_ranks_seen = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.backend)      # nccl = RCCL; communicators are created lazily on the current device
-        if a.backend == "nccl":
-            # one tiny collective up front: if RCCL cannot come up the run ends here with a non-zero exit (the launcher
-            # then stops the other ranks).  There is no per-rank fallback to another transport: ranks deciding that on
-            # their own could end up in different process groups.  `--backend gloo` selects the host-staged transport
-            # explicitly (debugging only; labelled in config.parallelism).
-            try:
-                t = torch.ones(1, device=dev)
-                dist.all_reduce(t)
+        # one tiny collective up front: every rank contributes 1, so the sum is the number of ranks the transport really
+        # connects.  If RCCL cannot come up the run ends here with a non-zero exit (the launcher then stops the other
+        # ranks).  There is no per-rank fallback to another transport: ranks deciding that on their own could end up in
+        # different process groups.  `--backend gloo` selects the host-staged transport explicitly (debugging only;
+        # labelled in config.parallelism).
+        try:
+            t = torch.ones(1, device=ctl)
+            dist.all_reduce(t)
+            if ctl.type == "cuda":
                 torch.cuda.synchronize()
-                if int(t.item()) != world:
-                    raise RuntimeError("allreduce returned %s" % t.item())
-            except Exception as exc:  # noqa: BLE001
-                sys.stderr.write("bench.py: RCCL did not come up on rank %d (%s)\n" % (rank, exc))
-                sys.stderr.flush()
-                os._exit(3)
+            rccl_ranks_seen = int(t.item())
+            if rccl_ranks_seen != world:
+                raise RuntimeError("allreduce of ones returned %s, expected %d" % (t.item(), world))
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("bench.py: %s did not come up on rank %d (%s)\n" % (a.backend, rank, exc))
+            sys.stderr.flush()
+            os._exit(3)
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -253,24 +319,12 @@ def main():
     def step_x6(i):
         nmf_algorithms_1D(A, W, H, params=p6).update(clamp=(i % 10 == 0))
 
-    for i in range(a.warmup):
-        step(i)
-    if world > 1:
-        barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(W).all() and torch.isfinite(H).all()
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=ctl)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     def timed(nsteps, step=step):
         """EXACTLY nsteps steps between barrier + device sync on both sides; max over ranks."""
@@ -284,12 +338,97 @@ def main():
         if world > 1:
             barrier()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # N > 1, before the timed region (untimed, part of the warm-up): how many column chunks the H phase's exchange is cut
+    # into (dist_nmf._fro_h_phase_overlapped: W^T A of chunk c+1 is computed while chunk c is being reduced) is decided from
+    # DATA -- 1 (one packed allreduce), 2 and 4 chunks are each timed over a few steps, every rank sees the same
+    # max-over-ranks times and therefore picks the same winner.
+    mg = None
+    if world > 1:
+        mg = {"rccl_ranks_seen": rccl_ranks_seen, "backend": a.backend}
+        if a.norm == "fro" and a.overlap_chunks == "auto":
+            ab, nab = {}, max(5, min(40, a.steps))
+            for c in (1, 2, 4):
+                p.overlap_chunks = c
+                for i in range(3):
+                    step(i)
+                ab[c] = timed(nab) / nab * 1e3
+            best = min(ab, key=ab.get)
+            p.overlap_chunks = best
+            mg["overlap_chunks_ab_ms_per_step"] = {str(c): v for c, v in ab.items()}
+            mg["overlap_chunks_ab_steps"] = nab
+            mg["overlap_chunks_used"] = best
+        elif a.overlap_chunks != "auto":
+            p.overlap_chunks = int(a.overlap_chunks)
+            mg["overlap_chunks_used"] = int(a.overlap_chunks)
+        p6.overlap_chunks = getattr(p, "overlap_chunks", 1)
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(W).all() and torch.isfinite(H).all()
+
+    # N > 1: where the step's time goes.  (a) the same step with the exchange stubbed out (NullExchange: every allreduce
+    # returns at once, so H diverges between ranks -- timing only; H is re-broadcast afterwards): per-rank compute-only
+    # ms; exposed_comm_ms = full step - slowest rank's compute-only step.  (b) the packed [W^T A | W^T W] allreduce alone.
+    if world > 1:
+        from pydnmfk_amd.dist_comm import NullExchange
+        pn = parse()
+        pn.__dict__.update(vars(p))
+        pn.comm1 = NullExchange(p.comm1)
+        H_keep = H.clone()
+
+        def step_nocomm(i):
+            nmf_algorithms_1D(A, W, H, params=pn).update(clamp=(i % 10 == 0))
+
+        for i in range(3):
+            step_nocomm(i)
+        nn = max(10, min(200, a.steps))
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nn):
+            step_nocomm(i)
+        torch.cuda.synchronize()
+        mine = (time.perf_counter() - t0) / nn * 1e3
+        per = [None] * world
+        dist.all_gather_object(per, mine)
+        H.copy_(H_keep)
+        H.copy_(comms.comm.bcast(H, root=0))
+        del H_keep
+        kp_ = 32 if k <= 32 else (64 if k <= 64 else 128)
+        xbuf = torch.rand(k * n + kp_ * kp_, device=dev)
+        for _ in range(3):
+            comms.comm.allreduce_(xbuf)
+        nx = 20
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nx):
+            comms.comm.allreduce_(xbuf)
+        torch.cuda.synchronize()
+        t_ar = max_over_ranks((time.perf_counter() - t0) / nx * 1e3)
+        del xbuf
+        mg["compute_only_ms_per_rank"] = per
+        mg["compute_only_ms"] = max(per)
+        mg["full_step_ms"] = elapsed / a.steps * 1e3
+        mg["exposed_comm_ms"] = elapsed / a.steps * 1e3 - max(per)
+        mg["allreduce_alone_ms"] = t_ar
+        mg["allreduce_bytes"] = 4 * (k * n + kp_ * kp_)
+        mg["note"] = ("compute_only = the same step with every exchange stubbed out (timing only); exposed_comm_ms = full "
+                      "step - slowest rank's compute-only step; allreduce_alone = the packed [W^T A | W^T W] message "
+                      "reduced back to back with nothing else on the GPU")
 
     out = None
     if rank == 0:
@@ -308,6 +447,8 @@ def main():
             "step_mfma_frac": (flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if a.gemm == "fp32" else None,
             "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
         }
+        if mg is not None:
+            out["multi_gpu"] = mg
 
     # A timed region of a few tens of ms (the driver's --steps 20) shows the boost clock; the big kernels are bound by the
     # clock the chip HOLDS under MFMA + HBM load.  Time the same step again over >= 300 steps (every rank takes part).
@@ -318,10 +459,11 @@ def main():
         if rank == 0:
             out["sustained"] = {"steps": ns, "seconds": el, "ms_per_step": el / ns * 1e3, "value": ns / el,
                                 "note": "same step, longer timed region (the headline value above is the K steps asked for)"}
+            out["sustained_ms_per_step"] = el / ns * 1e3
 
     # The same step with the two big contractions as six bf16 piece products per fp32 product (opt-in, params.gemm =
     # 'bf16x6'): reported NEXT TO the fp32-MFMA headline, never as it.  Same factors, same data, every rank takes part.
-    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
+    if world == 1 and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
         for i in range(5):
             step_x6(i)
         ns6 = max(100, int(1.5 / max(elapsed / a.steps, 1e-6)))
@@ -338,7 +480,7 @@ def main():
     # Informational: the same problem with X STORED as bfloat16 (params.precision = 'bfloat16': X is rounded once, arithmetic and
     # factors stay fp32) -- with the fp32-MFMA kernels (no gain at this rank: they are matrix-pipe bound) and with bf16x6, where
     # X is its own single piece and a product is three bf16 MFMAs.  A different X than the headline's, hence its own key.
-    if a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
+    if world == 1 and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
         A_f32 = A
         A = A_f32.to(torch.bfloat16)
         res16 = {}

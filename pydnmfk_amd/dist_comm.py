@@ -190,6 +190,34 @@ class _Done:
         return True
 
 
+class NullExchange:
+    """A communicator whose exchanges return at once (rank / size of the wrapped one).  MEASUREMENT ONLY: bench.py times
+    the step with it to separate a rank's compute from the exchange; on more than one rank the results are wrong by
+    construction (every rank keeps its own partial sums)."""
+
+    def __init__(self, comm):
+        self.rank, self.size, self.ranks = comm.rank, comm.size, comm.ranks
+        self.backend, self.device, self.group = comm.backend, comm.device, comm.group
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def allreduce_(self, t):
+        return t
+
+    def allreduce_begin(self, t):
+        return _Done()
+
+    def allreduce(self, x, op=None):
+        return x
+
+    def barrier(self):
+        pass
+
+
 def COMM_WORLD():
     """The world communicator (every rank of the torch.distributed job, or a single process)."""
     return TorchComm(None)

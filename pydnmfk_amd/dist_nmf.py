@@ -152,13 +152,17 @@ class nmf_algorithms_1D(_Base):
         """Column chunks of the H phase on a row grid of more than two ranks (the 8-GPU configuration): the exchange of
         chunk c runs on the communicator's stream while W^T A of chunk c+1 is computed, only the last exchange is
         exposed.  Up to two ranks the single packed allreduce stays (one latency, nothing worth hiding behind).
-        `params.overlap_chunks` (default 2) / `params.overlap_min_cols` (default 4096) tune it; 1 switches it off.
+        `params.overlap_chunks` (default 2 beyond two ranks; an explicit value is honoured from two ranks on -- bench.py
+        times 1 / 2 / 4 in its warm-up and keeps the fastest) / `params.overlap_min_cols` (default 4096) tune it; 1 switches it off.
         Compute-side cost of the chunks on the 8-GPU shard (32768 x 8192, k = 64, tools/chunkbench.py, no exchange):
         1 / 2 / 4 / 8 chunks = 0.654 / 0.668 / 0.752 / 0.816 ms per step -- two chunks cost 13 us and hide about half of
         the exchange, four cost more than a 2 MiB allreduce is expected to take, hence the default."""
-        if self.p_c != 1 or self.p_r <= 2:
+        if self.p_c != 1 or self.p_r < 2:
             return 1
-        nch = int(getattr(self.params, "overlap_chunks", 2))
+        nch = getattr(self.params, "overlap_chunks", None)
+        if nch is None:                                            # default: two ranks keep the single packed allreduce
+            nch = 2 if self.p_r > 2 else 1
+        nch = int(nch)
         if nch <= 1 or n_l < int(getattr(self.params, "overlap_min_cols", 4096)):
             return 1
         return max(1, min(nch, n_l // 64))

@@ -1,0 +1,78 @@
+"""bench.py as the driver (and a person) launches it: `python bench.py --gpus N` starts its own N ranks, N > 1 lines carry
+the exchange diagnostics.  CPU tier: the launcher refuses cleanly without GPUs.  GPU tier: two ranks stacked on the one
+GPU over the host-staged gloo transport (RCCL refuses two ranks on one device) -- the whole N > 1 code path of bench.py
+except the RCCL calls themselves, which tests/test_gpu_rccl.py covers on a one-rank group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_count_gpus_needs_no_hip():
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.count_gpus()
+    assert isinstance(n, int) and n >= 0
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK), reason="a GPU is present")
+def test_launcher_refuses_without_gpus():
+    """No GPU in this container: `--gpus 2` must end with ONE line saying why and a non-zero exit, before any rank starts."""
+    r = _run(["--gpus", "2", "--steps", "2"], timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr)
+    err = [ln for ln in r.stderr.splitlines() if ln.strip()]
+    assert len(err) == 1 and "--gpus 2" in err[0] and "GPU" in err[0], r.stderr
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cols", [1024, 4096])
+def test_two_ranks_on_one_gpu_gloo(cols):
+    r = _run(["--gpus", "2", "--rows", "8192", "--cols", str(cols), "--steps", "5", "--warmup", "2", "--backend", "gloo",
+              "--no-cpu-baseline"], env_extra={"DNMF_BENCH_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["scaling"] == "strong" and out["value"] > 0 and out["config"]["rows_per_gpu"] == 4096
+    mg = out["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 2 and mg["backend"] == "gloo"
+    assert len(mg["compute_only_ms_per_rank"]) == 2 and all(v > 0 for v in mg["compute_only_ms_per_rank"])
+    assert abs(mg["exposed_comm_ms"] - (mg["full_step_ms"] - mg["compute_only_ms"])) < 1e-9
+    assert set(mg["overlap_chunks_ab_ms_per_step"]) == {"1", "2", "4"} and mg["overlap_chunks_used"] in (1, 2, 4)
+    assert mg["allreduce_alone_ms"] > 0 and mg["allreduce_bytes"] == 4 * (64 * cols + 64 * 64)
+    assert out["roofline"]["bound"] == "mfma" and "cpu_baseline" not in out
+
+
+@pytest.mark.gpu
+def test_launcher_refuses_more_ranks_than_gpus_over_rccl():
+    """One GPU on the box: `--gpus 2` over RCCL must be refused by the parent (one line, exit 2), not fail inside RCCL."""
+    r = _run(["--gpus", "2", "--steps", "2"], timeout=120)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_small():
+    r = _run(["--rows", "8192", "--cols", "1024", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-sustained"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and "multi_gpu" not in out and out["value"] > 0
