@@ -13,6 +13,9 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdnmf_hip.so")
 TUNE_LIB = os.path.join(ROOT, "tools", "_build", "libdnmf_hip_tune.so")   # -DDNMF_TUNING: experiment switches (tools only)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-unit compiler flags.  dnmf_kl16: MFMA accumulators in VGPRs (no v_accvgpr copies around the division of the KL
+# products -- on gfx950 every fp32 vector instruction costs matrix-pipe time, csrc/dnmf_kl16.h)
+UNIT_FLAGS = {"dnmf_kl16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale():
@@ -51,7 +54,8 @@ def build_lib(force=False, report=False, tuning=False):
         src, obj = pair
         if only and only not in os.path.basename(src) and os.path.exists(obj):
             return ""
-        res = subprocess.run([HIPCC] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        res = subprocess.run([HIPCC] + flags + UNIT_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj],
+                             capture_output=True, text=True)
         if res.returncode != 0:
             sys.stderr.write(res.stderr)
             raise RuntimeError("hipcc failed on %s (%d)" % (os.path.basename(src), res.returncode))

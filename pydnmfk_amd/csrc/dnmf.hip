@@ -195,23 +195,6 @@ struct WsLayout {
     size_t g_off, s_off, x_off, part_off, total;  // G [KP*KP] | S = AtW / AH / UHT / WTU | x [KP] | partials
 };
 
-// k <= 16 kernels (dnmf_k16.h): DNMF_K16=0 switches them off (A/B runs)
-inline bool k16_on() {
-    static const bool on = tune("DNMF_K16", 1) != 0;
-    return on;
-}
-// row chunking of tn16_kernel: waves = nchunks x (n / (16 V)), 16-row partial slabs of ld = n
-struct Tn16Plan { int ncolblk; int nchunks; long rows_per_chunk; };
-Tn16Plan plan_tn16(long m, long n, int v) {
-    Tn16Plan p;
-    p.ncolblk = (int)(n / (16 * v));
-    long nchunks = std::max<long>(1, 4096 / std::max(1, p.ncolblk));   // ~4 waves per SIMD
-    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(m, 256)));
-    p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
-    p.nchunks = (int)cdiv(m, p.rows_per_chunk);
-    return p;
-}
-
 size_t partial_bytes(long m, long n, int k) {
     const int kt = kt_of(k), kp = 32 * kt;
     size_t b = 0;
@@ -221,6 +204,8 @@ size_t partial_bytes(long m, long n, int k) {
             Tn16Plan q = plan_tn16(m, n, v);
             b = std::max(b, (size_t)q.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(q.nchunks, k, n));
         }
+        const Tn16Plan w = plan_wtu16(m, n);                        // kl_wtu16 partial slabs
+        b = std::max(b, (size_t)w.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(w.nchunks, k, n));
     }
     {   // wta / kl_wtu: A [m x n]
         TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
@@ -243,6 +228,11 @@ size_t partial_bytes(long m, long n, int k) {
         const long cps = round_up(cdiv(n, ns), BK);
         const int nsp = (int)cdiv(n, cps);
         if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
+        if (k <= 16) {   // kl_uht16: 16-wide slabs, also for a single split (ranks below 16 go through the slab)
+            const long ns16 = std::min<long>(std::max<long>(1, 1024 / rowtiles), std::max<long>(1, n / 256));
+            const int nsp16 = (int)cdiv(n, round_up(cdiv(n, ns16), BK));
+            b = std::max(b, (size_t)nsp16 * m * 16 * sizeof(float) + reduce_scratch_bytes(nsp16, (int)m, k));
+        }
     }
     b = std::max(b, (size_t)1024 * kp * sizeof(float));  // colsum partials (at most 1024 slabs)
     // HALS W sweep: slots + norms + the m x KP block T of its first pass (only when the sweep is asked for a factor of

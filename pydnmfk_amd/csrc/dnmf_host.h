@@ -82,6 +82,39 @@ TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
     return p;
 }
 
+// k <= 16 kernels (dnmf_k16.h): DNMF_K16=0 switches them off (A/B runs)
+inline bool k16_on() {
+    static const bool on = tune("DNMF_K16", 1) != 0;
+    return on;
+}
+// row chunking of tn16_kernel: waves = nchunks x (n / (16 V)), 16-row partial slabs of ld = n
+struct Tn16Plan { int ncolblk; int nchunks; long rows_per_chunk; };
+Tn16Plan plan_tn16(long m, long n, int v) {
+    Tn16Plan p;
+    p.ncolblk = (int)(n / (16 * v));
+    long nchunks = std::max<long>(1, 4096 / std::max(1, p.ncolblk));   // ~4 waves per SIMD
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(m, 256)));
+    p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
+    p.nchunks = (int)cdiv(m, p.rows_per_chunk);
+    return p;
+}
+
+// Row chunking of kl_wtu16_kernel: waves = nchunks x (n / 64) and ALL of them must be resident at once -- a second,
+// partly filled round of waves runs one wave per SIMD with 4 KiB in flight each and is bound by the HBM latency (measured:
+// 4096 waves on 3072 slots took 0.50 ms, of which the last third of the waves 0.2 ms).  So the wave count is the largest
+// multiple of the column blocks that fits WTU16_SLOTS (256 CUs x 4 SIMDs x the waves per SIMD the register count admits).
+constexpr int WTU16_WAVES_PER_SIMD = 4;
+Tn16Plan plan_wtu16(long m, long n) {
+    Tn16Plan p;
+    p.ncolblk = (int)(n / 64);
+    const long slots = 1024L * WTU16_WAVES_PER_SIMD;
+    long nchunks = std::max<long>(1, slots / std::max(1, p.ncolblk));
+    nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(m, 64)));
+    p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
+    p.nchunks = (int)cdiv(m, p.rows_per_chunk);
+    return p;
+}
+
 inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
 
 inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
@@ -89,6 +122,45 @@ inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in
 // zero-padded factor images of the KL products (see pad_factors)
 size_t pad_bytes(long m, long n, int kp) {
     return align256((size_t)m * kp * sizeof(float)) + align256((size_t)kp * round_up(n, 4) * sizeof(float));
+}
+
+// Factors whose rank is not a whole number of 32-wide tiles, or whose rows are not 16-byte aligned -- an NMFk sweep visits
+// k = 2, 3, 5, ... -- send the NN-form kernels (S = W H in accumulators) down their predicated paths: per-element loads
+// behind exec-masked branches, at which hipcc drains vmcnt.  Measured on 32768 x 16384 (tools/klbench.py): a KL step takes
+// 1.78 ms at k = 32, 1.90 ms at k = 8 / 16 / 20 and 2.56-2.61 ms at k = 3 / 5 / 13.  Instead the factors are copied into
+// zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
+// A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
+// outputs beyond k are never stored.
+bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
+                        size_t ws_bytes, size_t own_need, hipStream_t st) {
+    const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
+    if (friendly || tune("DNMF_KL_PAD", 1) == 0) return false;
+    const size_t pb = pad_bytes(m, n, kp);
+    if (!ws || ws_bytes < align256(own_need) + pb) return false;
+    char* base = (char*)ws + align256(own_need);
+    float* Wp = (float*)base;
+    const long ldhp = round_up(n, 4);
+    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
+    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
+    return true;
+}
+
+struct UhtPlan { int nsplit; long cols_per_split; };
+
+UhtPlan plan_uht(long m, long n) {
+    UhtPlan u;
+    const long rowtiles = cdiv(m, 128);
+    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
+    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
+    u.cols_per_split = round_up(cdiv(n, ns), 32);          // 32 = BK, the column tile of the NT-shaped kernels
+    u.nsplit = (int)cdiv(n, u.cols_per_split);
+    return u;
 }
 
 template <typename TA> bool a_aligned(const TA* A) { return ((uintptr_t)A % (4 * sizeof(TA))) == 0; }

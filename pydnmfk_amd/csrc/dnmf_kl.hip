@@ -6,6 +6,14 @@
 #include "dnmf_stream.h"
 #include "dnmf_nn.h"
 
+// the 16-wide kernels for k <= 16 live in csrc/dnmf_kl16.hip (own compiler flags); 1 = not applicable
+__attribute__((visibility("hidden"))) int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, long ldw,
+                                                         const float* H, long ldh, int k, float eps, float* UHT, long ldo,
+                                                         void* ws, size_t ws_bytes, void* stream);
+__attribute__((visibility("hidden"))) int dnmf_kl16_wtu_(const float* A, long m, long n, long lda, const float* W, long ldw,
+                                                         const float* H, long ldh, int k, float eps, float* WTU, long ldo,
+                                                         void* ws, size_t ws_bytes, void* stream);
+
 extern "C" {
 
 static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
@@ -93,45 +101,6 @@ int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* 
     return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
 }
 
-// Factors whose rank is not a whole number of 32-wide tiles, or whose rows are not 16-byte aligned -- an NMFk sweep visits
-// k = 2, 3, 5, ... -- send the NN-form kernels (S = W H in accumulators) down their predicated paths: per-element loads
-// behind exec-masked branches, at which hipcc drains vmcnt.  Measured on 32768 x 16384 (tools/klbench.py): a KL step takes
-// 1.78 ms at k = 32, 1.90 ms at k = 8 / 16 / 20 and 2.56-2.61 ms at k = 3 / 5 / 13.  Instead the factors are copied into
-// zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
-// A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
-// outputs beyond k are never stored.
-static bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
-                        size_t ws_bytes, size_t own_need, hipStream_t st) {
-    const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
-    if (friendly || tune("DNMF_KL_PAD", 1) == 0) return false;
-    const size_t pb = pad_bytes(m, n, kp);
-    if (!ws || ws_bytes < align256(own_need) + pb) return false;
-    char* base = (char*)ws + align256(own_need);
-    float* Wp = (float*)base;
-    const long ldhp = round_up(n, 4);
-    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
-    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
-    return true;
-}
-
-struct UhtPlan { int nsplit; long cols_per_split; };
-
-static UhtPlan plan_uht(long m, long n) {
-    UhtPlan u;
-    const long rowtiles = cdiv(m, 128);
-    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
-    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
-    u.cols_per_split = round_up(cdiv(n, ns), BK);
-    u.nsplit = (int)cdiv(n, u.cols_per_split);
-    return u;
-}
-
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
                 float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
     const int kt = kt_of(k);
@@ -142,6 +111,7 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
     const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
     if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
     const int k_out = k;                                   // columns of UHT the caller gets
+    if (int rc16 = dnmf_kl16_uht_(A, m, n, lda, W, ldw, H, ldh, k, eps, UHT, ldo, ws, ws_bytes, stream); rc16 != 1) return rc16;
     if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
         pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
@@ -182,6 +152,7 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);
     const int k_out = k;                                   // rows of WTU the caller gets
+    if (int rc16 = dnmf_kl16_wtu_(A, m, n, lda, W, ldw, H, ldh, k, eps, WTU, ldo, ws, ws_bytes, stream); rc16 != 1) return rc16;
     if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
     a.kreal = k_out;

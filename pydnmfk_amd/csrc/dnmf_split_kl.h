@@ -35,15 +35,7 @@ __device__ __forceinline__ u32x4 ld8x2(const bf16_t* p, long second) {          
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-// a / d for 0 < d < inf away from the ends of the exponent range (d = S + eps here): reciprocal, one Newton step, quotient
-// and one residual correction -- the division sequence hipcc emits (v_div_scale / v_div_fmas / v_div_fixup) without its
-// range scaling: 6 VALU instructions instead of 10, same result wherever no intermediate underflows or overflows.
-__device__ __forceinline__ float div_pos(float a, float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    float q = a * r;
-    return fmaf(fmaf(-d, q, a), r, q);
-}
+// (div_pos, the division of U = A / (S + eps): dnmf_common.h)
 
 // swizzle key of a tile row whose length is CR 16-byte chunks (CR = 4, 8: 64- and 128-byte rows), see lds_idx / htile_store
 template <int CR>

@@ -153,6 +153,33 @@ def test_kl_pieces(ops, m, n, k):
     assert _rel(Hd.cpu().numpy(), H64 * (wtu / (x1[:, None].astype(np.float64) + EPS))) < 1e-6
 
 
+@pytest.mark.parametrize("m,n,k,pad", [(500, 96, 12, 0), (163968, 64, 16, 0), (2000, 4096, 16, 0), (777, 640, 16, 8),
+                                       (4096, 1024, 3, 4), (65, 32, 16, 0), (40000, 192, 14, 0)])
+def test_kl16_products(ops, m, n, k, pad):
+    """The 16-wide KL kernels (csrc/dnmf_kl16.h; dist_nmf.py:806-810): a column count that only the U H^T kernel takes
+    (n % 32 == 0, n % 64 != 0), many row chunks / column splits, sub-blocks of wider buffers (`pad` extra columns in every
+    leading dimension), ranks that go through the zero-padded factor images."""
+    A, W, H = _mk(m, n, k)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    U = A64 / (W64 @ H64 + EPS)
+
+    def view(x):
+        r, c = x.shape
+        big = torch.full((r, c + pad), 3.0, device="cuda")
+        big[:, :c] = _d(x)
+        return big[:, :c]
+
+    dA, dW, dH = view(A), view(W), view(H)
+    uht = torch.full((m, k + pad), 7.0, device="cuda")
+    ops.kl_uht(dA, dW, dH, EPS, uht[:, :k])
+    assert _rel(uht[:, :k].cpu().numpy(), U @ H64.T) < 5e-6
+    wtu = torch.full((k, n + pad), 7.0, device="cuda")
+    ops.kl_wtu(dA, dW, dH, EPS, wtu[:, :n])
+    assert _rel(wtu[:, :n].cpu().numpy(), W64.T @ U) < 5e-6
+    if pad:
+        assert float(uht[:, k:].min()) == 7.0 and float(wtu[:, n:].min()) == 7.0      # nothing written beyond the logical width
+
+
 @pytest.mark.parametrize("m,n,k", SHAPES)
 def test_norms_and_fit_helpers(ops, m, n, k):
     """np.linalg.norm(A)**2 and np.linalg.norm(A - W@H)**2 (pyDNMF.py:207-217); clamp (:155-157); normalise (:185-194)."""

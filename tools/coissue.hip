@@ -1,0 +1,93 @@
+// coissue.hip -- do fp32 VALU instructions overlap with fp32 MFMAs on one SIMD?  (MI355X_MICROARCH.md quantifies the overlap
+// for the bf16 MFMA shapes; the fp32-input MFMA runs at the fp32 VALU rate and the KL kernels put a division between two
+// fp32 products, so the answer decides what their ceiling is.)
+// Each trip: M independent v_mfma_f32_16x16x4_f32 (4 accumulator chains) and V independent VALU ops (v_fma_f32, or v_rcp_f32
+// for every fourth one with RCP = 1); W waves per SIMD; cycles per trip come from s_memtime.
+// Build: hipcc -O3 --offload-arch=gfx950 -o tools/coissue tools/coissue.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int M, int V, int RCP, int SHAPE>
+__global__ __launch_bounds__(256) void k(long trips, float* out, unsigned long long* cyc) {
+    const int lane = threadIdx.x & 63;
+    float a = 1.0f + lane * 1e-6f, b = 0.5f;
+    f32x4 acc[4];
+    f32x16 acc32[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
+    float x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = 1.0f + j + lane * 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (long t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < (M > V ? M : V); ++i) {
+            if (i < M) {
+                if constexpr (SHAPE == 16) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i & 3], 0, 0, 0);
+                else acc32[i & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32[i & 1], 0, 0, 0);
+            }
+            if (i < V) {
+                if (RCP && (i & 3) == 3) x[i & 15] = __builtin_amdgcn_rcpf(x[i & 15]);
+                else x[i & 15] = fmaf(x[i & 15], 0.999f, 0.001f);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc32[i][r];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += x[j];
+    if (s == 123.456f) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int M, int V, int RCP, int SHAPE>
+void run(int wps, float* out, unsigned long long* cyc) {
+    const long trips = 20000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int grid = 256 * wps;      // 4-wave workgroups: wps workgroups per CU = wps waves per SIMD
+    hipLaunchKernelGGL((k<M, V, RCP, SHAPE>), dim3(grid), dim3(256), 0, 0, trips / 10, out, cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k<M, V, RCP, SHAPE>), dim3(grid), dim3(256), 0, 0, trips, out, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    // s_memtime counts at 100 MHz steps of the shader clock? (MI355X_MICROARCH.md: tick = shader cycle)
+    printf("shape %2d  M=%2d V=%2d rcp=%d waves/SIMD=%d : %8.3f ms  %7.1f memtime ticks/trip  (%5.1f ns/trip)  MFMA-only floor %d cycles\n",
+           SHAPE, M, V, RCP, wps, ms, (double)c / trips, ms * 1e6 / trips, M * (SHAPE == 16 ? 32 : 64) * wps);
+}
+
+int main() {
+    float* out; unsigned long long* cyc;
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 64));
+    for (int wps = 1; wps <= 4; wps += (wps == 1 ? 1 : 2)) {     // 1, 2, 4
+        run<8, 0, 0, 16>(wps, out, cyc);
+        run<8, 8, 0, 16>(wps, out, cyc);
+        run<8, 16, 0, 16>(wps, out, cyc);
+        run<8, 32, 0, 16>(wps, out, cyc);
+        run<8, 64, 0, 16>(wps, out, cyc);
+        run<8, 32, 1, 16>(wps, out, cyc);
+        run<0, 32, 0, 16>(wps, out, cyc);
+        run<0, 64, 0, 16>(wps, out, cyc);
+        run<4, 0, 0, 32>(wps, out, cyc);
+        run<4, 32, 0, 32>(wps, out, cyc);
+        run<4, 64, 0, 32>(wps, out, cyc);
+    }
+    return 0;
+}

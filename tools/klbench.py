@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 A = torch.rand(m, n, device=dev, generator=g); W = torch.rand(m, k, device=dev, generator=g); H = torch.rand(k, n, device=dev, generator=g)
 UHT = torch.empty(m, k, device=dev); WTU = torch.empty(k, n, device=dev)
-def t(fn, reps=4, warm=1):
+def t(fn, reps=int(os.environ.get("REPS", "10")), warm=3):
     for _ in range(warm): fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for s, e in ev:
