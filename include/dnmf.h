@@ -15,9 +15,10 @@
  *   - return value: 0 on success, negative DNMF_E* on error (dnmf_last_error() has text);
  *   - k <= DNMF_MAX_K.  Internally k is padded to KP = 32/64/128; "gram" buffers G are
  *     always KP x KP, ld = KP, zero padded (dnmf_kp(k) returns KP).
- * Collectives are NOT in this library: the p_r x p_c grid exchanges (allreduce /
- * allgather / reduce_scatter over RCCL) are issued by the host between these calls,
- * exactly where the reference calls mpi4py (dist_nmf.py:681,707,114,163,169,195,202).
+ * Collectives: the kernels above the "Grid exchanges" section never communicate -- a host may issue the p_r x p_c grid
+ * exchanges itself between these calls, exactly where the reference calls mpi4py (dist_nmf.py:681,707,114,163,169,195,
+ * 202; pydnmfk_amd/dist_nmf.py does so over torch.distributed).  The last section binds RCCL at run time and offers
+ * communicators plus whole 1D steps that enqueue kernels -> allreduce -> kernels on one stream.
  */
 #ifndef DNMF_H
 #define DNMF_H
@@ -33,6 +34,7 @@ extern "C" {
 #define DNMF_EINVAL (-1)   /* bad shape / null pointer / k too large */
 #define DNMF_EWS (-2)      /* workspace too small */
 #define DNMF_EHIP (-3)     /* HIP launch error */
+#define DNMF_ECOMM (-4)    /* RCCL missing or an RCCL call failed */
 
 const char* dnmf_last_error(void);
 int dnmf_version(void);
@@ -193,6 +195,43 @@ int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W,
                        int k, float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream);
 int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
                            int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Grid exchanges inside the library (RCCL over xGMI; replaces MPI_comm, dist_comm.py:16-56, and the mpi4py calls of
+ * global_gram / global_mm, dist_nmf.py:681,707).  RCCL is bound at run time (dlopen; an RCCL already in the process -- the
+ * PyTorch host's -- is preferred), so the library loads without it; these entry points then return DNMF_ECOMM.
+ * One communicator handle per rank (= per process = per GPU; the current HIP device at dnmf_comm_create is the rank's GPU).
+ * Rank r sits at grid coordinates (i, j) = (r / p_c, r % p_c), the reference's Create_cart(reorder=False). ---- */
+#define DNMF_UNIQUE_ID_BYTES 128
+typedef struct dnmf_comm dnmf_comm_t;
+/* rank 0: fill 128 bytes that every rank must pass to dnmf_comm_create (the host broadcasts them: mpi4py bcast,
+ * torch.distributed broadcast_object_list, a file ...) */
+int dnmf_comm_unique_id(void* id_out);
+/* collective over all nranks processes; p_r * p_c == nranks; 2D grids also get the two sub-communicators
+ * (cart_1d_row = the p_r ranks of one grid column, cart_1d_column = the p_c ranks of one grid row, dist_comm.py:25-51) */
+int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p_c, dnmf_comm_t** out);
+int dnmf_comm_destroy(dnmf_comm_t* comm);
+int dnmf_comm_info(const dnmf_comm_t* comm, int* nranks, int* rank, int* p_r, int* p_c);
+/* column chunks of the overlapped H phase of dnmf_mu_fro_step_1d on a row grid (1 = one packed allreduce; <= 8) */
+int dnmf_comm_set_overlap_chunks(dnmf_comm_t* comm, int chunks);
+/* testing aid: with on != 0 a ONE-rank communicator still issues its RCCL calls (a 1 x 1 grid then behaves as a row grid),
+ * so that the exchange path can be exercised on a single GPU */
+int dnmf_comm_set_always_exchange(dnmf_comm_t* comm, int on);
+/* in-place SUM allreduce of `count` floats on `stream`; group 0 = all ranks, 1 = cart_1d_row, 2 = cart_1d_column
+ * (comm.allreduce of dist_nmf.py:114,681,707 and the host's scalar reductions) */
+int dnmf_comm_allreduce(dnmf_comm_t* comm, float* buf, size_t count, int group, void* stream);
+/* workspace of the two 1D steps below for a rank holding an m_l x n_l block (kernel scratch + the packed exchange buffers) */
+size_t dnmf_ws_bytes_1d(long m_l, long n_l, int k);
+/* One whole MU / Frobenius step of one rank of a 1D grid, exchanges included (nmf_algorithms_1D.update, dist_nmf.py:755-771
+ * with global_gram / global_mm :663-708): p_c == 1 (A, W row blocks; H replicated): fused W phase, then ONE allreduce of the
+ * packed [W^T A | W^T W] message (or overlapped column chunks, see dnmf_comm_set_overlap_chunks); p_r == 1: the mirror
+ * image with [A H^T | H H^T].  Everything is enqueued on `stream` (the chunked exchange on an internal stream, ordered by
+ * events); the call returns without synchronising.  Same arithmetic as the per-kernel entry points called in that order. */
+int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                        float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
+/* The same for MU / KL (dist_nmf.py:851-869 with sum_along_axis / glob_UX :776-811): [U H^T | rowsum H] is reduced when
+ * p_r == 1, [W^T U | colsum W] when p_c == 1. */
+int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                       float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
 
 #ifdef __cplusplus
 }

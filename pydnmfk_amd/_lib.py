@@ -73,7 +73,19 @@ for _n in ("aht", "wta", "aht_update_w", "mu_fro_step"):
 SIGNATURES["dnmf_kl_uht_bf16x6"] = SIGNATURES["dnmf_kl_uht"]
 SIGNATURES["dnmf_kl_wtu_bf16x6"] = SIGNATURES["dnmf_kl_wtu"]
 SIGNATURES["dnmf_mu_kl_step_bf16x6"] = SIGNATURES["dnmf_mu_kl_step"]
-_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t}
+# grid exchanges inside the library (csrc/dnmf_comm.hip); the communicator handle is an opaque pointer
+SIGNATURES["dnmf_comm_unique_id"] = [c_void_p]
+SIGNATURES["dnmf_comm_create"] = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
+SIGNATURES["dnmf_comm_destroy"] = [c_void_p]
+SIGNATURES["dnmf_comm_info"] = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+SIGNATURES["dnmf_comm_set_overlap_chunks"] = [c_void_p, c_int]
+SIGNATURES["dnmf_comm_set_always_exchange"] = [c_void_p, c_int]
+SIGNATURES["dnmf_comm_allreduce"] = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+SIGNATURES["dnmf_ws_bytes_1d"] = SIGNATURES["dnmf_ws_bytes"]
+SIGNATURES["dnmf_mu_fro_step_1d"] = SIGNATURES["dnmf_mu_fro_step"][:-1] + [c_void_p, c_void_p]
+SIGNATURES["dnmf_mu_kl_step_1d"] = SIGNATURES["dnmf_mu_fro_step_1d"]
+_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
+             "dnmf_ws_bytes_1d": c_size_t}
 
 
 def load():

@@ -1,0 +1,303 @@
+// dnmf_comm.hip -- the grid exchanges INSIDE the library: RCCL communicators for the p_r x p_c grid (dist_comm.py:16-56) and
+// whole 1D steps that enqueue  kernels -> ncclAllReduce -> kernels  on the caller's stream with no host code in between
+// (dist_nmf.py:663-771 Frobenius, :776-869 KL).  A host that is not PyTorch (the reference's mpi4py driver)
+// gets the packed single allreduce and the overlapped H phase through these entry points; the PyTorch host can use them
+// instead of torch.distributed (params.exchange = 'native').
+//
+// RCCL is bound at run time (dlopen): the library loads and every compute entry point works on a host without RCCL; the
+// first dnmf_comm_* call looks for an RCCL that is ALREADY in the process (PyTorch's own copy: two RCCL / HIP runtime
+// instances in one process do not share device state) and only then loads librccl.so.1 by name.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "dnmf_common.h"
+#include "dnmf_host.h"
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* origin = "";
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    const char* resident[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : resident)
+        if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = "already in the process";
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+        if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) r.origin = n;
+    if (!r.handle) return nullptr;
+#define BIND(field, sym) \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym)); \
+    if (!r.field) { r.handle = nullptr; return nullptr; }
+    BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
+    BIND(CommSplit, "ncclCommSplit") BIND(AllReduce, "ncclAllReduce") BIND(AllGather, "ncclAllGather")
+    BIND(ReduceScatter, "ncclReduceScatter") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
+    BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+    return &r;
+}
+
+constexpr int MAX_CHUNKS = 8;
+
+}  // namespace
+
+struct dnmf_comm {
+    ncclComm_t world = nullptr, row = nullptr, col = nullptr;   // row: the p_r ranks of one grid column; col: the p_c ranks of one grid row
+    int nranks = 1, rank = 0, p_r = 1, p_c = 1;
+    int overlap_chunks = 1;
+    int always = 0;                                              // testing: a one-rank communicator still issues its RCCL calls
+    hipStream_t xstream = nullptr;                               // exchanges of the overlapped H phase run here
+    hipEvent_t ready[MAX_CHUNKS] = {}, done[MAX_CHUNKS] = {};
+};
+
+namespace {
+
+int nccl_fail(const char* what, ncclResult_t e) {
+    Rccl* r = rccl();
+    return fail(DNMF_ECOMM, "%s: RCCL error %d (%s)", what, (int)e, r ? r->GetErrorString(e) : "?");
+}
+#define NCCL_OK(call, what) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) return nccl_fail(what, e_); } while (0)
+#define HIP_OK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(DNMF_EHIP, "%s: %s", what, hipGetErrorString(e_)); } while (0)
+
+inline size_t pad64(size_t x) { return (x + 63) / 64 * 64; }
+
+// in-place SUM over `c` (no-op for a one-rank communicator that was never created)
+int allreduce_f32(dnmf_comm* cm, ncclComm_t c, float* buf, size_t count, hipStream_t st) {
+    if (!c) return DNMF_OK;
+    NCCL_OK(rccl()->AllReduce(buf, buf, count, ncclFloat32, ncclSum, c, st), "allreduce");
+    (void)cm;
+    return DNMF_OK;
+}
+
+// workspace of the 1D steps: [kernel scratch of dnmf_ws_bytes | G (KP x KP) | packed exchange buffer]
+struct Ws1d { size_t g_off, x_off, total; };
+Ws1d ws1d_layout(long m_l, long n_l, int k) {
+    const int kp = 32 * kt_of(k);
+    Ws1d w;
+    size_t kws = dnmf_ws_bytes(m_l, n_l, k);                      // kernel scratch: the whole block and every chunk width of the
+    for (int nch = 2; nch <= MAX_CHUNKS; ++nch) {                 // overlapped H phase (the chunking of W^T A depends on the width)
+        const long cw = (cdiv(n_l, nch) + 63) / 64 * 64;
+        if (cw >= n_l) continue;
+        kws = std::max(kws, dnmf_ws_bytes(m_l, cw, k));
+        if (n_l % cw) kws = std::max(kws, dnmf_ws_bytes(m_l, n_l % cw, k));
+    }
+    w.g_off = align256(kws);
+    w.x_off = w.g_off + align256((size_t)kp * kp * sizeof(float));
+    const size_t big = std::max((size_t)k * n_l, (size_t)m_l * k);
+    // one packed message [product | pad | KP x KP] or up to MAX_CHUNKS chunk messages, each padded to 64 floats
+    w.total = w.x_off + align256((pad64(big) + (size_t)MAX_CHUNKS * 64 + (size_t)kp * kp + 128) * sizeof(float));
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dnmf_comm_unique_id(void* id_out) {
+    REQUIRE(id_out, "comm_unique_id: null pointer");
+    Rccl* r = rccl();
+    if (!r) return fail(DNMF_ECOMM, "comm_unique_id: no RCCL library found (librccl.so.1)");
+    ncclUniqueId id;
+    NCCL_OK(r->GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id_out, &id, DNMF_UNIQUE_ID_BYTES);
+    return DNMF_OK;
+}
+
+int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p_c, dnmf_comm_t** out) {
+    REQUIRE(unique_id && out && nranks >= 1 && rank >= 0 && rank < nranks && p_r >= 1 && p_c >= 1 && p_r * p_c == nranks,
+            "comm_create: bad arguments (nranks %d, rank %d, grid %d x %d)", nranks, rank, p_r, p_c);
+    static_assert(DNMF_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+    Rccl* r = rccl();
+    if (!r) return fail(DNMF_ECOMM, "comm_create: no RCCL library found (librccl.so.1)");
+    dnmf_comm* c = new dnmf_comm();
+    c->nranks = nranks; c->rank = rank; c->p_r = p_r; c->p_c = p_c;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t e = r->CommInitRank(&c->world, nranks, id, rank);
+    if (e != ncclSuccess) { delete c; return nccl_fail("ncclCommInitRank", e); }
+    if (p_r > 1 && p_c > 1) {            // rank = i * p_c + j (dist_comm.py:22, reorder = False)
+        const int i = rank / p_c, j = rank % p_c;
+        e = r->CommSplit(c->world, j, i, &c->row, nullptr);                    // same grid column j, ordered by i (dist_comm.py:25-37)
+        if (e == ncclSuccess) e = r->CommSplit(c->world, i, j, &c->col, nullptr);   // same grid row i, ordered by j (dist_comm.py:39-51)
+        if (e != ncclSuccess) { dnmf_comm_destroy(c); return nccl_fail("ncclCommSplit", e); }
+    }
+    if (hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create: stream"); }
+    for (int q = 0; q < MAX_CHUNKS; ++q)
+        if (hipEventCreateWithFlags(&c->ready[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->done[q], hipEventDisableTiming) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create: events"); }
+    *out = c;
+    return DNMF_OK;
+}
+
+int dnmf_comm_destroy(dnmf_comm_t* c) {
+    if (!c) return DNMF_OK;
+    Rccl* r = rccl();
+    for (int q = 0; q < MAX_CHUNKS; ++q) {
+        if (c->ready[q]) (void)hipEventDestroy(c->ready[q]);
+        if (c->done[q]) (void)hipEventDestroy(c->done[q]);
+    }
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (r) {
+        if (c->row) r->CommDestroy(c->row);
+        if (c->col) r->CommDestroy(c->col);
+        if (c->world) r->CommDestroy(c->world);
+    }
+    delete c;
+    return DNMF_OK;
+}
+
+int dnmf_comm_set_overlap_chunks(dnmf_comm_t* c, int chunks) {
+    REQUIRE(c && chunks >= 1 && chunks <= MAX_CHUNKS, "comm_set_overlap_chunks: 1 <= chunks <= %d", MAX_CHUNKS);
+    c->overlap_chunks = chunks;
+    return DNMF_OK;
+}
+
+int dnmf_comm_set_always_exchange(dnmf_comm_t* c, int on) {
+    REQUIRE(c, "comm_set_always_exchange: null communicator");
+    c->always = on != 0;
+    return DNMF_OK;
+}
+
+int dnmf_comm_info(const dnmf_comm_t* c, int* nranks, int* rank, int* p_r, int* p_c) {
+    REQUIRE(c, "comm_info: null communicator");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    if (p_r) *p_r = c->p_r;
+    if (p_c) *p_c = c->p_c;
+    return DNMF_OK;
+}
+
+int dnmf_comm_allreduce(dnmf_comm_t* c, float* buf, size_t count, int group, void* stream) {
+    REQUIRE(c && buf && group >= 0 && group <= 2, "comm_allreduce: bad arguments");
+    ncclComm_t g = group == 0 ? c->world : (group == 1 ? c->row : c->col);
+    if (group != 0 && !g && c->p_r > 1 && c->p_c > 1) return fail(DNMF_EINVAL, "comm_allreduce: sub-communicator missing");
+    if (group == 1 && !g) g = c->p_c == 1 ? c->world : nullptr;      // 1D grids: the long axis IS the world, the other has one rank
+    if (group == 2 && !g) g = c->p_r == 1 ? c->world : nullptr;
+    return allreduce_f32(c, g, buf, count, S(stream));
+}
+
+size_t dnmf_ws_bytes_1d(long m_l, long n_l, int k) {
+    if (kt_of(k) < 0 || m_l < 1 || n_l < 1) return 0;
+    return ws1d_layout(m_l, n_l, k).total;
+}
+
+// One MU / Frobenius step of a rank of a 1D grid (dist_nmf.py:716-771 with the exchanges of :681,:707).  p_c == 1: A and W
+// are row blocks, H is replicated -- the W phase is the fused local kernel, the H phase ONE allreduce of the packed
+// [W^T A (k x n_l) | pad | W^T W (KP x KP)] message (or `overlap_chunks` column chunks: W^T A of chunk c+1 is computed on
+// the caller's stream while chunk c is reduced on the communicator's stream; chunk 0 carries W^T W).  p_r == 1: the mirror
+// image (A and H column blocks, W replicated, [A H^T | H H^T] reduced).
+int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                        float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1, "mu_fro_step_1d: bad arguments");
+    REQUIRE(c->p_r == 1 || c->p_c == 1, "mu_fro_step_1d: a %d x %d grid is 2D", c->p_r, c->p_c);
+    const int kp = 32 * kt;
+    const Ws1d L = ws1d_layout(m_l, n_l, k);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_fro_step_1d: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    const size_t kws = L.g_off;                                   // kernel scratch: [0, g_off)
+    float* G = (float*)(base + L.g_off);
+    float* X = (float*)(base + L.x_off);
+    hipStream_t st = S(stream);
+    int rc;
+    if (w_update) {                                               // Fro_MU_update_W :716-732
+        if (c->p_c == 1) {
+            if ((rc = dnmf_gram_hht(H, k, n_l, ldh, G, ws, kws, stream))) return rc;
+            if ((rc = dnmf_aht_update_w(A, m_l, n_l, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
+        } else {
+            const size_t off = pad64((size_t)m_l * k);
+            float* AH = X; float* Gx = X + off;
+            if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;
+            if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;
+            if ((rc = allreduce_f32(c, c->world, X, off + (size_t)kp * kp, st))) return rc;
+            if ((rc = dnmf_mu_update_w(W, m_l, k, ldw, AH, k, Gx, eps, stream))) return rc;
+        }
+    }
+    const bool xr = c->p_r != 1 || c->always;                                 // which axis exchanges (always: a 1 x 1 grid acts as a row grid)
+    int nch = (c->p_c == 1 && xr) ? c->overlap_chunks : 1;                     // Fro_MU_update_H :736-751
+    if (nch > 1 && n_l / 64 < nch) nch = (int)std::max<long>(1, n_l / 64);
+    if (nch <= 1) {
+        const size_t off = pad64((size_t)k * n_l);
+        float* AtW = X; float* Gx = X + off;
+        if ((rc = dnmf_gram_wtw(W, m_l, k, ldw, Gx, ws, kws, stream))) return rc;
+        if ((rc = dnmf_wta(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, ws, kws, stream))) return rc;
+        if (xr && (rc = allreduce_f32(c, c->world, X, off + (size_t)kp * kp, st))) return rc;
+        if ((rc = dnmf_mu_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, clamp, stream))) return rc;
+    } else {
+        const long cw = (cdiv(n_l, nch) + 63) / 64 * 64;          // chunk width: ceil(n_l / nch) rounded up to 64 columns
+        float* Gx = X + pad64((size_t)k * std::min(cw, n_l));
+        if ((rc = dnmf_gram_wtw(W, m_l, k, ldw, Gx, ws, kws, stream))) return rc;
+        size_t off = 0;
+        float* chunk_ptr[MAX_CHUNKS]; long c0s[MAX_CHUNKS], c1s[MAX_CHUNKS];
+        int nq = 0;
+        for (long c0 = 0; c0 < n_l; c0 += cw, ++nq) {
+            const long c1 = std::min(n_l, c0 + cw);
+            const size_t ne = pad64((size_t)k * (c1 - c0));
+            float* AtW = X + off;
+            if ((rc = dnmf_wta(A + c0, m_l, c1 - c0, lda, W, k, ldw, AtW, c1 - c0, ws, kws, stream))) return rc;
+            const size_t span = ne + (nq == 0 ? (size_t)kp * kp : 0);          // chunk 0: [W^T A chunk | W^T W] in one message
+            HIP_OK(hipEventRecord(c->ready[nq], st), "mu_fro_step_1d: event record");
+            HIP_OK(hipStreamWaitEvent(c->xstream, c->ready[nq], 0), "mu_fro_step_1d: stream wait");
+            if ((rc = allreduce_f32(c, c->world, X + off, span, c->xstream))) return rc;
+            HIP_OK(hipEventRecord(c->done[nq], c->xstream), "mu_fro_step_1d: event record");
+            chunk_ptr[nq] = AtW; c0s[nq] = c0; c1s[nq] = c1;
+            off += span;
+        }
+        for (int q = 0; q < nq; ++q) {
+            HIP_OK(hipStreamWaitEvent(st, c->done[q], 0), "mu_fro_step_1d: stream wait");
+            if ((rc = dnmf_mu_update_h(H + c0s[q], k, c1s[q] - c0s[q], ldh, chunk_ptr[q], c1s[q] - c0s[q], Gx, eps, clamp, stream))) return rc;
+        }
+    }
+    if (clamp) return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+// One MU / KL step of a rank of a 1D grid (dist_nmf.py:813-869; exchanges :797,:707): [U H^T | rowsum(H)] is reduced when
+// W is replicated (p_r == 1), [W^T U | colsum(W)] when H is (p_c == 1).
+int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                       float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1, "mu_kl_step_1d: bad arguments");
+    REQUIRE(c->p_r == 1 || c->p_c == 1, "mu_kl_step_1d: a %d x %d grid is 2D", c->p_r, c->p_c);
+    const Ws1d L = ws1d_layout(m_l, n_l, k);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_kl_step_1d: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    const size_t kws = L.g_off;
+    float* X = (float*)(base + L.x_off);
+    hipStream_t st = S(stream);
+    int rc;
+    if (w_update) {                                               // KL_MU_update_W :813-830
+        const size_t off = pad64((size_t)m_l * k);
+        float* UHT = X; float* x2 = X + off;
+        if ((rc = dnmf_rowsum(H, k, n_l, ldh, x2, stream))) return rc;
+        if ((rc = dnmf_kl_uht(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, UHT, k, ws, kws, stream))) return rc;
+        if (c->p_c != 1 && (rc = allreduce_f32(c, c->world, X, off + (size_t)k, st))) return rc;
+        if ((rc = dnmf_kl_update_w(W, m_l, k, ldw, UHT, k, x2, eps, stream))) return rc;
+    }
+    const size_t off = pad64((size_t)k * n_l);                    // KL_MU_update_H :832-849
+    float* WTU = X; float* x1 = X + off;
+    if ((rc = dnmf_colsum(W, m_l, k, ldw, x1, ws, kws, stream))) return rc;
+    if ((rc = dnmf_kl_wtu(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, WTU, n_l, ws, kws, stream))) return rc;
+    if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, c->world, X, off + (size_t)k, st))) return rc;
+    if ((rc = dnmf_kl_update_h(H, k, n_l, ldh, WTU, n_l, x1, eps, clamp, stream))) return rc;
+    if (clamp) return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+}  // extern "C"

@@ -109,8 +109,29 @@ class nmf_algorithms_1D(_Base):
     def update(self, clamp=False):
         """One step; `clamp=True` additionally applies H = max(H, eps), W = max(W, eps) after it
         (what PyNMF.fit does when i % 10 == 0, pyDNMF.py:170-172)."""
+        if self._native_step(clamp):
+            return self.W_i, self.H_j
         self._dispatch(clamp)
         return self.W_i, self.H_j
+
+    def _native_step(self, clamp):
+        """`params.exchange = 'native'`: the whole MU step, exchanges included, is ONE library call (dnmf_mu_*_step_1d over
+        the RCCL communicator inside libdnmf_hip.so) -- same kernels in the same order as the choreography below, no Python
+        between the launches.  float32 data, the product's own operator set, more than one rank."""
+        if (self.p == 1 and not getattr(self.params, "native_always", False)) or self.method.upper() != 'MU' \
+                or self.norm.upper() not in ('FRO', 'KL'):
+            return False
+        if getattr(self.params, "exchange", None) != "native" or getattr(self.ops, "name", "") != "hip":
+            return False
+        if self.A_ij.dtype != torch.float32:
+            return False
+        from .engine import native_comm_for
+        nc = native_comm_for(self.params)
+        want = self._overlap_chunks(self.A_ij.shape[1]) if self.norm.upper() == 'FRO' else 1
+        if nc.overlap_chunks != want:
+            nc.set_overlap_chunks(want)
+        nc.step_1d(self.norm, self.A_ij, self.W_i, self.H_j, self.eps, self.W_update, clamp)
+        return True
 
     # ---- Frobenius (dist_nmf.py:716-771)
     def Fro_MU_update(self, W_update=True, clamp=False):

@@ -379,6 +379,80 @@ HIP_OPS_BF16X6 = HipOpsBf16x6()
 
 
 
+class NativeComm:
+    """The grid's RCCL communicators INSIDE libdnmf_hip.so (csrc/dnmf_comm.hip) and the whole-step entry points on top of
+    them: one library call enqueues kernels -> allreduce -> kernels, no Python between the launches.  Built from the host's
+    existing communicator (`comm`: a dist_comm.TorchComm over all ranks), which only carries the 128-byte RCCL id from rank 0
+    to the others.  `params.exchange = 'native'` makes nmf_algorithms_1D use it (PyNMF / bench.py create it)."""
+
+    def __init__(self, comm, p_r, p_c):
+        import ctypes
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeComm: needs a GPU (RCCL communicators live on the current HIP device)")
+        idbuf = ctypes.create_string_buffer(128)
+        if comm.rank == 0:
+            check(lib.dnmf_comm_unique_id(idbuf))
+        raw = comm.bcast(bytes(idbuf.raw), root=0)
+        h = ctypes.c_void_p()
+        check(lib.dnmf_comm_create(raw, int(comm.size), int(comm.rank), int(p_r), int(p_c), ctypes.byref(h)))
+        self.handle, self.size, self.rank, self.p_r, self.p_c = h, int(comm.size), int(comm.rank), int(p_r), int(p_c)
+        self.device = torch.cuda.current_device()
+        self._ws = None
+        self.overlap_chunks = 1
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.dnmf_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def set_overlap_chunks(self, n):
+        check(lib.dnmf_comm_set_overlap_chunks(self.handle, int(n)))
+        self.overlap_chunks = int(n)
+
+    def set_always_exchange(self, on=True):
+        """Testing aid: a one-rank communicator still issues its RCCL calls."""
+        check(lib.dnmf_comm_set_always_exchange(self.handle, int(bool(on))))
+
+    def allreduce_(self, t, group=0):
+        _req(t, "t", t.dim())
+        if not t.is_contiguous():
+            raise ValueError("allreduce_: contiguous tensors only")
+        check(lib.dnmf_comm_allreduce(self.handle, t.data_ptr(), t.numel(), int(group), _stream()))
+        return t
+
+    def _workspace(self, m, n, k, device):
+        nbytes = lib.dnmf_ws_bytes_1d(int(m), int(n), int(k))
+        if nbytes == 0:
+            raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def step_1d(self, norm, A, W, H, eps, w_update=True, clamp=False):
+        """One MU step (norm 'fro' / 'kl') of this rank of a 1D grid, exchanges included (dnmf_mu_{fro,kl}_step_1d)."""
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._workspace(m, n, k, A.device)
+        fn = lib.dnmf_mu_fro_step_1d if norm.lower() == "fro" else lib.dnmf_mu_kl_step_1d
+        check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                 int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(), self.handle, _stream()))
+
+
+def native_comm_for(params):
+    """The NativeComm of `params` when it asks for the in-library exchange (`params.exchange = 'native'`) on a 1D grid with
+    float32 data; created on first use and kept on the params bag (`params._native_comm`).  None otherwise."""
+    if getattr(params, "exchange", None) != "native":
+        return None
+    nc = getattr(params, "_native_comm", None)
+    if nc is None:
+        nc = NativeComm(params.comm1, params.p_r, params.p_c)
+        params._native_comm = nc
+    return nc
+
+
 def ops_for(params=None):
     """The operator set `params` asks for: `params.gemm` = 'fp32' (default: the fp32-MFMA contractions, the parity
     reference) or 'bf16x6' (HipOpsBf16x6)."""

@@ -35,3 +35,12 @@ def test_argument_validation_without_gpu():
     assert lib.dnmf_aht(None, 8, 8, 8, None, 4, 8, None, 4, None) == -1
     assert b"aht" in lib.dnmf_last_error()
     assert lib.dnmf_mu_fro_step(None, 8, 8, 8, None, 4, None, 8, 200, 1e-7, 1, 0, None, 0, None) == -1
+    # the exchange entry points (csrc/dnmf_comm.hip): argument checks come before any RCCL / HIP call
+    assert lib.dnmf_ws_bytes_1d(0, 10, 4) == 0
+    assert lib.dnmf_ws_bytes_1d(32768, 8192, 64) >= lib.dnmf_ws_bytes(32768, 8192, 64) + 4 * (64 * 8192 + 64 * 64)
+    assert lib.dnmf_comm_create(None, 2, 0, 2, 1, None) == -1 and b"comm_create" in lib.dnmf_last_error()
+    assert lib.dnmf_comm_unique_id(None) == -1
+    assert lib.dnmf_comm_allreduce(None, None, 4, 0, None) == -1
+    assert lib.dnmf_mu_fro_step_1d(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
+    assert lib.dnmf_mu_kl_step_1d(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
+    assert lib.dnmf_comm_destroy(None) == 0

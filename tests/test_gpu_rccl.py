@@ -113,6 +113,36 @@ def _child(port, q):
             nmf_algorithms_1D(Ad, W6, H6, params=args1).update(clamp=(i == 0))
         TorchComm.always_collective = True
         log["overlap"] = (float((W5 - W6).norm() / W6.norm()), float((H5 - H6).norm() / H6.norm()))
+        # --- the exchange INSIDE the library (csrc/dnmf_comm.hip, include/dnmf.h "Grid exchanges"): libdnmf_hip.so creates its
+        #     own RCCL communicator from a broadcast id and runs whole 1D steps -- kernels -> ncclAllReduce -> kernels, the
+        #     chunked exchange on its internal stream -- in ONE call.  Must equal the Python choreography bit for bit
+        #     (same kernels, same order, same buffers), for the packed allreduce and for 2 / 4 overlapped chunks, FRO and KL.
+        from pydnmfk_amd.engine import NativeComm
+        nc = NativeComm(world, 1, 1)
+        nc.set_always_exchange(True)
+        xx = torch.rand(70000, device=dev)
+        xx0 = xx.clone()
+        nc.allreduce_(xx)
+        assert torch.equal(xx, xx0)
+        native = {}
+        for norm in ("fro", "kl"):
+            for chunks in ((1, 2, 4) if norm == "fro" else (1,)):
+                ap = parse()
+                ap.comm1, ap.comm, ap.p_r, ap.p_c, ap.k, ap.m, ap.n = world, comms, 4, 1, k, m, n
+                ap.eps, ap.W_update, ap.norm, ap.method = eps, True, norm, "mu"
+                ap.overlap_min_cols, ap.overlap_chunks = 128, chunks
+                an = parse()
+                an.__dict__.update(vars(ap))
+                an.exchange, an.native_always, an._native_comm = "native", True, nc
+                Wp, Hp = torch.from_numpy(W0).to(dev), torch.from_numpy(H0).to(dev)
+                Wn, Hn = Wp.clone(), Hp.clone()
+                for i in range(3):
+                    nmf_algorithms_1D(Ad, Wp, Hp, params=ap).update(clamp=(i == 0))
+                    nmf_algorithms_1D(Ad, Wn, Hn, params=an).update(clamp=(i == 0))
+                assert nc.overlap_chunks == chunks
+                native["%s_%d" % (norm, chunks)] = bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
+        log["native"] = native
+        nc.close()
         # --- a whole fit with the nccl group up (relative_err allreduces a float64 pair on the device)
         args2 = parse()
         args2.comm1, args2.comm, args2.p_r, args2.p_c, args2.k = world, comms, 1, 1, k
@@ -144,3 +174,4 @@ def test_rccl_code_path_on_one_gpu():
         assert max(log["2d_%s" % norm]) <= 1e-6, log
     assert max(log["overlap"]) <= 2e-6, log
     assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log
+    assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True}, log
