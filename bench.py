@@ -21,8 +21,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   sustained    : when the timed region asked for is shorter than 2 s, the same step timed again over >= 300 steps
                  (its own ms/step: shows the clock the chip HOLDS under the load, not its boost)
   multi_gpu    : (N > 1) rccl_ranks_seen, per-rank compute-only ms (the same step with the exchange stubbed out) next to
-                 the full step -> exposed_comm_ms, the packed allreduce timed alone, and an A/B of the H phase's overlap
-                 chunking (overlap_chunks 1 / 2 / 4) measured in the warm-up; the fastest is used for the timed region
+                 the full step -> exposed_comm_ms, the packed allreduce timed alone, and an A/B of the exchange transport
+                 (torch.distributed vs the library's own RCCL communicator) x the H phase's overlap chunking (1 / 2 / 4)
+                 measured in the warm-up; the fastest pair is used for the timed region
   cpu_baseline : the numpy oracle (port of the reference's path) in the reference's process model -- P = min(8, cores)
                  single-thread processes, each on its 1/P row slab of X -- timed on the host (N=1 only)
 With no flags: N = 1 and 500 timed steps (about 2.3 s of GPU time).
@@ -61,6 +62,10 @@ def parse_args():
                     help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
                          "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "native"],
+                    help="N > 1: who issues the allreduce -- torch.distributed between the kernel launches, or the library's own "
+                         "RCCL communicator inside a one-call step (csrc/dnmf_comm.hip); 'auto' (default) times both in the "
+                         "warm-up and uses the faster")
     ap.add_argument("--overlap-chunks", default="auto",
                     help="N > 1: column chunks of the H phase's overlapped exchange; 'auto' (default) times 1 / 2 / 4 in "
                          "the warm-up and uses the fastest")
@@ -347,22 +352,42 @@ def main():
     mg = None
     if world > 1:
         mg = {"rccl_ranks_seen": rccl_ranks_seen, "backend": a.backend}
-        if a.norm == "fro" and a.overlap_chunks == "auto":
+        # exchange transports: torch.distributed (dist.all_reduce between the kernel launches) and, over RCCL, the
+        # library's own communicator, where a whole step -- kernels, allreduce, kernels -- is ONE C call (no Python between
+        # the launches; csrc/dnmf_comm.hip).  Both run the same kernels in the same order.
+        modes = ["torch"] if a.exchange in ("auto", "torch") else []
+        if a.backend == "nccl" and a.exchange in ("auto", "native") and a.gemm == "fp32":
+            ok, why = 1, None
+            try:
+                from pydnmfk_amd.engine import NativeComm
+                p._native_comm = NativeComm(comms.comm, world, 1)
+            except Exception as exc:  # noqa: BLE001
+                ok, why = 0, repr(exc)
+            ok = int(-max_over_ranks(-float(ok)))                  # usable only if every rank has it
+            if ok:
+                modes.append("native")
+            else:
+                mg["native_exchange_unavailable"] = why or "another rank could not create the library communicator"
+        if not modes:
+            sys.exit("bench.py: --exchange %s is not available (backend %s)" % (a.exchange, a.backend))
+        chunks = (1, 2, 4) if (a.overlap_chunks == "auto" and a.norm == "fro") else ((1,) if a.overlap_chunks == "auto" else (int(a.overlap_chunks),))
+        if len(modes) * len(chunks) > 1:
             ab, nab = {}, max(5, min(40, a.steps))
-            for c in (1, 2, 4):
-                p.overlap_chunks = c
-                for i in range(3):
-                    step(i)
-                ab[c] = timed(nab) / nab * 1e3
+            for mode in modes:
+                p.exchange = mode
+                for c in chunks:
+                    p.overlap_chunks = c
+                    for i in range(3):
+                        step(i)
+                    ab[(mode, c)] = timed(nab) / nab * 1e3
             best = min(ab, key=ab.get)
-            p.overlap_chunks = best
-            mg["overlap_chunks_ab_ms_per_step"] = {str(c): v for c, v in ab.items()}
-            mg["overlap_chunks_ab_steps"] = nab
-            mg["overlap_chunks_used"] = best
-        elif a.overlap_chunks != "auto":
-            p.overlap_chunks = int(a.overlap_chunks)
-            mg["overlap_chunks_used"] = int(a.overlap_chunks)
-        p6.overlap_chunks = getattr(p, "overlap_chunks", 1)
+            mg["exchange_ab_ms_per_step"] = {"%s/chunks=%d" % kc: v for kc, v in ab.items()}
+            mg["exchange_ab_steps"] = nab
+        else:
+            best = (modes[0], chunks[0])
+        p.exchange, p.overlap_chunks = best
+        mg["exchange_used"], mg["overlap_chunks_used"] = best
+        p6.overlap_chunks = p.overlap_chunks
 
     for i in range(a.warmup):
         step(i)
@@ -386,7 +411,7 @@ def main():
         from pydnmfk_amd.dist_comm import NullExchange
         pn = parse()
         pn.__dict__.update(vars(p))
-        pn.comm1 = NullExchange(p.comm1)
+        pn.comm1, pn.exchange = NullExchange(p.comm1), "torch"     # the stub lives on the Python side of the choreography
         H_keep = H.clone()
 
         def step_nocomm(i):

@@ -105,6 +105,11 @@ int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long
 /* UHT[m x k] = (A / (W H + eps)) H^T     (glob_UX(axis=0), dist_nmf.py:806,810; UHT_glob :337-338) */
 int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                 int k, float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream);
+/* The same product with H given as n / nh COLUMN BLOCKS stacked [q][k][nh] -- the receive buffer of the allgather of the
+ * ranks' k x nh slices (gather_W_H, dist_nmf.py:283-287; np.hstack there) -- so that the 2D step needs no re-assembly copy.
+ * n % nh == 0 and nh % 32 == 0 (DNMF_EINVAL otherwise: assemble H and call dnmf_kl_uht). */
+int dnmf_kl_uht_hblocks(const float* A, long m, long n, long lda, const float* W, long ldw, const float* Hs, long nh,
+                        int k, float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream);
 /* WTU[k x n] = W^T (A / (W H + eps))     (glob_UX(axis=1), dist_nmf.py:806,808; WTU_glob :311-312) */
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                 int k, float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream);

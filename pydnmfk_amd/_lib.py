@@ -44,6 +44,8 @@ SIGNATURES = {
                     c_long, c_void_p, c_size_t, c_void_p],
     "dnmf_kl_wtu": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
                     c_long, c_void_p, c_size_t, c_void_p],
+    "dnmf_kl_uht_hblocks": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
+                            c_long, c_void_p, c_size_t, c_void_p],
     "dnmf_rowsum": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
     "dnmf_colsum": [c_void_p, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
     "dnmf_kl_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],

@@ -8,8 +8,8 @@
 
 // the 16-wide kernels for k <= 16 live in csrc/dnmf_kl16.hip (own compiler flags); 1 = not applicable
 __attribute__((visibility("hidden"))) int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, long ldw,
-                                                         const float* H, long ldh, int k, float eps, float* UHT, long ldo,
-                                                         void* ws, size_t ws_bytes, void* stream);
+                                                         const float* H, long ldh, long hblk, int k, float eps, float* UHT,
+                                                         long ldo, void* ws, size_t ws_bytes, void* stream);
 __attribute__((visibility("hidden"))) int dnmf_kl16_wtu_(const float* A, long m, long n, long lda, const float* W, long ldw,
                                                          const float* H, long ldh, int k, float eps, float* WTU, long ldo,
                                                          void* ws, size_t ws_bytes, void* stream);
@@ -101,21 +101,61 @@ int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* 
     return column_err_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, num, den, stream);
 }
 
-int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+}  // extern "C"
+namespace {
+
+// H as column blocks [n / hblk][k][hblk] -> one zero-padded contiguous image [kp x round_up(n, 4)] (and W -> [m x kp]) at the
+// end of the workspace: the block-aware twin of pad_factors for ranks / alignments the interior paths do not take
+bool pad_factors_hblocks(const float*& W, long& ldw, const float*& H, long& ldh, long hblk, int& k, long m, long n, int kp,
+                         void* ws, size_t ws_bytes, size_t own_need, hipStream_t st) {
+    const size_t pb = pad_bytes(m, n, kp);
+    if (!ws || ws_bytes < align256(own_need) + pb) return false;
+    char* base = (char*)ws + align256(own_need);
+    float* Wp = (float*)base;
+    const long ldhp = round_up(n, 4);
+    float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
+    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
+    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
+    for (long q = 0; q * hblk < n; ++q)
+        if (hipMemcpy2DAsync(Hp + q * hblk, (size_t)ldhp * sizeof(float), H + q * k * hblk, (size_t)hblk * sizeof(float),
+                             (size_t)hblk * sizeof(float), (size_t)k, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
+    return true;
+}
+
+// hblk = 0: H is one k x n matrix (ldh).  hblk > 0: H is the stack of n / hblk column blocks [q][k][hblk] (ldh = hblk).
+int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, long hblk, int k,
                 float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k, "kl_uht: bad arguments");
+    REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldo >= k, "kl_uht: bad arguments");
+    REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0) : ldh >= n, "kl_uht: bad H layout (ldh %ld, block %ld, n %ld)", ldh, hblk, n);
     const int kp = 32 * kt;
-    const UhtPlan u = plan_uht(m, n);
+    const int k_out = k;                                   // columns of UHT the caller gets
+    if (int rc16 = dnmf_kl16_uht_(A, m, n, lda, W, ldw, H, ldh, hblk, k, eps, UHT, ldo, ws, ws_bytes, stream); rc16 != 1) return rc16;
+    UhtPlan u = plan_uht(m, n);
+    if (hblk) {                                            // a column split must not straddle a block: cols_per_split divides hblk
+        const long nb = n / hblk;
+        long s = std::max<long>(1, (u.nsplit + nb / 2) / nb);
+        auto fits = [&](long sp) { return hblk % sp == 0 && (hblk / sp) % BK == 0 &&
+                                          (size_t)(nb * sp) * m * kp * sizeof(float) + reduce_scratch_bytes((int)(nb * sp), (int)m, k) <= ws_bytes; };
+        while (s > 1 && !fits(s)) --s;
+        if (!fits(s) && nb * s > 1) return fail(DNMF_EWS, "kl_uht: workspace %zu too small for %ld column blocks", ws_bytes, nb);
+        u.cols_per_split = hblk / s;
+        u.nsplit = (int)(nb * s);
+    }
     const size_t pbytes = u.nsplit > 1 ? (size_t)u.nsplit * m * kp * sizeof(float) : 0;
     const size_t need = pbytes + reduce_scratch_bytes(u.nsplit, (int)m, k);
     if (u.nsplit > 1 && (!ws || ws_bytes < need)) return fail(DNMF_EWS, "kl_uht: workspace %zu < %zu", ws_bytes, need);
-    const int k_out = k;                                   // columns of UHT the caller gets
-    if (int rc16 = dnmf_kl16_uht_(A, m, n, lda, W, ldw, H, ldh, k, eps, UHT, ldo, ws, ws_bytes, stream); rc16 != 1) return rc16;
-    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0)
-        pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+    if (aligned16(A) && lda % 4 == 0 && n % 4 == 0) {
+        if (!hblk) pad_factors(W, ldw, H, ldh, k, m, n, kp, ws, ws_bytes, need, S(stream));
+        else if (!(k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H)) &&
+                 pad_factors_hblocks(W, ldw, H, ldh, hblk, k, m, n, kp, ws, ws_bytes, need, S(stream))) hblk = 0;
+    }
     NnArgs a = nn_args(A, m, n, lda, W, ldw, H, ldh, k, eps);
     a.kreal = k_out;                                       // (k may be the padded rank by now)
+    a.hblk = hblk; a.hextra = hblk ? (long)k * hblk - hblk : 0;
     const bool split = u.nsplit > 1;
     float* out = split ? (float*)ws : UHT;
     const long ldout = split ? kp : ldo;
@@ -137,6 +177,20 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
     if (rc || !split) return rc;
     return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
                          (float*)((char*)ws + pbytes), st);
+}
+
+}  // namespace
+extern "C" {
+
+int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+                float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    return kl_uht_impl(A, m, n, lda, W, ldw, H, ldh, 0, k, eps, UHT, ldo, ws, ws_bytes, stream);
+}
+
+int dnmf_kl_uht_hblocks(const float* A, long m, long n, long lda, const float* W, long ldw, const float* Hs, long nh, int k,
+                        float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    REQUIRE(nh >= 1, "kl_uht_hblocks: bad block width");
+    return kl_uht_impl(A, m, n, lda, W, ldw, Hs, nh, nh, k, eps, UHT, ldo, ws, ws_bytes, stream);
 }
 
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,

@@ -40,6 +40,7 @@ struct Kl16Args {
     float* P; long chunk_stride; long ldp;   // partial slabs: wtu16 [chunk][16][ldp], uht16 [split][m][16]
     long rows_per_chunk; int nchunks; int ncolblk;   // wtu16 (rows_per_chunk x lda x 4 B below 2 GiB: one descriptor per chunk)
     long cols_per_split;                             // uht16 (multiple of 32)
+    long hblk; long hextra;                          // uht16: H as column blocks [n / hblk][16][hblk] (see NnArgs in dnmf_nn.h); 0 = plain
 };
 
 // a / d for d = S + eps > 0: v_rcp_f32 (1 ulp) times a -- at most 1.5 ulp from the exact quotient.  Every further vector
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void kl_uht16_kernel(Kl16Args p) {
 
     // descriptors at (row0, cbeg) of A and (0, cbeg) of H; lane offsets in bytes (rows past the end re-read the last row)
     const i32x4 rsx = buf_rsrc(p.A + row0 * p.lda + cbeg);
-    const i32x4 rsy = buf_rsrc(p.H + cbeg);
+    const i32x4 rsy = buf_rsrc(p.H + cbeg + (p.hblk ? (cbeg / p.hblk) * p.hextra : 0));
     int vx[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {

@@ -9,8 +9,8 @@
 // Library-internal (called from csrc/dnmf_kl.hip).  Return 1 when the 16-wide kernel does not apply (the caller goes on to
 // the 32-wide kernels with its arguments untouched), else the launch status.
 __attribute__((visibility("hidden"))) int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, long ldw,
-                                                         const float* H, long ldh, int k, float eps, float* UHT, long ldo,
-                                                         void* ws, size_t ws_bytes, void* stream);
+                                                         const float* H, long ldh, long hblk, int k, float eps, float* UHT,
+                                                         long ldo, void* ws, size_t ws_bytes, void* stream);
 __attribute__((visibility("hidden"))) int dnmf_kl16_wtu_(const float* A, long m, long n, long lda, const float* W, long ldw,
                                                          const float* H, long ldh, int k, float eps, float* WTU, long ldo,
                                                          void* ws, size_t ws_bytes, void* stream);
@@ -20,9 +20,12 @@ static bool friendly16(const float* W, long ldw, const float* H, long ldh, int k
 }
 constexpr long WINDOW = 0x7fffffffL;          // the kernels address a tile / a chunk through one 2 GiB buffer descriptor
 
-int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
+// hblk > 0: H is the stack of n / hblk column blocks [q][k][hblk] (ldh = hblk); taken only with k = 16 and aligned factors
+// (other ranks go to the caller's block-aware padding and come back as one matrix)
+int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, long hblk, int k,
                    float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
     if (!(k <= 16 && k16_on() && aligned16(A) && lda % 4 == 0 && n % BK == 0 && m <= 0x7fffffffL)) return 1;
+    if (hblk && !friendly16(W, ldw, H, ldh, k)) return 1;
     const long ldh_img = friendly16(W, ldw, H, ldh, k) ? ldh : round_up(n, 4);
     if (128 * lda * 4 + n * 4 >= WINDOW || 16 * ldh_img * 4 + n * 4 >= WINDOW) return 1;
     hipStream_t st = S(stream);
@@ -35,6 +38,13 @@ int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, lon
         ns = std::min<long>(ns, std::max<long>(1, n / 256));
         u.cols_per_split = round_up(cdiv(n, ns), BK);
         u.nsplit = (int)cdiv(n, u.cols_per_split);
+        if (hblk) {                                        // a column split must not straddle a block of H
+            const long nb = n / hblk;
+            long s = std::max<long>(1, ns / nb);
+            while (s > 1 && !(hblk % s == 0 && (hblk / s) % BK == 0)) --s;
+            u.cols_per_split = hblk / s;
+            u.nsplit = (int)(nb * s);
+        }
     }
     const int k_out = k;
     const bool direct = u.nsplit == 1 && k == 16 && aligned16(UHT) && ldo % 4 == 0;
@@ -46,6 +56,7 @@ int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, lon
     a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.eps = eps;
     a.P = direct ? UHT : (float*)ws; a.ldp = direct ? ldo : 16; a.chunk_stride = direct ? 0 : m * 16;
     a.cols_per_split = u.cols_per_split;
+    a.hblk = hblk; a.hextra = hblk ? (long)16 * hblk - hblk : 0;
     hipLaunchKernelGGL(kl_uht16_kernel, dim3((unsigned)cdiv(m, 128), (unsigned)u.nsplit), dim3(256), kl_uht16_lds_bytes(), st, a);
     int rc = check_launch("kl_uht16");
     if (rc || direct) return rc;

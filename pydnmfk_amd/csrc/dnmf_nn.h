@@ -20,6 +20,9 @@ struct NnArgs {
     float* P; long chunk_stride; long ldp;           // NN_KL_WTU partials [rowblk][KP][ldp]
     long nrowblk; int ncolblk;
     int pipe;                                        // NN_KL_*: software-pipelined interior path (DNMF_KL_PIPE=0 switches it off)
+    long hblk; long hextra;                          // kl_uht: H given as column blocks [n / hblk][k][hblk] (an allgather's receive
+                                                     // buffer): columns [q hblk, (q+1) hblk) live at H + q hextra with ldh = hblk;
+                                                     // hblk = 0: one k x n matrix.  A column split never straddles a block.
     int kreal;                                       // NN_KL_*: the rank before zero padding to KP: S = W H skips the MFMA steps whose 8
                                                      // contraction indices are all padding (k <= 16: half of that product's matrix work)
 };
@@ -349,6 +352,7 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
     long cend = cbeg + cols_per_split;
     if (cend > p.n) cend = p.n;
     const long nt = (cend - cbeg + BK - 1) / BK;
+    const float* Hb = p.H + (p.hblk ? (cbeg / p.hblk) * p.hextra : 0);    // this split's column block of H (block uniform)
 
     f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
 #pragma unroll
@@ -363,8 +367,8 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
     float a_cur[4][4];
     const bool hrows_in = p.k >= KP;
     if (nt > 0) {
-        if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
-        else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, cbeg, tid);
+        if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, cbeg, tid);
+        else stage_load<KP, T, FAST, false>(hst, Hb, p.ldh, p.k, cend, 0, cbeg, tid);
         stage_store<KP, T>(smem, hst, tid);
         if (INTERIOR && cbeg + BK <= cend) {
 #pragma unroll
@@ -410,8 +414,8 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
             for (int e = 0; e < 4; ++e) st[4 * g + e] = a_cur[g][e] / (st[4 * g + e] + p.eps);   // U^T (dist_nmf.py:806)
         // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
         if (more) {
-            if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
-            else stage_load<KP, T, FAST, false>(hst, p.H, p.ldh, p.k, cend, 0, c1, tid);
+            if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
+            else stage_load<KP, T, FAST, false>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
             if (INTERIOR && c1 + BK <= cend) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);

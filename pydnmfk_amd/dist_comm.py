@@ -161,15 +161,30 @@ class TorchComm:
         return [recv[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)]
 
     def reduce_scatter_rows(self, full, counts):
-        """SUM reduce-scatter of a (sum(counts) x c) row-major buffer by row blocks (MPI Reduce_scatter)."""
+        """SUM reduce-scatter of a (sum(counts) x c) row-major buffer by row blocks (MPI Reduce_scatter, dist_nmf.py:169,202).
+        Over RCCL the wire carries what the reference's does -- one block per member: equal blocks go straight into
+        reduce_scatter_tensor; RAGGED blocks (a dimension that does not divide: real data) are first laid out at the pitch
+        of the largest one (p block copies of this rank's buffer, no zero fill: the padding rows are reduced into rows nobody
+        reads), instead of an allreduce of the whole buffer, which moves p times the bytes.  gloo (tests) has no
+        reduce-scatter: allreduce + slice, same sums."""
         if self._solo():
             return full
         c = full.shape[1]
-        if len(set(counts)) == 1 and self.backend != "gloo" and not self._staged(full):
-            out = full.new_empty(counts[0], c)
-            dist.reduce_scatter_tensor(out, full.contiguous(), group=self.group)
-            return out
-        t = full.clone()  # ragged blocks (or gloo, which has no reduce_scatter): allreduce + slice, same sums
+        if self.backend != "gloo" and not self._staged(full):
+            if len(set(counts)) == 1:
+                out = full.new_empty(counts[0], c)
+                dist.reduce_scatter_tensor(out, full.contiguous(), group=self.group)
+                return out
+            mx = max(counts)
+            padded = full.new_empty(self.size, mx, c)
+            off = 0
+            for q, cnt in enumerate(counts):
+                padded[q, :cnt].copy_(full[off: off + cnt])
+                off += cnt
+            out = full.new_empty(mx, c)
+            dist.reduce_scatter_tensor(out, padded.view(self.size * mx, c), group=self.group)
+            return out[: counts[self.rank]]
+        t = full.clone()
         self.allreduce_(t)
         off = sum(counts[: self.rank])
         return t[off: off + counts[self.rank]].contiguous()

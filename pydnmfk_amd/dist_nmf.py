@@ -313,9 +313,22 @@ class nmf_algorithms_2D(_Base):
             return torch.as_strided(b0, (sum(self.w_counts), self.k), (self.k, 1))
         return torch.cat(blocks, dim=0)                                             # vstack -> W_i [m_l x k]
 
-    def gather_H(self):
+    def gather_H(self, stacked=False):
+        """H_j [k x n_l] = hstack of the row group's slices (:283-287).  `stacked=True` returns the allgather's receive buffer
+        itself, viewed [p_r][k][n_h], when the slices are equal and whole k-tiles wide -- the KL kernels take H as column
+        blocks (`ops.kl_uht_hblocks`), so nothing is re-assembled; otherwise (and for the Frobenius contraction, whose NT
+        kernel wants one matrix) the blocks are concatenated: the one copy left on the 2D path, k x n_l floats."""
         blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
-        return torch.cat(blocks, dim=1).contiguous() if len(blocks) > 1 else blocks[0]  # hstack -> H_j [k x n_l]
+        if len(blocks) == 1:
+            return blocks[0]
+        if stacked and self._h_blockable():
+            nh = self.h_counts[0]
+            return torch.as_strided(blocks[0], (len(blocks), self.k, nh), (self.k * nh, nh, 1))
+        return torch.cat(blocks, dim=1)                                              # hstack -> H_j [k x n_l]
+
+    def _h_blockable(self):
+        hc = self.h_counts
+        return len(set(hc)) == 1 and hc[0] % 32 == 0 and getattr(self.ops, "kl_uht_hblocks", None) is not None
 
     def _scatter_to_W(self, V):
         """Reduce_scatter over the column group of an (m_l x k) buffer -> (m_w x k)  (:202, :340)."""
@@ -335,7 +348,10 @@ class nmf_algorithms_2D(_Base):
         slice is a contiguous block, which is what reduce_scatter_tensor cuts -- and nothing is transposed or copied."""
         k, hc = self.k, self.h_counts
         n_l = sum(hc)
-        if len(set(hc)) != 1:
+        # slices that do not start on 16-byte boundaries (n_h % 4 != 0) would send every launch but the first down the
+        # predicated kernels (and bf16x6 needs whole 128-column tiles): one aligned full-width product + the transposes then
+        sliceable = len(set(hc)) == 1 and hc[0] % 4 == 0 and (getattr(self.ops, "name", "") != "hip-bf16x6" or hc[0] % 128 == 0)
+        if not sliceable:
             Y = _buf(("Y", k, n_l), k * n_l, self.A_ij)[: k * n_l].view(k, n_l)
             product(0, n_l, Y)
             return self._scatter_to_H(Y)
@@ -396,17 +412,26 @@ class nmf_algorithms_2D(_Base):
         if W_update:                                               # KL_MU_update_W :351-369
             ops.rowsum(H, x)
             self.comm1.allreduce_(x)                               # sum_axis :346-349
-            W_i, H_j = self.gather_W(), self.gather_H()            # gather_W_H :367
-            UHT = ops.kl_uht(A, W_i, H_j, eps, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))  # :337-338
+            W_i, H_j = self.gather_W(), self.gather_H(stacked=True)   # gather_W_H :367
+            V = _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k)
+            if H_j.dim() == 3:                                     # the receive buffer as it is: H as column blocks
+                UHT = ops.kl_uht_hblocks(A, W_i, H_j, eps, V)      # :337-338
+            else:
+                UHT = ops.kl_uht(A, W_i, H_j, eps, V)
             sk = self._scatter_to_W(UHT)                           # :340
             ops.kl_update_w(W, sk, x, eps)                         # :369
         ops.colsum(W, x)                                           # KL_MU_update_H :371-389
         self.comm1.allreduce_(x)
         W_i = self.gather_W()                                      # :387 (the W phase changed W, not H: the H_j it
         if not W_update:                                           #  gathered is still current -- one exchange less)
-            H_j = self.gather_H()
-        ks = self._product_scattered_to_H(                         # :311-312, :314-316
-            lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[:, c0:c1], eps, out))
+            H_j = self.gather_H(stacked=True)
+        if H_j.dim() == 3:                                         # member q's columns are block q of the stack
+            nh = self.h_counts[0]
+            ks = self._product_scattered_to_H(                     # :311-312, :314-316
+                lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[c0 // nh], eps, out))
+        else:
+            ks = self._product_scattered_to_H(
+                lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[:, c0:c1], eps, out))
         ops.kl_update_h(H, ks, x, eps, clamp)                      # :389
         if clamp:
             ops.clamp_min(W, eps)

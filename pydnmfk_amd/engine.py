@@ -199,6 +199,18 @@ class HipOps:
                               out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
         return out
 
+    def kl_uht_hblocks(self, A, W, Hs, eps, out):
+        """kl_uht with H as column blocks: `Hs` is the contiguous stack [n / n_h][k][n_h] an allgather of the slices leaves."""
+        _req(A, "A"); _req(W, "W"); _req(Hs, "Hs", 3); _req(out, "UHT")
+        m, n = A.shape
+        nb, k, nh = Hs.shape
+        if not Hs.is_contiguous() or nb * nh != n or k != W.shape[1]:
+            raise ValueError("kl_uht_hblocks: Hs must be a contiguous [n / n_h][k][n_h] stack matching A and W")
+        ws = workspace(m, n, k, A.device)
+        check(lib.dnmf_kl_uht_hblocks(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), Hs.data_ptr(), nh, k, float(eps),
+                                      out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
     def kl_wtu(self, A, W, H, eps, out):
         _req(A, "A"); _req(W, "W"); _req(H, "H"); _req(out, "WTU")
         m, n = A.shape
@@ -297,6 +309,7 @@ class HipOpsBf16x6(HipOps):
     fp32 code either way."""
 
     name = "hip-bf16x6"
+    kl_uht_hblocks = None          # (no block-column variant of the split kernels: the 2D step concatenates H for them)
 
     @staticmethod
     def _ws6(m, n, k, device):

@@ -89,6 +89,11 @@ class OracleOps:
         out.copy_(torch.from_numpy(U @ _n(H).T))                        # :810
         return out
 
+    def kl_uht_hblocks(self, A, W, Hs, eps, out):
+        """H as the allgather's stacked column blocks [p][k][n_h]: np.hstack (dist_nmf.py:283-287), then kl_uht."""
+        assert Hs.dim() == 3 and Hs.is_contiguous()
+        return self.kl_uht(A, W, torch.cat(list(Hs), dim=1), eps, out)
+
     def kl_wtu(self, A, W, H, eps, out):
         U = _n(A) / (_n(W) @ _n(H) + np.float32(eps))
         out.copy_(torch.from_numpy(_n(W).T @ U))                        # :808

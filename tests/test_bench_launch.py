@@ -58,7 +58,8 @@ def test_two_ranks_on_one_gpu_gloo(cols):
     assert mg["rccl_ranks_seen"] == 2 and mg["backend"] == "gloo"
     assert len(mg["compute_only_ms_per_rank"]) == 2 and all(v > 0 for v in mg["compute_only_ms_per_rank"])
     assert abs(mg["exposed_comm_ms"] - (mg["full_step_ms"] - mg["compute_only_ms"])) < 1e-9
-    assert set(mg["overlap_chunks_ab_ms_per_step"]) == {"1", "2", "4"} and mg["overlap_chunks_used"] in (1, 2, 4)
+    assert set(mg["exchange_ab_ms_per_step"]) == {"torch/chunks=1", "torch/chunks=2", "torch/chunks=4"}
+    assert mg["overlap_chunks_used"] in (1, 2, 4) and mg["exchange_used"] == "torch"
     assert mg["allreduce_alone_ms"] > 0 and mg["allreduce_bytes"] == 4 * (64 * cols + 64 * 64)
     assert out["roofline"]["bound"] == "mfma" and "cpu_baseline" not in out
 
