@@ -180,6 +180,24 @@ def test_kl16_products(ops, m, n, k, pad):
         assert float(uht[:, k:].min()) == 7.0 and float(wtu[:, n:].min()) == 7.0      # nothing written beyond the logical width
 
 
+@pytest.mark.parametrize("m,nb,nh,k", [(1000, 4, 96, 64), (300, 2, 32, 128), (2048, 4, 512, 16), (700, 3, 64, 5), (129, 2, 160, 33),
+                                       (33000, 4, 2048, 128), (40000, 2, 1024, 16)])
+def test_kl_uht_with_h_as_column_blocks(ops, m, nb, nh, k):
+    """dnmf_kl_uht_hblocks: H handed over as the stack of column blocks [nb][k][nh] that an allgather of the ranks' slices
+    leaves (gather_W_H, dist_nmf.py:283-287) equals the product with the assembled H -- 32-wide and 16-wide kernels, ranks
+    that go through the zero-padded images, several column splits per block."""
+    n = nb * nh
+    A, W, H = _mk(m, n, k)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    U = A64 / (W64 @ H64 + EPS)
+    Hs = _d(np.ascontiguousarray(H.reshape(k, nb, nh).transpose(1, 0, 2)))
+    out = torch.full((m, k), 7.0, device="cuda")
+    ops.kl_uht_hblocks(_d(A), _d(W), Hs, EPS, out)
+    assert _rel(out.cpu().numpy(), U @ H64.T) < 5e-6
+    ref = ops.kl_uht(_d(A), _d(W), _d(H), EPS, torch.empty(m, k, device="cuda"))
+    assert _rel(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize("m,n,k", SHAPES)
 def test_norms_and_fit_helpers(ops, m, n, k):
     """np.linalg.norm(A)**2 and np.linalg.norm(A - W@H)**2 (pyDNMF.py:207-217); clamp (:155-157); normalise (:185-194)."""
