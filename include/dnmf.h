@@ -97,6 +97,11 @@ int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long 
  * resources the other's remaining workgroups need.  One process per GPU and one stream, the product's model, is safe. */
 int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                       void* ws, size_t ws_bytes, void* stream);
+/* Did a persistent W sweep on the current device give up waiting for its other workgroups since the last call?  (Its
+ * workgroups were not co-resident -- see above; the sweep then ends after about a second with NaN column norms instead of
+ * hanging the GPU, and sets a sticky per-device word.)  *timed_out = 0 / 1; the word is cleared.  This call SYNCHRONISES
+ * `stream` (the one entry point that does): call it where the host waits anyway, e.g. before the factors leave the GPU. */
+int dnmf_hals_sweep_status(int* timed_out, void* stream);
 /* H sweep: for kk: H[kk,:] = max(H[kk,:] + AtW[kk,:] - G[kk,:] H, eps), rows updated in sequence (dist_nmf.py:905-909) */
 int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
                        void* stream);

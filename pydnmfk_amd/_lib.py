@@ -39,6 +39,7 @@ SIGNATURES = {
     "dnmf_hals_w_scale": [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p],
     "dnmf_hals_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_void_p],
     "dnmf_hals_sweep_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_size_t, c_void_p],
+    "dnmf_hals_sweep_status": [ctypes.POINTER(c_int), c_void_p],
     "dnmf_hals_update_h": [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],
     "dnmf_kl_uht": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p,
                     c_long, c_void_p, c_size_t, c_void_p],

@@ -22,7 +22,6 @@
 #include "dnmf_tn.h"
 #include "dnmf_stream.h"
 #include "dnmf_update.h"
-#include "dnmf_hals.h"
 #include "dnmf_nn.h"
 #include "dnmf_k16.h"
 

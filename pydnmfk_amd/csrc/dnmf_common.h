@@ -43,6 +43,10 @@ __device__ void buf_st_f32(float v, i32x4 rsrc, int voff, int soff, int aux) __a
 __device__ void buf_st_f32x2(f32x2 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
+// persistent HALS W sweep (csrc/dnmf_hals.h); the workspace query (csrc/dnmf.hip) sizes its slot slab from these
+constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
+constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
+
 namespace {
 
 int fail(int code, const char* fmt, ...) {

@@ -138,8 +138,7 @@ namespace {
 // FIXED order -- the result is bitwise identical in every workgroup and from run to run (no floating-point atomics).
 // One memory round trip per column.  All workgroups must be co-resident (the host checks the occupancy and otherwise
 // takes the per-column path).
-constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
-constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
+// (HALS_WG / HALS_MAX_WG: dnmf_common.h)
 constexpr unsigned long long HALS_EMPTY = ~0ull;
 
 __device__ __forceinline__ double dshfl_xor(double v, int mask) {
@@ -188,6 +187,11 @@ __device__ __forceinline__ double block_sum_fixed(double v, double* red) {
 // each polling round (independent, unconditional loads -- a loop that waits for one slot after the other pays one memory
 // round trip per slot: measured 16 us per column on 512 workgroups), slots that are still empty are asked for again.
 // Returns the lane's sum in slot order.
+// Sticky per-device word: set when a polling wave of the persistent sweep gave up (below).  The host reads and clears it
+// with dnmf_hals_sweep_status (PyNMF does at the end of a HALS fit), so a sweep that lost its co-residency surfaces as an
+// error instead of as NaN factors.
+__device__ unsigned int g_hals_timeout = 0;
+
 template <int NQ>
 __device__ __forceinline__ double hals_poll(const unsigned long long* col, int nwg) {
     const int lane = threadIdx.x & 63;
@@ -195,9 +199,10 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bits[q] = (lane + 64 * q < nwg) ? HALS_EMPTY : 0ull;   // beyond the grid: +0.0, never awaited
     // Safety valve: a sweep whose workgroups are not all resident (two sweeps sharing the device, which the host-side
-    // occupancy check cannot see) would wait forever.  After ~2^21 polling rounds (about a second) the wave gives up; the
-    // missing slots keep their "empty" pattern, which is a NaN, so the column norm -- and with it W -- turns NaN instead
-    // of the GPU hanging.
+    // occupancy check cannot see) would wait forever.  After ~2^21 polling rounds (about a second) the wave gives up, sets
+    // the sticky word g_hals_timeout (dnmf_hals_sweep_status reports it to the host) and lets the missing slots keep their
+    // "empty" pattern, which is a NaN: the column norm -- and with it W -- turns NaN instead of the GPU hanging.
+    bool complete = false;
     for (unsigned spins = 0; spins < (1u << 21); ++spins) {
         unsigned long long v[NQ];
 #pragma unroll
@@ -211,9 +216,10 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
             bits[q] = bits[q] == HALS_EMPTY ? v[q] : bits[q];
             missing = missing || bits[q] == HALS_EMPTY;
         }
-        if (!__any(missing)) break;
+        if (!__any(missing)) { complete = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
+    if (!complete && lane == 0) __hip_atomic_store(&g_hals_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s += __longlong_as_double((long long)bits[q]);

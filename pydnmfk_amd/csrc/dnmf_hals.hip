@@ -1,4 +1,6 @@
 // dnmf_hals.hip -- C ABI of the HALS sweeps (csrc/dnmf_hals.h).  A translation unit of its own (see csrc/dnmf_kl.hip).
+#include <mutex>
+
 #include "dnmf_common.h"
 #include "dnmf_host.h"
 #include "dnmf_stream.h"
@@ -44,6 +46,7 @@ int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long 
 
 }  // extern "C"
 namespace {
+constexpr int DNMF_MAX_DEVICES = 64;
 // co-residency of the persistent sweep: workgroups the device can hold at once
 template <typename K>
 long resident_workgroups(K kernel, int threads, size_t lds) {
@@ -67,13 +70,24 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
     const bool vec = HASVEC && aligned16(W) && ldw % 4 == 0 && k % 4 == 0;
     const long grid = cdiv(m, HALS_WG);
     constexpr size_t lds = (size_t)KP * KP * sizeof(float);          // G staged per workgroup
-    static long cap_v = -1, cap_s = -1;
-    if (cap_v < 0) {
-        allow_lds(hals_w_sweep_kernel<KP, HASVEC>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
-        cap_v = resident_workgroups(hals_w_sweep_kernel<KP, HASVEC>, HALS_WG, lds); cap_s = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
+    // co-residency capacity per DEVICE (a process may drive several GPUs, or a CU-masked one), filled once per device under a
+    // lock (ctypes callers release the GIL)
+    static std::mutex mu;
+    static long cap_v[DNMF_MAX_DEVICES], cap_s[DNMF_MAX_DEVICES];
+    static bool have[DNMF_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DNMF_MAX_DEVICES) return 1;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!have[dev]) {
+            allow_lds(hals_w_sweep_kernel<KP, HASVEC>, lds); allow_lds(hals_w_sweep_kernel<KP, false>, lds);
+            cap_v[dev] = resident_workgroups(hals_w_sweep_kernel<KP, HASVEC>, HALS_WG, lds);
+            cap_s[dev] = resident_workgroups(hals_w_sweep_kernel<KP, false>, HALS_WG, lds);
+            have[dev] = true;
+        }
     }
-    if (grid > HALS_MAX_WG || grid > (vec ? cap_v : cap_s)) return 1;          // not applicable: the caller takes the column path
-    REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "hals_sweep_w: leading dimension beyond the 32-bit tile offsets");
+    if (grid > HALS_MAX_WG || grid > (vec ? cap_v[dev] : cap_s[dev])) return 1;   // not applicable: the caller takes the column path
+    if (ldw >= (1L << 23) || ldah >= (1L << 23)) return 1;                        // beyond the 32-bit tile offsets of pass 1: column path
     if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
         return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
     {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
@@ -124,6 +138,20 @@ int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long l
     }
     if (rc != 1) return rc;
     return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column
+}
+
+int dnmf_hals_sweep_status(int* timed_out, void* stream) {
+    REQUIRE(timed_out, "hals_sweep_status: null pointer");
+    hipStream_t st = S(stream);
+    unsigned int v = 0;
+    const unsigned int zero = 0;
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(DNMF_EHIP, "hals_sweep_status: stream synchronize failed");
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_hals_timeout), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(DNMF_EHIP, "hals_sweep_status: read failed");
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_hals_timeout), &zero, sizeof(zero), 0, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(DNMF_EHIP, "hals_sweep_status: clear failed");
+    *timed_out = v != 0;
+    return DNMF_OK;
 }
 
 int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,

@@ -79,7 +79,12 @@ class _Base:
         the reference calls utils.norm (utils.py:388-391)."""
         ops, eps, k = self.ops, self.eps, self.k
         if not allreduce_norm or self.comm1.size == 1:
-            ops.hals_update_w(W, AH, G, eps)
+            # `params.hals_sweep = 'columns'`: k column launches instead of the persistent sweep, whose workgroups wait for
+            # each other and must all be resident (a GPU shared with another process or stream cannot promise that)
+            if getattr(self.params, "hals_sweep", None) == "columns" and hasattr(ops, "hals_update_w_columns"):
+                ops.hals_update_w_columns(W, AH, G, eps)
+            else:
+                ops.hals_update_w(W, AH, G, eps)
             return
         ss2 = ops.hals_ss2(k, W)
         for kk in range(k):

@@ -8,7 +8,7 @@ exception is the data matrix A of the Frobenius paths, which may be STORED as bf
 """
 import torch
 
-from ._lib import check, lib
+from ._lib import DnmfError, check, lib
 
 _ws_cache = {}
 
@@ -174,6 +174,18 @@ class HipOps:
         ws = workspace(m, k, k, W.device)
         check(lib.dnmf_hals_sweep_w(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), float(eps),
                                     ws.data_ptr(), ws.numel(), _stream()))
+
+    def hals_check(self):
+        """Raise if a persistent W sweep on this device gave up waiting for its other workgroups (they were not co-resident:
+        another process or stream shared the GPU).  W is NaN after such a sweep; `params.hals_sweep = 'columns'` selects the
+        one-launch-per-column sweep, which needs no co-residency.  Synchronises the current stream."""
+        import ctypes
+        flag = ctypes.c_int(0)
+        check(lib.dnmf_hals_sweep_status(ctypes.byref(flag), _stream()))
+        if flag.value:
+            raise DnmfError("HALS: a persistent W sweep timed out -- its workgroups were not all resident (is the GPU shared "
+                            "with another process or stream?); the factors are NaN.  Set params.hals_sweep = 'columns' to use "
+                            "the per-column sweep, which needs no co-residency.")
 
     def hals_update_w_columns(self, W, AH, G, eps):
         """The same sweep as k column launches (what the persistent kernel falls back to; kept callable for A/B tests)."""

@@ -173,6 +173,8 @@ class PyNMF:
                 else:
                     self.W_i, self.H_j = self.normalize_features(self.W_i, self.H_j)
                 self.relative_err()
+                if self.method.lower() == 'hals' and hasattr(ops, "hals_check"):
+                    ops.hals_check()                                # a persistent W sweep that lost its co-residency raises here
                 if self.verbose is True and self.rank == 0:
                     print('relative error is:', self.recon_err)
                 W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)

@@ -319,6 +319,46 @@ def test_hals_persistent_w_sweep_large(ops, m, k):
     assert torch.allclose(outs[0].double().norm(dim=0), torch.ones(k, dtype=torch.float64, device=dev), atol=1e-5)
 
 
+def test_hals_sweep_status_tracks_lost_coresidency(ops):
+    """Two persistent W sweeps enqueued on two streams, each large enough to want the whole device: whichever way the
+    dispatcher interleaves them, the sticky status word must tell the truth -- set exactly when a sweep gave up waiting
+    (its W is then NaN), clear when both finished normally (their W then equals the per-column sweep) -- and
+    HipOps.hals_check must raise on it.  The query clears the word."""
+    from pydnmfk_amd._lib import DnmfError
+    from pydnmfk_amd.engine import new_gram
+    import ctypes
+    from pydnmfk_amd._lib import lib
+    dev = torch.device("cuda")
+    m, k = 262144, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    H = torch.rand(k, 512, device=dev, generator=g)
+    G = ops.gram_hht(H, new_gram(k, dev))
+    Ws = [torch.rand(m, k, device=dev, generator=g) for _ in range(2)]
+    AHs = [torch.rand(m, k, device=dev, generator=g) * 200.0 for _ in range(2)]
+    refs = []
+    for W, AH in zip(Ws, AHs):
+        Wc = W.clone()
+        ops.hals_update_w_columns(Wc, AH, G, EPS)
+        refs.append(Wc)
+    ops.hals_check()                                                   # nothing has timed out so far
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for st, W, AH in zip(streams, Ws, AHs):
+        with torch.cuda.stream(st):
+            ops.hals_update_w(W, AH, G, EPS)
+    torch.cuda.synchronize()
+    lost = bool(torch.isnan(Ws[0]).any() or torch.isnan(Ws[1]).any())
+    if lost:
+        with pytest.raises(DnmfError, match="co-residency|resident"):
+            ops.hals_check()
+    else:
+        ops.hals_check()
+        for W, R in zip(Ws, refs):
+            assert float((W - R).norm() / R.norm()) < 2e-4
+    flag = ctypes.c_int(7)
+    assert lib.dnmf_hals_sweep_status(ctypes.byref(flag), None) == 0 and flag.value == 0      # cleared by the query above
+
+
 def test_errors_are_loud(ops):
     from pydnmfk_amd._lib import DnmfError
     with pytest.raises(TypeError):
