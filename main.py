@@ -49,6 +49,8 @@ FLAGS = [
     ('prune', _flag, False, False, 'drop all-zero rows / columns before factorising'),
     ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
     ('gemm', str, 'fp32', False, 'arithmetic of the two big Frobenius contractions: fp32 (fp32 MFMA) or bf16x6 (six bf16 piece products, fp32-grade)'),
+    ('rng', str, 'device', False, 'where random numbers are drawn: device (the data block goes to the GPU once, perturbations and the rand init are drawn there) or numpy (the reference\'s host stream: every fit draws and uploads host arrays)'),
+    ('hals_sweep', str, 'persistent', False, 'W sweep of method hals on a rank with local norms: persistent (one launch; needs the GPU to itself) or columns'),
     # NMFk
     ('perturbations', int, 20, False, 'perturbed copies per rank'),
     ('noise_var', float, 0.015, False, 'perturbation amplitude'),
@@ -86,12 +88,20 @@ def main():
     if args.rank == 0:
         print('Starting ', args.process, '...')
     A_ij = data_read(args).read()
+    if args.rng == 'device':
+        # the rank's block goes to the GPU ONCE (bf16 storage is rounded here); PyNMF / PyNMFk then work on device tensors:
+        # perturbations and the rand init are drawn on the GPU, factors stay there between the fits of an NMFk sweep
+        from pydnmfk_amd.pyDNMF import storage_dtype
+        A_ij = torch.from_numpy(np.ascontiguousarray(A_ij)).to(device=torch.device("cuda", torch.cuda.current_device()),
+                                                               dtype=storage_dtype(A_ij, args))
+    elif args.rng != 'numpy':
+        raise SystemExit("--rng must be device or numpy")
     if args.process == 'pyDNMF':
         args.results_paths = args.results_path
         nmf = PyNMF(A_ij, factors=None, save_factors=True, params=args)
         W, H, err = nmf.fit()
         if args.rank == 0:
-            print('relative error =', err)
+            print('relative error =', float(err))
     elif args.process == 'pyDNMFk':
         nopt = PyNMFk(A_ij, factors=None, params=args).fit()
         if args.rank == 0:

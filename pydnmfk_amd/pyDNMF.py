@@ -128,6 +128,8 @@ class PyNMF:
             return DistSVD(self.params, self.A_ij, ops=self._ops()).nnsvd(flag=1, verbose=0)
         if self.init != 'rand':
             raise NotImplementedError("init='%s': 'rand', 'nnsvd' or factors=... are provided" % self.init)
+        if getattr(self.params, "rng", None) == "device" and self.device.type == "cuda":
+            return self._init_factors_device()
         f32 = np.float32
         if self.topo == '2d':
             W = np.random.rand(self.params.m_loc, self.k).astype(f32)
@@ -141,6 +143,31 @@ class PyNMF:
             W = np.random.rand(self.m_loc, self.k).astype(f32) if self.rank == 0 else None
             W = self.comm1.bcast(W, root=0)
         return _to_device(W, self.device), _to_device(H, self.device)
+
+    def _init_factors_device(self):
+        """`params.rng = 'device'` (what main.py / pyDNMFk_Runner select): the same uniform [0,1) init (pyDNMF.py:110-129),
+        drawn ON the GPU -- no m x k / k x n host arrays, no PCIe copy per fit (an NMFk sweep makes 20 x K fits).  Seeded by
+        `params.init_seed` (NMFk sets one per perturbation; per-rank factors add the rank) or torch's global generator; the
+        replicated factor of a 1D grid still comes from rank 0.  A different random stream than numpy's: the parity
+        fixtures use the default `rng = 'numpy'`."""
+        dev = self.device
+        seed = getattr(self.params, "init_seed", None)
+
+        def draw(shape, salt):
+            if seed is None:
+                return torch.rand(shape, dtype=torch.float32, device=dev)
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed) * 1000003 + salt)
+            return torch.rand(shape, dtype=torch.float32, device=dev, generator=g)
+        if self.topo == '2d':
+            return draw((self.params.m_loc, self.k), 2 * self.rank + 1), draw((self.k, self.params.n_loc), 2 * self.rank + 2)
+        if self.p_c == 1:
+            W = draw((self.m_loc, self.k), 2 * self.rank + 1)
+            H = self.comm1.bcast(draw((self.k, self.n_loc), 0) if self.rank == 0 else torch.empty(self.k, self.n_loc, device=dev), root=0)
+        else:
+            H = draw((self.k, self.n_loc), 2 * self.rank + 2)
+            W = self.comm1.bcast(draw((self.m_loc, self.k), 0) if self.rank == 0 else torch.empty(self.m_loc, self.k, device=dev), root=0)
+        return W.contiguous(), H.contiguous()
 
     def _ops(self):
         if self.ops is None:

@@ -147,6 +147,8 @@ class PyNMFk:
                 print('Current perturbation =', perturbation)
             data = sample(data=self.A_ij, noise_var=self.noise_var, method=self.sampling, seed=perturbation * 1000).fit()
             self.params.W_update = True
+            if getattr(self.params, "rng", None) == "device":       # device-drawn init: one seed per (perturbation, k)
+                self.params.init_seed = perturbation * 1000 + self.k
             results.append(PyNMF(data, factors=None, params=self.params, ops=self.ops).fit())          # :230
             self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
         self.params.flag = 1
@@ -179,6 +181,7 @@ class PyNMFk:
         self.AvgH = _median_np_semantics(self.Hall)                                                     # :243
         self.AvgW = centroids
         self.params.W_update = False                                                                    # :245
+        self.params.init_seed = None
         numpy_io = not isinstance(self.A_ij, torch.Tensor)
         f0 = [_np(self.AvgW), _np(self.AvgH)] if numpy_io else [self.AvgW, self.AvgH]
         regressH = PyNMF(self.A_ij, factors=f0, params=self.params, ops=self.ops)

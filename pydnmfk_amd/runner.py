@@ -16,12 +16,13 @@ from .pyDNMFk import PyNMFk
 class pyDNMFk_Runner:
     def __init__(self, init="rand", itr=5000, norm="kl", method="mu", verbose=False, checkpoint=False,
                  timing_stats=False, prune=False, precision="float32", perturbations=20, noise_var=0.015,
-                 sill_thr=0.6, sampling="uniform", process="pyDNMF"):
+                 sill_thr=0.6, sampling="uniform", process="pyDNMF", rng="device"):
         self.init, self.itr, self.norm, self.method = init, itr, norm, method
         self.verbose, self.checkpoint, self.timing_stats, self.prune = verbose, checkpoint, timing_stats, prune
         self.precision = precision
         self.perturbations, self.noise_var, self.sill_thr, self.sampling = perturbations, noise_var, sill_thr, sampling
         self.process = process
+        self.rng = rng      # 'device': the block is uploaded once, random numbers are drawn on the GPU; 'numpy': the reference's host stream
         self.fpath = self.ftype = self.fname = self.results_path = None
         self.k_range = self.step_k = None
         if self.process not in ["pyDNMFk", "pyDNMF"]:
@@ -51,6 +52,12 @@ class pyDNMFk_Runner:
         if self.verbose and self.rank == 0:
             print("Reading data now")
         A_ij = data_read(self).read()
+        numpy_out = True
+        if self.rng == "device" and torch.cuda.is_available():
+            import numpy as np
+            from .pyDNMF import storage_dtype
+            A_ij = torch.from_numpy(np.ascontiguousarray(A_ij)).to(device=torch.device("cuda", torch.cuda.current_device()),
+                                                                   dtype=storage_dtype(A_ij, self))
         if self.verbose and self.rank == 0:
             print('Starting ' + self.process + '...')
         results = dict()
@@ -58,6 +65,8 @@ class pyDNMFk_Runner:
             results["nopt"] = PyNMFk(A_ij, factors=None, params=self).fit()
         else:
             W, H, err = PyNMF(A_ij, factors=None, params=self).fit()
+            if numpy_out and isinstance(W, torch.Tensor):      # the reference's runner hands numpy arrays back
+                W, H = W.cpu().numpy(), H.cpu().numpy()
             results["W"], results["H"], results["err"] = W, H, err
         if self.rank == 0 and self.verbose:
             print('Done ' + self.process + '.')

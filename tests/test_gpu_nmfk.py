@@ -76,6 +76,26 @@ def test_cli_nmfk_end_to_end(tmp_path, golden_dir):
         assert (base / "W_reg_factors" / "W_0.npy").exists() and (base / "H_reg_factors" / "H_0.npy").exists()
 
 
+@pytest.mark.parametrize("rng", ["device", "numpy"])
+def test_cli_nmfk_device_resident_sweep(tmp_path, rng):
+    """main.py --process=pyDNMFk the way BASELINE config 5 runs it (HALS / Frobenius, bf16-stored X, 20 perturbations) on the
+    6-feature problem of tests/test_gpu_nmfk_sweep.py: `--rng device` (the CLI default) uploads the block once and draws
+    perturbations and the rand init on the GPU, `--rng numpy` is the reference's host stream; both must recover rank 6."""
+    import os
+    import subprocess
+    import sys
+    from tests.test_gpu_nmfk_sweep import TRUE_K, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.save(tmp_path / "synth6.npy", synth())
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--process=pyDNMFk", "--p_r=1", "--p_c=1",
+           "--fpath=%s/" % tmp_path, "--fname=synth6", "--ftype=npy", "--itr=60", "--norm=fro", "--method=hals",
+           "--precision=bfloat16", "--start_k=2", "--end_k=10", "--step_k=1", "--perturbations=20", "--noise_var=0.03",
+           "--sill_thr=0.8", "--init=rand", "--rng=%s" % rng, "--results_path=%s/res/" % tmp_path]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert ("Estimated k with NMFk is  %d" % TRUE_K) in out.stdout, out.stdout[-500:]
+
+
 def test_cli_bf16_precision(tmp_path, golden_dir):
     """main.py --precision bfloat16 --method hals (BASELINE config 5 flags): X is held as bf16 on the GPU, the factors
     come back float32 and reproduce the rounded matrix as well as the reported error says."""

@@ -2,6 +2,8 @@
   c2   : config 2  -- synthetic fp32 X 65536 x 4096, k = 32, MU/FRO, 1 GPU                  -> it/s
   c4   : config 4  -- per-rank block of 131072 x 65536 on a 4 x 2 grid = 32768 x 32768, k = 128, MU/KL step (no exchange)
   c5   : config 5  -- NMFk sweep k = 2..16 step 2, HALS/FRO, perturbations P, itr I on 65536 x 4096: fp32 vs bf16 storage
+  c5cli: the same sweep entered through main.py (the reference's entry point): .npy on disk -> data_read -> one upload ->
+         PyNMFk with --rng device (and --rng numpy, the host random stream, for comparison)
 Prints one JSON line per config."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -91,3 +93,32 @@ if "c5" in which:
             print(json.dumps({"config": "c5 proxy: NMFk k=2..16 step 2, %s/FRO, %d perturbations x %d itr, %dx%d, X stored %s" % (
                 method.upper(), P, I, m, n, prec), "seconds": round(dt, 2), "nopt": int(nopt),
                 "ms_per_iteration_avg": round(dt / (nfit * I) * 1e3, 3)}))
+
+if "c5cli" in which:
+    # the path a user reaches from the reference's entry point must be the device-resident one
+    import contextlib, io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import main as cli
+    m, n, P, I = 65536, 4096, int(os.environ.get("C5_P", 4)), int(os.environ.get("C5_ITR", 100))
+    rs = np.random.RandomState(7)
+    X = (rs.rand(m, 6).astype(np.float32) @ rs.rand(6, n).astype(np.float32) + 0.01 * rs.rand(m, n).astype(np.float32))
+    os.makedirs("/tmp/c5cli", exist_ok=True)
+    np.save("/tmp/c5cli/planted.npy", X)
+    del X
+    for rng in ("device", "numpy"):
+        for prec in ("float32", "bfloat16"):
+            argv = ["main.py", "--process=pyDNMFk", "--p_r=1", "--p_c=1", "--fpath=/tmp/c5cli/", "--fname=planted", "--ftype=npy",
+                    "--itr=%d" % I, "--norm=fro", "--method=hals", "--precision=%s" % prec, "--start_k=2", "--end_k=16", "--step_k=2",
+                    "--perturbations=%d" % P, "--noise_var=0.015", "--sill_thr=0.6", "--init=rand", "--rng=%s" % rng,
+                    "--results_path=/tmp/c5cli/res_%s_%s/" % (rng, prec)]
+            old = sys.argv
+            sys.argv = argv
+            buf = io.StringIO()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with contextlib.redirect_stdout(buf):
+                cli.main()
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            sys.argv = old
+            est = [ln for ln in buf.getvalue().splitlines() if "Estimated k" in ln]
+            print(json.dumps({"config": "c5cli: main.py --process=pyDNMFk k=2..16 step 2, HALS/FRO, %d perturbations x %d itr, %dx%d, X stored %s, --rng %s (file read + upload included)" % (
+                P, I, m, n, prec, rng), "seconds": round(dt, 2), "stdout": est[-1] if est else None}))
