@@ -44,6 +44,32 @@ int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, lon
     NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
     a.out = out;
     const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
+    hipStream_t stq = st;
+    // H staged through LDS, waves walking row chunks (resid_lds_kernel) when the block is big enough to give every wave a
+    // chunk of several row blocks; small blocks keep one tile per wave (resid_kernel)
+    static const int lds_on = (int)tune("DNMF_RESID_LDS", 1);
+    if (lds_on && fast && k % 32 == 0 && n >= 128 && m >= 4096) {
+        const int nt = 4;
+        TnPlan pl = plan_tn(m, n, kt, nt);
+        {                                                          // one wave per SIMD (1024 waves): half of plan_tn's round
+            const long nch = std::max<long>(1, pl.nchunks / 2);
+            pl.rows_per_chunk = round_up(cdiv(m, nch), 32);
+        }
+        const long rpc = std::max<long>(1, round_up(pl.rows_per_chunk, 32) / 32);
+        const long nchunks = cdiv(a.nrowblk, rpc);
+        a.ncolblk = (int)cdiv(n, 128);
+        const dim3 grid2((unsigned)(cdiv(nchunks, 4) * a.ncolblk)), block2(256);
+        const size_t lds = (size_t)(32 * kt) * 128 * sizeof(float);
+#define RL_CASE(KT_)                                                                                 \
+        if (kt == KT_) {                                                                             \
+            static bool once = false;                                                                \
+            if (!once) { allow_lds(resid_lds_kernel<KT_, true, TA>, lds); once = true; }              \
+            hipLaunchKernelGGL((resid_lds_kernel<KT_, true, TA>), grid2, block2, lds, stq, a, rpc);  \
+        }
+        RL_CASE(1) RL_CASE(2) RL_CASE(4)
+#undef RL_CASE
+        return check_launch("resid_sqnorm(lds)");
+    }
     const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
 #define RS_CASE(KT_)                                                                   \
     if (kt == KT_) {                                                                   \

@@ -105,6 +105,104 @@ __global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
     block_atomic_sum(total, p.out);
 }
 
+// The same residual with the H operand staged through LDS (round 3).  resid_kernel above reads its B operand -- four floats
+// of a row of H per MFMA group -- from global memory: 64 vector loads per 32 x 128 tile that all hit the cache but keep the
+// texture path busy and leave the single wave of a tile waiting (58 % of the fp32 MFMA peak at k = 64).  Here a workgroup's
+// four waves share one block of 128 columns, whose KP x 128 block of H is loop invariant and staged ONCE (lane-contiguous
+// rows: conflict-free ds_read_b128 as the B operand), and each wave walks a chunk of 32-row blocks -- the structure of
+// kl_wtu_kernel.  Interior chunks are software pipelined: the 16 A rows of a block are requested at the top of its product
+// (their latency hides under 64 KT MFMAs), the W fragments of block b+1 during the product of block b (one load per MFMA
+// group, second register set), the H values of step s+1 are read from LDS during step s.  Edge chunks (ragged rows or
+// columns, k < KP) take resid_tile.
+template <int KT, typename TA>
+__device__ __forceinline__ double resid_chunk_pipe(const NnArgs& p, const float* smem, long rb0, long rb1, long col0, int li, int h) {
+    constexpr int NT = 4, CW = 128, NS = 4 * KT;
+    const TA* Ab = reinterpret_cast<const TA*>(p.A) + col0 + NT * li;     // + row * lda
+    const float* Wf = p.W + 4 * h;                                        // + (row0 + li) * ldw + 8 s
+    float w0[NS][4], w1[NS][4];
+    double total = 0.0;
+    auto block = [&](long rb, float (&wc)[NS][4], float (&wn)[NS][4], long nxt) {
+        const long row0 = rb * 32;
+        Raw<TA, NT> araw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) araw[r].load_nt(Ab + (row0 + crow(r, h)) * p.lda);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int ne = 0; ne < NT; ++ne)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+        float hb[2][4][NT];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[0][e], &smem[(4 * h + e) * CW + NT * li]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            load_vec_raw<4>(wn[s], Wf + (nxt * 32 + li) * p.ldw + 8 * s);        // next block's fragment of this step
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[(s + 1) & 1][e], &smem[(8 * (s + 1) + 4 * h + e) * CW + NT * li]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ne = 0; ne < NT; ++ne) acc[ne] = MFMA32(wc[s][e], hb[s & 1][e][ne], acc[ne]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a[NT];
+            araw[r].get(a);
+#pragma unroll
+            for (int ne = 0; ne < NT; ++ne) {
+                const float d = a[ne] - acc[ne][r];
+                part = fmaf(d, d, part);
+            }
+        }
+        total += (double)part;
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) load_vec_raw<4>(w0[s], Wf + (rb0 * 32 + li) * p.ldw + 8 * s);
+    long rb = rb0;
+    for (; rb + 2 <= rb1; rb += 2) {
+        block(rb, w0, w1, rb + 1);
+        block(rb + 1, w1, w0, rb + 2 < rb1 ? rb + 2 : rb + 1);             // past the end: re-read (unused)
+    }
+    if (rb < rb1) block(rb, w0, w1, rb);
+    return total;
+}
+
+template <int KT, bool FAST, typename TA = float>
+__global__ __launch_bounds__(256, 1) void resid_lds_kernel(NnArgs p, long rowblks_per_chunk) {   // one wave per SIMD: 224+ live registers (two waves spill)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KP = 32 * KT, CW = 128;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const long nchunks = cdiv(p.nrowblk, rowblks_per_chunk);
+    const long colblk = blockIdx.x % p.ncolblk;
+    const long chunk = (blockIdx.x / p.ncolblk) * 4 + wid;
+    const long col0 = colblk * CW;
+    for (int idx = tid; idx < KP * (CW / 4); idx += 256) {          // stage H[0:KP][col0:col0+CW] (zero outside k x n)
+        const int jj = idx / (CW / 4), c4 = (idx % (CW / 4)) * 4;
+        float d[4];
+        load_vec<4, FAST>(d, p.H + (long)jj * p.ldh, col0 + c4, p.n, jj < p.k);
+        *reinterpret_cast<f32x4*>(&smem[jj * CW + c4]) = f32x4{d[0], d[1], d[2], d[3]};
+    }
+    __syncthreads();
+    double total = 0.0;
+    if (chunk < nchunks) {
+        const long rb0 = chunk * rowblks_per_chunk;
+        long rb1 = rb0 + rowblks_per_chunk;
+        if (rb1 > p.nrowblk) rb1 = p.nrowblk;
+        if (FAST && p.k == KP && col0 + CW <= p.n && rb1 * 32 <= p.m) {
+            total = resid_chunk_pipe<KT, TA>(p, smem, rb0, rb1, col0, li, h);
+        } else {
+            for (long rb = rb0; rb < rb1; ++rb) total += (double)resid_tile<KT, FAST, false, false, TA>(p, rb * 32, col0, li, h);
+        }
+    }
+    block_atomic_sum(total, p.out);
+}
+
 // Per-column residual statistics (PyNMF.column_err, pyDNMF.py:221-239): num[c] += sum_i (A[i][c] - (W H)[i][c])^2 and
 // den[c] += sum_i A[i][c]^2 over this rank's rows -- the residual kernel's tile loop with one accumulator pair per
 // column instead of one scalar.  A wave owns a 128-column block and walks a chunk of 32-row blocks; fp32 partial sums per
