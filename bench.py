@@ -162,6 +162,61 @@ def cpu_baseline(n, k, m_full, steps=3):
             "host_cores": cores, "host_cpu": model, "seconds_per_iter": t, "gflops_whole_job": flops / t / 1e9}
 
 
+def _cpu_allcores_rank(m_s, n, k, steps, q):
+    """The non-reference threading variant: ONE process, the BLAS library free to use every host core."""
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.pop(v, None)
+    import numpy as np
+    from oracle import nmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        nthreads = max([int(d.get("num_threads", 1)) for d in threadpool_info()] or [1])
+    except ImportError:
+        nthreads = os.cpu_count() or 1
+    rng = np.random.default_rng(1234)
+    A = rng.random((m_s, n), dtype=np.float32)
+    W = rng.random((m_s, k), dtype=np.float32)
+    H = np.random.default_rng(99).random((k, n), dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    orc.fro_mu_step_local(A, W, H, eps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.fro_mu_step_local(A, W, H, eps)
+    q.put(((time.perf_counter() - t0) / steps, nthreads))
+
+
+def cpu_baseline_allcores(n, k, m_full, steps=3):
+    """One process with all host cores' BLAS threads on a 1/8 row slab of X (the oracle's step; the whole-X iteration time
+    is 8 x the slab's: the step is linear in the rows).  Labelled non-reference: the reference pins one BLAS thread per
+    rank (main.py:3)."""
+    import multiprocessing as mp
+    import queue
+    frac = 8
+    m_s = m_full // frac
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    saved = {v: os.environ.pop(v) for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS") if v in os.environ}
+    try:
+        pr = ctx.Process(target=_cpu_allcores_rank, args=(m_s, n, k, steps, q))
+        pr.start()
+    finally:
+        os.environ.update(saved)
+    try:
+        t, nthreads = q.get(timeout=300)
+    except queue.Empty:
+        pr.kill()
+        return {"value": None, "unit": "iter/s", "kind": "port", "sample": "FAILED: no result within 300 s"}
+    pr.join(timeout=5)
+    t_full = t * frac
+    flops = 4.0 * m_full * n * k + 4.0 * (m_full + n) * k * k
+    return {"value": 1.0 / t_full, "unit": "iter/s", "cores": nthreads, "kind": "port", "threading": "non-reference",
+            "sample": "oracle fro_mu_step_local, ONE process with %d BLAS threads on a %dx%d row slab (1/%d of X), k=%d, 1 warm-up "
+                      "+ %d timed steps: %.3f s per slab step, x %d = %.2f s per iteration of the whole X (the step is linear in "
+                      "the rows); non-reference threading (the reference pins one BLAS thread per rank)" % (
+                          nthreads, m_s, n, frac, k, steps, t, frac, t_full),
+            "seconds_per_iter": t_full, "gflops_whole_job": flops / t_full / 1e9}
+
+
 def pmc_traffic(role, workload="bench"):
     """HBM bytes per launch of a kernel from the NEWEST committed PMC pass of the given profiled workload
     (profiles/<tag>_<workload>_pmc.json: separate --pmc runs of tools/collect_profiles.sh, FETCH_SIZE doubled per
@@ -646,6 +701,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(n, k, m)
+            out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, k, m)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
