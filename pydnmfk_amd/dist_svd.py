@@ -46,7 +46,8 @@ class DistSVD:
     def svd(self):
         """(singular values [k], U [m_loc x k], V [k x n_loc]); the factor along the sharded axis is local, the other
         one replicated (dist_svd.py:149-186).  Block subspace iteration on A^T A (row-sharded A) or A A^T (column-
-        sharded A); stops when the Ritz values have settled to 1e-7 relative or after `params.svd_itr` (60) passes."""
+        sharded A); stops when every wanted Ritz value has settled to 1e-7 relative to ITSELF (floor: the fp32 operator's
+        resolution, singular values below ~3e-4 s_1) or after `params.svd_itr` (60) passes."""
         ops, A, kk = self.ops, self.A, self.k
         dev = A.device
         row_sharded = self.proc_cols == 1           # A is m_loc x n: the replicated basis lives in the n-space
@@ -70,8 +71,16 @@ class DistSVD:
             T = (B.double().t() @ Z.double().t())
             lam = torch.linalg.eigvalsh(0.5 * (T + T.t()))
             B = self._orth(Z.t())
-            if lam_prev is not None and float((lam - lam_prev)[-kk:].abs().max()) <= 1e-7 * float(lam.abs().max()):
-                break                                                   # (eigvalsh ascends: the last kk are the wanted ones)
+            if lam_prev is not None:
+                # per COMPONENT: every wanted Ritz value settled relative to ITSELF (|d lam_i| <= 1e-7 lam_i), with an absolute
+                # floor at the resolution of the fp32 operator (values below 1e-7 lam_max -- singular values below ~3e-4 s_1 --
+                # are rounding noise of A^T A applied in float32 and cannot settle further).  A test against lam_max alone
+                # accepted trailing vectors (s_k / s_1 < 1e-3) that had not converged.
+                w, wp = lam[-kk:], lam_prev[-kk:]                       # (eigvalsh ascends: the last kk are the wanted ones)
+                tol = torch.clamp(1e-7 * w.abs(), min=1e-7 * 1e-7 * float(lam.abs().max()))
+                floor = w.abs() <= 1e-7 * float(lam.abs().max())
+                if bool((((w - wp).abs() <= tol) | floor).all()):
+                    break
             lam_prev = lam
         # Rayleigh-Ritz in the converged basis: Y = A B (or A^T B), T = Y^T Y = B^T A^T A B
         if row_sharded:

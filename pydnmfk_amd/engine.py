@@ -65,6 +65,19 @@ def kp(k):
     return v
 
 
+def _scratch(nbytes, device):
+    """ONE scratch buffer per (device, stream), grown on demand and shared by every operator set (fp32 and bf16x6 entry points
+    alike: calls are stream-ordered and none keeps state in the scratch between calls)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _ws_cache.pop(key, None)                # release the smaller buffer before asking for the larger one
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
 def workspace(m, n, k, device):
     """Scratch buffer large enough for any entry point on an m x n block: one buffer per device, grown on demand (an
     NMFk sweep over k would otherwise keep one buffer per rank alive).  Stream-ordered reuse: every entry point is
@@ -72,12 +85,7 @@ def workspace(m, n, k, device):
     nbytes = lib.dnmf_ws_bytes(int(m), int(n), int(k))
     if nbytes == 0:
         raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    return _scratch(nbytes, device)
 
 
 def new_gram(k, device):
@@ -328,13 +336,7 @@ class HipOpsBf16x6(HipOps):
         nbytes = lib.dnmf_ws_bytes_bf16x6(int(m), int(n), int(k))
         if nbytes == 0:
             raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
-        key = ("x6", device.index if device.index is not None else torch.cuda.current_device(),
-               torch.cuda.current_stream(device).cuda_stream)
-        ws = _ws_cache.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            _ws_cache[key] = ws
-        return ws
+        return _scratch(nbytes, device)         # the same buffer the inherited fp32 operators use
 
     def aht(self, A, H, out):
         sfx = _req_a(A); _req(H, "H"); _req(out, "AH")
