@@ -61,6 +61,27 @@ __device__ __forceinline__ void stage_load(f32x4 (&v)[(R + T / 8 - 1) / (T / 8)]
     }
 }
 
+// MUBUF flavour of the interior stage_load (round 3): the thread's chunk of row it * T/8 + (tid >> 3) sits at byte offset
+// vo[it] from the descriptor's base (the tile origin of the workgroup), the k-tile at the wave-uniform byte offset `so` -- no
+// vector address arithmetic per load (the pointer form costs ~2 v_lshl_add_u64 per load, and on gfx950 every fp32 vector
+// instruction takes matrix-pipe time).  Rows beyond R carry BUF_OOB (the load returns 0, no branch).
+template <int R, int T>
+__device__ __forceinline__ void stage_offsets(int (&vo)[(R + T / 8 - 1) / (T / 8)], long ld, int tid) {
+    constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+        const int rl = it * RP + (tid >> 3);
+        vo[it] = (R % RP == 0 || rl < R) ? (int)(rl * ld * 4) + (tid & 7) * 16 : BUF_OOB;
+    }
+}
+template <int NP, bool NTL>
+__device__ __forceinline__ void stage_load_buf(f32x4 (&v)[NP], i32x4 rs, const int (&vo)[NP], int so) {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) v[it] = buf_ld_f32x4(rs, vo[it], so, NTL ? 2 : 0);
+}
+// one 2 GiB descriptor covers a workgroup's rows of X / all rows of Y over its column range
+__device__ __forceinline__ bool buf_window_ok(long rows, long ld, long ncols) { return (rows * ld + ncols) * 4 < 0x7fffffffL; }
+
 template <int R, int T>
 __device__ __forceinline__ void stage_store(float* tile, const f32x4 (&v)[(R + T / 8 - 1) / (T / 8)], int tid) {
     constexpr int RP = T / 8, NP = (R + RP - 1) / RP;
@@ -261,14 +282,20 @@ __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const int rg = wave % NRG, ks = wave / NRG;
     f32x4 x0[NPX], y0[NPY], x1[NPX], y1[NPY];
-    const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
-    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long kt) {
-        kt = kt < nk ? kt : nk - 1;
+    const int kshift = STAGGER ? (int)((blockIdx.x * 37u) % (unsigned)nk) : 0;
+    const i32x4 rsx = buf_rsrc(X + row0 * ldx + cbeg), rsy = buf_rsrc(Y + cbeg);
+    int vox[NPX], voy[NPY];
+    stage_offsets<BM, T>(vox, ldx, tid);
+    stage_offsets<KP, T>(voy, ldy, tid);
+    const int nki = (int)nk;
+    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long ktl) {
+        int kt = (int)ktl;
+        kt = kt < nki ? kt : nki - 1;
         kt += kshift;
-        kt = kt >= nk ? kt - nk : kt;
-        const long c0 = cbeg + kt * BK;
-        stage_load<BM, T, true, true, NTX>(xr, X, ldx, 0, 0, row0, c0, tid);
-        stage_load<KP, T, true, true>(yr, Y, ldy, KP, 0, 0, c0, tid);
+        kt = kt >= nki ? kt - nki : kt;
+        const int so = kt * (BK * 4);                      // wave uniform
+        stage_load_buf<NPX, NTX>(xr, rsx, vox, so);
+        stage_load_buf<NPY, false>(yr, rsy, voy, so);
     };
     auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
         stage_store<BM, T>(st, xr, tid);
@@ -340,14 +367,20 @@ __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const flo
     constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
     const int tid = threadIdx.x, lane = tid & 63, rg = tid >> 6, li = lane & 31, h = lane >> 5;
     f32x4 x0[NPX], y0[NPY], x1[NPX], y1[NPY], x2[NPX], y2[NPY];
-    const long kshift = STAGGER ? (long)((blockIdx.x * 37u) % (unsigned long)nk) : 0;
-    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long kt) {
-        kt = kt < nk ? kt : nk - 1;
+    const int kshift = STAGGER ? (int)((blockIdx.x * 37u) % (unsigned)nk) : 0;
+    const i32x4 rsx = buf_rsrc(X + row0 * ldx + cbeg), rsy = buf_rsrc(Y + cbeg);
+    int vox[NPX], voy[NPY];
+    stage_offsets<BM, T>(vox, ldx, tid);
+    stage_offsets<KP, T>(voy, ldy, tid);
+    const int nki = (int)nk;
+    auto load = [&](f32x4 (&xr)[NPX], f32x4 (&yr)[NPY], long ktl) {
+        int kt = (int)ktl;
+        kt = kt < nki ? kt : nki - 1;
         kt += kshift;
-        kt = kt >= nk ? kt - nk : kt;
-        const long c0 = cbeg + kt * BK;
-        stage_load<BM, T, true, true, NTX>(xr, X, ldx, 0, 0, row0, c0, tid);
-        stage_load<KP, T, true, true>(yr, Y, ldy, KP, 0, 0, c0, tid);
+        kt = kt >= nki ? kt - nki : kt;
+        const int so = kt * (BK * 4);                      // wave uniform
+        stage_load_buf<NPX, NTX>(xr, rsx, vox, so);
+        stage_load_buf<NPY, false>(yr, rsy, voy, so);
     };
     auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
         stage_store<BM, T>(st, xr, tid);
@@ -414,12 +447,14 @@ __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __r
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
+    // the two- / three-tile loops address their tiles through MUBUF descriptors: 2 GiB windows from the tile origin
+    const bool bufok = buf_window_ok(BM, ldx, cend - cbeg) && buf_window_ok(KP, ldy, cend - cbeg);
     constexpr int PF1 = (PF == 3 || PF == 4) ? 1 : PF;
     if constexpr (PF == 4 && KS == 1 && std::is_same<TX, float>::value) {
-        if (interior) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
+        if (interior && bufok) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
         else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
     } else if constexpr (PF == 3 && std::is_same<TX, float>::value) {
-        if (interior) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
+        if (interior && bufok) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
         else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
     } else {
         if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);

@@ -69,6 +69,65 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
                 yo[u] = (int)((2 * u + h) * ldy + yc);
             }
             const long rlastb = rbeg + (nb - 1) * 2 * U;   // first row of the last full batch
+            // round 3: fp32 operands whose chunk fits one 2 GiB window are addressed through MUBUF descriptors at the chunk's
+            // first row -- lane offset loop invariant, batch offset scalar: no vector address arithmetic in the loop (the
+            // pointer form costs one v_lshl_add_u64 per load, and every vector instruction takes matrix-pipe time here)
+            constexpr bool F32 = std::is_same<TY, float>::value;
+            const bool bufok = F32 && ((rend - rbeg + 8) * ldx + xcols) * 4 < 0x7fffffffL && ((rend - rbeg + 8) * ldy + ycols) * 4 < 0x7fffffffL;
+            if (F32 && bufok) {
+                if constexpr (F32) {
+                    const i32x4 rsx = buf_rsrc(X + rbeg * ldx), rsy = buf_rsrc(reinterpret_cast<const float*>(Y) + rbeg * ldy);
+                    const int ldx4 = (int)(ldx * 4), ldy4 = (int)(ldy * 4);
+                    int xb[U], yb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { xb[u] = xo[u] * 4; yb[u] = yo[u] * 4; }
+                    auto ldb = [&](float (&a)[U][KT], Raw<TY, NT> (&q)[U], int u, int rrel) {
+                        buf_load<KT, 0>(a[u], rsx, xb[u], rrel * ldx4);
+                        buf_load<NT, NTY ? 2 : 0>(q[u].v, rsy, yb[u], rrel * ldy4);
+                    };
+#pragma unroll
+                    for (int u = 0; u < U; ++u) ldb(a0, q0, u, 0);
+                    const int nbi = (int)nb, rlast_rel = (int)(rlastb - rbeg);
+                    int rr = 0, b = 0;
+                    for (; b + 2 <= nbi; b += 2) {
+                        const int r1 = rr + 2 * U;
+                        int r2 = rr + 4 * U;
+                        r2 = r2 < rlast_rel ? r2 : rlast_rel;          // prefetch past the end re-reads the last batch (unused)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            ldb(a1, q1, u, r1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            float bb[NT];
+                            q0[u].get(bb);
+#pragma unroll
+                            for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                                for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a0[u][ke], bb[ne], acc[ke][ne]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            ldb(a0, q0, u, r2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            float bb[NT];
+                            q1[u].get(bb);
+#pragma unroll
+                            for (int ke = 0; ke < KT; ++ke)
+#pragma unroll
+                                for (int ne = 0; ne < NT; ++ne) acc[ke][ne] = MFMA32(a1[u][ke], bb[ne], acc[ke][ne]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        rr += 4 * U;
+                    }
+                    r += (long)rr;
+                    if (b < nbi) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) q0[u].get(b0[u]);
+                        tn_comp<KT, NT, U>(acc, a0, b0);
+                        r += 2 * U;
+                    }
+                }
+            } else {
             {
                 const float* X0 = X + r * ldx; const TY* Y0 = Y + r * ldy;
 #pragma unroll
@@ -117,6 +176,7 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
                 for (int u = 0; u < U; ++u) q0[u].get(b0[u]);
                 tn_comp<KT, NT, U>(acc, a0, b0);
                 r += 2 * U;
+            }
             }
         }
     }

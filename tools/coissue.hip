@@ -54,6 +54,62 @@ __global__ __launch_bounds__(256) void k(long trips, float* out, unsigned long l
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// The same question for LDS reads (ds_read_b128, conflict free) and for global loads that hit the L2 (16 B per lane from a
+// 64 KiB buffer): M MFMAs (32x32x2) + NDS LDS reads + NGL global loads per trip, the loaded values folded into a register that
+// is consumed after the loop (the loads complete, nothing waits on them inside the trip beyond hipcc's own counters).
+template <int M, int NDS, int NGL>
+__global__ __launch_bounds__(256) void k2(long trips, const f32x4* __restrict__ gbuf, float* out) {
+    __shared__ f32x4 lds[1024];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = f32x4{1.f * i, 2.f, 3.f, 4.f};
+    __syncthreads();
+    float a = 1.0f + lane * 1e-6f, b = 0.5f;
+    f32x16 acc32[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+    int off = threadIdx.x;
+    for (long t = 0; t < trips; ++t) {
+        f32x4 dv[NDS > 0 ? NDS : 1], gv[NGL > 0 ? NGL : 1];
+#pragma unroll
+        for (int i = 0; i < NDS; ++i) dv[i] = lds[(off + 64 * i) & 1023];
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) gv[i] = gbuf[(off + 256 * i) & 4095];
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc32[i & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32[i & 1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NDS; ++i) sink[i & 3] += dv[i][i & 3];
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) sink[i & 3] += gv[i][i & 3];
+        off = (off + 7) & 1023;
+    }
+    float s = sink[0] + sink[1] + sink[2] + sink[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc32[i][r];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int M, int NDS, int NGL>
+void run2(int wps, const f32x4* gbuf, float* out) {
+    const long trips = 20000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int grid = 256 * wps;
+    hipLaunchKernelGGL((k2<M, NDS, NGL>), dim3(grid), dim3(256), 0, 0, trips / 10, gbuf, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k2<M, NDS, NGL>), dim3(grid), dim3(256), 0, 0, trips, gbuf, out);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("32x32x2  M=%2d ds_read_b128=%2d global_load_dwordx4=%2d waves/SIMD=%d : %8.3f ms (%6.1f ns/trip; each trip also has the %d vector adds that consume the loads)\n",
+           M, NDS, NGL, wps, ms, ms * 1e6 / trips, NDS + NGL);
+}
+
 template <int M, int V, int RCP, int SHAPE>
 void run(int wps, float* out, unsigned long long* cyc) {
     const long trips = 20000;
@@ -88,6 +144,16 @@ int main() {
         run<4, 0, 0, 32>(wps, out, cyc);
         run<4, 32, 0, 32>(wps, out, cyc);
         run<4, 64, 0, 32>(wps, out, cyc);
+    }
+    f32x4* gbuf; CK(hipMalloc(&gbuf, 4096 * sizeof(f32x4))); CK(hipMemset(gbuf, 0, 4096 * sizeof(f32x4)));
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        run2<8, 0, 0>(wps, gbuf, out);
+        run2<8, 8, 0>(wps, gbuf, out);
+        run2<8, 16, 0>(wps, gbuf, out);
+        run2<8, 0, 4>(wps, gbuf, out);
+        run2<8, 0, 8>(wps, gbuf, out);
+        run2<0, 16, 0>(wps, gbuf, out);
+        run2<0, 0, 8>(wps, gbuf, out);
     }
     return 0;
 }
