@@ -250,6 +250,13 @@ __global__ __launch_bounds__(256) void colerr_kernel(NnArgs p, double* __restric
     }
 }
 
+// U = A / (S + eps) of the KL products (dist_nmf.py:806), round 3: eps is the INITIAL value of the S accumulators and the
+// quotient is a * v_rcp_f32(d) -- 2 vector instructions per element where hipcc's IEEE division sequence + the add are 11.
+// On gfx950 every fp32 vector instruction takes ~3.3 cycles of matrix-pipe time (tools/coissue.hip), and the division sits
+// between the two products of every element: 8 % of a KL pass at k = 128, 17 % at k = 64, 30 % at k = 32 before.  At most 1.5 ulp
+// from the exact quotient; U is summed over thousands of rows / columns right after (same form as csrc/dnmf_kl16.h).
+__device__ __forceinline__ float kl_quot(float a, float d) { return a * __builtin_amdgcn_rcpf(d); }
+
 // KL H-side: P[chunk][j][c] = sum_{i in chunk} W[i][j] * A[i][c] / (S[i][c] + eps)          (dist_nmf.py:806,808)
 // A workgroup = 4 waves that share one block of CW = 32*NT columns and each own a chunk of 32-row blocks.  The
 // KP x CW block of H those columns need is loop invariant: it is staged ONCE per workgroup into LDS (row jj,
@@ -272,7 +279,7 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
 #pragma unroll
     for (int ne = 0; ne < NT; ++ne)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ne][r] = p.eps;        // S + eps: eps is the accumulators' initial value (no add per element)
     const long wrow = row0 + li;
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
@@ -290,7 +297,7 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
+        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = kl_quot(areg[r][ne], acc[ne][r]);  // U (dist_nmf.py:806)
     // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -336,7 +343,7 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
 #pragma unroll
         for (int ne = 0; ne < NT; ++ne)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[ne][r] = p.eps;
         float hb[2][4][NT];                                 // H operand of step s+1 read from LDS during step s
 #pragma unroll
         for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[0][e], &smem[(4 * h + e) * CW + NT * li]);
@@ -364,7 +371,7 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
 #pragma unroll
         for (int r = 0; r < 16; ++r)                        // phase 2
 #pragma unroll
-            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = areg[r][ne] / (acc[ne][r] + p.eps);   // U (dist_nmf.py:806)
+            for (int ne = 0; ne < NT; ++ne) acc[ne][r] = kl_quot(areg[r][ne], acc[ne][r]);   // U (dist_nmf.py:806)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {                      // phase 3
             issue_next(nxt, r);
@@ -486,7 +493,7 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
         const float* Hs = smem + cur * STAGE;
         f32x16 st;  // S^T tile: rows c, lanes i
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int r = 0; r < 16; ++r) st[r] = p.eps;
         {   // The four H values of step s+1 are read while the four (dependent) MFMAs of step s run: hipcc otherwise reads
             // ONE value ahead and every MFMA of this product waits out an LDS latency (single wave per SIMD at k = 128).
             float hv[2][4];
@@ -509,7 +516,7 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) st[4 * g + e] = a_cur[g][e] / (st[4 * g + e] + p.eps);   // U^T (dist_nmf.py:806)
+            for (int e = 0; e < 4; ++e) st[4 * g + e] = kl_quot(a_cur[g][e], st[4 * g + e]);   // U^T (dist_nmf.py:806)
         // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
         if (more) {
             if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
