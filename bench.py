@@ -671,14 +671,14 @@ def main():
             "dnmf_gram_hht (nt_kernel split + reduce)": {"ms": t["gram_hht"]},
             "dnmf_sqnorm = sqnorm_kernel (||A||^2, once per fit)": {
                 "ms": t_sq, "algorithmic_gbs": 4.0 * m_l * n / t_sq / 1e6, "frac_hbm": 4.0 * m_l * n / t_sq / 1e6 / PEAK_HBM_GBS},
-            "dnmf_resid_sqnorm = resid_kernel (||A - W H||^2, once per fit)": {
+            "dnmf_resid_sqnorm = resid_lds_kernel (||A - W H||^2, once per fit)": {
                 "ms": t_res, "tflops": fl_res / t_res / 1e9, "frac_mfma": fl_res / t_res / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                 "algorithmic_gbs": 4.0 * m_l * n / t_res / 1e6},
         }
         if rank == 0:
             r_nt = mfma_entry(kname_nt + " (dnmf_aht_update_w)", t["aht_update_w"], fl_nt, "nt")
             r_tn = mfma_entry(kname_tn + " (dnmf_wta, incl. the reduction of the partial slabs)", t["wta"], fl_tn, "tn")
-            r_res = mfma_entry("resid_kernel<KT=%d> (dnmf_resid_sqnorm)" % kt, t_res, fl_res, "resid_kernel")
+            r_res = mfma_entry("resid_lds_kernel<KT=%d> (dnmf_resid_sqnorm)" % kt, t_res, fl_res, "resid_lds_kernel")
             r_upd = hbm_entry("update_h_seq_kernel<KT=%d> (dnmf_mu_update_h: H *= S / (G H + eps), %d x 2^22)" % (kt, k),
                               t_upd, by_upd, "algorithmic bytes = 12 per element of H (read H, read S, write H)",
                               role="update_h_seq_kernel<2", workload="elt")
