@@ -326,19 +326,25 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
                                                   long rb1, long col0, int li, int h) {
     constexpr int CW = 32 * NT;
     float areg[16][NT], wfrag[4 * KT][4], w3[16][KT];
-    const float* Ab = p.A + col0 + NT * li;                 // + row * lda
-    const float* Wf = p.W + 4 * h;                          // + wrow * ldw + 8 s     (S product: lane = row li)
-    const float* W3 = p.W + (long)KT * li;                  // + row * ldw            (third phase: lane = column group)
-    auto issue_next = [&](long rb, int r) {                 // block rb's A row crow(r,h) and W fragment s = r
-        load_vec_raw_nt<NT>(areg[r], Ab + (rb * 32 + crow(r, h)) * p.lda);
-        if (r < 4 * KT) load_vec_raw<4>(wfrag[r], Wf + (rb * 32 + li) * p.ldw + 8 * r);
+    // MUBUF addressing (round 3): descriptors at the chunk's first row; a lane's offset is loop invariant, the row / block
+    // part of every address is a scalar offset -- no vector address arithmetic beside the MFMAs.  (The caller checks that
+    // one chunk of A and of W fits the 2 GiB window.)
+    const i32x4 rsa = buf_rsrc(p.A + rb0 * 32 * p.lda + col0), rsw = buf_rsrc(p.W + rb0 * 32 * p.ldw);
+    const int lda4 = (int)(p.lda * 4), ldw4 = (int)(p.ldw * 4);
+    const int va = 4 * h * lda4 + NT * li * 4;              // A[.. + crow(r, h)][col0 + NT li]: crow = (r&3) + 8 (r>>2) + 4 h
+    const int vwf = li * ldw4 + 16 * h;                     // W[.. + li][8 s + 4 h]          (S product: lane = row li)
+    const int vw3 = 4 * h * ldw4 + KT * li * 4;             // W[.. + crow(s, h)][KT li]      (third phase: lane = column group)
+    auto urow = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    auto issue_next = [&](int rbr, int r) {                 // block rb0 + rbr: A row crow(r,h) and W fragment s = r
+        buf_load<NT, 2>(areg[r], rsa, va, (rbr * 32 + urow(r)) * lda4);
+        if (r < 4 * KT) buf_load<4, 0>(wfrag[r], rsw, vwf, rbr * 32 * ldw4 + 32 * r);
     };
 #pragma unroll
-    for (int r = 0; r < 16; ++r) issue_next(rb0, r);
+    for (int r = 0; r < 16; ++r) issue_next(0, r);
     static_assert(4 * KT <= 16, "one W fragment per third-phase step");
-    for (long rb = rb0; rb < rb1; ++rb) {
-        const long row0 = rb * 32;
-        const long nxt = rb + 1 < rb1 ? rb + 1 : rb;        // past the end: re-read this block (unused)
+    const int nrb = (int)(rb1 - rb0);
+    for (int rbr = 0; rbr < nrb; ++rbr) {
+        const int nxt = rbr + 1 < nrb ? rbr + 1 : rbr;      // past the end: re-read this block (unused)
         f32x16 acc[NT];
 #pragma unroll
         for (int ne = 0; ne < NT; ++ne)
@@ -349,10 +355,10 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
         for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[0][e], &smem[(4 * h + e) * CW + NT * li]);
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {                  // phase 1
-            if (s < 16) load_vec_raw<KT>(w3[s], W3 + (row0 + crow(s, h)) * p.ldw);
+            if (s < 16) buf_load<KT, 0>(w3[s], rsw, vw3, (rbr * 32 + urow(s)) * ldw4);
             if (4 * KT < 16 && s == 4 * KT - 1) {
 #pragma unroll
-                for (int q = 4 * KT; q < 16; ++q) load_vec_raw<KT>(w3[q], W3 + (row0 + crow(q, h)) * p.ldw);
+                for (int q = 4 * KT; q < 16; ++q) buf_load<KT, 0>(w3[q], rsw, vw3, (rbr * 32 + urow(q)) * ldw4);
             }
             if (s + 1 < 4 * KT) {
 #pragma unroll
@@ -418,7 +424,8 @@ __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, 
     // (A merely branch-free block, its 16 A loads issued as one VMEM block ahead of the MFMAs, was 8-20 % slower than
     // the predicated one.)
     const long rb0 = chunk * rowblks_per_chunk;
-    if (FAST && p.pipe && p.k == KP && col0 + CW <= p.n && rb1 * 32 <= p.m) {
+    if (FAST && p.pipe && p.k == KP && col0 + CW <= p.n && rb1 * 32 <= p.m &&
+        buf_window_ok((rb1 - rb0 + 1) * 32, p.lda, CW) && buf_window_ok((rb1 - rb0 + 1) * 32, p.ldw, KP)) {   // (one descriptor per chunk)
         kl_wtu_chunk_pipe<KT, NT>(out, p, smem, rb0, rb1, col0, li, h);
     } else {
         for (long rb = rb0; rb < rb1; ++rb) kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
@@ -458,6 +465,17 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
     if (cend > p.n) cend = p.n;
     const long nt = (cend - cbeg + BK - 1) / BK;
     const float* Hb = p.H + (p.hblk ? (cbeg / p.hblk) * p.hextra : 0);    // this split's column block of H (block uniform)
+    // interior workgroups (round 3): A pieces and H tiles through MUBUF descriptors at (first row of the workgroup, cbeg) --
+    // a loop-invariant lane offset + the tile's scalar column offset, no vector address arithmetic beside the MFMAs
+    const bool buf = INTERIOR && buf_window_ok(128, p.lda, cend - cbeg) && buf_window_ok(KP, p.ldh, cend - cbeg);
+    i32x4 rsa = {0, 0, 0, 0}, rsh = {0, 0, 0, 0};
+    int va = 0, vh[NY];
+    if constexpr (INTERIOR) {
+        rsa = buf_rsrc(p.A + (long)blockIdx.x * 128 * p.lda + cbeg);
+        rsh = buf_rsrc(Hb + cbeg);
+        va = (int)((wave * 32 + li) * p.lda * 4) + 16 * h;
+        stage_offsets<KP, T>(vh, p.ldh, tid);
+    }
 
     f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
 #pragma unroll
@@ -472,10 +490,14 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
     float a_cur[4][4];
     const bool hrows_in = p.k >= KP;
     if (nt > 0) {
-        if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, cbeg, tid);
+        if (buf && cbeg + BK <= cend) stage_load_buf<NY, false>(hst, rsh, vh, 0);
+        else if (hrows_in && cbeg + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, cbeg, tid);
         else stage_load<KP, T, FAST, false>(hst, Hb, p.ldh, p.k, cend, 0, cbeg, tid);
         stage_store<KP, T>(smem, hst, tid);
-        if (INTERIOR && cbeg + BK <= cend) {
+        if (buf && cbeg + BK <= cend) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) buf_load<4, 0>(a_cur[g], rsa, va + 32 * g, 0);
+        } else if (INTERIOR && cbeg + BK <= cend) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, cbeg + 8 * g + 4 * h, cend, rok);
         } else {
@@ -519,9 +541,14 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
             for (int e = 0; e < 4; ++e) st[4 * g + e] = kl_quot(a_cur[g][e], st[4 * g + e]);   // U^T (dist_nmf.py:806)
         // the A registers are free now: fetch the next tile's pieces (and the next H tile) under the second product
         if (more) {
-            if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
+            const int so = (int)((c1 - cbeg) * 4);             // block uniform
+            if (buf && c1 + BK <= cend) stage_load_buf<NY, false>(hst, rsh, vh, so);
+            else if (hrows_in && c1 + BK <= cend) stage_load<KP, T, FAST, true>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
             else stage_load<KP, T, FAST, false>(hst, Hb, p.ldh, p.k, cend, 0, c1, tid);
-            if (INTERIOR && c1 + BK <= cend) {
+            if (buf && c1 + BK <= cend) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) buf_load<4, 0>(a_cur[g], rsa, va + 32 * g, so);
+            } else if (INTERIOR && c1 + BK <= cend) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) load_tile_vec<4, FAST, INTERIOR>(a_cur[g], p.A + arow * p.lda, c1 + 8 * g + 4 * h, cend, rok);
             } else {
