@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--norm", default="fro")
     ap.add_argument("--no-collectives", action="store_true", help="same shard, single-GPU path (no RCCL calls)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="torch: dist.all_reduce between the launches; native: the library's own RCCL communicator, one C call per step")
+    ap.add_argument("--chunks", type=int, default=None, help="overlap chunks of the H phase (default: the path's own default)")
     a = ap.parse_args()
     from pydnmfk_amd.dist_comm import MPI_comm, TorchComm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -46,6 +49,13 @@ def main():
     p.p_r, p.p_c = (1, 1) if a.no_collectives else (a.ranks, 1)
     p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
     p.norm, p.method, p.W_update, p.eps = a.norm, "mu", True, 1.1920929e-07
+    if a.chunks is not None:
+        p.overlap_chunks = a.chunks
+    if a.exchange == "native" and not a.no_collectives:
+        from pydnmfk_amd.engine import NativeComm
+        p.exchange, p.native_always = "native", True
+        p._native_comm = NativeComm(comms.comm, 1, 1)
+        p._native_comm.set_always_exchange(True)
     g = torch.Generator(device=dev).manual_seed(1)
     A = torch.rand(m_l, n, device=dev, generator=g)
     W = torch.rand(m_l, k, device=dev, generator=g)
@@ -64,6 +74,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = {"ranks_emulated": a.ranks, "rows_per_rank": m_l, "n": n, "k": k, "collectives": not a.no_collectives,
+           "exchange": a.exchange, "chunks": a.chunks,
            "ms_per_step": round(el / a.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 4)}
     print(json.dumps(out))
     if not a.no_collectives:
