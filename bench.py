@@ -62,6 +62,10 @@ def parse_args():
                     help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
                          "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="diagnostic, single GPU: run ONE rank's share of an R-GPU row grid (m / R rows) with the REAL exchange calls on "
+                         "a one-rank group (RCCL has no wire to cross: kernels, launch overheads and the collectives' fixed costs are "
+                         "real, the transfer is not) -- exercises the whole N > 1 path of this program, A/B included, on one GPU")
     ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "native"],
                     help="N > 1: who issues the allreduce -- torch.distributed between the kernel launches, or the library's own "
                          "RCCL communicator inside a one-call step (csrc/dnmf_comm.hip); 'auto' (default) times both in the "
@@ -316,6 +320,17 @@ def main():
     dev = torch.device("cuda", local)
     ctl = dev if a.backend == "nccl" else torch.device("cpu")      # where control-plane scalars of this bench are reduced
     rccl_ranks_seen = None
+    emu = a.emulate_ranks if (world == 1 and a.emulate_ranks > 1) else 0
+    if emu:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(sk.getsockname()[1])
+        sk.close()
+        dist.init_process_group(a.backend, rank=0, world_size=1)
+        from pydnmfk_amd.dist_comm import TorchComm
+        TorchComm.always_collective = True      # the one-rank communicator still issues its collectives
+        rccl_ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.backend)      # nccl = RCCL; communicators are created lazily on the current device
@@ -344,13 +359,15 @@ def main():
 
     m, n, k = a.m, a.n, a.k
     comms = MPI_comm(None, world, 1)
+    grid_r = emu or world                       # rows of the process grid the step is written for
+    multi = world > 1 or emu > 1
     p = parse()
-    p.comm1, p.comm, p.p_r, p.p_c, p.k, p.m, p.n = comms.comm, comms, world, 1, k, m, n
+    p.comm1, p.comm, p.p_r, p.p_c, p.k, p.m, p.n = comms.comm, comms, grid_r, 1, k, m, n
     p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
     p.norm, p.method, p.W_update, p.eps = a.norm, "mu", True, 1.1920929e-07
     p.gemm = a.gemm
     ops = ops_for(p)
-    m_l = determine_block_params(rank, (world, 1), (m, n)).determine_block_shape_asymm()[0]
+    m_l = determine_block_params(rank, (grid_r, 1), (m, n)).determine_block_shape_asymm()[0]
 
     # synthetic data, generated on device: X ~ U[0,1), W0 per rank, H0 from rank 0
     g = torch.Generator(device=dev)
@@ -405,8 +422,11 @@ def main():
     # DATA -- 1 (one packed allreduce), 2 and 4 chunks are each timed over a few steps, every rank sees the same
     # max-over-ranks times and therefore picks the same winner.
     mg = None
-    if world > 1:
+    if multi:
         mg = {"rccl_ranks_seen": rccl_ranks_seen, "backend": a.backend}
+        if emu:
+            mg["emulated"] = ("ONE rank's share of a %d-GPU row grid on a single GPU: real kernels, launches and collective calls on a "
+                              "one-rank group, no wire time" % emu)
         # exchange transports: torch.distributed (dist.all_reduce between the kernel launches) and, over RCCL, the
         # library's own communicator, where a whole step -- kernels, allreduce, kernels -- is ONE C call (no Python between
         # the launches; csrc/dnmf_comm.hip).  Both run the same kernels in the same order.
@@ -416,6 +436,14 @@ def main():
             try:
                 from pydnmfk_amd.engine import NativeComm
                 p._native_comm = NativeComm(comms.comm, world, 1)
+                if emu:                                            # a one-rank communicator that still issues its RCCL calls
+                    p._native_comm.set_always_exchange(True)
+                    p.native_always = True
+                t1 = torch.ones(4, device=dev)                     # smoke: the library's communicator reduces over every rank
+                p._native_comm.allreduce_(t1)
+                torch.cuda.synchronize()
+                if int(t1[0].item()) != world:
+                    raise RuntimeError("library allreduce of ones returned %s, expected %d" % (t1[0].item(), world))
             except Exception as exc:  # noqa: BLE001
                 ok, why = 0, repr(exc)
             ok = int(-max_over_ranks(-float(ok)))                  # usable only if every rank has it
@@ -462,11 +490,15 @@ def main():
     # N > 1: where the step's time goes.  (a) the same step with the exchange stubbed out (NullExchange: every allreduce
     # returns at once, so H diverges between ranks -- timing only; H is re-broadcast afterwards): per-rank compute-only
     # ms; exposed_comm_ms = full step - slowest rank's compute-only step.  (b) the packed [W^T A | W^T W] allreduce alone.
-    if world > 1:
+    if multi:
         from pydnmfk_amd.dist_comm import NullExchange
         pn = parse()
         pn.__dict__.update(vars(p))
-        pn.comm1, pn.exchange = NullExchange(p.comm1), "torch"     # the stub lives on the Python side of the choreography
+        native_used = getattr(p, "exchange", "torch") == "native"
+        if native_used:
+            p._native_comm.set_null_exchange(True)                 # same one-call step, RCCL calls skipped
+        else:
+            pn.comm1 = NullExchange(p.comm1)                       # same Python choreography, exchanges return at once
         H_keep = H.clone()
 
         def step_nocomm(i):
@@ -475,13 +507,16 @@ def main():
         for i in range(3):
             step_nocomm(i)
         nn = max(10, min(200, a.steps))
-        barrier()
+        if world > 1:
+            barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(nn):
             step_nocomm(i)
         torch.cuda.synchronize()
         mine = (time.perf_counter() - t0) / nn * 1e3
+        if native_used:
+            p._native_comm.set_null_exchange(False)
         per = [None] * world
         dist.all_gather_object(per, mine)
         H.copy_(H_keep)
@@ -492,7 +527,8 @@ def main():
         for _ in range(3):
             comms.comm.allreduce_(xbuf)
         nx = 20
-        barrier()
+        if world > 1:
+            barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(nx):
@@ -506,7 +542,7 @@ def main():
         mg["exposed_comm_ms"] = elapsed / a.steps * 1e3 - max(per)
         mg["allreduce_alone_ms"] = t_ar
         mg["allreduce_bytes"] = 4 * (k * n + kp_ * kp_)
-        mg["note"] = ("compute_only = the same step with every exchange stubbed out (timing only); exposed_comm_ms = full "
+        mg["note"] = ("compute_only = the same step on the same transport with every exchange stubbed out (timing only); exposed_comm_ms = full "
                       "step - slowest rank's compute-only step; allreduce_alone = the packed [W^T A | W^T W] message "
                       "reduced back to back with nothing else on the GPU")
 
@@ -520,8 +556,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if a.gemm == "fp32" else "f32 operands as 3 bf16 pieces, 6 bf16 MFMA products per fp32 product, fp32 accumulation",
             "data": "synthetic",
-            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)" % (
-                a.norm.upper(), m, n, k, world), "m": m, "n": n, "k": k, "rows_per_gpu": m_l, "gemm": a.gemm,
+            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)%s" % (
+                a.norm.upper(), m, n, k, grid_r, " -- EMULATED: one rank's share on one GPU, not a whole-job number" if emu else ""), "m": m, "n": n, "k": k, "rows_per_gpu": m_l, "gemm": a.gemm,
                 "parallelism": ("row-sharded X, allreduce[W^T A | W^T W] over %s" % ("RCCL" if a.backend == "nccl" else a.backend + " (host staged)")) if world > 1 else "single GPU"},
             "step_tflops_per_gpu": flops_iter / world / (ms * 1e-3) / 1e12,
             "step_mfma_frac": (flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if a.gemm == "fp32" else None,
@@ -543,7 +579,7 @@ def main():
 
     # The same step with the two big contractions as six bf16 piece products per fp32 product (opt-in, params.gemm =
     # 'bf16x6'): reported NEXT TO the fp32-MFMA headline, never as it.  Same factors, same data, every rank takes part.
-    if world == 1 and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
+    if not multi and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
         for i in range(5):
             step_x6(i)
         ns6 = max(100, int(1.5 / max(elapsed / a.steps, 1e-6)))
@@ -560,7 +596,7 @@ def main():
     # Informational: the same problem with X STORED as bfloat16 (params.precision = 'bfloat16': X is rounded once, arithmetic and
     # factors stay fp32) -- with the fp32-MFMA kernels (no gain at this rank: they are matrix-pipe bound) and with bf16x6, where
     # X is its own single piece and a product is three bf16 MFMAs.  A different X than the headline's, hence its own key.
-    if world == 1 and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
+    if not multi and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
         A_f32 = A
         A = A_f32.to(torch.bfloat16)
         res16 = {}
@@ -698,13 +734,17 @@ def main():
             out["kernels"] = kern
 
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
+        if not multi and not a.no_cpu_baseline:
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(n, k, m)
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, k, m)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
+    if multi:
+        nc = getattr(p, "_native_comm", None)
+        if nc is not None:
+            nc.close()
         dist.destroy_process_group()
 
 

@@ -226,6 +226,9 @@ int dnmf_comm_set_overlap_chunks(dnmf_comm_t* comm, int chunks);
 /* testing aid: with on != 0 a ONE-rank communicator still issues its RCCL calls (a 1 x 1 grid then behaves as a row grid),
  * so that the exchange path can be exercised on a single GPU */
 int dnmf_comm_set_always_exchange(dnmf_comm_t* comm, int on);
+/* measurement aid: with on != 0 the step entry points skip their RCCL calls (everything else -- kernels, events, the internal
+ * stream -- as usual), so a rank's compute can be timed without the exchange; results are WRONG on more than one rank */
+int dnmf_comm_set_null_exchange(dnmf_comm_t* comm, int on);
 /* in-place SUM allreduce of `count` floats on `stream`; group 0 = all ranks, 1 = cart_1d_row, 2 = cart_1d_column
  * (comm.allreduce of dist_nmf.py:114,681,707 and the host's scalar reductions) */
 int dnmf_comm_allreduce(dnmf_comm_t* comm, float* buf, size_t count, int group, void* stream);

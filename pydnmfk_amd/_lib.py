@@ -83,6 +83,7 @@ SIGNATURES["dnmf_comm_destroy"] = [c_void_p]
 SIGNATURES["dnmf_comm_info"] = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_set_overlap_chunks"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_set_always_exchange"] = [c_void_p, c_int]
+SIGNATURES["dnmf_comm_set_null_exchange"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_allreduce"] = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
 SIGNATURES["dnmf_ws_bytes_1d"] = SIGNATURES["dnmf_ws_bytes"]
 SIGNATURES["dnmf_mu_fro_step_1d"] = SIGNATURES["dnmf_mu_fro_step"][:-1] + [c_void_p, c_void_p]

@@ -442,6 +442,11 @@ class NativeComm:
         """Testing aid: a one-rank communicator still issues its RCCL calls."""
         check(lib.dnmf_comm_set_always_exchange(self.handle, int(bool(on))))
 
+    def set_null_exchange(self, on=True):
+        """Measurement aid: the step entry points skip their RCCL calls (a rank's compute without the exchange; wrong results
+        on more than one rank)."""
+        check(lib.dnmf_comm_set_null_exchange(self.handle, int(bool(on))))
+
     def allreduce_(self, t, group=0):
         _req(t, "t", t.dim())
         if not t.is_contiguous():

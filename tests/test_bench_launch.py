@@ -77,3 +77,19 @@ def test_single_gpu_line_small():
     assert r.returncode == 0, r.stderr[-4000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 1 and "multi_gpu" not in out and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_emulated_rank_runs_the_rccl_exchange_paths():
+    """`--emulate-ranks 8` on the one GPU: one rank's share of the 8-GPU row grid with the REAL RCCL calls on a one-rank
+    group -- both exchange transports (torch.distributed and the library's own communicator) x 1 / 2 / 4 overlap chunks are
+    timed in the warm-up, i.e. every line of bench.py's N > 1 path runs over RCCL before a multi-GPU node ever sees it."""
+    r = _run(["--emulate-ranks", "8", "--rows", "65536", "--cols", "4096", "--steps", "10", "--warmup", "2", "--no-kernel-timing"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == 1 and "EMULATED" in out["config"]["workload"] and out["config"]["rows_per_gpu"] == 8192
+    assert mg["backend"] == "nccl" and "native_exchange_unavailable" not in mg
+    assert set(mg["exchange_ab_ms_per_step"]) == {"%s/chunks=%d" % (t, c) for t in ("torch", "native") for c in (1, 2, 4)}
+    assert mg["exchange_used"] in ("torch", "native") and mg["overlap_chunks_used"] in (1, 2, 4)
+    assert mg["compute_only_ms"] > 0 and mg["allreduce_alone_ms"] > 0
