@@ -183,6 +183,36 @@ def test_swim_2x2_kl_known_answer():
     print("swim 2x2 KL known answer (%s): nopt" % (gemm or "fp32"), outs[0][0], "min silhouettes", outs[0][1], "seconds", round(outs[0][2], 1))
 
 
+
+def test_swim_kl_known_answer_on_one_rank(tmp_path, golden_dir):
+    """The reference's swim known answer (examples/dist_pynmfk_2d_Swim.py:23-50: KL / MU, k = 14..18, 5000 iterations, rand
+    init, noise 0.016, sill_thr 0.6, 20 perturbations -> nopt == 16) with every reference parameter EXCEPT the grid: one
+    rank, device-resident (`rng = 'device'`), so the 500 000 KL steps (the 16-wide kernels up to k = 16, the 32-wide ones
+    beyond) run without a host transport in between and the whole sweep fits the regular GPU tier.  The estimate is a
+    statistical property of the factorisations, not of the process grid; the 2 x 2 run of the example itself is
+    test_swim_2x2_kl_known_answer (gated: ~15 min over the host-staged test transport)."""
+    import time
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from pydnmfk_amd.utils import parse
+    A = torch.from_numpy(np.ascontiguousarray(np.load(golden_dir + "/data_swim.npz")["A"].astype(np.float32))).cuda()
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.size, args.rank, args.comm, args.p_r, args.p_c = 1, 0, comms, 1, 1
+    args.row_comm, args.col_comm, args.comm1 = comms.cart_1d_row(), comms.cart_1d_column(), comms.comm
+    args.fpath, args.fname, args.ftype = "../data/", "swim", "mat"
+    args.start_k, args.end_k, args.sill_thr, args.itr, args.init = 14, 18, 0.6, 5000, "rand"
+    args.noise_var, args.verbose, args.norm, args.method, args.checkpoint = 0.016, False, "kl", "mu", False
+    args.prune, args.rng, args.results_path = False, "device", str(tmp_path) + "/"
+    t0 = time.time()
+    nmfk = PyNMFk(A, factors=None, params=args)
+    nopt = nmfk.fit()
+    sil = {k: round(float(np.min(v["clusterSilhouetteCoefficients"])), 3) for k, v in nmfk.stats.items()}
+    print("swim KL known answer on one rank: nopt", nopt, "min silhouettes", sil, "seconds", round(time.time() - t0, 1))
+    assert nopt == 16, (nopt, sil)
+    assert sil[16] > 0.6 and sil[17] < 0.6, sil
+
+
 @pytest.mark.parametrize("gemm", ["fp32", "bf16x6"])
 def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):
     """The same example cut to what fits the regular GPU tier (k = 16..17, 800 iterations): every rank of the 2 x 2 grid
