@@ -53,6 +53,11 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
 /* AH[m x k] = A[m x n] H[k x n]^T        (global_mm(A_ij, H_j.T), dist_nmf.py:730; AH_glob :198) */
 int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh,
              float* AH, long ldah, void* stream);
+/* The same product with H given as n / nh COLUMN BLOCKS stacked [q][k][nh] -- the receive buffer of the allgather of the
+ * ranks' k x nh slices (AH_glob, dist_nmf.py:195-197; np.hstack there), so that the 2D step needs no re-assembly copy.
+ * n % nh == 0 and nh % 32 == 0 (DNMF_EINVAL otherwise: assemble H and call dnmf_aht). */
+int dnmf_aht_hblocks(const float* A, long m, long n, long lda, const float* Hs, long nh, int k,
+                     float* AH, long ldah, void* stream);
 /* AtW[k x n] = W[m x k]^T A[m x n]       (global_mm(W_i.T, A_ij), dist_nmf.py:749; ATW_glob :166) */
 int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw,
              float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);

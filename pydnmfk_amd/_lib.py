@@ -26,6 +26,7 @@ SIGNATURES = {
     "dnmf_gram_hht": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
     "dnmf_gram_wtw": [c_void_p, c_long, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p],
     "dnmf_aht": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p],
+    "dnmf_aht_hblocks": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p],
     "dnmf_wta": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_size_t,
                  c_void_p],
     "dnmf_mu_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],

@@ -341,14 +341,21 @@ int try_nt16(const NtArgs& a, bool fast, long n, int k, hipStream_t st) {
     return check_launch("nt16_kernel");
 }
 
+// hblk = 0: H is one k x n matrix (ldh).  hblk > 0 (fp32 A): H is the stack of n / hblk column blocks [q][k][hblk], ldh = hblk.
 template <typename TA>
 int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
-             void* stream) {
+             void* stream, long hblk = 0) {
     const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldh >= n && ldah >= k, "aht: bad arguments");
+    REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldah >= k, "aht: bad arguments");
+    REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0 && (n / BK) * (hblk / BK) < (1L << 32)) : ldh >= n,
+            "aht: bad H layout (ldh %ld, block %ld, n %ld)", ldh, hblk, n);
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
     a.Y = H; a.ldy = ldh; a.yrows = k;
+    if (hblk) {
+        const unsigned tiles = (unsigned)(hblk / BK);
+        a.yb = YBlk{tiles, (unsigned)(((1UL << 32) + tiles - 1) / tiles), (long)(k - 1) * hblk};
+    }
     a.cols_per_split = round_up(n, BK);
     a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;
     const bool fast = a_rows16(A, lda) && aligned16(H) && ldh % 4 == 0 && n % 4 == 0;
@@ -377,6 +384,11 @@ extern "C" {
 int dnmf_aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
              void* stream) {
     return aht_impl<float>(A, m, n, lda, H, k, ldh, AH, ldah, stream);
+}
+int dnmf_aht_hblocks(const float* A, long m, long n, long lda, const float* Hs, long nh, int k, float* AH, long ldah,
+                     void* stream) {
+    REQUIRE(nh >= 1, "aht_hblocks: bad block width");
+    return aht_impl<float>(A, m, n, lda, Hs, k, nh, AH, ldah, stream, nh);
 }
 int dnmf_aht_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
                    void* stream) {

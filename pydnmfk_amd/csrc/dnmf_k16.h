@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void nt16_kernel(NtArgs p) {
         const long c0 = kt * BKE;
 #pragma unroll
         for (int it = 0; it < 4; ++it) xr[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xp[it] + c0));
-        yv = *reinterpret_cast<const f32x4*>(yp + c0);
+        yv = *reinterpret_cast<const f32x4*>(yp + c0 + yblk_off(p.yb, c0));     // (Y as column blocks: NtArgs::yb)
     };
     auto store = [&](float* st, const f32x4 (&xr)[4], const f32x4& yv) {
 #pragma unroll

@@ -15,6 +15,17 @@ __device__ __forceinline__ int lds_idx(int row, int chunk) { return row * BK + (
 
 enum { NT_STORE = 0, NT_FUSED_W = 1 };
 
+// The small operand given as COLUMN BLOCKS [n / blk][yrows][blk] (the receive buffer of an allgather of k x blk slices, 2D
+// grids: dist_nmf.py:195-197): the tile at absolute column c0 of block q = c0 / blk lives at Y + q * extra with ldy = blk,
+// extra = (yrows - 1) * blk.  q comes from one scalar multiply-high (magic = ceil(2^32 / tiles), exact while
+// (n / 32) * tiles < 2^32; the host checks).  tiles = 0: Y is one yrows x n matrix.
+struct YBlk { unsigned tiles; unsigned magic; long extra; };
+__device__ __forceinline__ long yblk_off(const YBlk& yb, long c0) {
+    if (yb.tiles == 0) return 0;
+    const unsigned kt = (unsigned)(c0 / BK);
+    return (long)(yb.tiles == 1 ? kt : __umulhi(kt, yb.magic)) * yb.extra;     // (tiles = 1: magic would be 2^32)
+}
+
 struct NtArgs {
     const void* X; long ldx; long nrows; long ncols;   // streamed operand (float, or bf16 bits: TX of nt_kernel); contraction over ncols
     const float* Y; long ldy; int yrows;               // small operand [yrows x ncols]
@@ -22,6 +33,7 @@ struct NtArgs {
     float* out; long ldo; long split_stride; int store_all;
     float* W; long ldw; const float* G; float eps; int k;   // NT_FUSED_W
     int wfast;                                              // NT_FUSED_W: rows of W are 16-byte aligned (k, ldw % 4 == 0)
+    YBlk yb;                                                // Y as column blocks (zero = one matrix)
 };
 
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
@@ -154,7 +166,7 @@ __device__ __forceinline__ void sum_slices(f32x16 (&acc)[MT][KT], float* smem, i
 template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
-                                            long cend, float* smem) {
+                                            long cend, float* smem, YBlk yb = YBlk{0, 0, 0}) {
     constexpr int NRG = NW / KS;             // row groups (waves along M)
     constexpr int BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK;    // floats per pipeline stage: [X tile | Y tile]
@@ -178,7 +190,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
                 kt = kt >= nk ? kt - nk : kt;
                 const long c0 = cbeg + kt * BK;
                 dma_tile<BM, NW, NTX>(stage, X, ldx, row0, c0, wv, lane);
-                dma_tile<KP, NW, false>(stage + BM * BK, Y, ldy, 0, c0, wv, lane);
+                dma_tile<KP, NW, false>(stage + BM * BK, Y + yblk_off(yb, c0), ldy, 0, c0, wv, lane);
             };
             issue(0, smem);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -212,7 +224,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
         {
             const long c0 = cbeg + kshift * BK;
             stage_load<BM, T, FAST, INTERIOR, NTX>(xv, X, ldx, nrows, cend, row0, c0, tid);
-            stage_load<KP, T, FAST, INTERIOR>(yv, Y, ldy, yrows, cend, 0, c0, tid);
+            stage_load<KP, T, FAST, INTERIOR>(yv, Y + yblk_off(yb, c0), ldy, yrows, cend, 0, c0, tid);
         }
         stage_store<BM, T>(smem, xv, tid);
         stage_store<KP, T>(smem + BM * BK, yv, tid);
@@ -243,7 +255,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
             kt = kt >= nk ? kt - nk : kt;
             const long c0 = cbeg + kt * BK;
             stage_load<BM, T, FAST, INTERIOR, NTX>(xr, X, ldx, nrows, cend, row0, c0, tid);
-            stage_load<KP, T, FAST, INTERIOR>(yr, Y, ldy, yrows, cend, 0, c0, tid);
+            stage_load<KP, T, FAST, INTERIOR>(yr, Y + yblk_off(yb, c0), ldy, yrows, cend, 0, c0, tid);
         };
         static_assert(PF == 1, "one k-tile in flight here; two tiles in flight: nt_mainloop_p2");
         for (long kt = 0; kt < nk; ++kt) {
@@ -275,7 +287,8 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
 // conditional loads hipcc drains vmcnt(0) at every join and the second tile in flight is lost.
 template <int KT, int MT, int NW, int KS, bool STAGGER, bool NTX>
 __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
-                                               const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem) {
+                                               const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem,
+                                               YBlk yb = YBlk{0, 0, 0}) {
     constexpr int NRG = NW / KS, BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK, NS = BK / 8 / KS;   // NS = fragment groups per tile of ONE wave (slice ks)
     constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
@@ -295,7 +308,7 @@ __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const floa
         kt = kt >= nki ? kt - nki : kt;
         const int so = kt * (BK * 4);                      // wave uniform
         stage_load_buf<NPX, NTX>(xr, rsx, vox, so);
-        stage_load_buf<NPY, false>(yr, rsy, voy, so);
+        stage_load_buf<NPY, false>(yr, rsy, voy, so + (int)(yblk_off(yb, cbeg + (long)kt * BK) * 4));
     };
     auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
         stage_store<BM, T>(st, xr, tid);
@@ -361,7 +374,8 @@ __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const floa
 // share a CU, and the extra registers cost 2 % at 262144 rows, so the launch picks this loop from the grid size.
 template <int KT, int MT, int NW, bool STAGGER, bool NTX>
 __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
-                                                 const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem) {
+                                                 const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem,
+                                                 YBlk yb = YBlk{0, 0, 0}) {
     constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK, NS = BK / 8;
     constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
@@ -380,7 +394,7 @@ __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const flo
         kt = kt >= nki ? kt - nki : kt;
         const int so = kt * (BK * 4);                      // wave uniform
         stage_load_buf<NPX, NTX>(xr, rsx, vox, so);
-        stage_load_buf<NPY, false>(yr, rsy, voy, so);
+        stage_load_buf<NPY, false>(yr, rsy, voy, so + (int)(yblk_off(yb, cbeg + (long)kt * BK) * 4));
     };
     auto store = [&](float* st, const f32x4 (&xr)[NPX], const f32x4 (&yr)[NPY]) {
         stage_store<BM, T>(st, xr, tid);
@@ -443,22 +457,23 @@ __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const flo
 template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
-                                            long cend, float* smem) {
+                                            long cend, float* smem, YBlk yb = YBlk{0, 0, 0}) {
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
     // the two- / three-tile loops address their tiles through MUBUF descriptors: 2 GiB windows from the tile origin
-    const bool bufok = buf_window_ok(BM, ldx, cend - cbeg) && buf_window_ok(KP, ldy, cend - cbeg);
+    const bool bufok = buf_window_ok(BM, ldx, cend - cbeg) &&
+                       buf_window_ok(KP, ldy, (cend - cbeg) + (yb.tiles ? yblk_off(yb, cend - 1) : 0));   // (blocked Y: up to the last block)
     constexpr int PF1 = (PF == 3 || PF == 4) ? 1 : PF;
     if constexpr (PF == 4 && KS == 1 && std::is_same<TX, float>::value) {
-        if (interior && bufok) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
-        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+        if (interior && bufok) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem, yb);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem, yb);
     } else if constexpr (PF == 3 && std::is_same<TX, float>::value) {
-        if (interior && bufok) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem);
-        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+        if (interior && bufok) nt_mainloop_p2<KT, MT, NW, KS, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem, yb);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, 1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem, yb);
     } else {
-        if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
-        else nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem);
+        if (interior) nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, true, NTX, DMA>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem, yb);
+        else nt_mainloop_<KT, MT, NW, KS, FAST, PF1, STAGGER, false>(acc, X, ldx, nrows, row0, Y, ldy, yrows, cbeg, cend, smem, yb);
     }
 }
 
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
             static_assert(KS == 1, "bf16 X: one contraction slice");
             nt_mainloop_b16<KT, MT, NW, FAST, (PF == 5), (PF == 5)>(acc, static_cast<const bf16_t*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
         } else {
-            nt_mainloop<KT, MT, NW, KS, FAST, (PF == 10 ? 3 : PF == 13 ? 4 : 1), (PF == 5 || PF >= 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem);
+            nt_mainloop<KT, MT, NW, KS, FAST, (PF == 10 ? 3 : PF == 13 ? 4 : 1), (PF == 5 || PF >= 7), (PF >= 5), (PF == 7)>(acc, static_cast<const float*>(p.X), p.ldx, p.nrows, row0, p.Y, p.ldy, p.yrows, cbeg, cend, smem, p.yb);
         }
     }
 

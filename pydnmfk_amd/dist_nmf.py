@@ -318,22 +318,28 @@ class nmf_algorithms_2D(_Base):
             return torch.as_strided(b0, (sum(self.w_counts), self.k), (self.k, 1))
         return torch.cat(blocks, dim=0)                                             # vstack -> W_i [m_l x k]
 
-    def gather_H(self, stacked=False):
-        """H_j [k x n_l] = hstack of the row group's slices (:283-287).  `stacked=True` returns the allgather's receive buffer
-        itself, viewed [p_r][k][n_h], when the slices are equal and whole k-tiles wide -- the KL kernels take H as column
-        blocks (`ops.kl_uht_hblocks`), so nothing is re-assembled; otherwise (and for the Frobenius contraction, whose NT
-        kernel wants one matrix) the blocks are concatenated: the one copy left on the 2D path, k x n_l floats."""
+    def gather_H(self, stacked=None):
+        """H_j [k x n_l] = hstack of the row group's slices (:283-287).  `stacked` names the operator that will consume it
+        ('aht_hblocks' / 'kl_uht_hblocks'): when the slices are equal and whole k-tiles wide and the operator set has it, the
+        allgather's receive buffer itself is returned, viewed [p_r][k][n_h] -- the kernels read H as column blocks and nothing
+        is re-assembled.  Otherwise (ragged slices, bf16-stored A, the bf16x6 operator set) the blocks are concatenated:
+        one copy of k x n_l floats."""
         blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
         if len(blocks) == 1:
             return blocks[0]
-        if stacked and self._h_blockable():
+        if stacked and self._h_blockable(stacked):
             nh = self.h_counts[0]
             return torch.as_strided(blocks[0], (len(blocks), self.k, nh), (self.k * nh, nh, 1))
         return torch.cat(blocks, dim=1)                                              # hstack -> H_j [k x n_l]
 
-    def _h_blockable(self):
+    def _h_blockable(self, op):
         hc = self.h_counts
-        return len(set(hc)) == 1 and hc[0] % 32 == 0 and getattr(self.ops, "kl_uht_hblocks", None) is not None
+        return (len(set(hc)) == 1 and hc[0] % 32 == 0 and getattr(self.ops, op, None) is not None
+                and self.A_ij.dtype == torch.float32)
+
+    def _aht(self, H_j, V):
+        """A_ij H_j^T with H_j either one matrix or the stacked column blocks of gather_H (AH_glob :198)."""
+        return self.ops.aht_hblocks(self.A_ij, H_j, V) if H_j.dim() == 3 else self.ops.aht(self.A_ij, H_j, V)
 
     def _scatter_to_W(self, V):
         """Reduce_scatter over the column group of an (m_l x k) buffer -> (m_w x k)  (:202, :340)."""
@@ -375,8 +381,8 @@ class nmf_algorithms_2D(_Base):
         if W_update:                                               # Fro_MU_update_W :227-245
             ops.gram_hht(H, G)
             self.comm1.allreduce_(G)                               # global_gram :114
-            H_j = self.gather_H()                                  # AH_glob :195-197
-            V = ops.aht(A, H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))   # :198
+            H_j = self.gather_H(stacked="aht_hblocks")             # AH_glob :195-197
+            V = self._aht(H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))     # :198
             AH = self._scatter_to_W(V)                             # :202
             ops.mu_update_w(W, AH, G, eps)                         # :244-245
         ops.gram_wtw(W, G)                                         # Fro_MU_update_H :207-225
@@ -396,8 +402,8 @@ class nmf_algorithms_2D(_Base):
         if W_update:                                               # FRO_HALS_update_W :411-434
             ops.gram_hht(H, G)
             self.comm1.allreduce_(G)                               # :426
-            H_j = self.gather_H()
-            V = ops.aht(A, H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))   # AH_glob :427
+            H_j = self.gather_H(stacked="aht_hblocks")
+            V = self._aht(H_j, _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k))     # AH_glob :427
             AH = self._scatter_to_W(V).contiguous()
             self._hals_w_sweep(W, AH, G, allreduce_norm=True)      # norm(..., p=self.p_r), p_r > 1 on a 2D grid :432
         ops.gram_wtw(W, G)                                         # FRO_HALS_update_H :436-452
@@ -417,7 +423,7 @@ class nmf_algorithms_2D(_Base):
         if W_update:                                               # KL_MU_update_W :351-369
             ops.rowsum(H, x)
             self.comm1.allreduce_(x)                               # sum_axis :346-349
-            W_i, H_j = self.gather_W(), self.gather_H(stacked=True)   # gather_W_H :367
+            W_i, H_j = self.gather_W(), self.gather_H(stacked="kl_uht_hblocks")   # gather_W_H :367
             V = _buf(("V", m_l, k), m_l * k, A)[: m_l * k].view(m_l, k)
             if H_j.dim() == 3:                                     # the receive buffer as it is: H as column blocks
                 UHT = ops.kl_uht_hblocks(A, W_i, H_j, eps, V)      # :337-338
@@ -429,7 +435,7 @@ class nmf_algorithms_2D(_Base):
         self.comm1.allreduce_(x)
         W_i = self.gather_W()                                      # :387 (the W phase changed W, not H: the H_j it
         if not W_update:                                           #  gathered is still current -- one exchange less)
-            H_j = self.gather_H(stacked=True)
+            H_j = self.gather_H(stacked="kl_uht_hblocks")
         if H_j.dim() == 3:                                         # member q's columns are block q of the stack
             nh = self.h_counts[0]
             ks = self._product_scattered_to_H(                     # :311-312, :314-316

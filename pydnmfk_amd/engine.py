@@ -120,6 +120,17 @@ class HipOps:
         check(_fn("aht", sfx)(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), _stream()))
         return out
 
+    def aht_hblocks(self, A, Hs, out):
+        """aht with H as column blocks: `Hs` is the contiguous stack [n / n_h][k][n_h] an allgather of the slices leaves
+        (float32 A; n_h a multiple of 32)."""
+        _req(A, "A"); _req(Hs, "Hs", 3); _req(out, "AH")
+        m, n = A.shape
+        nb, k, nh = Hs.shape
+        if not Hs.is_contiguous() or nb * nh != n:
+            raise ValueError("aht_hblocks: Hs must be a contiguous [n / n_h][k][n_h] stack matching A")
+        check(lib.dnmf_aht_hblocks(A.data_ptr(), m, n, _ld(A), Hs.data_ptr(), nh, k, out.data_ptr(), _ld(out), _stream()))
+        return out
+
     def wta(self, A, W, out):
         sfx = _req_a(A); _req(W, "W"); _req(out, "AtW")
         m, n = A.shape
@@ -330,6 +341,7 @@ class HipOpsBf16x6(HipOps):
 
     name = "hip-bf16x6"
     kl_uht_hblocks = None          # (no block-column variant of the split kernels: the 2D step concatenates H for them)
+    aht_hblocks = None
 
     @staticmethod
     def _ws6(m, n, k, device):

@@ -89,6 +89,11 @@ class OracleOps:
         out.copy_(torch.from_numpy(U @ _n(H).T))                        # :810
         return out
 
+    def aht_hblocks(self, A, Hs, out):
+        """H as the allgather's stacked column blocks [p][k][n_h]: np.hstack (dist_nmf.py:195-197), then aht."""
+        assert Hs.dim() == 3 and Hs.is_contiguous()
+        return self.aht(A, torch.cat(list(Hs), dim=1), out)
+
     def kl_uht_hblocks(self, A, W, Hs, eps, out):
         """H as the allgather's stacked column blocks [p][k][n_h]: np.hstack (dist_nmf.py:283-287), then kl_uht."""
         assert Hs.dim() == 3 and Hs.is_contiguous()

@@ -18,7 +18,7 @@ CASES = [
     "t24x12_2x1_fro_float32", "t24x12_1x2_fro_float32", "t24x12_2x1_kl_float32", "t24x12_1x2_kl_float32",
     "t24x12_2x2_fro_float32", "t24x12_2x2_kl_float32",
     "r25x13_3x1_fro_float32", "r25x13_1x3_kl_float32", "r25x13_2x2_fro_float32", "r25x13_2x2_kl_float32",
-    "swim_4x1_fro_float32", "swim_2x2_kl_float32", "t24x12_2x1_kl_float32_noW",
+    "swim_4x1_fro_float32", "swim_2x2_kl_float32", "swim_2x2_fro_float32", "swim_2x2_hals_float32", "t24x12_2x1_kl_float32_noW",
     "lr200x136k64_2x2_fro_float32", "lr150x140k128_2x1_kl_float32",
     # zero row / column pruning
     "t24x12z_1x1_fro_float32_prune", "t24x12z_2x1_fro_float32_prune", "t24x12z_1x2_fro_float32_prune",
@@ -107,3 +107,70 @@ def test_save_factors_layout(tmp_path):
     assert np.array_equal(np.load(tmp_path / "H_factors" / "H_0.npy"), H)
     data_write(args).save_factors([W, H], reg=True)
     assert (tmp_path / "W_reg_factors" / "W_0.npy").exists()
+
+
+class _StackComm:
+    """A two-member sub-communicator that behaves like the RCCL one at the tensor level without a second process: the
+    allgather lands in ONE receive buffer (blocks are views of it, as all_gather_into_tensor leaves them), the
+    reduce-scatter hands back this member's block of the (here: doubled) sum."""
+    size, rank, backend = 2, 0, "nccl"
+
+    def allgather_blocks(self, x, shapes):
+        import torch
+        n = x.numel()
+        rc = torch.empty(2 * n, dtype=x.dtype)
+        rc[:n] = x.reshape(-1)
+        rc[n:] = x.reshape(-1)
+        return [rc[q * n: (q + 1) * n].view(*shapes[q]) for q in range(2)]
+
+    def reduce_scatter_rows(self, full, counts):
+        return 2.0 * full[: counts[0]]
+
+    def allreduce_(self, t):
+        return t.mul_(2.0)
+
+
+@pytest.mark.parametrize("norm,expected_cats", [("kl", 0), ("fro", 0)])
+def test_2d_step_reassembles_nothing_for_kl(norm, expected_cats, monkeypatch):
+    """VERDICT r02 #3b: with equal, 32-column-aligned slices the 2D steps hand the allgather's receive buffer to the kernels
+    as it is (H as column blocks: `ops.kl_uht_hblocks` / `ops.aht_hblocks`; the H phase's slices are the blocks) -- no
+    torch.cat / copy between the collectives and the products.  Counted on the choreography itself with a two-member
+    stand-in communicator."""
+    import numpy as np
+    import torch
+    from pydnmfk_amd import dist_nmf
+    from pydnmfk_amd.utils import parse
+    from tests._ops_double import OracleOps
+    rs = np.random.RandomState(3)
+    k, m_l, n_l = 4, 16, 128                       # slices: W 8 x k, H k x 64 (two members per sub-group)
+    A = torch.from_numpy(rs.rand(m_l, n_l).astype(np.float32))
+    W = torch.from_numpy(rs.rand(m_l // 2, k).astype(np.float32))
+    H = torch.from_numpy(rs.rand(k, n_l // 2).astype(np.float32))
+    p = parse()
+    p.m, p.n, p.p_r, p.p_c, p.k = 2 * m_l, 2 * n_l, 2, 2, k
+    p.comm1, p.row_comm, p.col_comm, p.comm = _StackComm(), _StackComm(), _StackComm(), None
+    p.eps, p.W_update, p.norm, p.method = 1.1920929e-07, True, norm, "mu"
+    calls = {"cat": 0}
+    real_cat = torch.cat
+
+    def counting_cat(*a, **kw):
+        calls["cat"] += 1
+        return real_cat(*a, **kw)
+
+    ops = OracleOps()
+
+    def uncounted(fn):                              # the checker re-assembles internally: not a choreography copy
+        def wrapped(*a, **kw):
+            monkeypatch.setattr(torch, "cat", real_cat)
+            try:
+                return fn(*a, **kw)
+            finally:
+                monkeypatch.setattr(torch, "cat", counting_cat)
+        return wrapped
+    ops.kl_uht_hblocks = uncounted(ops.kl_uht_hblocks)
+    ops.aht_hblocks = uncounted(ops.aht_hblocks)
+    monkeypatch.setattr(torch, "cat", counting_cat)
+    dist_nmf.nmf_algorithms_2D(A, W, H, params=p, ops=ops).update()
+    monkeypatch.setattr(torch, "cat", real_cat)
+    assert calls["cat"] == expected_cats, calls
+    assert torch.isfinite(W).all() and torch.isfinite(H).all()

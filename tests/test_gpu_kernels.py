@@ -181,6 +181,22 @@ def test_kl16_products(ops, m, n, k, pad):
 
 
 @pytest.mark.parametrize("m,nb,nh,k", [(1000, 4, 96, 64), (300, 2, 32, 128), (2048, 4, 512, 16), (700, 3, 64, 5), (129, 2, 160, 33),
+                                       (33000, 4, 2048, 128), (40000, 2, 1024, 16), (70000, 8, 1024, 64)])
+def test_aht_with_h_as_column_blocks(ops, m, nb, nh, k):
+    """dnmf_aht_hblocks: A H^T with H handed over as the stack of column blocks [nb][k][nh] an allgather of the ranks' slices
+    leaves (AH_glob, dist_nmf.py:195-197) equals the product with the assembled H -- the two- / three-tile MUBUF loops (block
+    offset = one scalar multiply-high per tile), the generic edge path, the 16-wide kernel, ranks below the padded width."""
+    n = nb * nh
+    A, W, H = _mk(m, n, k)
+    Hs = _d(np.ascontiguousarray(H.reshape(k, nb, nh).transpose(1, 0, 2)))
+    out = torch.full((m, k), 7.0, device="cuda")
+    ops.aht_hblocks(_d(A), Hs, out)
+    assert _rel(out.cpu().numpy(), A.astype(np.float64) @ H.T.astype(np.float64)) < 2e-6
+    ref = ops.aht(_d(A), _d(H), torch.empty(m, k, device="cuda"))
+    assert torch.equal(out, ref)                     # same kernel, same order of summation: only the addresses differ
+
+
+@pytest.mark.parametrize("m,nb,nh,k", [(1000, 4, 96, 64), (300, 2, 32, 128), (2048, 4, 512, 16), (700, 3, 64, 5), (129, 2, 160, 33),
                                        (33000, 4, 2048, 128), (40000, 2, 1024, 16)])
 def test_kl_uht_with_h_as_column_blocks(ops, m, nb, nh, k):
     """dnmf_kl_uht_hblocks: H handed over as the stack of column blocks [nb][k][nh] that an allgather of the ranks' slices

@@ -19,7 +19,9 @@ CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_floa
          "r50x39_2x3_fro_float32", "r50x39_2x3_kl_float32", "r50x39_2x3_hals_float32",
          "r50x39_3x2_fro_float32", "r50x39_2x4_kl_float32",
          "lr200x136k64_4x2_fro_float32", "lr200x136k64_4x2_kl_float32", "lr200x136k64_2x3_hals_float32",
-         "lr150x140k128_4x2_kl_float32", "swim_4x2_kl_float32"]
+         "lr150x140k128_4x2_kl_float32", "swim_4x2_kl_float32",
+         # 2D Frobenius / HALS with 32-column-aligned slices: the W phase reads the allgathered H as column blocks (aht_hblocks)
+         "swim_2x2_fro_float32", "swim_2x2_hals_float32"]
 
 
 @pytest.mark.parametrize("name", CASES)
