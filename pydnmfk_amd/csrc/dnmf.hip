@@ -347,14 +347,14 @@ int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long 
              void* stream, long hblk = 0) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldah >= k, "aht: bad arguments");
-    REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0 && (n / BK) * (hblk / BK) < (1L << 32)) : ldh >= n,
+    REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0 && (n / 16) * (hblk / 16) < (1L << 32)) : ldh >= n,
             "aht: bad H layout (ldh %ld, block %ld, n %ld)", ldh, hblk, n);
     NtArgs a{};
     a.X = A; a.ldx = lda; a.nrows = m; a.ncols = n;
     a.Y = H; a.ldy = ldh; a.yrows = k;
     if (hblk) {
-        const unsigned tiles = (unsigned)(hblk / BK);
-        a.yb = YBlk{tiles, (unsigned)(((1UL << 32) + tiles - 1) / tiles), (long)(k - 1) * hblk};
+        const unsigned long units = (unsigned long)(hblk / 16);
+        a.yb = YBlk{(unsigned)(((1UL << 32) + units - 1) / units), (long)(k - 1) * hblk};
     }
     a.cols_per_split = round_up(n, BK);
     a.out = AH; a.ldo = ldah; a.split_stride = 0; a.store_all = 0;

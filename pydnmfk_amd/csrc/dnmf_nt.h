@@ -17,13 +17,13 @@ enum { NT_STORE = 0, NT_FUSED_W = 1 };
 
 // The small operand given as COLUMN BLOCKS [n / blk][yrows][blk] (the receive buffer of an allgather of k x blk slices, 2D
 // grids: dist_nmf.py:195-197): the tile at absolute column c0 of block q = c0 / blk lives at Y + q * extra with ldy = blk,
-// extra = (yrows - 1) * blk.  q comes from one scalar multiply-high (magic = ceil(2^32 / tiles), exact while
-// (n / 32) * tiles < 2^32; the host checks).  tiles = 0: Y is one yrows x n matrix.
-struct YBlk { unsigned tiles; unsigned magic; long extra; };
+// extra = (yrows - 1) * blk.  q comes from ONE scalar multiply-high on 16-column units (blk is a multiple of 32, so a block
+// has at least two units and magic = ceil(2^32 / (blk / 16)) fits 32 bits; exact while (n / 16) * (blk / 16) < 2^32, which
+// the host checks) -- branch free: a plain k x n matrix is magic = extra = 0.  (A first version tested `tiles == 0` per
+// tile: two scalar branches in every k-tile of the main loops.)
+struct YBlk { unsigned magic; long extra; };
 __device__ __forceinline__ long yblk_off(const YBlk& yb, long c0) {
-    if (yb.tiles == 0) return 0;
-    const unsigned kt = (unsigned)(c0 / BK);
-    return (long)(yb.tiles == 1 ? kt : __umulhi(kt, yb.magic)) * yb.extra;     // (tiles = 1: magic would be 2^32)
+    return (long)__umulhi((unsigned)(c0 >> 4), yb.magic) * yb.extra;
 }
 
 struct NtArgs {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void sum_slices(f32x16 (&acc)[MT][KT], float* smem, i
 template <int KT, int MT, int NW, int KS, bool FAST, int PF, bool STAGGER, bool INTERIOR, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
-                                            long cend, float* smem, YBlk yb = YBlk{0, 0, 0}) {
+                                            long cend, float* smem, YBlk yb = YBlk{0, 0}) {
     constexpr int NRG = NW / KS;             // row groups (waves along M)
     constexpr int BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK;    // floats per pipeline stage: [X tile | Y tile]
@@ -288,7 +288,7 @@ __device__ __forceinline__ void nt_mainloop_(f32x16 (&acc)[MT][KT], const TX* __
 template <int KT, int MT, int NW, int KS, bool STAGGER, bool NTX>
 __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
                                                const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem,
-                                               YBlk yb = YBlk{0, 0, 0}) {
+                                               YBlk yb = YBlk{0, 0}) {
     constexpr int NRG = NW / KS, BM = 32 * MT * NRG, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK, NS = BK / 8 / KS;   // NS = fragment groups per tile of ONE wave (slice ks)
     constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
@@ -375,7 +375,7 @@ __device__ __forceinline__ void nt_mainloop_p2(f32x16 (&acc)[MT][KT], const floa
 template <int KT, int MT, int NW, bool STAGGER, bool NTX>
 __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const float* __restrict__ X, long ldx, long row0,
                                                  const float* __restrict__ Y, long ldy, long cbeg, long nk, float* smem,
-                                                 YBlk yb = YBlk{0, 0, 0}) {
+                                                 YBlk yb = YBlk{0, 0}) {
     constexpr int BM = 32 * MT * NW, KP = 32 * KT, T = 64 * NW;
     constexpr int STAGE = (BM + KP) * BK, NS = BK / 8;
     constexpr int NPX = (BM + T / 8 - 1) / (T / 8), NPY = (KP + T / 8 - 1) / (T / 8);
@@ -457,13 +457,13 @@ __device__ __forceinline__ void nt_mainloop_p3t(f32x16 (&acc)[MT][KT], const flo
 template <int KT, int MT, int NW, int KS, bool FAST, int PF = 1, bool STAGGER = false, bool NTX = false, bool DMA = false, typename TX = float>
 __device__ __forceinline__ void nt_mainloop(f32x16 (&acc)[MT][KT], const TX* __restrict__ X, long ldx, long nrows,
                                             long row0, const float* __restrict__ Y, long ldy, int yrows, long cbeg,
-                                            long cend, float* smem, YBlk yb = YBlk{0, 0, 0}) {
+                                            long cend, float* smem, YBlk yb = YBlk{0, 0}) {
     constexpr int BM = 32 * MT * (NW / KS), KP = 32 * KT;
     // block-uniform: every tile this workgroup stages is fully in bounds
     const bool interior = FAST && row0 + BM <= nrows && yrows >= KP && (cend - cbeg) % BK == 0;
     // the two- / three-tile loops address their tiles through MUBUF descriptors: 2 GiB windows from the tile origin
     const bool bufok = buf_window_ok(BM, ldx, cend - cbeg) &&
-                       buf_window_ok(KP, ldy, (cend - cbeg) + (yb.tiles ? yblk_off(yb, cend - 1) : 0));   // (blocked Y: up to the last block)
+                       buf_window_ok(KP, ldy, (cend - cbeg) + yblk_off(yb, cend - 1));   // (blocked Y: up to the last block)
     constexpr int PF1 = (PF == 3 || PF == 4) ? 1 : PF;
     if constexpr (PF == 4 && KS == 1 && std::is_same<TX, float>::value) {
         if (interior && bufok) nt_mainloop_p3t<KT, MT, NW, STAGGER, NTX>(acc, X, ldx, row0, Y, ldy, cbeg, (cend - cbeg) / BK, smem, yb);
