@@ -225,3 +225,35 @@ def test_config4_block_kl_checksums():
     assert torch.isfinite(W).all() and torch.isfinite(H).all() and float(W.min()) >= 0 and float(H.min()) >= 0
     d1 = kl_div(W, H)
     assert d1 < d0
+
+
+@pytest.mark.parametrize("k", [16, 9, 32])
+def test_headline_size_kl_checksums_small_rank(k):
+    """The KL products at the full 262144 x 8192 (8 GiB: offsets beyond 2^32 bytes, MUBUF windows re-based per chunk / per
+    workgroup) for the ranks an NMFk sweep visits -- k = 16 (the 16-wide kernels on the factors as they are), k = 9 (through
+    the zero-padded 16-wide images), k = 32 (the 32-wide kernels' MUBUF paths) -- tied to each other and to a plain sum:
+        <U H^T, W> = <W^T U, H> = sum(A * WH / (WH + eps)) ~= sum(A);
+    a spike in the far corner of A must reach both products (the last rows / columns are really read)."""
+    from pydnmfk_amd.engine import HIP_OPS as ops
+    m, n = 262144, 8192
+    EPS = float(np.finfo(np.float32).eps)
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(13 + k)
+    A = torch.rand(m, n, device=dev, generator=g)
+    W = torch.rand(m, k, device=dev, generator=g)
+    H = torch.rand(k, n, device=dev, generator=g)
+    UHT = ops.kl_uht(A, W, H, EPS, torch.empty(m, k, device=dev))
+    WTU = ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, device=dev))
+    lhs, rhs = float((UHT.double() * W.double()).sum()), float((WTU.double() * H.double()).sum())
+    sa = float(A.double().sum())
+    assert abs(lhs - rhs) / abs(rhs) < 1e-6
+    assert abs(lhs - sa) / sa < 1e-5
+    # far-corner spike: U[m-1][n-1] grows by spike / (W H + eps)[m-1][n-1]
+    spike = 1000.0
+    A[m - 1, n - 1] += spike
+    UHT2 = ops.kl_uht(A, W, H, EPS, torch.empty(m, k, device=dev))
+    WTU2 = ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, device=dev))
+    d = spike / (float(W[m - 1].double() @ H[:, n - 1].double()) + EPS)
+    assert torch.allclose((UHT2[m - 1] - UHT[m - 1]).double(), d * H[:, n - 1].double(), rtol=2e-3, atol=1e-2)
+    assert torch.allclose((WTU2[:, n - 1] - WTU[:, n - 1]).double(), d * W[m - 1].double(), rtol=2e-3, atol=1e-2)
+    assert torch.equal(UHT2[: m - 1], UHT[: m - 1]) and torch.equal(WTU2[:, : n - 1], WTU[:, : n - 1])
