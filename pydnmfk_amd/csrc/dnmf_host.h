@@ -131,6 +131,31 @@ size_t pad_bytes(long m, long n, int kp) {
 // zero-padded images [m x KP] / [KP x n] at the end of the workspace (two strided device copies, a few MB against the GB of
 // A) and the kernels run their interior paths on those; zero columns of W / zero rows of H contribute nothing and the
 // outputs beyond k are never stored.
+// one launch writes both images: Wp [m x kp] (columns >= k zero) and Hp [kp x ldhp] (rows >= k, columns >= n zero); a thread
+// per output float4.  (Round 3: the two memsets + two 2D copies this replaces were four ~5 us launches per KL product --
+// 9 % of a KL step at the NMFk sweep shape, 65536 x 4096, k = 8.)
+__global__ __launch_bounds__(256) void pad_factors_kernel(const float* __restrict__ W, long ldw, long m, int k, float* __restrict__ Wp,
+                                                          int kp, const float* __restrict__ H, long ldh, long n,
+                                                          float* __restrict__ Hp, long ldhp) {
+    const long wq = m * (kp / 4), hq = (long)kp * (ldhp / 4);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < wq + hq; idx += (long)gridDim.x * 256) {
+        float d[4];
+        if (idx < wq) {
+            const long r = idx / (kp / 4);
+            const int c = (int)(idx % (kp / 4)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = c + e < k ? W[r * ldw + c + e] : 0.f;
+            *reinterpret_cast<f32x4*>(Wp + r * kp + c) = f32x4{d[0], d[1], d[2], d[3]};
+        } else {
+            const long j = idx - wq;
+            const long r = j / (ldhp / 4), c = (j % (ldhp / 4)) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = (r < k && c + e < n) ? H[r * ldh + c + e] : 0.f;
+            *reinterpret_cast<f32x4*>(Hp + r * ldhp + c) = f32x4{d[0], d[1], d[2], d[3]};
+        }
+    }
+}
+
 bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k, long m, long n, int kp, void* ws,
                         size_t ws_bytes, size_t own_need, hipStream_t st) {
     const bool friendly = k == kp && aligned16(W) && ldw % 4 == 0 && aligned16(H) && ldh % 4 == 0;
@@ -141,12 +166,10 @@ bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k,
     float* Wp = (float*)base;
     const long ldhp = round_up(n, 4);
     float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
-    if (hipMemsetAsync(Wp, 0, (size_t)m * kp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Wp, (size_t)kp * sizeof(float), W, (size_t)ldw * sizeof(float), (size_t)k * sizeof(float), (size_t)m,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
-    if (hipMemsetAsync(Hp, 0, (size_t)kp * ldhp * sizeof(float), st) != hipSuccess) return false;
-    if (hipMemcpy2DAsync(Hp, (size_t)ldhp * sizeof(float), H, (size_t)ldh * sizeof(float), (size_t)n * sizeof(float), (size_t)k,
-                         hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    const long quads = m * (kp / 4) + (long)kp * (ldhp / 4);
+    const unsigned grid = (unsigned)std::min<long>(cdiv(quads, 256), 4096);
+    hipLaunchKernelGGL(pad_factors_kernel, dim3(grid), dim3(256), 0, st, W, ldw, m, k, Wp, kp, H, ldh, n, Hp, ldhp);
+    if (hipGetLastError() != hipSuccess) return false;
     W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
     return true;
 }
