@@ -120,6 +120,9 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
  * n % nh == 0 and nh % 32 == 0 (DNMF_EINVAL otherwise: assemble H and call dnmf_kl_uht). */
 int dnmf_kl_uht_hblocks(const float* A, long m, long n, long lda, const float* W, long ldw, const float* Hs, long nh,
                         int k, float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream);
+/* scratch bytes for dnmf_kl_uht_hblocks (one partial slab per column split, and a split never straddles a block: narrow
+ * blocks need more slabs than dnmf_ws_bytes reserves); >= dnmf_ws_bytes(m, n, k) */
+size_t dnmf_ws_bytes_hblocks(long m, long n, int k, long nh);
 /* WTU[k x n] = W^T (A / (W H + eps))     (glob_UX(axis=1), dist_nmf.py:806,808; WTU_glob :311-312) */
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                 int k, float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream);

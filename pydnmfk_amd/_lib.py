@@ -89,8 +89,9 @@ SIGNATURES["dnmf_comm_allreduce"] = [c_void_p, c_void_p, c_size_t, c_int, c_void
 SIGNATURES["dnmf_ws_bytes_1d"] = SIGNATURES["dnmf_ws_bytes"]
 SIGNATURES["dnmf_mu_fro_step_1d"] = SIGNATURES["dnmf_mu_fro_step"][:-1] + [c_void_p, c_void_p]
 SIGNATURES["dnmf_mu_kl_step_1d"] = SIGNATURES["dnmf_mu_fro_step_1d"]
+SIGNATURES["dnmf_ws_bytes_hblocks"] = [c_long, c_long, c_int, c_long]
 _RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
-             "dnmf_ws_bytes_1d": c_size_t}
+             "dnmf_ws_bytes_1d": c_size_t, "dnmf_ws_bytes_hblocks": c_size_t}
 
 
 def load():

@@ -213,6 +213,17 @@ int dnmf_kl_uht(const float* A, long m, long n, long lda, const float* W, long l
     return kl_uht_impl(A, m, n, lda, W, ldw, H, ldh, 0, k, eps, UHT, ldo, ws, ws_bytes, stream);
 }
 
+size_t dnmf_ws_bytes_hblocks(long m, long n, int k, long nh) {
+    const int kt = kt_of(k);
+    if (kt < 0 || m < 1 || n < 1 || nh < 1 || n % nh) return 0;
+    const int kp = 32 * kt;
+    // a column split never straddles a block: at least n / nh splits, at most twice the planner's count
+    const UhtPlan u = plan_uht(m, n);
+    const long nb = n / nh, nsp = nb * std::max<long>(1, (u.nsplit + nb / 2) / nb);
+    const size_t slabs = (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes((int)nsp, (int)m, k);
+    return std::max(dnmf_ws_bytes(m, n, k), align256(slabs) + pad_bytes(m, n, kp));
+}
+
 int dnmf_kl_uht_hblocks(const float* A, long m, long n, long lda, const float* W, long ldw, const float* Hs, long nh, int k,
                         float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {
     REQUIRE(nh >= 1, "kl_uht_hblocks: bad block width");

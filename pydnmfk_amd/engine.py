@@ -237,7 +237,10 @@ class HipOps:
         nb, k, nh = Hs.shape
         if not Hs.is_contiguous() or nb * nh != n or k != W.shape[1]:
             raise ValueError("kl_uht_hblocks: Hs must be a contiguous [n / n_h][k][n_h] stack matching A and W")
-        ws = workspace(m, n, k, A.device)
+        nbytes = lib.dnmf_ws_bytes_hblocks(int(m), int(n), int(k), int(nh))
+        if nbytes == 0:
+            raise ValueError("kl_uht_hblocks: bad shape m=%d n=%d k=%d n_h=%d" % (m, n, k, nh))
+        ws = _scratch(nbytes, A.device)
         check(lib.dnmf_kl_uht_hblocks(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), Hs.data_ptr(), nh, k, float(eps),
                                       out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
         return out

@@ -191,3 +191,38 @@ def test_random_shapes_update_kernels(r, k, pad, off, seed):
             if ss > 0:
                 Wr[:, kk] /= ss
         assert _rel(W4.cpu().numpy(), Wr) < 1e-4
+
+
+def _shapes_blocks(seed, count):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        k = int(rs.choice([1, 3, 4, 8, 12, 16, 20, 32, 33, 64, 72, 128]))
+        m = int(rs.choice([5, 32, 33, 96, 128, 130, 256, 300, 640, 1024, 1500, 4100]))
+        nb = int(rs.choice([1, 2, 3, 4, 8]))
+        nh = 32 * int(rs.choice([1, 2, 3, 4, 5, 8, 16]))
+        out.append((m, nb, nh, k, int(rs.randint(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("m,nb,nh,k,seed", _shapes_blocks(_SEED + 7, max(40, _COUNT // 4)))
+def test_random_shapes_h_as_column_blocks(m, nb, nh, k, seed):
+    """dnmf_aht_hblocks / dnmf_kl_uht_hblocks on random grids of column blocks: bit-identical (aht) / equal to rounding (kl_uht:
+    the column splits may differ) to the same product with the assembled H, and right against float64."""
+    from pydnmfk_amd.engine import HIP_OPS as ops
+    rs = np.random.RandomState(seed)
+    n = nb * nh
+    A = rs.rand(m, n).astype(np.float32)
+    A[rs.rand(m, n) < 0.1] = 0.0
+    W = rs.rand(m, k).astype(np.float32)
+    H = rs.rand(k, n).astype(np.float32)
+    dev = torch.device("cuda")
+    dA, dW, dH = (torch.from_numpy(x).to(dev) for x in (A, W, H))
+    Hs = torch.from_numpy(np.ascontiguousarray(H.reshape(k, nb, nh).transpose(1, 0, 2))).to(dev)
+    A64, W64, H64 = A.astype(np.float64), W.astype(np.float64), H.astype(np.float64)
+    out = ops.aht_hblocks(dA, Hs, torch.full((m, k), 3.0, device=dev))
+    assert torch.equal(out, ops.aht(dA, dH, torch.empty(m, k, device=dev)))
+    assert _rel(out.cpu().numpy(), A64 @ H64.T) < 2e-6
+    U = A64 / (W64 @ H64 + EPS)
+    uht = ops.kl_uht_hblocks(dA, dW, Hs, EPS, torch.full((m, k), 3.0, device=dev))
+    assert _rel(uht.cpu().numpy(), U @ H64.T) < 5e-6
