@@ -148,7 +148,7 @@ class nmf_algorithms_1D(_Base):
         m_l, n_l = A.shape
         if W_update:                                               # Fro_MU_update_W :716-732
             if self.p_c == 1:                                      # no exchange: fused single pass over A
-                G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+                G = _buf(("G", kp), kp * kp, A)[: kp * kp].view(kp, kp)
                 ops.gram_hht(H, G)
                 ops.aht_update_w(A, H, G, W, eps)
             else:                                                  # allreduce [A H^T | H H^T] (:681,:707)
@@ -377,7 +377,7 @@ class nmf_algorithms_2D(_Base):
         ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
         kp = _kp(k)
         m_l, n_l = A.shape
-        G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+        G = _buf(("G", kp), kp * kp, A)[: kp * kp].view(kp, kp)
         if W_update:                                               # Fro_MU_update_W :227-245
             ops.gram_hht(H, G)
             self.comm1.allreduce_(G)                               # global_gram :114
@@ -398,7 +398,7 @@ class nmf_algorithms_2D(_Base):
         ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
         kp = _kp(k)
         m_l, n_l = A.shape
-        G = _buf(("G", kp), kp * kp, A).view(kp, kp)
+        G = _buf(("G", kp), kp * kp, A)[: kp * kp].view(kp, kp)
         if W_update:                                               # FRO_HALS_update_W :411-434
             ops.gram_hht(H, G)
             self.comm1.allreduce_(G)                               # :426

@@ -174,3 +174,33 @@ def test_2d_step_reassembles_nothing_for_kl(norm, expected_cats, monkeypatch):
     monkeypatch.setattr(torch, "cat", real_cat)
     assert calls["cat"] == expected_cats, calls
     assert torch.isfinite(W).all() and torch.isfinite(H).all()
+
+
+def test_scratch_buffers_survive_a_shrinking_rank():
+    """The choreography's scratch tensors are cached per role and only ever grow: a step at k = 64 followed by one at k = 5
+    on the same device (an NMFk run restarted at a smaller k, a regression fit after a sweep) must carve its k x k block
+    out of the larger buffer instead of viewing all of it."""
+    import numpy as np
+    import torch
+    from pydnmfk_amd import dist_nmf
+    from pydnmfk_amd.utils import parse
+    from tests._ops_double import OracleOps
+    dist_nmf.release_buffers()
+    for k in (64, 5, 33, 2):
+        rs = np.random.RandomState(k)
+        m_l, n_l = 16, 128
+        A = torch.from_numpy(rs.rand(m_l, n_l).astype(np.float32))
+        W = torch.from_numpy(rs.rand(m_l // 2, k).astype(np.float32))
+        H = torch.from_numpy(rs.rand(k, n_l // 2).astype(np.float32))
+        for norm, method in (("fro", "mu"), ("kl", "mu"), ("fro", "hals")):
+            p = parse()
+            p.m, p.n, p.p_r, p.p_c, p.k = 2 * m_l, 2 * n_l, 2, 2, k
+            p.comm1, p.row_comm, p.col_comm, p.comm = _StackComm(), _StackComm(), _StackComm(), None
+            p.eps, p.W_update, p.norm, p.method = 1.1920929e-07, True, norm, method
+            dist_nmf.nmf_algorithms_2D(A, W.clone(), H.clone(), params=p, ops=OracleOps()).update()
+        # 1D row grid with an exchange in the W phase (p_r = 1 < p_c): the packed [A H^T | H H^T] buffer
+        p = parse()
+        p.m, p.n, p.p_r, p.p_c, p.k = m_l, 2 * n_l, 1, 2, k
+        p.comm1, p.eps, p.W_update, p.norm, p.method = _StackComm(), 1.1920929e-07, True, "fro", "mu"
+        dist_nmf.nmf_algorithms_1D(A, torch.from_numpy(rs.rand(m_l, k).astype(np.float32)), torch.from_numpy(rs.rand(k, n_l).astype(np.float32)), params=p, ops=OracleOps()).update()
+    dist_nmf.release_buffers()

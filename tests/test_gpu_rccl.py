@@ -141,6 +141,28 @@ def _child(port, q):
                     nmf_algorithms_1D(Ad, Wn, Hn, params=an).update(clamp=(i == 0))
                 assert nc.overlap_chunks == chunks
                 native["%s_%d" % (norm, chunks)] = bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
+        # the same on shapes the tiles do not divide (ragged rows / columns, ranks below the padded width, a rank on the
+        # 16-wide kernels, W_update = False): the C step's workspace layout and chunk arithmetic against the Python one
+        odd = True
+        for (mm, nn, kk, nrm, chunks, wupd) in [(1000, 260, 5, "fro", 2, True), (257, 131, 33, "kl", 1, True), (3000, 777, 16, "fro", 4, True),
+                                                (130, 8200, 128, "fro", 2, False), (513, 640, 16, "kl", 1, True), (64, 4100, 7, "fro", 4, True)]:
+            rq = np.random.RandomState(mm + nn + kk)
+            Aq = torch.from_numpy(rq.rand(mm, nn).astype(np.float32)).to(dev)
+            Wq0, Hq0 = rq.rand(mm, kk).astype(np.float32), rq.rand(kk, nn).astype(np.float32)
+            ap = parse()
+            ap.comm1, ap.comm, ap.p_r, ap.p_c, ap.k, ap.m, ap.n = world, comms, 4, 1, kk, mm, nn
+            ap.eps, ap.W_update, ap.norm, ap.method = eps, wupd, nrm, "mu"
+            ap.overlap_min_cols, ap.overlap_chunks = 64, chunks
+            an = parse()
+            an.__dict__.update(vars(ap))
+            an.exchange, an.native_always, an._native_comm = "native", True, nc
+            Wp, Hp = torch.from_numpy(Wq0).to(dev), torch.from_numpy(Hq0).to(dev)
+            Wn, Hn = Wp.clone(), Hp.clone()
+            for i in range(2):
+                nmf_algorithms_1D(Aq, Wp, Hp, params=ap).update(clamp=(i == 0))
+                nmf_algorithms_1D(Aq, Wn, Hn, params=an).update(clamp=(i == 0))
+            odd = odd and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
+        native["odd_shapes"] = odd
         log["native"] = native
         nc.close()
         # --- a whole fit with the nccl group up (relative_err allreduces a float64 pair on the device)
@@ -174,4 +196,4 @@ def test_rccl_code_path_on_one_gpu():
         assert max(log["2d_%s" % norm]) <= 1e-6, log
     assert max(log["overlap"]) <= 2e-6, log
     assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log
-    assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True}, log
+    assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True, "odd_shapes": True}, log
