@@ -447,7 +447,11 @@ class NativeComm:
             lib.dnmf_comm_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        # not while the interpreter shuts down: the HIP / RCCL runtimes may already be gone, and the process is ending anyway
+        import sys
+        if not sys.is_finalizing():
+            self.close()
 
     def set_overlap_chunks(self, n):
         check(lib.dnmf_comm_set_overlap_chunks(self.handle, int(n)))
