@@ -110,6 +110,61 @@ void run2(int wps, const f32x4* gbuf, float* out) {
            M, NDS, NGL, wps, ms, ms * 1e6 / trips, NDS + NGL);
 }
 
+
+// What clock does the chip hold under fp32 MFMAs alone?  k3: M v_mfma_f32_32x32x2_f32 per trip on operands that are random per
+// lane and change from MFMA to MFMA (RND = 1) or constants (RND = 0), 4 waves per SIMD; the clock = s_memtime ticks per 10 ns of
+// wall_clock64 (block 0).  The NT / TN kernels of the library hold 2.0 GHz at 93-97 % MFMA busy on random data.
+template <int RND>
+__global__ __launch_bounds__(256) void k3(long trips, float* out, unsigned long long* cyc) {
+    const int lane = threadIdx.x & 63;
+    float a[8], b[8];
+    unsigned x = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        a[i] = RND ? (x >> 8) * (1.0f / 16777216.0f) + 1e-3f : 1.0f;
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        b[i] = RND ? (x >> 8) * (1.0f / 16777216.0f) + 1e-3f : 0.5f;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
+    for (long t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 7], b[(i + (i >> 3)) & 7], acc[i & 3], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+    (void)lane;
+}
+
+template <int RND>
+void run3(float* out, unsigned long long* cyc) {
+    const long trips = 200000;                                 // 16 x 64 cycles x 4 waves per SIMD = 4096 cycles per trip: ~0.4 s
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k3<RND>), dim3(1024), dim3(256), 0, 0, trips / 10, out, cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k3<RND>), dim3(1024), dim3(256), 0, 0, trips, out, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c[2]; CK(hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost));
+    printf("fp32 MFMA 32x32x2 only, %s operands, 4 waves/SIMD: %8.2f ms, %.1f cycles per MFMA and SIMD, clock held %.3f GHz (%.1f TFLOP/s)\n",
+           RND ? "random" : "constant", ms, (double)c[0] / trips / 16 / 4 * 4, (double)c[0] / (double)c[1] * 0.1,
+           1024.0 * 4 * trips * 16 * 4096 * 2 / (ms * 1e-3) * 1e-12);
+}
+
 template <int M, int V, int RCP, int SHAPE>
 void run(int wps, float* out, unsigned long long* cyc) {
     const long trips = 20000;
@@ -132,6 +187,7 @@ void run(int wps, float* out, unsigned long long* cyc) {
 int main() {
     float* out; unsigned long long* cyc;
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&cyc, 64));
+    if (getenv("COISSUE_CLOCK_ONLY")) { run3<0>(out, cyc); run3<1>(out, cyc); run3<0>(out, cyc); run3<1>(out, cyc); return 0; }
     for (int wps = 1; wps <= 4; wps += (wps == 1 ? 1 : 2)) {     // 1, 2, 4
         run<8, 0, 0, 16>(wps, out, cyc);
         run<8, 8, 0, 16>(wps, out, cyc);
