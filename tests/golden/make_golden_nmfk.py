@@ -43,8 +43,25 @@ def dataset():
     return (W @ H + 0.01 * rs.rand(m, n)).astype(np.float32)
 
 
-def run(grid):
-    A = dataset()
+def dataset_kl5():
+    """second problem (round 3): five latent features, count-like data, fitted with the KL objective"""
+    rs = np.random.RandomState(23)
+    m, n, k = 60, 52, 5
+    x = np.linspace(1, m, m)
+    W = np.stack([np.exp(-(x - c) ** 2 / 14.0) for c in (6, 18, 30, 42, 54)], axis=1)
+    H = rs.rand(k, n) ** 2
+    return (W @ H + 0.01 * rs.rand(m, n)).astype(np.float32)
+
+
+CASES = {   # name -> (dataset, start_k, end_k, norm, itr, output stem)
+    "fro3": (dataset, 1, 5, "fro", 300, "nmfk"),
+    "kl5": (dataset_kl5, 3, 7, "kl", 400, "nmfk_kl5"),
+}
+
+
+def run(grid, case="fro3"):
+    make, k0, k1, norm, itr, stem = CASES[case]
+    A = make()
     p_r, p_c = grid
     tmp = tempfile.mkdtemp()
     out = {}
@@ -56,9 +73,9 @@ def run(grid):
         args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = comm.size, rank, comms.comm, comms, p_r, p_c
         args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
         args.fpath, args.fname, args.ftype = tmp + "/", "synth", "npy"
-        args.start_k, args.end_k, args.step_k = 1, 5, 1
-        args.sill_thr, args.itr, args.init, args.verbose = 0.8, 300, "rand", False
-        args.norm, args.method, args.prune = "fro", "mu", False
+        args.start_k, args.end_k, args.step_k = k0, k1, 1
+        args.sill_thr, args.itr, args.init, args.verbose = 0.8, itr, "rand", False
+        args.norm, args.method, args.prune = norm, "mu", False
         args.perturbations, args.noise_var, args.checkpoint = 6, 0.03, False
         args.results_path = tmp + "/results/"
         s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
@@ -67,17 +84,17 @@ def run(grid):
 
     res = MPI.run_ranks(p_r * p_c, body)
     out["nopt"] = np.array(res[0])
-    for k in range(1, 6):
+    for k in range(k0, k1 + 1):
         with h5py.File(tmp + "/results/synth/%d/results.h5" % k, "r") as hf:
             for key in hf.keys():
                 out["k%d_%s" % (k, key)] = np.array(hf[key])
     out["A"] = A
-    out["meta"] = np.array(json.dumps(dict(grid=list(grid), start_k=1, end_k=5, perturbations=6, noise_var=0.03,
-                                           itr=300, sill_thr=0.8, norm="fro", method="mu")))
-    np.savez_compressed(os.path.join(HERE, "nmfk_%dx%d.npz" % tuple(grid)), **out)
+    out["meta"] = np.array(json.dumps(dict(grid=list(grid), start_k=k0, end_k=k1, perturbations=6, noise_var=0.03,
+                                           itr=itr, sill_thr=0.8, norm=norm, method="mu")))
+    np.savez_compressed(os.path.join(HERE, "%s_%dx%d.npz" % ((stem,) + tuple(grid))), **out)
     shutil.rmtree(tmp, ignore_errors=True)
     print(grid, "nopt =", res, {k: (round(float(out["k%d_clusterSilhouetteCoefficients" % k].min()), 3),
-                                     round(float(out["k%d_avgErr" % k]), 5)) for k in range(1, 6)})
+                                     round(float(out["k%d_avgErr" % k]), 5)) for k in range(k0, k1 + 1)})
 
 
 def checkpoint_fixture():
@@ -107,6 +124,9 @@ if __name__ == "__main__":
     # nondeterministically here (real MPI ranks are separate processes).  run((2, 1)) is still useful as a smoke check.
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
         checkpoint_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] in CASES:
+        run((1, 1), sys.argv[1])
     else:
         run((1, 1))
+        run((1, 1), "kl5")
         checkpoint_fixture()

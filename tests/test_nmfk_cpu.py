@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 
-def _args(tmp, comms, ops=None):
+def _args(tmp, comms, ops=None, meta=None):
+    """the parameters of tests/golden/make_golden_nmfk.py (`meta`: the fixture's own record of them, for the second case)"""
     from pydnmfk_amd.utils import parse
     args = parse()
     args.comm1, args.comm, args.p_r, args.p_c = comms.comm, comms, comms.p_r, comms.p_c
@@ -19,6 +20,9 @@ def _args(tmp, comms, ops=None):
     args.norm, args.method, args.prune = "fro", "mu", False
     args.perturbations, args.noise_var, args.checkpoint = 6, 0.03, False
     args.results_path = str(tmp) + "/results/"
+    if meta is not None:
+        args.start_k, args.end_k, args.itr, args.norm = meta["start_k"], meta["end_k"], meta["itr"], meta["norm"]
+        assert (meta["perturbations"], meta["noise_var"], meta["sill_thr"], meta["method"]) == (6, 0.03, 0.8, "mu")
     return args
 
 
@@ -62,6 +66,46 @@ def test_nmfk_matches_reference_statistics(tmp_path, golden_dir):
         assert set(st) == {"clusterSilhouetteCoefficients", "avgSilhouetteCoefficients", "L_err", "L_errDist", "avgErr",
                            "ErrTol", "AIC"}
         assert st["ErrTol"].shape == (6,)
+
+
+def check_against_golden_kl5(nmfk, nopt, z, tight=False):
+    """second fixture (nmfk_kl5_1x1.npz): five features, KL objective, k = 3..7 -- the reference estimates 5 (minimum
+    silhouette 0.99 at k = 5, 0.72 / 0.33 below it, negative above it).  tight: the float64-accumulating checker back end
+    follows the reference's float32 numpy run to 1e-7 on every statistic, unstable clusterings included; the fp32 MFMA
+    kernels are held to the levels."""
+    assert nopt == int(z["nopt"]) == 5
+    for k in range(3, 8):
+        st = nmfk.stats[k]
+        ref_sil = z["k%d_clusterSilhouetteCoefficients" % k]
+        sil = np.asarray(st["clusterSilhouetteCoefficients"])
+        assert sil.shape == ref_sil.shape == (k,)
+        err, ref_err = st["avgErr"], float(z["k%d_avgErr" % k])
+        if tight:
+            assert np.allclose(sil, ref_sil, atol=5e-3), (k, sil, ref_sil)
+            assert abs(err / ref_err - 1) < 1e-5, (k, err, ref_err)
+            assert abs(float(st["L_errDist"]) / float(z["k%d_L_errDist" % k]) - 1) < (1e-5 if k <= 5 else 1e-2), k
+            assert abs(st["AIC"] / float(z["k%d_AIC" % k]) - 1) < 1e-6, k
+        elif k == 5:
+            assert np.allclose(sil, ref_sil, atol=0.08), (k, sil, ref_sil)
+            assert abs(err / ref_err - 1) < 2e-2, (k, err, ref_err)
+        else:     # over- / under-complete KL fits end in different local minima per summation order: levels only
+            assert sil.min() < 0.8, (k, sil)
+            assert abs(err / ref_err - 1) < 0.15, (k, err, ref_err)
+        assert np.asarray(st["L_err"]).shape == (52,)
+    assert abs(float(nmfk.stats[5]["L_errDist"]) / float(z["k5_L_errDist"]) - 1) < 2e-2
+    assert abs(nmfk.stats[5]["AIC"] / float(z["k5_AIC"]) - 1) < 1e-2
+
+
+def test_nmfk_kl_matches_reference_statistics(tmp_path, golden_dir):
+    """The KL objective through the NMFk driver against the reference's PyNMFk on a five-feature problem
+    (make_golden_nmfk.py kl5; pyDNMFk.py:26-67, 218-258 with dist_nmf.py:806-849 inside every fit)."""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from tests._ops_double import OracleOps
+    z = np.load(golden_dir + "/nmfk_kl5_1x1.npz")
+    comms = MPI_comm(None, 1, 1)
+    nmfk = PyNMFk(z["A"], factors=None, params=_args(tmp_path, comms, meta=json.loads(str(z["meta"]))), ops=OracleOps())
+    check_against_golden_kl5(nmfk, nmfk.fit(), z, tight=True)
 
 
 def test_sample_follows_reference_stream():
