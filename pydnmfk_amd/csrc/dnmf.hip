@@ -478,7 +478,7 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
         }
     }
     const int nt = tn_nt(kt);
-    TnPlan p = plan_tn(m, n, kt, nt);
+    TnPlan p = plan_tn(m, n, kt, nt, 256, wta_waves(m, n, kt, sizeof(TA)));
     const size_t pbytes = (size_t)p.nchunks * p.chunk_stride * sizeof(float);
     const size_t need = pbytes + reduce_scratch_bytes(p.nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "wta: workspace %zu < %zu", ws_bytes, need);

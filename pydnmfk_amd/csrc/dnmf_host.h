@@ -69,10 +69,11 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
 // ---- chunking heuristics (shared by the ws-size query and the launches)
 struct TnPlan { int ncolblk; int nchunks; long rows_per_chunk; long ldp; long chunk_stride; };
 
-TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
+TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256, long waves = 0) {
     TnPlan p;
     p.ncolblk = (int)cdiv(ycols, 32 * nt);
-    static const long target_waves = tune("DNMF_TN_WAVES", 2048);  // one resident round: 256 CUs x 2 waves/SIMD (tunable for experiments)
+    static const long forced = tune("DNMF_TN_WAVES", 0);           // (experiments of the tuning build)
+    const long target_waves = forced ? forced : waves ? waves : 2048;   // default: one resident round, 256 CUs x 2 waves/SIMD
     long nchunks = std::max<long>(1, target_waves / p.ncolblk);
     nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(nrows, min_rows)));
     p.rows_per_chunk = round_up(cdiv(nrows, nchunks), 16);
@@ -80,6 +81,14 @@ TnPlan plan_tn(long nrows, long ycols, int kt, int nt, long min_rows = 256) {
     p.ldp = (long)p.ncolblk * 32 * nt;
     p.chunk_stride = p.ldp * 32 * kt;
     return p;
+}
+
+// W^T A with one accumulator tile per column block (k <= 32) on fp32 A below 4 GiB: ONE wave per SIMD (1024 waves) -- half the
+// partial slabs, and at this rank a single wave's loads keep up with the HBM (measured, k = 32: 0.202 -> 0.183 ms at 65536 x
+// 4096, 0.435 -> 0.398 at 131072 x 4096, 0.375 -> 0.355 at 65536 x 8192, 0.186 -> 0.178 at 32768 x 8192; from 4 GiB on two
+// waves per SIMD are 1-2 % faster, and at k = 64 the two are equal).  Wave counts that are not a multiple of 1024 lose 20 %.
+inline long wta_waves(long m, long n, int kt, size_t elt) {
+    return (kt == 1 && elt == 4 && (double)m * (double)n < (double)(1L << 30)) ? 1024 : 0;
 }
 
 // k <= 16 kernels (dnmf_k16.h): DNMF_K16=0 switches them off (A/B runs)
@@ -92,7 +101,10 @@ struct Tn16Plan { int ncolblk; int nchunks; long rows_per_chunk; };
 Tn16Plan plan_tn16(long m, long n, int v) {
     Tn16Plan p;
     p.ncolblk = (int)(n / (16 * v));
-    long nchunks = std::max<long>(1, 4096 / std::max(1, p.ncolblk));   // ~4 waves per SIMD
+    // 2 waves per SIMD.  (4 until round 3: 0.195 -> 0.170 ms at 65536 x 4096, 0.343 -> 0.324 at 32768 x 16384, 1.307 -> 1.285 at
+    // 262144 x 8192, k = 16 -- half the partial slabs to write and reduce, and the HBM stream does not need the waves.)
+    static const long target = tune("DNMF_TN16_WAVES", 2048);
+    long nchunks = std::max<long>(1, target / std::max(1, p.ncolblk));
     nchunks = std::min<long>(nchunks, std::max<long>(1, cdiv(m, 256)));
     p.rows_per_chunk = round_up(cdiv(m, nchunks), 16);
     p.nchunks = (int)cdiv(m, p.rows_per_chunk);
