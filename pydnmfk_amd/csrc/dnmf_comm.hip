@@ -31,26 +31,27 @@ struct Rccl {
 };
 
 Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
-    const char* resident[] = {"librccl.so", "librccl.so.1"};
-    for (const char* n : resident)
-        if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = "already in the process";
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
-        if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) r.origin = n;
-    if (!r.handle) return nullptr;
+    // bound once (function-local static: initialisation is serialised by the language, callers on any thread see the result)
+    static Rccl* const inst = []() -> Rccl* {
+        static Rccl r;
+        const char* resident[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : resident)
+            if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = "already in the process";
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if (!r.handle && (r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) r.origin = n;
+        if (!r.handle) return nullptr;
 #define BIND(field, sym) \
-    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym)); \
-    if (!r.field) { r.handle = nullptr; return nullptr; }
-    BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
-    BIND(CommSplit, "ncclCommSplit") BIND(AllReduce, "ncclAllReduce") BIND(AllGather, "ncclAllGather")
-    BIND(ReduceScatter, "ncclReduceScatter") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
-    BIND(GetErrorString, "ncclGetErrorString")
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym)); \
+        if (!r.field) return nullptr;
+        BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
+        BIND(CommSplit, "ncclCommSplit") BIND(AllReduce, "ncclAllReduce") BIND(AllGather, "ncclAllGather")
+        BIND(ReduceScatter, "ncclReduceScatter") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
+        BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
-    return &r;
+        return &r;
+    }();
+    return inst;
 }
 
 constexpr int MAX_CHUNKS = 8;
