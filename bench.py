@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_CLOCK_GHZ = 2.4            # the clock that peak is quoted at (256 CUs x 256 flop per CU and clock)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 # measured on an MI355X with tools/ceilbench.hip (profiles/r01d_ceilings.txt): what the matrix pipe sustains while the
 # contraction's HBM stream (128 B per 32x32x2 MFMA at k = 64) runs beside it, and plain streaming reads
@@ -577,6 +578,34 @@ def main():
                                 "note": "same step, longer timed region (the headline value above is the K steps asked for)"}
             out["sustained_ms_per_step"] = el / ns * 1e3
 
+    # Which shader clock does the GPU hold under this step?  A one-wave probe (dnmf_clock_probe) samples s_memtime against the
+    # 100 MHz wall clock on a stream of its own while the same steps run once more, untimed.  The roofline fractions in this
+    # line are quoted against the 2.4 GHz peak clock; the fp32 passes hold about 2.0 GHz (full-rate fp32 MFMAs + the HBM stream
+    # meet the board's power limit -- DESIGN.md section 3), so frac = (matrix-pipe busy) x (held / peak clock).
+    if not multi and rank == 0 and not a.no_kernel_timing:
+        from pydnmfk_amd.engine import ClockProbe
+        ms_step = elapsed / a.steps * 1e3
+
+        def held_clock(fn, window_ms=60.0):
+            nrep = max(3, int(window_ms / ms_step) + 1)
+            torch.cuda.synchronize()
+            pr = ClockProbe(nrep * ms_step * 1.3 + 2.0, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(nrep):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            dur = e0.elapsed_time(e1)
+            g = pr.held_ghz(0.3 * dur, 0.95 * dur)                # the clock needs a few ms to settle; the tail is idle
+            return None if g is None else round(g, 3)
+
+        hc = held_clock(step)
+        out["held_clock_ghz"] = hc
+        out["peak_clock_ghz"] = PEAK_CLOCK_GHZ
+        if hc and out.get("step_mfma_frac") is not None:
+            out["step_mfma_frac_at_held_clock"] = out["step_mfma_frac"] * PEAK_CLOCK_GHZ / hc
+
     # The same step with the two big contractions as six bf16 piece products per fp32 product (opt-in, params.gemm =
     # 'bf16x6'): reported NEXT TO the fp32-MFMA headline, never as it.  Same factors, same data, every rank takes part.
     if not multi and a.gemm == "fp32" and not a.no_bf16x6 and a.norm == "fro" and 32 < k <= 128 and n % 128 == 0:
@@ -587,6 +616,7 @@ def main():
         if rank == 0:
             out["bf16x6"] = {
                 "value": ns6 / el6, "unit": "iter/s", "ms_per_step": el6 / ns6 * 1e3, "steps": ns6,
+                "held_clock_ghz": held_clock(step_x6) if not a.no_kernel_timing else None,
                 "speedup_vs_fp32_mfma": (ns6 / el6) / (out["sustained"]["value"] if "sustained" in out else out["value"]),
                 "step_algorithmic_hbm_gbs_per_gpu": (8.0 * m_l * n + 12.0 * (m_l + n) * k) / (el6 / ns6) / 1e9,   # X is read twice per step
                 "note": "opt-in arithmetic (params.gemm='bf16x6', bench.py --gemm bf16x6): fp32 operands cut into three bf16 "
@@ -675,6 +705,10 @@ def main():
                 e["traffic"] = tr["bytes"]
                 e["traffic_note"] = ("HBM bytes per launch from the committed PMC pass %s, kernel %s (FETCH_SIZE x2 + "
                                      "WRITE_SIZE); a constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
+            hc = out.get("held_clock_ghz") if out else None
+            if hc:        # measured live over the whole step (dnmf_clock_probe): the peak above is at PEAK_CLOCK_GHZ
+                e["held_clock_ghz_of_step"] = hc
+                e["frac_at_held_clock"] = e["frac"] * PEAK_CLOCK_GHZ / hc
             return e
 
         def hbm_entry(kernel, ms_, nbytes, note, role=None, workload="bench"):

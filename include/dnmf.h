@@ -254,6 +254,15 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
 int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
                        float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
 
+/* ---- measurement aid (no counterpart in the reference) ----
+ * Which shader clock does the GPU hold right now?  Launches ONE wave on `stream` that writes `n` pairs {s_memtime (shader
+ * cycles), wall_clock64 (the constant 100 MHz reference)} into samples[2 n], sleeping `naps` x ~4 us between two pairs, and
+ * returns at once.  Launched on its own stream BEFORE the work of interest, it keeps one wave slot of one CU while that work
+ * runs; (d memtime / d wall) x 0.1 between consecutive pairs is the clock in GHz over that interval.  The fp32 passes of a
+ * step hold about 2.0 GHz of the 2.4 GHz peak clock (full-rate fp32 MFMAs + a 4 TB/s HBM stream meet the board's power limit):
+ * bench.py quotes roofline fractions against the peak clock and reports this one next to them.  1 <= n, 0 <= naps <= 1000. */
+int dnmf_clock_probe(unsigned long long* samples, int n, int naps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,7 @@ SIGNATURES = {
     "dnmf_scale_cols_div": [c_void_p, c_long, c_int, c_long, c_void_p, c_float, c_void_p],
     "dnmf_scale_rows_mul": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
     "dnmf_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p],
+    "dnmf_clock_probe": [c_void_p, c_int, c_int, c_void_p],
     "dnmf_column_err": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_void_p,
                         c_void_p],
     "dnmf_resid_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,

@@ -593,6 +593,17 @@ int dnmf_scale_rows_mul(float* H, int k, long n, long ldh, const float* s, void*
 
 }  // extern "C"
 namespace {
+// one wave that samples the shader clock while other kernels run (include/dnmf.h: dnmf_clock_probe)
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* buf, int n, int naps) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long c = __builtin_amdgcn_s_memtime(), w = wall_clock64();
+        __builtin_nontemporal_store(c, &buf[2 * i]);
+        __builtin_nontemporal_store(w, &buf[2 * i + 1]);
+        for (int s = 0; s < naps; ++s) __builtin_amdgcn_s_sleep(127);       // 127 x 64 cycles
+    }
+}
+
 template <typename TA>
 int sqnorm_impl(const TA* A, long m, long n, long lda, double* out, void* stream) {
     REQUIRE(A && out && m >= 1 && n >= 1 && lda >= n, "sqnorm: bad arguments");
@@ -613,6 +624,12 @@ int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* str
 }
 int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void* stream) {
     return sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, out, stream);
+}
+
+int dnmf_clock_probe(unsigned long long* samples, int n, int naps, void* stream) {
+    REQUIRE(samples && n >= 1 && naps >= 0 && naps <= 1000, "clock_probe: bad arguments");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, S(stream), samples, n, naps);
+    return check_launch("clock_probe");
 }
 
 int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {

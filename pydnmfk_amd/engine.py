@@ -92,6 +92,38 @@ def new_gram(k, device):
     return torch.zeros(kp(k), kp(k), dtype=torch.float32, device=device)
 
 
+class ClockProbe:
+    """The shader clock the GPU holds while other work runs (dnmf_clock_probe; a measurement aid, bench.py / tools).
+
+        probe = ClockProbe(duration_ms)      # starts one sampling wave on a stream of its own, returns at once
+        ... enqueue the work on the current stream, synchronise ...
+        ghz = probe.held_ghz(t0_ms, t1_ms)   # median clock between t0 and t1 after the probe started (None: no samples)
+    """
+
+    def __init__(self, duration_ms, device=None, period_us=20.0):
+        naps = max(1, int(round(period_us / 4.0)))
+        self.n = max(8, int(duration_ms * 1000.0 / (naps * 4.0) * 1.5) + 64)   # naps are ~4 us at 2 GHz, longer when the clock drops
+        self.buf = torch.zeros(2 * self.n, dtype=torch.int64, device=device or torch.device("cuda", torch.cuda.current_device()))
+        self.stream = torch.cuda.Stream(device=self.buf.device)
+        self.stream.wait_stream(torch.cuda.current_stream())          # (the zero fill above ran on the current stream)
+        check(lib.dnmf_clock_probe(self.buf.data_ptr(), self.n, naps, self.stream.cuda_stream))
+
+    def samples(self):
+        """(t_ms since the probe's first sample, GHz over the interval that ends there), after a device synchronisation"""
+        self.stream.synchronize()
+        b = self.buf.cpu().view(-1, 2).double()
+        b = b[b[:, 1] > 0]
+        if b.shape[0] < 2:
+            return torch.empty(0), torch.empty(0)
+        ghz = (b[1:, 0] - b[:-1, 0]) / (b[1:, 1] - b[:-1, 1]) * 0.1
+        return (b[1:, 1] - b[0, 1]) * 1e-5, ghz
+
+    def held_ghz(self, t0_ms=0.0, t1_ms=float("inf")):
+        t, ghz = self.samples()
+        x = ghz[(t >= t0_ms) & (t <= t1_ms)]
+        return float(x.median()) if x.numel() else None
+
+
 class HipOps:
     """The operator set the update choreography (dist_nmf.py) is written against."""
 

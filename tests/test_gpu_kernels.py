@@ -383,3 +383,21 @@ def test_errors_are_loud(ops):
         ops.sqnorm(torch.rand(4, 4, device="cuda", dtype=torch.float64))        # float64
     with pytest.raises((ValueError, DnmfError)):
         ops.gram_wtw(torch.rand(300, 200, device="cuda"), torch.empty(128, 128, device="cuda"))  # k > 128
+
+
+def test_clock_probe_reads_a_plausible_clock():
+    """dnmf_clock_probe (measurement aid): s_memtime against the 100 MHz wall clock while a kernel runs -- a gfx950 shader clock
+    lies between 0.1 and 2.6 GHz, and the samples are ordered in time."""
+    from pydnmfk_amd.engine import ClockProbe, HIP_OPS as ops
+    A = torch.rand(8192, 4096, device="cuda")
+    pr = ClockProbe(5.0)
+    for _ in range(20):
+        ops.sqnorm(A)
+    torch.cuda.synchronize()
+    t, ghz = pr.samples()
+    assert t.numel() >= 8 and bool((t[1:] > t[:-1]).all())
+    g = pr.held_ghz()
+    assert g is not None and 0.1 < g < 2.6, g
+    with pytest.raises(Exception):
+        from pydnmfk_amd._lib import lib, check
+        check(lib.dnmf_clock_probe(0, 4, 1, 0))
