@@ -226,3 +226,49 @@ def test_random_shapes_h_as_column_blocks(m, nb, nh, k, seed):
     U = A64 / (W64 @ H64 + EPS)
     uht = ops.kl_uht_hblocks(dA, dW, Hs, EPS, torch.full((m, k), 3.0, device=dev))
     assert _rel(uht.cpu().numpy(), U @ H64.T) < 5e-6
+
+
+def _shapes_large(seed, count):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        k = int(rs.choice([2, 8, 16, 17, 32, 33, 64, 100, 128]))
+        m = int(rs.choice([4097, 8192, 12345, 16384, 30000, 32768, 50001, 65536, 70000]))
+        n = int(rs.choice([256, 1000, 1024, 2048, 3000, 4096, 4100, 8192]))
+        out.append((m, n, k, int(rs.randint(0, 3)), int(rs.randint(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k,ldpad,seed", _shapes_large(_SEED + 11, 24))
+def test_random_large_shapes(m, n, k, ldpad, seed):
+    """The row-chunk / column-split plans at realistic sizes (W^T A with one or two waves per SIMD, the 16-wide kernels' slabs,
+    split A H^T, many workgroup rounds, ragged last chunks, padded leading dimensions): the four big products and a whole
+    MU/FRO + MU/KL step against float64 on the device (dist_nmf.py:705-751, 806-849)."""
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    lda = n + 4 * ldpad
+    Abuf = torch.rand(m, lda, device=dev, generator=g)
+    Abuf[torch.rand(m, lda, device=dev, generator=g) < 0.05] = 0.0
+    A = Abuf[:, :n]
+    W = torch.rand(m, k, device=dev, generator=g) + 0.05
+    H = torch.rand(k, n, device=dev, generator=g) + 0.05
+    A64, W64, H64 = A.double(), W.double(), H.double()
+
+    def rel(x, ref):
+        return float((x.double() - ref).norm() / ref.norm())
+
+    assert rel(ops.aht(A, H, torch.full((m, k), 3.0, device=dev)), A64 @ H64.t()) < 2e-6
+    assert rel(ops.wta(A, W, torch.full((k, n), 3.0, device=dev)), W64.t() @ A64) < 2e-6
+    Ws, Hs = W.clone(), H.clone()
+    ops.mu_fro_step(A, Ws, Hs, EPS, True, False)
+    W_ref = W64 * ((A64 @ H64.t()) / (W64 @ (H64 @ H64.t()) + EPS))
+    H_ref = H64 * ((W_ref.t() @ A64) / ((W_ref.t() @ W_ref) @ H64 + EPS))
+    assert rel(Ws, W_ref) < 1e-5 and rel(Hs, H_ref) < 2e-5
+    Ws, Hs = W.clone(), H.clone()
+    ops.mu_kl_step(A, Ws, Hs, EPS, True, False)
+    U = A64 / (W64 @ H64 + EPS)
+    W_ref = W64 * (U @ H64.t()) / (H64.sum(1)[None, :] + EPS)
+    U = A64 / (W_ref @ H64 + EPS)
+    H_ref = H64 * (W_ref.t() @ U) / (W_ref.sum(0)[:, None] + EPS)
+    assert rel(Ws, W_ref) < 1e-5 and rel(Hs, H_ref) < 2e-5
