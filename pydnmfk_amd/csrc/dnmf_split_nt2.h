@@ -105,8 +105,12 @@ __device__ __forceinline__ void ntx2_mainloop(f32x16 (&acc)[1][KT], const float*
 #pragma unroll
             for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < 3; ++s) {
+                    if constexpr ((ABL & 4) != 0) {                    // ablation: half the H fragment reads (wrong results)
+                        if (jt > 0) { B[u][jt][s] = B[u][0][s]; continue; }
+                    }
                     B[u][jt][s] = *reinterpret_cast<const u32x4*>(hc + (u ? fofs1 : fofs0) + jt * 2048 + s * HPIECE);
+                }
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 12>([&](auto p_) {
                 constexpr int u = decltype(p_)::value / 6, pr = decltype(p_)::value % 6;

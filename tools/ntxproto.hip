@@ -124,6 +124,7 @@ int main(int argc, char** argv) {
     run("ntx_kernel, second main loop", ntx_kernel<KT, NT_STORE, 2, float, 4, 4, 1>, lds0);
     run("nt2 NSET=4", ntx2_kernel<KT, NT_STORE, 2, 4>, nt2_lds_bytes<KT>());
     run("nt2 NSET=2", ntx2_kernel<KT, NT_STORE, 2, 2>, nt2_lds_bytes<KT>());
+    run("nt2 NSET=2 half the H reads", ntx2_kernel<KT, NT_STORE, 2, 2, 4>, nt2_lds_bytes<KT>());
     run("nt2 NSET=2 no MFMA", ntx2_kernel<KT, NT_STORE, 2, 2, 1>, nt2_lds_bytes<KT>());
     run("nt2 NSET=2 no cut", ntx2_kernel<KT, NT_STORE, 2, 2, 2>, nt2_lds_bytes<KT>());
     run("nt2 NSET=2 no MFMA, no cut", ntx2_kernel<KT, NT_STORE, 2, 2, 3>, nt2_lds_bytes<KT>());
