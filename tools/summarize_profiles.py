@@ -72,6 +72,9 @@ with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
     for r in rows[:18]:
         f.write("| `%s` | %s | %.1f | %.2f | %s |\n" % (short(r["Name"])[:70], r["Calls"], float(r["AverageNs"]) / 1e3,
                                                      float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+    if any("clock_probe_kernel" in r["Name"] for r in rows):
+        f.write("\n(`clock_probe_kernel` = bench.py's one-wave clock probe: it SLEEPS beside the steps it watches; its duration is the "
+                "length of the watched window, not GPU work, and the percentages of the other rows are understated by its share.)\n")
     f.write("\n## PMC passes (separate runs; per-dispatch averages)\n\n| kernel | us (pmc) | clock GHz | MFMA busy | HBM read GB | HBM write GB | L2 hit |\n|---|---|---|---|---|---|---|\n")
     for n, c in sorted(pmc.items()):
         f.write("| `%s` | %.1f | %s | %s | %s | %s | %s |\n" % (
