@@ -77,6 +77,17 @@ def parse_args():
     return ap.parse_args()
 
 
+def flush_c_stdio():
+    """RCCL 2.26 writes a version banner to C stdout when its first communicator comes up; on a pipe that text stays in the C
+    buffer until the process exits, i.e. it would land AFTER rank 0's JSON line.  Flushing the C streams before the line is
+    printed keeps the JSON the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def event_time_ms(fn, reps=5, warm=2):
     import torch
     for _ in range(warm):
@@ -779,6 +790,7 @@ def main():
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(n, k, m)
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, k, m)
+        flush_c_stdio()                                           # (RCCL's version banner sits in C stdio until here)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
