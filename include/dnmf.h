@@ -61,6 +61,14 @@ int dnmf_aht_hblocks(const float* A, long m, long n, long lda, const float* Hs, 
 /* AtW[k x n] = W[m x k]^T A[m x n]       (global_mm(W_i.T, A_ij), dist_nmf.py:749; ATW_glob :166) */
 int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw,
              float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+/* W^T A AND the Gram matrix of the same W in one call: AtW as dnmf_wta, G as dnmf_gram_wtw (KP x KP, zero padded) -- the two
+ * reductions the H phase sends through ONE allreduce (dist_nmf.py:705 twice, :681 / :707, :747-748).  For k <= 16 the Gram
+ * rides in the same two launches: the wave of column block 0 of every row chunk sums W^T W over its rows (the W value a lane
+ * holds is the A and the B operand of that product: one more MFMA per step, no more loads), the reduction launch sums the
+ * partial tiles.  For k > 16 it is dnmf_gram_wtw followed by dnmf_wta (a riding Gram in the 32-wide kernel was measured:
+ * no gain over the two launches it saves).  `ws` >= dnmf_ws_bytes(m, n, k). */
+int dnmf_wta_gram(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+                  float* G, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Multiplicative updates (element-wise multiply/divide with the small k x k product) ----
  * G must be symmetric (the Gram matrices are).  These two kernels address a tile through 32-bit offsets: leading
@@ -165,6 +173,8 @@ int dnmf_aht_bf16a(const void* A, long m, long n, long lda, const float* H, int 
                    float* AH, long ldah, void* stream);
 int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw,
                    float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream);
+int dnmf_wta_gram_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+                        float* G, void* ws, size_t ws_bytes, void* stream);
 int dnmf_aht_update_w_bf16a(const void* A, long m, long n, long lda, const float* H, int k, long ldh,
                             const float* G, float* W, long ldw, float eps, void* stream);
 int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,

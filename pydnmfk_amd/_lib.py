@@ -29,6 +29,8 @@ SIGNATURES = {
     "dnmf_aht_hblocks": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p],
     "dnmf_wta": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_size_t,
                  c_void_p],
+    "dnmf_wta_gram": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                      c_size_t, c_void_p],
     "dnmf_mu_update_w": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p],
     "dnmf_mu_update_h": [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_float, c_int, c_void_p],
     "dnmf_aht_update_w": [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_void_p, c_long,
@@ -65,7 +67,7 @@ SIGNATURES = {
                           c_void_p],
 }
 # bf16 storage of A: same argument lists as the fp32 twins (A is passed as a device pointer either way)
-for _n in ("aht", "wta", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "column_err"):
+for _n in ("aht", "wta", "wta_gram", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "column_err"):
     SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
 # bf16x6 contractions: the fp32 argument lists, aht / aht_update_w with a workspace added
 SIGNATURES["dnmf_ws_bytes_bf16x6"] = SIGNATURES["dnmf_ws_bytes"]

@@ -201,7 +201,7 @@ size_t partial_bytes(long m, long n, int k) {
         for (int v = 4; v <= 8; v += 4) {
             if (n % (16 * v)) continue;
             Tn16Plan q = plan_tn16(m, n, v);
-            b = std::max(b, (size_t)q.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(q.nchunks, k, n));
+            b = std::max(b, (size_t)q.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(q.nchunks, k, n) + GRAM_RIDE_BYTES);
         }
         const Tn16Plan w = plan_wtu16(m, n);                        // kl_wtu16 partial slabs
         b = std::max(b, (size_t)w.nchunks * 16 * n * sizeof(float) + reduce_scratch_bytes(w.nchunks, k, n));
@@ -454,11 +454,16 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
 
 }  // extern "C"
 namespace {
+// G != nullptr: also G = W^T W (KP x KP, zero padded; dist_nmf.py:705) -- for k <= 16 inside the same two launches (the wave of
+// column block 0 of every row chunk accumulates it, the reduction launch sums the partial tiles), otherwise dnmf_gram_wtw first.
 template <typename TA>
 int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
-             void* ws, size_t ws_bytes, void* stream) {
+             void* ws, size_t ws_bytes, void* stream, float* G = nullptr) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || alias_ok(lda)) && ldw >= k && ldatw >= n, "wta: bad arguments");
+    const int kp = 32 * kt;
+    static const bool gram_ride = tune("DNMF_WTA_GRAM", 1) != 0;
+    auto gram_first = [&]() { return G ? dnmf_gram_wtw(W, m, k, ldw, G, ws, ws_bytes, stream) : DNMF_OK; };
     {   // rank k <= 16: 16-wide kernel (16-byte aligned rows of A, whole column blocks, workspace permitting)
         constexpr int V = std::is_same<TA, bf16_t>::value ? 8 : 4;
         if (k <= 16 && k16_on() && a_rows16(A, lda) && n % (16 * V) == 0 && lda != 0) {
@@ -469,11 +474,22 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
                 a.X = W; a.ldx = ldw; a.xcols = k; a.Y = A; a.ldy = lda; a.ycols = n;
                 a.nrows = m; a.rows_per_chunk = q.rows_per_chunk; a.nchunks = q.nchunks; a.ncolblk = q.ncolblk;
                 a.P = (float*)ws; a.chunk_stride = 16 * n; a.ldp = n;
+                const size_t gb = (size_t)q.nchunks * 256 * sizeof(float);            // partial Gram tiles behind the slabs
+                const bool ride = G && gram_ride && reduce_slices(q.nchunks) == 1 && pb + gb <= ws_bytes;
+                int rc;
+                if (!ride && (rc = gram_first())) return rc;
                 hipStream_t st = S(stream);
-                hipLaunchKernelGGL((tn16_kernel<TA>), dim3((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4)), dim3(256), 0, st, a);
-                int rc = check_launch("tn16_kernel");
-                if (rc) return rc;
-                return launch_reduce((const float*)ws, 16 * n, n, q.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)ws + pb), st);
+                const dim3 grid16((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4));
+                if (ride) {
+                    a.Pg = (float*)((char*)ws + pb);
+                    hipLaunchKernelGGL((tn16_kernel<TA, true>), grid16, dim3(256), 0, st, a);
+                } else {
+                    hipLaunchKernelGGL((tn16_kernel<TA>), grid16, dim3(256), 0, st, a);
+                }
+                if ((rc = check_launch("tn16_kernel"))) return rc;
+                const GramTail gt{a.Pg, G, 16, k, kp, q.nchunks};
+                return launch_reduce((const float*)ws, 16 * n, n, q.nchunks, AtW, ldatw, k, n, k, n, (float*)((char*)ws + pb), st,
+                                     ride ? &gt : nullptr);
             }
         }
     }
@@ -489,8 +505,11 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
     // the streamed A is read 4 elements per lane, W only KT per lane (1 float for k <= 32): W's alignment need is KT-wide
     const bool fast = a_aligned(A) && lda % 4 == 0 && n % 4 == 0 &&
                       ((uintptr_t)W % (4 * kt)) == 0 && ldw % kt == 0 && k % kt == 0;
-    int rc = launch_tn<TN_PARTIAL, TA>(kt, fast, a, S(stream));
-    if (rc) return rc;
+    // (the riding Gram was also built for the 32-wide kernel at 16 < k <= 32: no gain -- 0.3707 vs 0.3706 ms per iteration at
+    // 65536 x 4096, k = 32, where the two launches it saves cost 6 us -- so these ranks keep dnmf_gram_wtw)
+    int rc;
+    if ((rc = gram_first())) return rc;
+    if ((rc = launch_tn<TN_PARTIAL, TA>(kt, fast, a, S(stream)))) return rc;
     return launch_reduce((const float*)ws, p.chunk_stride, p.ldp, p.nchunks, AtW, ldatw, k, n, k, n,
                          (float*)((char*)ws + pbytes), S(stream));
 }
@@ -504,6 +523,17 @@ int dnmf_wta(const float* A, long m, long n, long lda, const float* W, int k, lo
 int dnmf_wta_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
                    void* ws, size_t ws_bytes, void* stream) {
     return wta_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream);
+}
+
+int dnmf_wta_gram(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw, float* G,
+                  void* ws, size_t ws_bytes, void* stream) {
+    REQUIRE(G, "wta_gram: null Gram buffer");
+    return wta_impl<float>(A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream, G);
+}
+int dnmf_wta_gram_bf16a(const void* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
+                        float* G, void* ws, size_t ws_bytes, void* stream) {
+    REQUIRE(G, "wta_gram: null Gram buffer");
+    return wta_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, k, ldw, AtW, ldatw, ws, ws_bytes, stream, G);
 }
 
 }  // extern "C"
@@ -684,8 +714,7 @@ int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, 
         if ((rc = aht_update_w_impl<TA>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
     }
     const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
-    if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
-    if ((rc = wta_impl<TA>(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream))) return rc;
+    if ((rc = wta_impl<TA>(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream, G))) return rc;   // + W^T W (:705)
     if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);                      // pyDNMF.py:155-157
     return DNMF_OK;

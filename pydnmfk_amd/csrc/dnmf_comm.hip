@@ -242,8 +242,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
     if (nch <= 1) {
         const size_t off = pad64((size_t)k * n_l);
         float* AtW = X; float* Gx = X + off;
-        if ((rc = dnmf_gram_wtw(W, m_l, k, ldw, Gx, ws, kws, stream))) return rc;
-        if ((rc = dnmf_wta(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, ws, kws, stream))) return rc;
+        if ((rc = dnmf_wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;
         if (xr && (rc = allreduce_f32(c, c->world, X, off + (size_t)kp * kp, st))) return rc;
         if ((rc = dnmf_mu_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, clamp, stream))) return rc;
     } else {

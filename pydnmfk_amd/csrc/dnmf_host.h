@@ -40,27 +40,35 @@ inline size_t reduce_scratch_bytes(int nsplit, int rows_out, long cols_out) {
 }
 
 // `scratch` must hold reduce_scratch_bytes(nsplit, rows_out, cols_out)
+// room behind the partial slabs of W^T A for the partial Gram tiles of dnmf_wta_gram (<= 64 chunks x 16 x 16 floats)
+constexpr size_t GRAM_RIDE_BYTES = 2 * REDUCE_SLICE * 256 * sizeof(float);
+
+// `gram` (optional, single-stage reductions only): the partial Gram tiles of a GRAM kernel are summed by one extra workgroup of
+// the same launch (dnmf_tn.h: GramTail)
 int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out, long ldo, int rows, long cols,
-                  int rows_out, long cols_out, float* scratch, hipStream_t st) {
+                  int rows_out, long cols_out, float* scratch, hipStream_t st, const GramTail* gram = nullptr) {
     const long total = (long)rows_out * cdiv(cols_out, 4);
     const unsigned gx = (unsigned)cdiv(total, 64);
     const int ny = reduce_slices(nsplit);
+    const GramTail gt = gram ? *gram : GramTail{nullptr, nullptr, 0, 0, 0, 0};
+    const unsigned extra = gram ? (unsigned)gram_tail_blocks(gram->k) : 0u;
+    if (gram && ny != 1) return fail(DNMF_EINVAL, "reduce: a Gram tail needs a single-stage reduction (%d partials)", nsplit);
     static const bool wide = tune("DNMF_REDUCE_WIDE", 1) != 0;
     if (wide && ny == 1 && rows == rows_out && cols == cols_out && cols % 4 == 0 && cols >= 4096 && ldo % 4 == 0 &&
         aligned16(out) && aligned16(P) && ldp % 4 == 0 && stride % 4 == 0) {
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, P, stride, ldp,
-                           nsplit, out, ldo, rows, cols);
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256) + extra), dim3(256), 0, st, P, stride, ldp,
+                           nsplit, out, ldo, rows, cols, gt);
         return check_launch("reduce_partials_wide");
     }
     if (ny == 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
-                           0L, rows, cols, rows_out, cols_out);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx + extra, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
+                           0L, rows, cols, rows_out, cols_out, gt);
     } else {
         const long ld2 = round_up(cols_out, 4), ys = (long)rows_out * ld2;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, ny), dim3(256), 0, st, P, stride, ldp, nsplit, REDUCE_SLICE,
-                           scratch, ld2, ys, rows, cols, rows_out, cols_out);
+                           scratch, ld2, ys, rows, cols, rows_out, cols_out, gt);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, ys, ld2, ny, ny, out,
-                           ldo, 0L, rows_out, cols_out, rows_out, cols_out);
+                           ldo, 0L, rows_out, cols_out, rows_out, cols_out, gt);
     }
     return check_launch("reduce_partials");
 }

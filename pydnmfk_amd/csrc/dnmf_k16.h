@@ -162,14 +162,12 @@ constexpr size_t nt16_lds_bytes(bool b16) { return 2ul * (128 * BK + 16 * (b16 ?
 // One wave owns 16 V columns (V = elements per 16-byte load: 4 fp32 / 8 bf16) and a chunk of rows; a step contracts 4
 // rows: lane (c16, kq) loads Y[r + kq][col0 + V c16 .. + V - 1] (one row = 256 contiguous bytes across 16 lanes) and
 // X[r + kq][j = c16]; V MFMAs per step.  Branch-free pipeline of U steps per batch, one batch ahead (tn_mainloop).
-template <typename TY>
-__global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
+// GRAM: the wave also sums X^T X over its rows -- the lane's X value is the A AND the B operand of that product (A[i = c16][k =
+// kq] = X[r + kq][c16] = B[k = kq][n = c16]): one more MFMA per step, no more loads.  Run in ONE wave per row chunk (tn16_kernel).
+template <typename TY, bool GRAM>
+__device__ __forceinline__ void tn16_body(const TnArgs& p, long chunk, long colblk, f32x4* accg) {
     constexpr int V = std::is_same<TY, bf16_t>::value ? 8 : 4, U = 4;
     const int lane = threadIdx.x & 63, c16 = lane & 15, kq = lane >> 4;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long gw = (long)blockIdx.x * 4 + wid;
-    const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;
-    if (chunk >= p.nchunks) return;
     const long col0 = colblk * 16 * V;
     const long rbeg = chunk * p.rows_per_chunk;
     long rend = rbeg + p.rows_per_chunk;
@@ -192,6 +190,7 @@ __global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
         q[u].get(bb);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = MFMA16(w[u], bb[v], acc[v]);
+        if constexpr (GRAM) *accg = MFMA16(w[u], w[u], *accg);
     };
     long r = rbeg;
     const long nb = (rend - rbeg) / (4 * U);
@@ -233,6 +232,7 @@ __global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
         load_vec<V, true>(bb, Y + (r + kq) * p.ldy, col0 + V * c16, p.ycols, ok);
 #pragma unroll
         for (int v = 0; v < V; ++v) acc[v] = MFMA16(w, bb[v], acc[v]);
+        if constexpr (GRAM) *accg = MFMA16(w, w, *accg);
     }
     // acc[v] (register r, lane (c16, kq)) = C[j = 4 kq + r][c = col0 + V c16 + v]
     float* Pc = p.P + chunk * p.chunk_stride;
@@ -245,6 +245,26 @@ __global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
 #pragma unroll
         for (int v = 0; v < V; v += 4) *reinterpret_cast<f32x4*>(dst + v) = f32x4{d[v], d[v + 1], d[v + 2], d[v + 3]};
     }
+}
+
+template <typename TY, bool GRAM = false>
+__global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long gw = (long)blockIdx.x * 4 + wid;
+    const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;
+    if (chunk >= p.nchunks) return;
+    if constexpr (GRAM) {
+        if (colblk == 0) {                       // wave-uniform: the whole loop is instantiated twice, no conditional MFMA in it
+            const int lane = threadIdx.x & 63, c16 = lane & 15, kq = lane >> 4;
+            f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+            tn16_body<TY, true>(p, chunk, colblk, &accg);
+            float* g = p.Pg + chunk * 256;       // accg (register r, lane (c16, kq)) = G[j = 4 kq + r][j' = c16]; j, j' >= xcols never read
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[(4 * kq + r) * 16 + c16] = accg[r];
+            return;
+        }
+    }
+    tn16_body<TY, false>(p, chunk, colblk, nullptr);
 }
 
 }  // namespace

@@ -13,6 +13,7 @@ struct TnArgs {
     const void* Y; long ldy; long ycols;     // [nrows x ycols]  -> output cols c (float, or bf16 bits: TY of tn_kernel)
     long nrows; long rows_per_chunk; int nchunks; int ncolblk;
     float* P; long chunk_stride; long ldp;   // P[chunk][KP][ldp]
+    float* Pg;                               // tn16_kernel<., GRAM>: partial X^T X per chunk [chunk][16][16]
 };
 
 template <int KT, int NT, bool FAST, int U, typename TY>
@@ -232,6 +233,29 @@ __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
     }
 }
 
+// Optional tail of a reduction launch: one extra workgroup sums the partial Gram tiles a GRAM kernel wrote ([nsplit][dim][dim],
+// dim = 16 / 32) into the zero-padded kp x kp Gram buffer G -- entries beyond k x k are written as 0, the garbage the clamped
+// lanes left there is never read.  Sums in slab order: bitwise deterministic.
+struct GramTail { const float* Pg; float* G; int dim, k, kp, nsplit; };
+inline int gram_tail_blocks(int k) { return (k * k + 255) / 256; }      // host: extra workgroups of the reduction launch
+// Tail workgroup b: the live entries b * 256 + thread of the k x k tile, one per thread, eight slab loads in flight (this is a
+// latency chain next to a reduction that takes ~5 us: a first version walked the padded tile in ONE workgroup, 2 entries x 32
+// dependent loads per thread at k = 16, and cost +9 us per iteration); workgroup 0 also writes the zero padding.
+__device__ __forceinline__ void gram_tail(const GramTail& t, int b) {
+    const int e = b * 256 + threadIdx.x;
+    if (e < t.k * t.k) {
+        const int j = e / t.k, jj = e % t.k;
+        const float* __restrict__ src = t.Pg + j * t.dim + jj;
+        float s = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < t.nsplit; ++q) s += src[(long)q * t.dim * t.dim];
+        t.G[j * t.kp + jj] = s;
+    }
+    if (b == 0)
+        for (int idx = threadIdx.x; idx < t.kp * t.kp; idx += 256)
+            if (idx / t.kp >= t.k || idx % t.kp >= t.k) t.G[idx] = 0.f;
+}
+
 // out[y][j][c] = sum_{s in slice y} P[s][j][c], j < rows, c < cols.  256 threads = 64 consecutive float4 outputs x 4
 // split lanes; lane g sums splits g, g+4, ... of its slice in order, the four lane sums are combined in fixed order
 // through LDS -> bitwise deterministic.  Everything else inside [rows_out x cols_out] is written as 0 (zero padding
@@ -239,8 +263,12 @@ __global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, long stride, long ldp,
                                                               int nsplit, int splits_per_y, float* __restrict__ out,
                                                               long ldo, long y_stride, int rows, long cols,
-                                                              int rows_out, long cols_out) {
+                                                              int rows_out, long cols_out, GramTail gt) {
     __shared__ f32x4 red[256];
+    if (gt.Pg && (int)blockIdx.x >= (int)gridDim.x - (gt.k * gt.k + 255) / 256) {     // (single-stage launches only: gridDim.y == 1)
+        gram_tail(gt, (int)blockIdx.x - ((int)gridDim.x - (gt.k * gt.k + 255) / 256));
+        return;
+    }
     const long c4 = cdiv(cols_out, 4);
     const long total = (long)rows_out * c4;
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -272,7 +300,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // association; single stage only (nsplit <= 64).
 __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ P, long stride, long ldp,
                                                                    int nsplit, float* __restrict__ out, long ldo, int rows,
-                                                                   long cols) {
+                                                                   long cols, GramTail gt) {
+    if (gt.Pg && (int)blockIdx.x >= (int)gridDim.x - (gt.k * gt.k + 255) / 256) {
+        gram_tail(gt, (int)blockIdx.x - ((int)gridDim.x - (gt.k * gt.k + 255) / 256));
+        return;
+    }
     const long c4 = cols / 4;                       // cols % 4 == 0 (host checked)
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)rows * c4) return;

@@ -166,8 +166,7 @@ class nmf_algorithms_1D(_Base):
             off = _pad64(k * n_l)                                  # Fro_MU_update_H :736-751
             buf = _buf(("atwg", k, n_l), off + kp * kp, A)
             AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
-            ops.gram_wtw(W, G)
-            ops.wta(A, W, AtW)
+            ops.wta_gram(A, W, AtW, G)                             # W^T A and W^T W (:705), one call
             if self.p_r != 1:                                      # allreduce [W^T A | W^T W] (:681,:707)
                 self.comm1.allreduce_(buf[: off + kp * kp])
             ops.mu_update_h(H, AtW, G, eps, clamp)
@@ -236,8 +235,7 @@ class nmf_algorithms_1D(_Base):
         off = _pad64(k * n_l)                                      # FRO_HALS_update_H :893-909
         buf = _buf(("atwg", k, n_l), off + kp * kp, A)
         AtW, G = buf[: k * n_l].view(k, n_l), buf[off: off + kp * kp].view(kp, kp)
-        ops.gram_wtw(W, G)                                         # :902
-        ops.wta(A, W, AtW)                                         # :903
+        ops.wta_gram(A, W, AtW, G)                                 # :902-903
         if self.p_r != 1:
             self.comm1.allreduce_(buf[: off + kp * kp])
         ops.hals_update_h(H, AtW, G, eps)                          # :905-909

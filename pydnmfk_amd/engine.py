@@ -172,6 +172,20 @@ class HipOps:
                            ws.data_ptr(), ws.numel(), _stream()))
         return out
 
+    def wta_gram(self, A, W, out, G):
+        """out = W^T A and G = W^T W (KP x KP, zero padded): the H phase's two reductions (dist_nmf.py:705, :747-748); for k <= 16
+        the Gram rides in the W^T A launches (dnmf_wta_gram).  Operator sets that override `wta` keep their own product."""
+        if type(self).wta is not HipOps.wta:
+            self.gram_wtw(W, G)
+            return self.wta(A, W, out)
+        sfx = _req_a(A); _req(W, "W"); _req(out, "AtW"); _req(G, "G")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = workspace(m, n, k, A.device)
+        check(_fn("wta_gram", sfx)(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out), G.data_ptr(),
+                                ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
     # ---- updates
     def mu_update_w(self, W, AH, G, eps):
         _req(W, "W"); _req(AH, "AH"); _req(G, "G")

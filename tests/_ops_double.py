@@ -37,6 +37,10 @@ class OracleOps:
         out.copy_(torch.from_numpy(np.matmul(_n(W).T, _n(A))))
         return out
 
+    def wta_gram(self, A, W, out, G):
+        self.gram_wtw(W, G)
+        return self.wta(A, W, out)
+
     def mu_update_w(self, W, AH, G, eps):
         k = W.shape[1]
         w = _n(W)

@@ -401,3 +401,33 @@ def test_clock_probe_reads_a_plausible_clock():
     with pytest.raises(Exception):
         from pydnmfk_amd._lib import lib, check
         check(lib.dnmf_clock_probe(0, 4, 1, 0))
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 64, 1), (37, 64, 3), (300, 128, 8), (1000, 256, 16), (4100, 512, 16), (70000, 4096, 16),
+                                   (65, 100, 5), (513, 130, 16), (257, 64, 17), (1000, 260, 24), (5000, 512, 32), (66000, 4096, 32),
+                                   (300, 256, 33), (2000, 512, 64), (300, 128, 128)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_wta_gram_is_wta_plus_gram(m, n, k, bf16):
+    """dnmf_wta_gram: W^T A bit-identical to dnmf_wta (the same kernels compute it), W^T W equal to the float64 product and
+    zero padded -- the riding Gram accumulator of the k <= 32 kernels (16-wide, 32-wide, vector and generic paths, ragged row
+    chunks), and the two-call form above k = 32 (dist_nmf.py:705, :747-748)."""
+    from pydnmfk_amd.engine import HIP_OPS as ops, new_gram
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(m * 7 + n + k)
+    A = torch.rand(m, n, device=dev, generator=g)
+    if bf16:
+        A = A.to(torch.bfloat16)
+    W = torch.rand(m, k, device=dev, generator=g)
+    ref = ops.wta(A, W, torch.empty(k, n, device=dev))
+    G = torch.full_like(new_gram(k, dev), 7.0)
+    out = ops.wta_gram(A, W, torch.full((k, n), 3.0, device=dev), G)
+    assert torch.equal(out, ref)
+    G64 = W.double().t() @ W.double()
+    assert float((G[:k, :k].double() - G64).norm() / G64.norm()) < 2e-6
+    Z = G.clone()
+    Z[:k, :k] = 0
+    assert float(Z.abs().max()) == 0.0
+    assert torch.equal(G[:k, :k], G[:k, :k].t())        # the same products in the same order on both sides of the diagonal
+    G2 = torch.full_like(G, 5.0)
+    ops.wta_gram(A, W, torch.empty(k, n, device=dev), G2)
+    assert torch.equal(G, G2)                             # run-to-run bit reproducible

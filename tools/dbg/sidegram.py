@@ -30,6 +30,16 @@ def forked():
     ops.mu_update_h(H, AtW, G2, 1e-7, False)
 
 
+def nogram():        # upper bound of folding W^T W into the W^T A kernel: the step without its two launches (wrong G2)
+    ops.gram_hht(H, G1); ops.aht_update_w(A, H, G1, W, 1e-7)
+    ops.wta(A, W, AtW); ops.mu_update_h(H, AtW, G2, 1e-7, False)
+
+
+def fusedgram():     # dnmf_wta_gram: W^T W rides in the W^T A kernel (one more MFMA per step in one wave per row chunk)
+    ops.gram_hht(H, G1); ops.aht_update_w(A, H, G1, W, 1e-7)
+    ops.wta_gram(A, W, AtW, G2); ops.mu_update_h(H, AtW, G2, 1e-7, False)
+
+
 def t(fn, n=300):
     for _ in range(20): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -39,4 +49,4 @@ def t(fn, n=300):
 
 
 for _ in range(2):
-    print("k=%d serial %.4f ms  forked %.4f ms" % (k, t(serial), t(forked)))
+    print("k=%d serial %.4f ms  forked %.4f ms  without W^T W %.4f ms  riding W^T W %.4f ms" % (k, t(serial), t(forked), t(nogram), t(fusedgram)))
