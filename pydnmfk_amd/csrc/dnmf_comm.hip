@@ -86,6 +86,63 @@ int allreduce_f32(dnmf_comm* cm, ncclComm_t c, float* buf, size_t count, hipStre
     return DNMF_OK;
 }
 
+// equal blocks of `count` floats: recv[q * count ...] = member q's send (MPI Allgather, dist_nmf.py:163-165, :195-197).  A
+// group that was never created (one member) copies -- or, with `always`, goes through the world communicator of the one rank.
+int allgather_f32(dnmf_comm* cm, ncclComm_t c, const float* send, float* recv, size_t count, hipStream_t st) {
+    if (!c && cm->always && cm->nranks == 1) c = cm->world;
+    if (!c || cm->null_exchange) {
+        HIP_OK(hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, st), "allgather: copy");
+        return DNMF_OK;
+    }
+    NCCL_OK(rccl()->AllGather(send, recv, count, ncclFloat32, c, st), "allgather");
+    return DNMF_OK;
+}
+
+// SUM reduce-scatter of members x count floats: recv = this member's block of the sum (MPI Reduce_scatter, :169, :202)
+int reduce_scatter_f32(dnmf_comm* cm, ncclComm_t c, const float* send, float* recv, size_t count, int member, hipStream_t st) {
+    if (!c && cm->always && cm->nranks == 1) c = cm->world;
+    if (!c || cm->null_exchange) {
+        HIP_OK(hipMemcpyAsync(recv, send + (size_t)member * count, count * sizeof(float), hipMemcpyDeviceToDevice, st), "reduce_scatter: copy");
+        return DNMF_OK;
+    }
+    NCCL_OK(rccl()->ReduceScatter(send, recv, count, ncclFloat32, ncclSum, c, st), "reduce_scatter");
+    return DNMF_OK;
+}
+
+// workspace of the 2D steps: [kernel scratch | G | Hs (k x n_l) | V (m_l x k) | Sw (m_w x k) | Wi (m_l x k) | Yb (k x n_l) | Sh (k x n_h) | x]
+struct Ws2d { size_t g_off, hs_off, v_off, sw_off, wi_off, yb_off, sh_off, x_off, total; };
+Ws2d ws2d_layout(long m_l, long n_l, int k, int p_r, int p_c) {
+    const int kp = 32 * kt_of(k);
+    const long m_w = m_l / p_c, n_h = n_l / p_r;
+    size_t kws = std::max(dnmf_ws_bytes(m_l, n_l, k), dnmf_ws_bytes(m_l, n_h, k));
+    if (n_h % 32 == 0) kws = std::max(kws, dnmf_ws_bytes_hblocks(m_l, n_l, k, n_h));
+    Ws2d w;
+    size_t o = align256(kws);
+    auto take = [&](size_t floats) { const size_t at = o; o += align256(floats * sizeof(float)); return at; };
+    w.g_off = take((size_t)kp * kp);
+    w.hs_off = take((size_t)k * n_l);
+    w.v_off = take((size_t)m_l * k);
+    w.sw_off = take((size_t)m_w * k);
+    w.wi_off = take((size_t)m_l * k);
+    w.yb_off = take((size_t)k * n_l);
+    w.sh_off = take((size_t)k * n_h);
+    w.x_off = take(128);
+    w.total = o;
+    return w;
+}
+
+// the 2D steps take EVEN grids only: every rank's A block is m_l x n_l with m_l = p_c m_w, n_l = p_r n_h, the factor slices are
+// contiguous (ldw == k, ldh == n_h) and a column slice is a whole number of 16-byte vectors -- what the allgather /
+// reduce-scatter of equal blocks need.  Ragged grids (a dimension that does not divide) stay with the host choreography
+// (pydnmfk_amd/dist_nmf.py pads them), the caller falls back on DNMF_EINVAL.
+int check_2d(const char* what, const dnmf_comm* c, long m_l, long n_l, long m_w, long n_h, long ldw, long ldh, int k) {
+    if (c->p_r * c->p_c != c->nranks) return fail(DNMF_EINVAL, "%s: communicator grid %d x %d", what, c->p_r, c->p_c);
+    if (m_w < 1 || n_h < 1 || m_w * c->p_c != m_l || n_h * c->p_r != n_l || n_h % 4 != 0 || ldw != k || ldh != n_h)
+        return fail(DNMF_EINVAL, "%s: uneven grid or strided factor slices (A %ld x %ld, W slice %ld x %d ld %ld, H slice %d x %ld ld %ld on "
+                    "%d x %d): use the host choreography", what, m_l, n_l, m_w, k, ldw, k, n_h, ldh, c->p_r, c->p_c);
+    return DNMF_OK;
+}
+
 // workspace of the 1D steps: [kernel scratch of dnmf_ws_bytes | G (KP x KP) | packed exchange buffer]
 struct Ws1d { size_t g_off, x_off, total; };
 Ws1d ws1d_layout(long m_l, long n_l, int k) {
@@ -303,6 +360,94 @@ int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, l
     if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, c->world, X, off + (size_t)k, st))) return rc;
     if ((rc = dnmf_kl_update_h(H, k, n_l, ldh, WTU, n_l, x1, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+size_t dnmf_ws_bytes_2d(long m_l, long n_l, int k, int p_r, int p_c) {
+    if (kt_of(k) < 0 || m_l < 1 || n_l < 1 || p_r < 1 || p_c < 1 || m_l % p_c || n_l % p_r) return 0;
+    return ws2d_layout(m_l, n_l, k, p_r, p_c).total;
+}
+
+// One MU / Frobenius step of a rank of a p_r x p_c grid (nmf_algorithms_2D.update, dist_nmf.py:207-263 with global_gram :107-117,
+// AH_glob :186-205, ATW_glob :154-172): the rank holds A_ij (m_l x n_l), its slice W_ij (m_w x k) of the grid row's W_i and its
+// slice H_ij (k x n_h) of the grid column's H_j.  Row group = the p_r ranks of its grid column (they share H_j's columns), column
+// group = the p_c ranks of its grid row (they share W_i's rows).
+int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                        int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "mu_fro_step_2d: bad arguments");
+    int rc;
+    if ((rc = check_2d("mu_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
+    const int kp = 32 * kt, p_r = c->p_r, p_c = c->p_c;
+    const Ws2d L = ws2d_layout(m_l, n_l, k, p_r, p_c);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_fro_step_2d: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    const size_t kws = L.g_off;
+    float *G = (float*)(base + L.g_off), *Hs = (float*)(base + L.hs_off), *V = (float*)(base + L.v_off), *Sw = (float*)(base + L.sw_off),
+          *Wi = (float*)(base + L.wi_off), *Yb = (float*)(base + L.yb_off), *Sh = (float*)(base + L.sh_off);
+    hipStream_t st = S(stream);
+    const int i = c->rank / p_c, j = c->rank % p_c;                // grid position (dist_comm.py:22): member i of the row group, j of the column group
+    if (w_update) {                                                // Fro_MU_update_W :227-245
+        if ((rc = dnmf_gram_hht(H, k, n_h, ldh, G, ws, kws, stream))) return rc;
+        if ((rc = allreduce_f32(c, c->world, G, (size_t)kp * kp, st))) return rc;                        // global_gram :114
+        if ((rc = allgather_f32(c, c->row, H, Hs, (size_t)k * n_h, st))) return rc;                       // AH_glob :195-197
+        if (p_r == 1) rc = dnmf_aht(A, m_l, n_l, lda, Hs, k, n_l, V, k, stream);                          // :198
+        else if (n_h % 32 == 0) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hs, n_h, k, V, k, stream);        // H as received: column blocks
+        else rc = fail(DNMF_EINVAL, "mu_fro_step_2d: column slices of %ld are not whole 32-column tiles: use the host choreography", n_h);
+        if (rc) return rc;
+        if ((rc = reduce_scatter_f32(c, c->col, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :202
+        if ((rc = dnmf_mu_update_w(W, m_w, k, ldw, Sw, k, G, eps, stream))) return rc;                    // :244-245
+    }
+    if ((rc = dnmf_gram_wtw(W, m_w, k, ldw, G, ws, kws, stream))) return rc;                              // Fro_MU_update_H :207-225
+    if ((rc = allreduce_f32(c, c->world, G, (size_t)kp * kp, st))) return rc;
+    if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                           // ATW_glob :163-165
+    for (int q = 0; q < p_r; ++q)                                  // :166 slice by slice: member q's k x n_h block is contiguous
+        if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
+    if ((rc = reduce_scatter_f32(c, c->row, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :169-171
+    if ((rc = dnmf_mu_update_h(H, k, n_h, ldh, Sh, n_h, G, eps, clamp, stream))) return rc;               // :224-225
+    if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+// The same for MU / KL (dist_nmf.py:351-407 with sum_axis :346-349, gather_W_H :268-291, UHT_glob :330-343, WTU_glob :294-318)
+int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                       int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "mu_kl_step_2d: bad arguments");
+    int rc;
+    if ((rc = check_2d("mu_kl_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
+    const int p_r = c->p_r, p_c = c->p_c;
+    if (p_r > 1 && n_h % 32 != 0)
+        return fail(DNMF_EINVAL, "mu_kl_step_2d: column slices of %ld are not whole 32-column tiles: use the host choreography", n_h);
+    const Ws2d L = ws2d_layout(m_l, n_l, k, p_r, p_c);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_kl_step_2d: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    const size_t kws = L.g_off;
+    float *Hs = (float*)(base + L.hs_off), *V = (float*)(base + L.v_off), *Sw = (float*)(base + L.sw_off), *Wi = (float*)(base + L.wi_off),
+          *Yb = (float*)(base + L.yb_off), *Sh = (float*)(base + L.sh_off), *x = (float*)(base + L.x_off);
+    hipStream_t st = S(stream);
+    const int i = c->rank / p_c, j = c->rank % p_c;
+    // H_j as the row group's slices stacked [p_r][k][n_h]: gathered once per step (the W phase changes W, not H)
+    if ((rc = allgather_f32(c, c->row, H, Hs, (size_t)k * n_h, st))) return rc;                           // gather_W_H :283-287
+    if (w_update) {                                                // KL_MU_update_W :351-369
+        if ((rc = dnmf_rowsum(H, k, n_h, ldh, x, stream))) return rc;
+        if ((rc = allreduce_f32(c, c->world, x, (size_t)k, st))) return rc;                               // sum_axis :346-349
+        if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                       // :276-280
+        if (p_r == 1) rc = dnmf_kl_uht(A, m_l, n_l, lda, Wi, k, Hs, n_l, k, eps, V, k, ws, kws, stream);  // :337-338
+        else rc = dnmf_kl_uht_hblocks(A, m_l, n_l, lda, Wi, k, Hs, n_h, k, eps, V, k, ws, kws, stream);
+        if (rc) return rc;
+        if ((rc = reduce_scatter_f32(c, c->col, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :340
+        if ((rc = dnmf_kl_update_w(W, m_w, k, ldw, Sw, k, x, eps, stream))) return rc;                    // :369
+    }
+    if ((rc = dnmf_colsum(W, m_w, k, ldw, x, ws, kws, stream))) return rc;                                // KL_MU_update_H :371-389
+    if ((rc = allreduce_f32(c, c->world, x, (size_t)k, st))) return rc;
+    if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                           // :387
+    for (int q = 0; q < p_r; ++q)                                  // WTU_glob :311-312 slice by slice (block q of the stack = those columns of H_j)
+        if ((rc = dnmf_kl_wtu(A + q * n_h, m_l, n_h, lda, Wi, k, Hs + (size_t)q * k * n_h, n_h, k, eps, Yb + (size_t)q * k * n_h, n_h,
+                              ws, kws, stream))) return rc;
+    if ((rc = reduce_scatter_f32(c, c->row, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :314-316
+    if ((rc = dnmf_kl_update_h(H, k, n_h, ldh, Sh, n_h, x, eps, clamp, stream))) return rc;               // :389
+    if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;
 }
 

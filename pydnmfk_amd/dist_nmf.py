@@ -303,8 +303,26 @@ class nmf_algorithms_2D(_Base):
                              for q in range(self.p_r)]
 
     def update(self, clamp=False):
-        self._dispatch(clamp)
+        if not self._native_step(clamp):
+            self._dispatch(clamp)
         return self.W_ij, self.H_ij
+
+    def _native_step(self, clamp):
+        """`params.exchange = 'native'` on an EVEN grid: the whole MU step -- kernels, allreduce / allgather / reduce-scatter over
+        the RCCL communicators inside libdnmf_hip.so, kernels -- is ONE library call (dnmf_mu_*_step_2d): same kernels in the
+        same order as the choreography below.  Ragged grids, bf16-stored A and the other operator sets keep the choreography."""
+        if getattr(self.params, "exchange", None) != "native" or getattr(self.ops, "name", "") != "hip":
+            return False
+        if self.method.upper() != 'MU' or self.norm.upper() not in ('FRO', 'KL') or self.A_ij.dtype != torch.float32:
+            return False
+        if getattr(self.params, "_slice_counts", None) is not None:         # pruned factors: sizes no longer follow the grid
+            return False
+        from .engine import native_comm_for
+        nc = native_comm_for(self.params)
+        if not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
+            return False
+        nc.step_2d(self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
+        return True
 
     # ---- gathers (dist_nmf.py:163-165, :195-197, :268-291)
     def gather_W(self):

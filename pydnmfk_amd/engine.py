@@ -538,9 +538,33 @@ class NativeComm:
                  int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(), self.handle, _stream()))
 
 
+    def step_2d(self, norm, A, W, H, eps, w_update=True, clamp=False):
+        """One MU step (norm 'fro' / 'kl') of this rank of a 2D grid, exchanges included (dnmf_mu_{fro,kl}_step_2d): W, H are the
+        rank's SLICES (m_w x k, k x n_h).  Raises DnmfError (DNMF_EINVAL) on uneven grids -- `step_2d_ok` tells beforehand."""
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        nbytes = lib.dnmf_ws_bytes_2d(int(m), int(n), int(k), self.p_r, self.p_c)
+        if nbytes == 0:
+            raise ValueError("step_2d: bad problem shape m=%d n=%d k=%d on %d x %d" % (m, n, k, self.p_r, self.p_c))
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != A.device:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+        fn = lib.dnmf_mu_fro_step_2d if norm.lower() == "fro" else lib.dnmf_mu_kl_step_2d
+        check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), W.shape[0], _ld(W), H.data_ptr(), H.shape[1], _ld(H), k, float(eps),
+                 int(bool(w_update)), int(bool(clamp)), self._ws.data_ptr(), self._ws.numel(), self.handle, _stream()))
+
+    def step_2d_ok(self, A, W, H):
+        """The even-grid condition of the 2D entry points (include/dnmf.h): equal, contiguous factor slices, column slices of
+        whole 16-byte vectors, and of whole 32-column tiles when more than one rank shares a grid column."""
+        m, n = A.shape
+        mw, nh = W.shape[0], H.shape[1]
+        return (mw * self.p_c == m and nh * self.p_r == n and nh % 4 == 0 and (self.p_r == 1 or nh % 32 == 0)
+                and W.is_contiguous() and H.is_contiguous())
+
+
 def native_comm_for(params):
-    """The NativeComm of `params` when it asks for the in-library exchange (`params.exchange = 'native'`) on a 1D grid with
-    float32 data; created on first use and kept on the params bag (`params._native_comm`).  None otherwise."""
+    """The NativeComm of `params` when it asks for the in-library exchange (`params.exchange = 'native'`); created on first use
+    and kept on the params bag (`params._native_comm`).  None otherwise."""
     if getattr(params, "exchange", None) != "native":
         return None
     nc = getattr(params, "_native_comm", None)

@@ -163,6 +163,39 @@ def _child(port, q):
                 nmf_algorithms_1D(Aq, Wn, Hn, params=an).update(clamp=(i == 0))
             odd = odd and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
         native["odd_shapes"] = odd
+        # --- the 2D entry points (dnmf_mu_{fro,kl}_step_2d: allreduce + allgather + reduce-scatter inside the library) on the
+        #     one-rank communicator == the Python 2D choreography bit for bit; shapes on the 16-wide and 32-wide kernels, W_update
+        #     False, clamp; an uneven column slice is refused (the host then keeps the choreography)
+        two_d = True
+        for (mm, nn, kk, nrm, wupd) in [(4096, 1024, 64, "fro", True), (4096, 1024, 64, "kl", True), (1000, 260, 5, "fro", True),
+                                        (513, 640, 16, "kl", True), (300, 128, 33, "kl", False), (2049, 512, 128, "fro", False)]:
+            rq = np.random.RandomState(mm + nn + kk + 1)
+            Aq = torch.from_numpy(rq.rand(mm, nn).astype(np.float32)).to(dev)
+            Wq0, Hq0 = rq.rand(mm, kk).astype(np.float32), rq.rand(kk, nn).astype(np.float32)
+            ap = parse()
+            ap.comm1, ap.comm, ap.p_r, ap.p_c, ap.k, ap.m, ap.n = world, comms, 1, 1, kk, mm, nn
+            ap.row_comm, ap.col_comm = args.row_comm, args.col_comm
+            ap.eps, ap.W_update, ap.norm, ap.method = eps, wupd, nrm, "mu"
+            an = parse()
+            an.__dict__.update(vars(ap))
+            an.exchange, an._native_comm = "native", nc
+            Wp, Hp = torch.from_numpy(Wq0).to(dev), torch.from_numpy(Hq0).to(dev)
+            Wn, Hn = Wp.clone(), Hp.clone()
+            for i in range(2):
+                nmf_algorithms_2D(Aq, Wp, Hp, params=ap).update(clamp=(i == 0))
+                alg = nmf_algorithms_2D(Aq, Wn, Hn, params=an)
+                assert alg._native_step.__func__ is nmf_algorithms_2D._native_step and nc.step_2d_ok(Aq, Wn, Hn)
+                alg.update(clamp=(i == 0))
+            two_d = two_d and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
+        native["2d"] = two_d
+        Aq = torch.rand(64, 130, device=dev)                      # 130 columns: not whole 16-byte vectors
+        Wq, Hq = torch.rand(64, 8, device=dev), torch.rand(8, 130, device=dev)
+        assert not nc.step_2d_ok(Aq, Wq, Hq)
+        try:
+            nc.step_2d("fro", Aq, Wq, Hq, eps)
+            native["2d_refuses_uneven"] = False
+        except Exception as ex:  # noqa: BLE001
+            native["2d_refuses_uneven"] = "host choreography" in str(ex)
         log["native"] = native
         nc.close()
         # --- a whole fit with the nccl group up (relative_err allreduces a float64 pair on the device)
@@ -196,4 +229,5 @@ def test_rccl_code_path_on_one_gpu():
         assert max(log["2d_%s" % norm]) <= 1e-6, log
     assert max(log["overlap"]) <= 2e-6, log
     assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log
-    assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True, "odd_shapes": True}, log
+    assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True, "odd_shapes": True, "2d": True,
+                             "2d_refuses_uneven": True}, log
