@@ -237,6 +237,22 @@ int dnmf_comm_unique_id(void* id_out);
 /* collective over all nranks processes; p_r * p_c == nranks; 2D grids also get the two sub-communicators
  * (cart_1d_row = the p_r ranks of one grid column, cart_1d_column = the p_c ranks of one grid row, dist_comm.py:25-51) */
 int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p_c, dnmf_comm_t** out);
+/* A communicator whose collectives the HOST performs (no RCCL in the process, or a transport of the host's own -- a GPU-aware
+ * MPI under the reference's mpi4py driver; the multi-rank tests of this repository drive it with gloo):
+ * every exchange of the step entry points calls fn(user, op, group, send, recv, count, stream) on the calling thread.
+ *   op    DNMF_ALLREDUCE       recv == send: in-place SUM of `count` floats over the group (dist_nmf.py:114, :681, :707)
+ *         DNMF_ALLGATHER       recv[q * count ...] = member q's `count` floats, members in group order (:163-165, :195-197)
+ *         DNMF_REDUCE_SCATTER  send = members x count floats; recv = this member's block of the SUM (:169-171, :202)
+ *   group 0 = all ranks, 1 = cart_1d_row (the p_r ranks of a grid column, ordered by grid row), 2 = cart_1d_column (the p_c
+ *         ranks of a grid row, ordered by grid column) -- dist_comm.py:16-56; groups of one member are never passed
+ *   send / recv are DEVICE pointers; everything enqueued on `stream` before the call produces `send`, everything enqueued
+ *   after it consumes `recv`: the function either enqueues its transfer on `stream` or synchronises it, moves the data and
+ *   returns when `recv` is complete.  Return 0, or non-zero to fail the step (DNMF_ECOMM). */
+#define DNMF_ALLREDUCE 0
+#define DNMF_ALLGATHER 1
+#define DNMF_REDUCE_SCATTER 2
+typedef int (*dnmf_collective_fn)(void* user, int op, int group, const float* send, float* recv, size_t count, void* stream);
+int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collective_fn fn, void* user, dnmf_comm_t** comm);
 int dnmf_comm_destroy(dnmf_comm_t* comm);
 int dnmf_comm_info(const dnmf_comm_t* comm, int* nranks, int* rank, int* p_r, int* p_c);
 /* column chunks of the overlapped H phase of dnmf_mu_fro_step_1d on a row grid (1 = one packed allreduce; <= 8) */

@@ -83,6 +83,8 @@ SIGNATURES["dnmf_mu_kl_step_bf16x6"] = SIGNATURES["dnmf_mu_kl_step"]
 # grid exchanges inside the library (csrc/dnmf_comm.hip); the communicator handle is an opaque pointer
 SIGNATURES["dnmf_comm_unique_id"] = [c_void_p]
 SIGNATURES["dnmf_comm_create"] = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
+COLLECTIVE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p)   # dnmf_collective_fn
+SIGNATURES["dnmf_comm_create_hosted"] = [c_int, c_int, c_int, c_int, COLLECTIVE_FN, c_void_p, ctypes.POINTER(c_void_p)]
 SIGNATURES["dnmf_comm_destroy"] = [c_void_p]
 SIGNATURES["dnmf_comm_info"] = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_set_overlap_chunks"] = [c_void_p, c_int]

@@ -64,6 +64,8 @@ struct dnmf_comm {
     int overlap_chunks = 1;
     int always = 0;                                              // testing: a one-rank communicator still issues its RCCL calls
     int null_exchange = 0;                                       // measurement: the steps skip their RCCL calls (wrong results on > 1 rank)
+    dnmf_collective_fn hook = nullptr;                           // host-supplied collectives instead of RCCL (dnmf_comm_create_hosted)
+    void* hook_user = nullptr;
     hipStream_t xstream = nullptr;                               // exchanges of the overlapped H phase run here
     hipEvent_t ready[MAX_CHUNKS] = {}, done[MAX_CHUNKS] = {};
 };
@@ -79,32 +81,65 @@ int nccl_fail(const char* what, ncclResult_t e) {
 
 inline size_t pad64(size_t x) { return (x + 63) / 64 * 64; }
 
-// in-place SUM over `c` (no-op for a one-rank communicator that was never created)
-int allreduce_f32(dnmf_comm* cm, ncclComm_t c, float* buf, size_t count, hipStream_t st) {
-    if (!c || cm->null_exchange) return DNMF_OK;
+// The three collectives of the path over a GROUP of the grid: 0 = all ranks, 1 = cart_1d_row (the p_r ranks of a grid column),
+// 2 = cart_1d_column (the p_c ranks of a grid row) -- dist_comm.py:16-56.  A group of one member is the identity (unless `always`
+// asks a one-rank communicator to issue its calls anyway); a hosted communicator hands every call to the host's function.
+enum { G_WORLD = 0, G_ROW = 1, G_COL = 2 };
+enum { OP_ALLREDUCE = DNMF_ALLREDUCE, OP_ALLGATHER = DNMF_ALLGATHER, OP_REDUCE_SCATTER = DNMF_REDUCE_SCATTER };
+
+int group_size(const dnmf_comm* cm, int g) { return g == G_WORLD ? cm->nranks : g == G_ROW ? cm->p_r : cm->p_c; }
+ncclComm_t group_comm(const dnmf_comm* cm, int g) {
+    if (g == G_WORLD) return cm->world;
+    if (g == G_ROW) return cm->row ? cm->row : (cm->p_c == 1 ? cm->world : nullptr);   // 1D grids: the long axis IS the world
+    return cm->col ? cm->col : (cm->p_r == 1 ? cm->world : nullptr);
+}
+// 0: run the collective on *out; 1: identity (nothing to exchange); < 0: error
+int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
+    if (cm->null_exchange) return 1;
+    if (group_size(cm, g) == 1 && !cm->always) return 1;
+    if (cm->hook) { *out = nullptr; return 0; }
+    ncclComm_t c = group_comm(cm, g);
+    if (!c && group_size(cm, g) == 1) c = cm->world;              // `always` on a one-rank communicator
+    if (!c) return fail(DNMF_EINVAL, "%s: sub-communicator %d missing", what, g);
+    *out = c;
+    return 0;
+}
+
+// in-place SUM over the group
+int allreduce_f32(dnmf_comm* cm, int g, float* buf, size_t count, hipStream_t st) {
+    ncclComm_t c;
+    const int r = resolve(cm, g, &c, "allreduce");
+    if (r) return r < 0 ? r : DNMF_OK;
+    if (cm->hook) return cm->hook(cm->hook_user, OP_ALLREDUCE, g, buf, buf, count, st) ? fail(DNMF_ECOMM, "allreduce: the host collective failed") : DNMF_OK;
     NCCL_OK(rccl()->AllReduce(buf, buf, count, ncclFloat32, ncclSum, c, st), "allreduce");
     return DNMF_OK;
 }
 
-// equal blocks of `count` floats: recv[q * count ...] = member q's send (MPI Allgather, dist_nmf.py:163-165, :195-197).  A
-// group that was never created (one member) copies -- or, with `always`, goes through the world communicator of the one rank.
-int allgather_f32(dnmf_comm* cm, ncclComm_t c, const float* send, float* recv, size_t count, hipStream_t st) {
-    if (!c && cm->always && cm->nranks == 1) c = cm->world;
-    if (!c || cm->null_exchange) {
+// equal blocks of `count` floats: recv[q * count ...] = member q's send (MPI Allgather, dist_nmf.py:163-165, :195-197)
+int allgather_f32(dnmf_comm* cm, int g, const float* send, float* recv, size_t count, hipStream_t st) {
+    ncclComm_t c;
+    const int r = resolve(cm, g, &c, "allgather");
+    if (r < 0) return r;
+    if (r) {                                                       // one member (or a stubbed exchange): its own block
         HIP_OK(hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, st), "allgather: copy");
         return DNMF_OK;
     }
+    if (cm->hook) return cm->hook(cm->hook_user, OP_ALLGATHER, g, send, recv, count, st) ? fail(DNMF_ECOMM, "allgather: the host collective failed") : DNMF_OK;
     NCCL_OK(rccl()->AllGather(send, recv, count, ncclFloat32, c, st), "allgather");
     return DNMF_OK;
 }
 
 // SUM reduce-scatter of members x count floats: recv = this member's block of the sum (MPI Reduce_scatter, :169, :202)
-int reduce_scatter_f32(dnmf_comm* cm, ncclComm_t c, const float* send, float* recv, size_t count, int member, hipStream_t st) {
-    if (!c && cm->always && cm->nranks == 1) c = cm->world;
-    if (!c || cm->null_exchange) {
-        HIP_OK(hipMemcpyAsync(recv, send + (size_t)member * count, count * sizeof(float), hipMemcpyDeviceToDevice, st), "reduce_scatter: copy");
+int reduce_scatter_f32(dnmf_comm* cm, int g, const float* send, float* recv, size_t count, int member, hipStream_t st) {
+    ncclComm_t c;
+    const int r = resolve(cm, g, &c, "reduce_scatter");
+    if (r < 0) return r;
+    if (r) {
+        const size_t at = group_size(cm, g) == 1 ? 0 : (size_t)member * count;
+        HIP_OK(hipMemcpyAsync(recv, send + at, count * sizeof(float), hipMemcpyDeviceToDevice, st), "reduce_scatter: copy");
         return DNMF_OK;
     }
+    if (cm->hook) return cm->hook(cm->hook_user, OP_REDUCE_SCATTER, g, send, recv, count, st) ? fail(DNMF_ECOMM, "reduce_scatter: the host collective failed") : DNMF_OK;
     NCCL_OK(rccl()->ReduceScatter(send, recv, count, ncclFloat32, ncclSum, c, st), "reduce_scatter");
     return DNMF_OK;
 }
@@ -203,6 +238,20 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
     return DNMF_OK;
 }
 
+int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collective_fn fn, void* user, dnmf_comm_t** out) {
+    REQUIRE(fn && out && nranks >= 1 && rank >= 0 && rank < nranks && p_r >= 1 && p_c >= 1 && p_r * p_c == nranks,
+            "comm_create_hosted: bad arguments (nranks %d, rank %d, grid %d x %d)", nranks, rank, p_r, p_c);
+    dnmf_comm* c = new dnmf_comm();
+    c->nranks = nranks; c->rank = rank; c->p_r = p_r; c->p_c = p_c;
+    c->hook = fn; c->hook_user = user;
+    if (hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create_hosted: stream"); }
+    for (int q = 0; q < MAX_CHUNKS; ++q)
+        if (hipEventCreateWithFlags(&c->ready[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->done[q], hipEventDisableTiming) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create_hosted: events"); }
+    *out = c;
+    return DNMF_OK;
+}
+
 int dnmf_comm_destroy(dnmf_comm_t* c) {
     if (!c) return DNMF_OK;
     Rccl* r = rccl();
@@ -249,11 +298,7 @@ int dnmf_comm_info(const dnmf_comm_t* c, int* nranks, int* rank, int* p_r, int* 
 
 int dnmf_comm_allreduce(dnmf_comm_t* c, float* buf, size_t count, int group, void* stream) {
     REQUIRE(c && buf && group >= 0 && group <= 2, "comm_allreduce: bad arguments");
-    ncclComm_t g = group == 0 ? c->world : (group == 1 ? c->row : c->col);
-    if (group != 0 && !g && c->p_r > 1 && c->p_c > 1) return fail(DNMF_EINVAL, "comm_allreduce: sub-communicator missing");
-    if (group == 1 && !g) g = c->p_c == 1 ? c->world : nullptr;      // 1D grids: the long axis IS the world, the other has one rank
-    if (group == 2 && !g) g = c->p_r == 1 ? c->world : nullptr;
-    return allreduce_f32(c, g, buf, count, S(stream));
+    return allreduce_f32(c, group, buf, count, S(stream));
 }
 
 size_t dnmf_ws_bytes_1d(long m_l, long n_l, int k) {
@@ -289,7 +334,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
             float* AH = X; float* Gx = X + off;
             if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;
             if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;
-            if ((rc = allreduce_f32(c, c->world, X, off + (size_t)kp * kp, st))) return rc;
+            if ((rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
             if ((rc = dnmf_mu_update_w(W, m_l, k, ldw, AH, k, Gx, eps, stream))) return rc;
         }
     }
@@ -300,7 +345,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
         const size_t off = pad64((size_t)k * n_l);
         float* AtW = X; float* Gx = X + off;
         if ((rc = dnmf_wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;
-        if (xr && (rc = allreduce_f32(c, c->world, X, off + (size_t)kp * kp, st))) return rc;
+        if (xr && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
         if ((rc = dnmf_mu_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, clamp, stream))) return rc;
     } else {
         const long cw = (cdiv(n_l, nch) + 63) / 64 * 64;          // chunk width: ceil(n_l / nch) rounded up to 64 columns
@@ -317,7 +362,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
             const size_t span = ne + (nq == 0 ? (size_t)kp * kp : 0);          // chunk 0: [W^T A chunk | W^T W] in one message
             HIP_OK(hipEventRecord(c->ready[nq], st), "mu_fro_step_1d: event record");
             HIP_OK(hipStreamWaitEvent(c->xstream, c->ready[nq], 0), "mu_fro_step_1d: stream wait");
-            if ((rc = allreduce_f32(c, c->world, X + off, span, c->xstream))) return rc;
+            if ((rc = allreduce_f32(c, G_WORLD, X + off, span, c->xstream))) return rc;
             HIP_OK(hipEventRecord(c->done[nq], c->xstream), "mu_fro_step_1d: event record");
             chunk_ptr[nq] = AtW; c0s[nq] = c0; c1s[nq] = c1;
             off += span;
@@ -350,14 +395,14 @@ int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, l
         float* UHT = X; float* x2 = X + off;
         if ((rc = dnmf_rowsum(H, k, n_l, ldh, x2, stream))) return rc;
         if ((rc = dnmf_kl_uht(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, UHT, k, ws, kws, stream))) return rc;
-        if (c->p_c != 1 && (rc = allreduce_f32(c, c->world, X, off + (size_t)k, st))) return rc;
+        if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)k, st))) return rc;
         if ((rc = dnmf_kl_update_w(W, m_l, k, ldw, UHT, k, x2, eps, stream))) return rc;
     }
     const size_t off = pad64((size_t)k * n_l);                    // KL_MU_update_H :832-849
     float* WTU = X; float* x1 = X + off;
     if ((rc = dnmf_colsum(W, m_l, k, ldw, x1, ws, kws, stream))) return rc;
     if ((rc = dnmf_kl_wtu(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, WTU, n_l, ws, kws, stream))) return rc;
-    if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, c->world, X, off + (size_t)k, st))) return rc;
+    if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)k, st))) return rc;
     if ((rc = dnmf_kl_update_h(H, k, n_l, ldh, WTU, n_l, x1, eps, clamp, stream))) return rc;
     if (clamp) return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
     return DNMF_OK;
@@ -389,21 +434,21 @@ int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, 
     const int i = c->rank / p_c, j = c->rank % p_c;                // grid position (dist_comm.py:22): member i of the row group, j of the column group
     if (w_update) {                                                // Fro_MU_update_W :227-245
         if ((rc = dnmf_gram_hht(H, k, n_h, ldh, G, ws, kws, stream))) return rc;
-        if ((rc = allreduce_f32(c, c->world, G, (size_t)kp * kp, st))) return rc;                        // global_gram :114
-        if ((rc = allgather_f32(c, c->row, H, Hs, (size_t)k * n_h, st))) return rc;                       // AH_glob :195-197
+        if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                        // global_gram :114
+        if ((rc = allgather_f32(c, G_ROW, H, Hs, (size_t)k * n_h, st))) return rc;                       // AH_glob :195-197
         if (p_r == 1) rc = dnmf_aht(A, m_l, n_l, lda, Hs, k, n_l, V, k, stream);                          // :198
         else if (n_h % 32 == 0) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hs, n_h, k, V, k, stream);        // H as received: column blocks
         else rc = fail(DNMF_EINVAL, "mu_fro_step_2d: column slices of %ld are not whole 32-column tiles: use the host choreography", n_h);
         if (rc) return rc;
-        if ((rc = reduce_scatter_f32(c, c->col, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :202
+        if ((rc = reduce_scatter_f32(c, G_COL, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :202
         if ((rc = dnmf_mu_update_w(W, m_w, k, ldw, Sw, k, G, eps, stream))) return rc;                    // :244-245
     }
     if ((rc = dnmf_gram_wtw(W, m_w, k, ldw, G, ws, kws, stream))) return rc;                              // Fro_MU_update_H :207-225
-    if ((rc = allreduce_f32(c, c->world, G, (size_t)kp * kp, st))) return rc;
-    if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                           // ATW_glob :163-165
+    if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;
+    if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                           // ATW_glob :163-165
     for (int q = 0; q < p_r; ++q)                                  // :166 slice by slice: member q's k x n_h block is contiguous
         if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
-    if ((rc = reduce_scatter_f32(c, c->row, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :169-171
+    if ((rc = reduce_scatter_f32(c, G_ROW, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :169-171
     if ((rc = dnmf_mu_update_h(H, k, n_h, ldh, Sh, n_h, G, eps, clamp, stream))) return rc;               // :224-225
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;
@@ -428,24 +473,24 @@ int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, l
     hipStream_t st = S(stream);
     const int i = c->rank / p_c, j = c->rank % p_c;
     // H_j as the row group's slices stacked [p_r][k][n_h]: gathered once per step (the W phase changes W, not H)
-    if ((rc = allgather_f32(c, c->row, H, Hs, (size_t)k * n_h, st))) return rc;                           // gather_W_H :283-287
+    if ((rc = allgather_f32(c, G_ROW, H, Hs, (size_t)k * n_h, st))) return rc;                           // gather_W_H :283-287
     if (w_update) {                                                // KL_MU_update_W :351-369
         if ((rc = dnmf_rowsum(H, k, n_h, ldh, x, stream))) return rc;
-        if ((rc = allreduce_f32(c, c->world, x, (size_t)k, st))) return rc;                               // sum_axis :346-349
-        if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                       // :276-280
+        if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;                               // sum_axis :346-349
+        if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                       // :276-280
         if (p_r == 1) rc = dnmf_kl_uht(A, m_l, n_l, lda, Wi, k, Hs, n_l, k, eps, V, k, ws, kws, stream);  // :337-338
         else rc = dnmf_kl_uht_hblocks(A, m_l, n_l, lda, Wi, k, Hs, n_h, k, eps, V, k, ws, kws, stream);
         if (rc) return rc;
-        if ((rc = reduce_scatter_f32(c, c->col, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :340
+        if ((rc = reduce_scatter_f32(c, G_COL, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :340
         if ((rc = dnmf_kl_update_w(W, m_w, k, ldw, Sw, k, x, eps, stream))) return rc;                    // :369
     }
     if ((rc = dnmf_colsum(W, m_w, k, ldw, x, ws, kws, stream))) return rc;                                // KL_MU_update_H :371-389
-    if ((rc = allreduce_f32(c, c->world, x, (size_t)k, st))) return rc;
-    if ((rc = allgather_f32(c, c->col, W, Wi, (size_t)m_w * k, st))) return rc;                           // :387
+    if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;
+    if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                           // :387
     for (int q = 0; q < p_r; ++q)                                  // WTU_glob :311-312 slice by slice (block q of the stack = those columns of H_j)
         if ((rc = dnmf_kl_wtu(A + q * n_h, m_l, n_h, lda, Wi, k, Hs + (size_t)q * k * n_h, n_h, k, eps, Yb + (size_t)q * k * n_h, n_h,
                               ws, kws, stream))) return rc;
-    if ((rc = reduce_scatter_f32(c, c->row, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :314-316
+    if ((rc = reduce_scatter_f32(c, G_ROW, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :314-316
     if ((rc = dnmf_kl_update_h(H, k, n_h, ldh, Sh, n_h, x, eps, clamp, stream))) return rc;               // :389
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;

@@ -126,7 +126,7 @@ class nmf_algorithms_1D(_Base):
         if (self.p == 1 and not getattr(self.params, "native_always", False)) or self.method.upper() != 'MU' \
                 or self.norm.upper() not in ('FRO', 'KL'):
             return False
-        if getattr(self.params, "exchange", None) != "native" or getattr(self.ops, "name", "") != "hip":
+        if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
         if self.A_ij.dtype != torch.float32:
             return False
@@ -311,7 +311,7 @@ class nmf_algorithms_2D(_Base):
         """`params.exchange = 'native'` on an EVEN grid: the whole MU step -- kernels, allreduce / allgather / reduce-scatter over
         the RCCL communicators inside libdnmf_hip.so, kernels -- is ONE library call (dnmf_mu_*_step_2d): same kernels in the
         same order as the choreography below.  Ragged grids, bf16-stored A and the other operator sets keep the choreography."""
-        if getattr(self.params, "exchange", None) != "native" or getattr(self.ops, "name", "") != "hip":
+        if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
         if self.method.upper() != 'MU' or self.norm.upper() not in ('FRO', 'KL') or self.A_ij.dtype != torch.float32:
             return False

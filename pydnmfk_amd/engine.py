@@ -488,6 +488,34 @@ class NativeComm:
         self._ws = None
         self.overlap_chunks = 1
 
+    @classmethod
+    def hosted(cls, size, rank, p_r, p_c, collective):
+        """A communicator whose collectives the HOST performs (dnmf_comm_create_hosted): `collective(op, group, send_ptr,
+        recv_ptr, count, stream_ptr) -> 0` is called on the calling thread for every exchange of the step entry points (op
+        0 / 1 / 2 = allreduce / allgather / reduce-scatter, group 0 / 1 / 2 = world / cart_1d_row / cart_1d_column, device
+        pointers; include/dnmf.h).  No RCCL involved: the multi-rank tests run the C steps over gloo this way."""
+        import ctypes
+        from ._lib import COLLECTIVE_FN
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeComm: needs a GPU")
+        self = cls.__new__(cls)
+
+        def _cb(user, op, group, send, recv, count, stream):
+            try:
+                return int(collective(int(op), int(group), int(send or 0), int(recv or 0), int(count), int(stream or 0)))
+            except Exception:                                         # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = COLLECTIVE_FN(_cb)                                  # keep the trampoline alive as long as the communicator
+        h = ctypes.c_void_p()
+        check(lib.dnmf_comm_create_hosted(int(size), int(rank), int(p_r), int(p_c), self._cb, None, ctypes.byref(h)))
+        self.handle, self.size, self.rank, self.p_r, self.p_c = h, int(size), int(rank), int(p_r), int(p_c)
+        self.device = torch.cuda.current_device()
+        self._ws = None
+        self.overlap_chunks = 1
+        return self
+
     def close(self):
         if getattr(self, "handle", None):
             lib.dnmf_comm_destroy(self.handle)
@@ -562,14 +590,52 @@ class NativeComm:
                 and W.is_contiguous() and H.is_contiguous())
 
 
+def _torch_hosted_collective(groups):
+    """The three collectives of dnmf_comm_create_hosted on top of dist_comm.TorchComm objects (`groups`: {0: world, 1:
+    cart_1d_row, 2: cart_1d_column}) -- any torch.distributed backend, gloo included: the device buffers are copied into
+    tensors of our own, exchanged, and copied back, with the stream drained on both sides.  A correctness transport (the
+    multi-rank tests run the C step entry points with it); RCCL is the product's."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    D2D = 3
+
+    def collective(op, group, send, recv, count, stream):
+        comm = groups[group]
+        n = comm.size
+        torch.cuda.synchronize()                                    # everything that produces `send` has run
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.empty(count * (n if op == 2 else 1), dtype=torch.float32, device=dev)
+        if hip.hipMemcpy(t.data_ptr(), send, t.numel() * 4, D2D):
+            return 1
+        if op == 0:
+            out = comm.allreduce_(t)
+        elif op == 1:
+            out = torch.cat([b.reshape(-1) for b in comm.allgather_blocks(t, [(count,)] * n)])
+        else:
+            out = comm.reduce_scatter_rows(t.view(n, count), [1] * n).reshape(-1)
+        out = out.contiguous()
+        torch.cuda.synchronize()
+        if hip.hipMemcpy(recv, out.data_ptr(), out.numel() * 4, D2D):
+            return 1
+        return 0
+    return collective
+
+
 def native_comm_for(params):
     """The NativeComm of `params` when it asks for the in-library exchange (`params.exchange = 'native'`); created on first use
     and kept on the params bag (`params._native_comm`).  None otherwise."""
-    if getattr(params, "exchange", None) != "native":
+    mode = getattr(params, "exchange", None)
+    if mode not in ("native", "native-hosted"):
         return None
     nc = getattr(params, "_native_comm", None)
     if nc is None:
-        nc = NativeComm(params.comm1, params.p_r, params.p_c)
+        if mode == "native":
+            nc = NativeComm(params.comm1, params.p_r, params.p_c)
+        else:       # 'native-hosted': the C step entry points over the host's torch.distributed groups (any backend)
+            groups = {0: params.comm1, 1: getattr(params, "row_comm", None) or params.comm1,
+                      2: getattr(params, "col_comm", None) or params.comm1}
+            nc = NativeComm.hosted(params.comm1.size, params.comm1.rank, params.p_r, params.p_c, _torch_hosted_collective(groups))
         params._native_comm = nc
     return nc
 
