@@ -96,7 +96,7 @@ ncclComm_t group_comm(const dnmf_comm* cm, int g) {
 // 0: run the collective on *out; 1: identity (nothing to exchange); < 0: error
 int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
     if (cm->null_exchange) return 1;
-    if (group_size(cm, g) == 1 && !cm->always) return 1;
+    if (group_size(cm, g) == 1 && (!cm->always || cm->hook)) return 1;   // (a hosted communicator never sees a group of one)
     if (cm->hook) { *out = nullptr; return 0; }
     ncclComm_t c = group_comm(cm, g);
     if (!c && group_size(cm, g) == 1) c = cm->world;              // `always` on a one-rank communicator
