@@ -282,13 +282,16 @@ int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, l
 
 /* The 2D grid (p_r > 1 and p_c > 1; nmf_algorithms_2D.update, dist_nmf.py:66-91).  The rank at grid position (i, j) = rank / p_c,
  * rank % p_c holds A_ij (m_l x n_l), the slice W_ij (m_w x k, contiguous: ldw == k) of its grid row's W_i and the slice H_ij
- * (k x n_h, contiguous: ldh == n_h) of its grid column's H_j.  EVEN grids only -- m_l == p_c m_w, n_l == p_r n_h, n_h % 4 == 0, and
- * n_h % 32 == 0 when p_r > 1 (the kernels then read the allgathered H as column blocks, no re-assembly): what an allgather /
- * reduce-scatter of equal blocks needs.  Anything else returns DNMF_EINVAL and the caller keeps the host choreography, which
- * pads ragged blocks (pydnmfk_amd/dist_nmf.py).  Exchanges: allreduce of the Gram matrix / the factor sums over all ranks
- * (:114, :346-349), allgather of H_ij over the p_r ranks of a grid column and of W_ij over the p_c ranks of a grid row (:163-165,
- * :195-197, :268-291), reduce-scatter of the products back to the slices (:169-171, :202, :314-316, :340) -- all enqueued on
- * `stream`, no host synchronisation. */
+ * (k x n_h, contiguous: ldh == n_h) of its grid column's H_j; the slice sizes follow the reference's partition rule (utils.py:36-41:
+ * of p members the first total % p hold one item more), m_w of m_l over the p_c ranks of the grid row, n_h of n_l over the p_r
+ * ranks of the grid column -- anything else returns DNMF_EINVAL (pruned factors: the host keeps its choreography).  Exchanges:
+ * allreduce of the Gram matrix / the factor sums over all ranks (:114, :346-349), allgather of H_ij over the p_r ranks of a grid
+ * column and of W_ij over the p_c ranks of a grid row (:163-165, :195-197, :268-291), reduce-scatter of the products back to the
+ * slices (:169-171, :202, :314-316, :340) -- all enqueued on `stream`, no host synchronisation.  Equal slices of whole
+ * 32-column tiles: the kernels read the gathered H as column blocks and the H-phase product is formed slice by slice into the
+ * reduce-scatter's send buffer (nothing is re-assembled); ragged slices (a dimension that does not divide: real data) are
+ * exchanged at the pitch of the largest one, as MPI's Allgatherv / Reduce_scatter counts do, and H_j / W_i are assembled by
+ * device copies. */
 size_t dnmf_ws_bytes_2d(long m_l, long n_l, int k, int p_r, int p_c);
 /* Fro_MU_update on the 2D grid (dist_nmf.py:207-263 with global_gram :107-117, AH_glob :186-205, ATW_glob :154-172) */
 int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,

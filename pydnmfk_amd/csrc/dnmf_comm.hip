@@ -144,37 +144,157 @@ int reduce_scatter_f32(dnmf_comm* cm, int g, const float* send, float* recv, siz
     return DNMF_OK;
 }
 
-// workspace of the 2D steps: [kernel scratch | G | Hs (k x n_l) | V (m_l x k) | Sw (m_w x k) | Wi (m_l x k) | Yb (k x n_l) | Sh (k x n_h) | x]
-struct Ws2d { size_t g_off, hs_off, v_off, sw_off, wi_off, yb_off, sh_off, x_off, total; };
+// ---- 2D grids: slices of a block over the members of a sub-communicator follow the reference's partition rule (utils.py:36-41):
+// the first total % p members hold one item more
+struct Split {
+    int p; long base, rem;
+    long count(int q) const { return base + (q < rem ? 1 : 0); }
+    long start(int q) const { return (long)q * base + std::min<long>(q, rem); }
+    long maxc() const { return base + (rem > 0 ? 1 : 0); }
+    bool equal() const { return rem == 0; }
+};
+inline Split split_of(long total, int p) { return Split{p, total / p, total % p}; }
+
+// workspace of the 2D steps: kernel scratch | G | the exchange buffers (sized for the padded, ragged form)
+struct Ws2d { size_t g_off, hs_off, hj_off, v_off, vp_off, sw_off, wp_off, wg_off, wi_off, y_off, yb_off, sh_off, x_off, total; };
 Ws2d ws2d_layout(long m_l, long n_l, int k, int p_r, int p_c) {
     const int kp = 32 * kt_of(k);
-    const long m_w = m_l / p_c, n_h = n_l / p_r;
-    size_t kws = std::max(dnmf_ws_bytes(m_l, n_l, k), dnmf_ws_bytes(m_l, n_h, k));
-    if (n_h % 32 == 0) kws = std::max(kws, dnmf_ws_bytes_hblocks(m_l, n_l, k, n_h));
+    const Split ws = split_of(m_l, p_c), hs = split_of(n_l, p_r);
+    const long mw = ws.maxc(), nh = hs.maxc();
+    size_t kws = std::max(dnmf_ws_bytes(m_l, n_l, k), dnmf_ws_bytes(m_l, std::max<long>(1, hs.base), k));
+    if (hs.equal() && hs.base % 32 == 0) kws = std::max(kws, dnmf_ws_bytes_hblocks(m_l, n_l, k, hs.base));
     Ws2d w;
     size_t o = align256(kws);
     auto take = [&](size_t floats) { const size_t at = o; o += align256(floats * sizeof(float)); return at; };
     w.g_off = take((size_t)kp * kp);
-    w.hs_off = take((size_t)k * n_l);
-    w.v_off = take((size_t)m_l * k);
-    w.sw_off = take((size_t)m_w * k);
-    w.wi_off = take((size_t)m_l * k);
-    w.yb_off = take((size_t)k * n_l);
-    w.sh_off = take((size_t)k * n_h);
+    w.hs_off = take((size_t)p_r * k * nh + (size_t)k * nh);     // gathered H slices [p_r][k nh] (+ this rank's padded send block)
+    w.hj_off = take((size_t)k * n_l);                           // H_j assembled (ragged / narrow slices)
+    w.v_off = take((size_t)m_l * k);                            // A H^T or U H^T of the block
+    w.vp_off = take((size_t)p_c * mw * k);                      // ... laid out at the pitch of the largest W slice
+    w.sw_off = take((size_t)mw * k);                            // this rank's slice of the reduced product
+    w.wp_off = take((size_t)mw * k);                            // this rank's W slice, padded
+    w.wg_off = take((size_t)p_c * mw * k);                      // gathered W slices
+    w.wi_off = take((size_t)m_l * k);                           // W_i assembled
+    w.y_off = take((size_t)k * n_l);                            // full-width H-phase product
+    w.yb_off = take((size_t)p_r * k * nh);                      // ... as member blocks
+    w.sh_off = take((size_t)k * nh);
     w.x_off = take(128);
     w.total = o;
     return w;
 }
 
-// the 2D steps take EVEN grids only: every rank's A block is m_l x n_l with m_l = p_c m_w, n_l = p_r n_h, the factor slices are
-// contiguous (ldw == k, ldh == n_h) and a column slice is a whole number of 16-byte vectors -- what the allgather /
-// reduce-scatter of equal blocks need.  Ragged grids (a dimension that does not divide) stay with the host choreography
-// (pydnmfk_amd/dist_nmf.py pads them), the caller falls back on DNMF_EINVAL.
 int check_2d(const char* what, const dnmf_comm* c, long m_l, long n_l, long m_w, long n_h, long ldw, long ldh, int k) {
     if (c->p_r * c->p_c != c->nranks) return fail(DNMF_EINVAL, "%s: communicator grid %d x %d", what, c->p_r, c->p_c);
-    if (m_w < 1 || n_h < 1 || m_w * c->p_c != m_l || n_h * c->p_r != n_l || n_h % 4 != 0 || ldw != k || ldh != n_h)
-        return fail(DNMF_EINVAL, "%s: uneven grid or strided factor slices (A %ld x %ld, W slice %ld x %d ld %ld, H slice %d x %ld ld %ld on "
-                    "%d x %d): use the host choreography", what, m_l, n_l, m_w, k, ldw, k, n_h, ldh, c->p_r, c->p_c);
+    const int i = c->rank / c->p_c, j = c->rank % c->p_c;
+    const Split ws = split_of(m_l, c->p_c), hs = split_of(n_l, c->p_r);
+    if (m_l < c->p_c || n_l < c->p_r || m_w != ws.count(j) || n_h != hs.count(i) || ldw != k || ldh != n_h)
+        return fail(DNMF_EINVAL, "%s: factor slices off the partition rule or strided (A %ld x %ld on %d x %d at (%d, %d): W slice %ld x %d "
+                    "ld %ld, expected %ld rows; H slice %d x %ld ld %ld, expected %ld columns): use the host choreography",
+                    what, m_l, n_l, c->p_r, c->p_c, i, j, m_w, k, ldw, ws.count(j), k, n_h, ldh, hs.count(i));
+    return DNMF_OK;
+}
+
+#define COPY2D(dst, dpitch, src, spitch, width, height, what)                                                                   \
+    HIP_OK(hipMemcpy2DAsync((dst), (size_t)(dpitch) * sizeof(float), (src), (size_t)(spitch) * sizeof(float),                   \
+                            (size_t)(width) * sizeof(float), (size_t)(height), hipMemcpyDeviceToDevice, st), what)
+#define COPY1D(dst, src, count, what) \
+    HIP_OK(hipMemcpyAsync((dst), (src), (size_t)(count) * sizeof(float), hipMemcpyDeviceToDevice, st), what)
+
+// The exchanges of a 2D step, shared by the Frobenius and the KL form.  How H_j reaches the kernels mirrors gather_H /
+// _product_scattered_to_H of pydnmfk_amd/dist_nmf.py exactly (the same kernels on the same operand shapes: same bits):
+//   blocked  equal slices of whole 32-column tiles, p_r > 1: the allgather's receive buffer [p_r][k][n_h] IS the operand
+//   else     H_j (k x n_l) is assembled from the (padded) slices
+//   sliced   equal slices of whole 16-byte vectors: the H-phase product is formed slice by slice into the reduce-scatter's
+//            send buffer; else one full-width product, cut into member blocks at the pitch of the largest slice
+struct Grid2d {
+    dnmf_comm* c; hipStream_t st; int k, i, j; long m_l, n_l, m_w, n_h; Split ws, hs; bool blocked, sliced;
+    char* base; Ws2d L;
+    float* at(size_t off) const { return (float*)(base + off); }
+
+    // H_j from the row group: returns the operand pointer (*hb = leading dimension, or the block width when blocked)
+    int gather_h(const float* H, const float** Hop, long* hb) {
+        float* Hs = at(L.hs_off);
+        const long nh = hs.maxc();
+        int rc;
+        if (c->p_r == 1) { *Hop = H; *hb = n_l; return DNMF_OK; }                                        // (one member: its slice is H_j)
+        if (hs.equal()) {
+            if ((rc = allgather_f32(c, G_ROW, H, Hs, (size_t)k * n_h, st))) return rc;
+            if (blocked) { *Hop = Hs; *hb = n_h; return DNMF_OK; }
+        } else {                                                                                          // ragged: blocks padded to the largest
+            float* mine = Hs + (size_t)c->p_r * k * nh;
+            COPY1D(mine, H, (size_t)k * n_h, "gather_h: pad");
+            if ((rc = allgather_f32(c, G_ROW, mine, Hs, (size_t)k * nh, st))) return rc;
+        }
+        float* Hj = at(L.hj_off);
+        const size_t pitch = hs.equal() ? (size_t)k * n_h : (size_t)k * nh;
+        for (int q = 0; q < c->p_r; ++q)
+            COPY2D(Hj + hs.start(q), n_l, Hs + q * pitch, hs.count(q), hs.count(q), k, "gather_h: assemble");
+        *Hop = Hj; *hb = n_l;
+        return DNMF_OK;
+    }
+    // W_i (m_l x k) from the column group
+    int gather_w(const float* W, const float** Wi_out) {
+        int rc;
+        if (c->p_c == 1) { *Wi_out = W; return DNMF_OK; }
+        float* Wi = at(L.wi_off);
+        if (ws.equal()) {
+            if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;
+        } else {
+            float *Wp = at(L.wp_off), *Wg = at(L.wg_off);
+            const size_t pitch = (size_t)ws.maxc() * k;
+            COPY1D(Wp, W, (size_t)m_w * k, "gather_w: pad");
+            if ((rc = allgather_f32(c, G_COL, Wp, Wg, pitch, st))) return rc;
+            for (int q = 0; q < c->p_c; ++q) COPY1D(Wi + ws.start(q) * k, Wg + q * pitch, (size_t)ws.count(q) * k, "gather_w: assemble");
+        }
+        *Wi_out = Wi;
+        return DNMF_OK;
+    }
+    // reduce-scatter of V (m_l x k) over the column group -> this rank's m_w x k slice
+    int scatter_to_w(const float* V, const float** out) {
+        int rc;
+        if (c->p_c == 1) { *out = V; return DNMF_OK; }
+        float* Sw = at(L.sw_off);
+        if (ws.equal()) {
+            if ((rc = reduce_scatter_f32(c, G_COL, V, Sw, (size_t)m_w * k, j, st))) return rc;
+        } else {
+            float* Vp = at(L.vp_off);
+            const size_t pitch = (size_t)ws.maxc() * k;
+            for (int q = 0; q < c->p_c; ++q) COPY1D(Vp + q * pitch, V + ws.start(q) * k, (size_t)ws.count(q) * k, "scatter_to_w: pad");
+            if ((rc = reduce_scatter_f32(c, G_COL, Vp, Sw, pitch, j, st))) return rc;
+        }
+        *out = Sw;
+        return DNMF_OK;
+    }
+    // reduce-scatter of the H-phase product over the row group -> this rank's k x n_h slice.  sliced: Yb holds the member
+    // blocks already; else Y (k x n_l) is cut into blocks at the pitch of the largest slice first.
+    int scatter_to_h(const float* Y, const float** out) {
+        int rc;
+        float *Yb = at(L.yb_off), *Sh = at(L.sh_off);
+        if (c->p_r == 1) { *out = sliced ? Yb : Y; return DNMF_OK; }
+        size_t pitch = (size_t)k * n_h;
+        if (!sliced) {
+            pitch = (size_t)k * hs.maxc();
+            for (int q = 0; q < c->p_r; ++q)
+                COPY2D(Yb + q * pitch, hs.count(q), Y + hs.start(q), n_l, hs.count(q), k, "scatter_to_h: blocks");
+        }
+        if ((rc = reduce_scatter_f32(c, G_ROW, Yb, Sh, pitch, i, st))) return rc;
+        *out = Sh;
+        return DNMF_OK;
+    }
+};
+
+int grid2d_init(Grid2d& g, const char* what, dnmf_comm* c, long m_l, long n_l, long m_w, long n_h, long ldw, long ldh, int k,
+                void* ws, size_t ws_bytes, void* stream) {
+    int rc;
+    if ((rc = check_2d(what, c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
+    g.c = c; g.st = S(stream); g.k = k; g.i = c->rank / c->p_c; g.j = c->rank % c->p_c;
+    g.m_l = m_l; g.n_l = n_l; g.m_w = m_w; g.n_h = n_h;
+    g.ws = split_of(m_l, c->p_c); g.hs = split_of(n_l, c->p_r);
+    g.blocked = c->p_r > 1 && g.hs.equal() && n_h % 32 == 0;
+    g.sliced = g.hs.equal() && n_h % 4 == 0;
+    g.L = ws2d_layout(m_l, n_l, k, c->p_r, c->p_c);
+    if (ws_bytes < g.L.total) return fail(DNMF_EWS, "%s: workspace %zu < %zu", what, ws_bytes, g.L.total);
+    g.base = (char*)ws;
     return DNMF_OK;
 }
 
@@ -409,7 +529,7 @@ int dnmf_mu_kl_step_1d(const float* A, long m_l, long n_l, long lda, float* W, l
 }
 
 size_t dnmf_ws_bytes_2d(long m_l, long n_l, int k, int p_r, int p_c) {
-    if (kt_of(k) < 0 || m_l < 1 || n_l < 1 || p_r < 1 || p_c < 1 || m_l % p_c || n_l % p_r) return 0;
+    if (kt_of(k) < 0 || p_r < 1 || p_c < 1 || m_l < p_c || n_l < p_r) return 0;
     return ws2d_layout(m_l, n_l, k, p_r, p_c).total;
 }
 
@@ -421,35 +541,37 @@ int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, 
                         int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "mu_fro_step_2d: bad arguments");
+    Grid2d g;
     int rc;
-    if ((rc = check_2d("mu_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
-    const int kp = 32 * kt, p_r = c->p_r, p_c = c->p_c;
-    const Ws2d L = ws2d_layout(m_l, n_l, k, p_r, p_c);
-    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_fro_step_2d: workspace %zu < %zu", ws_bytes, L.total);
-    char* base = (char*)ws;
-    const size_t kws = L.g_off;
-    float *G = (float*)(base + L.g_off), *Hs = (float*)(base + L.hs_off), *V = (float*)(base + L.v_off), *Sw = (float*)(base + L.sw_off),
-          *Wi = (float*)(base + L.wi_off), *Yb = (float*)(base + L.yb_off), *Sh = (float*)(base + L.sh_off);
-    hipStream_t st = S(stream);
-    const int i = c->rank / p_c, j = c->rank % p_c;                // grid position (dist_comm.py:22): member i of the row group, j of the column group
+    if ((rc = grid2d_init(g, "mu_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream))) return rc;
+    const int kp = 32 * kt;
+    const size_t kws = g.L.g_off;
+    float *G = g.at(g.L.g_off), *V = g.at(g.L.v_off), *Y = g.at(g.L.y_off), *Yb = g.at(g.L.yb_off);
+    hipStream_t st = g.st;
     if (w_update) {                                                // Fro_MU_update_W :227-245
         if ((rc = dnmf_gram_hht(H, k, n_h, ldh, G, ws, kws, stream))) return rc;
-        if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                        // global_gram :114
-        if ((rc = allgather_f32(c, G_ROW, H, Hs, (size_t)k * n_h, st))) return rc;                       // AH_glob :195-197
-        if (p_r == 1) rc = dnmf_aht(A, m_l, n_l, lda, Hs, k, n_l, V, k, stream);                          // :198
-        else if (n_h % 32 == 0) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hs, n_h, k, V, k, stream);        // H as received: column blocks
-        else rc = fail(DNMF_EINVAL, "mu_fro_step_2d: column slices of %ld are not whole 32-column tiles: use the host choreography", n_h);
+        if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                          // global_gram :114
+        const float* Hop; long hb;
+        if ((rc = g.gather_h(H, &Hop, &hb))) return rc;                                                   // AH_glob :195-197
+        if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream);                 // :198, H as received
+        else rc = dnmf_aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
         if (rc) return rc;
-        if ((rc = reduce_scatter_f32(c, G_COL, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :202
-        if ((rc = dnmf_mu_update_w(W, m_w, k, ldw, Sw, k, G, eps, stream))) return rc;                    // :244-245
+        const float* AH;
+        if ((rc = g.scatter_to_w(V, &AH))) return rc;                                                     // :202
+        if ((rc = dnmf_mu_update_w(W, m_w, k, ldw, AH, k, G, eps, stream))) return rc;                    // :244-245
     }
     if ((rc = dnmf_gram_wtw(W, m_w, k, ldw, G, ws, kws, stream))) return rc;                              // Fro_MU_update_H :207-225
     if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;
-    if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                           // ATW_glob :163-165
-    for (int q = 0; q < p_r; ++q)                                  // :166 slice by slice: member q's k x n_h block is contiguous
-        if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
-    if ((rc = reduce_scatter_f32(c, G_ROW, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :169-171
-    if ((rc = dnmf_mu_update_h(H, k, n_h, ldh, Sh, n_h, G, eps, clamp, stream))) return rc;               // :224-225
+    const float* Wi;
+    if ((rc = g.gather_w(W, &Wi))) return rc;                                                             // ATW_glob :163-165
+    if (g.sliced) {                                                // :166 slice by slice: member q's k x n_h block is contiguous
+        for (int q = 0; q < c->p_r; ++q)
+            if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
+    } else if ((rc = dnmf_wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;
+    const float* AtW;
+    if ((rc = g.scatter_to_h(Y, &AtW))) return rc;                                                        // :169-171
+    const long ldatw = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
+    if ((rc = dnmf_mu_update_h(H, k, n_h, ldh, AtW, ldatw, G, eps, clamp, stream))) return rc;            // :224-225
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;
 }
@@ -459,39 +581,41 @@ int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, l
                        int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "mu_kl_step_2d: bad arguments");
+    Grid2d g;
     int rc;
-    if ((rc = check_2d("mu_kl_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
-    const int p_r = c->p_r, p_c = c->p_c;
-    if (p_r > 1 && n_h % 32 != 0)
-        return fail(DNMF_EINVAL, "mu_kl_step_2d: column slices of %ld are not whole 32-column tiles: use the host choreography", n_h);
-    const Ws2d L = ws2d_layout(m_l, n_l, k, p_r, p_c);
-    if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_kl_step_2d: workspace %zu < %zu", ws_bytes, L.total);
-    char* base = (char*)ws;
-    const size_t kws = L.g_off;
-    float *Hs = (float*)(base + L.hs_off), *V = (float*)(base + L.v_off), *Sw = (float*)(base + L.sw_off), *Wi = (float*)(base + L.wi_off),
-          *Yb = (float*)(base + L.yb_off), *Sh = (float*)(base + L.sh_off), *x = (float*)(base + L.x_off);
-    hipStream_t st = S(stream);
-    const int i = c->rank / p_c, j = c->rank % p_c;
-    // H_j as the row group's slices stacked [p_r][k][n_h]: gathered once per step (the W phase changes W, not H)
-    if ((rc = allgather_f32(c, G_ROW, H, Hs, (size_t)k * n_h, st))) return rc;                           // gather_W_H :283-287
+    if ((rc = grid2d_init(g, "mu_kl_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream))) return rc;
+    const size_t kws = g.L.g_off;
+    float *V = g.at(g.L.v_off), *Y = g.at(g.L.y_off), *Yb = g.at(g.L.yb_off), *x = g.at(g.L.x_off);
+    hipStream_t st = g.st;
+    // H_j: gathered once per step (the W phase changes W, not H)
+    const float* Hop; long hb;
+    if ((rc = g.gather_h(H, &Hop, &hb))) return rc;                                                       // gather_W_H :283-287
+    const float* Wi;
     if (w_update) {                                                // KL_MU_update_W :351-369
         if ((rc = dnmf_rowsum(H, k, n_h, ldh, x, stream))) return rc;
-        if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;                               // sum_axis :346-349
-        if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                       // :276-280
-        if (p_r == 1) rc = dnmf_kl_uht(A, m_l, n_l, lda, Wi, k, Hs, n_l, k, eps, V, k, ws, kws, stream);  // :337-338
-        else rc = dnmf_kl_uht_hblocks(A, m_l, n_l, lda, Wi, k, Hs, n_h, k, eps, V, k, ws, kws, stream);
+        if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;                                // sum_axis :346-349
+        if ((rc = g.gather_w(W, &Wi))) return rc;                                                         // :276-280
+        if (g.blocked) rc = dnmf_kl_uht_hblocks(A, m_l, n_l, lda, Wi, k, Hop, hb, k, eps, V, k, ws, kws, stream);   // :337-338
+        else rc = dnmf_kl_uht(A, m_l, n_l, lda, Wi, k, Hop, hb, k, eps, V, k, ws, kws, stream);
         if (rc) return rc;
-        if ((rc = reduce_scatter_f32(c, G_COL, V, Sw, (size_t)m_w * k, j, st))) return rc;               // :340
-        if ((rc = dnmf_kl_update_w(W, m_w, k, ldw, Sw, k, x, eps, stream))) return rc;                    // :369
+        const float* UHT;
+        if ((rc = g.scatter_to_w(V, &UHT))) return rc;                                                    // :340
+        if ((rc = dnmf_kl_update_w(W, m_w, k, ldw, UHT, k, x, eps, stream))) return rc;                   // :369
     }
     if ((rc = dnmf_colsum(W, m_w, k, ldw, x, ws, kws, stream))) return rc;                                // KL_MU_update_H :371-389
     if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;
-    if ((rc = allgather_f32(c, G_COL, W, Wi, (size_t)m_w * k, st))) return rc;                           // :387
-    for (int q = 0; q < p_r; ++q)                                  // WTU_glob :311-312 slice by slice (block q of the stack = those columns of H_j)
-        if ((rc = dnmf_kl_wtu(A + q * n_h, m_l, n_h, lda, Wi, k, Hs + (size_t)q * k * n_h, n_h, k, eps, Yb + (size_t)q * k * n_h, n_h,
-                              ws, kws, stream))) return rc;
-    if ((rc = reduce_scatter_f32(c, G_ROW, Yb, Sh, (size_t)k * n_h, i, st))) return rc;                  // :314-316
-    if ((rc = dnmf_kl_update_h(H, k, n_h, ldh, Sh, n_h, x, eps, clamp, stream))) return rc;               // :389
+    if ((rc = g.gather_w(W, &Wi))) return rc;                                                             // :387
+    if (g.sliced) {                                                // WTU_glob :311-312 slice by slice
+        for (int q = 0; q < c->p_r; ++q) {
+            const float* Hq = g.blocked ? Hop + (size_t)q * k * n_h : Hop + q * n_h;                      // block q of the stack / those columns of H_j
+            if ((rc = dnmf_kl_wtu(A + q * n_h, m_l, n_h, lda, Wi, k, Hq, g.blocked ? n_h : hb, k, eps, Yb + (size_t)q * k * n_h, n_h,
+                                  ws, kws, stream))) return rc;
+        }
+    } else if ((rc = dnmf_kl_wtu(A, m_l, n_l, lda, Wi, k, Hop, hb, k, eps, Y, n_l, ws, kws, stream))) return rc;
+    const float* WTU;
+    if ((rc = g.scatter_to_h(Y, &WTU))) return rc;                                                        // :314-316
+    const long ldwtu = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
+    if ((rc = dnmf_kl_update_h(H, k, n_h, ldh, WTU, ldwtu, x, eps, clamp, stream))) return rc;            // :389
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;
 }

@@ -308,9 +308,10 @@ class nmf_algorithms_2D(_Base):
         return self.W_ij, self.H_ij
 
     def _native_step(self, clamp):
-        """`params.exchange = 'native'` on an EVEN grid: the whole MU step -- kernels, allreduce / allgather / reduce-scatter over
-        the RCCL communicators inside libdnmf_hip.so, kernels -- is ONE library call (dnmf_mu_*_step_2d): same kernels in the
-        same order as the choreography below.  Ragged grids, bf16-stored A and the other operator sets keep the choreography."""
+        """`params.exchange = 'native'`: the whole MU step -- kernels, allreduce / allgather / reduce-scatter over the RCCL
+        communicators inside libdnmf_hip.so, kernels -- is ONE library call (dnmf_mu_*_step_2d): same kernels in the same
+        order as the choreography below, even and ragged grids.  Pruned factors, bf16-stored A and the other operator sets
+        keep the choreography."""
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
         if self.method.upper() != 'MU' or self.norm.upper() not in ('FRO', 'KL') or self.A_ij.dtype != torch.float32:

@@ -568,7 +568,8 @@ class NativeComm:
 
     def step_2d(self, norm, A, W, H, eps, w_update=True, clamp=False):
         """One MU step (norm 'fro' / 'kl') of this rank of a 2D grid, exchanges included (dnmf_mu_{fro,kl}_step_2d): W, H are the
-        rank's SLICES (m_w x k, k x n_h).  Raises DnmfError (DNMF_EINVAL) on uneven grids -- `step_2d_ok` tells beforehand."""
+        rank's SLICES (m_w x k, k x n_h), even or ragged per the partition rule.  Raises DnmfError (DNMF_EINVAL) on slices off that
+        rule or strided -- `step_2d_ok` tells beforehand."""
         _req(A, "A"); _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
@@ -582,11 +583,13 @@ class NativeComm:
                  int(bool(w_update)), int(bool(clamp)), self._ws.data_ptr(), self._ws.numel(), self.handle, _stream()))
 
     def step_2d_ok(self, A, W, H):
-        """The even-grid condition of the 2D entry points (include/dnmf.h): equal, contiguous factor slices, column slices of
-        whole 16-byte vectors, and of whole 32-column tiles when more than one rank shares a grid column."""
+        """What the 2D entry points take (include/dnmf.h): contiguous factor slices whose sizes follow the partition rule of
+        the grid (utils.py:36-41: the first total % p members hold one item more) -- even or ragged."""
         m, n = A.shape
-        mw, nh = W.shape[0], H.shape[1]
-        return (mw * self.p_c == m and nh * self.p_r == n and nh % 4 == 0 and (self.p_r == 1 or nh % 32 == 0)
+        i, j = self.rank // self.p_c, self.rank % self.p_c
+        mw = m // self.p_c + (1 if j < m % self.p_c else 0)
+        nh = n // self.p_r + (1 if i < n % self.p_r else 0)
+        return (m >= self.p_c and n >= self.p_r and W.shape[0] == mw and H.shape[1] == nh
                 and W.is_contiguous() and H.is_contiguous())
 
 

@@ -33,14 +33,16 @@ def _rank(rank, world, port, cfg, q):
         A = (rs.rand(m, n) + 0.05).astype(np.float32)
         A[rs.rand(m, n) < 0.1] = 0.0
         W0, H0 = (rs.rand(m, k) + 0.05).astype(np.float32), (rs.rand(k, n) + 0.05).astype(np.float32)
-        m_l, n_l = m // p_r, n // p_c
-        A_ij = torch.from_numpy(np.ascontiguousarray(A[i * m_l:(i + 1) * m_l, j * n_l:(j + 1) * n_l])).to(dev)
+        def part(total, p, q):        # the partition rule (utils.py:36-41): (start, count) of member q
+            return q * (total // p) + min(q, total % p), total // p + (1 if q < total % p else 0)
+        (r0, m_l), (c0, n_l) = part(m, p_r, i), part(n, p_c, j)
+        A_ij = torch.from_numpy(np.ascontiguousarray(A[r0:r0 + m_l, c0:c0 + n_l])).to(dev)
         two_d = p_r > 1 and p_c > 1
         if two_d:                      # the rank's slices of its grid row's W_i and its grid column's H_j (utils.py:99-115)
-            m_w, n_h = m_l // p_c, n_l // p_r
-            w0, h0 = i * m_l + j * m_w, j * n_l + i * n_h
+            (ws_, m_w), (hs_, n_h) = part(m_l, p_c, j), part(n_l, p_r, i)
+            w0, h0 = r0 + ws_, c0 + hs_
         else:                          # 1D: the factor along the split axis is the rank's block, the other is replicated
-            m_w, n_h, w0, h0 = m_l, n_l, i * m_l, j * n_l
+            m_w, n_h, w0, h0 = m_l, n_l, r0, c0
         Wb, Hb = W0[w0:w0 + m_w], H0[:, h0:h0 + n_h]
         eps = float(np.finfo(np.float32).eps)
 
@@ -74,11 +76,18 @@ def _rank(rank, world, port, cfg, q):
         q.put((rank, None, traceback.format_exc()))
 
 
+# Ragged grids (a dimension that does not divide): the library exchanges blocks at the pitch of the largest one where the gloo
+# fall-back of the choreography allreduces the whole buffer -- the same sums in a different ring order once a group has more than
+# two members, so those cases are held to 2e-6 instead of bit equality.
 CASES = [   # p_r, p_c, m, n, k, norm, W_update, overlap chunks of the 1D row grid
     (2, 1, 512, 256, 16, "fro", True, 1), (4, 1, 1024, 512, 64, "fro", True, 2), (3, 1, 300, 260, 5, "kl", True, 1),
     (1, 2, 256, 512, 32, "fro", True, 1), (1, 3, 200, 384, 8, "kl", True, 1),
     (2, 2, 512, 256, 16, "fro", True, 1), (2, 2, 512, 256, 16, "kl", True, 1), (2, 3, 240, 192, 33, "fro", True, 1),
     (2, 3, 240, 192, 8, "kl", False, 1), (4, 2, 200, 256, 64, "kl", True, 1), (3, 2, 300, 192, 128, "fro", False, 1),
+    # ragged / narrow slices: rows and columns that do not divide, equal slices that are not whole tiles, 16-wide and 32-wide kernels
+    (2, 2, 515, 262, 16, "fro", True, 1), (2, 2, 515, 262, 16, "kl", True, 1), (2, 2, 512, 264, 24, "kl", True, 1), (2, 2, 512, 136, 8, "fro", True, 1),
+    (2, 3, 241, 199, 33, "fro", True, 1), (3, 2, 301, 197, 5, "kl", True, 1), (4, 2, 203, 259, 64, "fro", True, 1), (2, 4, 150, 140, 7, "kl", False, 1),
+    (3, 1, 301, 260, 16, "fro", True, 1), (1, 3, 200, 385, 8, "kl", True, 1),
 ]
 
 
@@ -100,5 +109,11 @@ def test_c_steps_over_a_hosted_transport_equal_the_choreography(cfg):
         assert err is None, "rank %d failed:\n%s" % (rank, err)
         took, eq, dw, dh, moved = out
         assert took == 3, (rank, "the library's step entry point was not taken", out)
-        assert eq, (rank, dw, dh)
+        p_r, p_c, m, n = cfg[:4]
+        two_d = p_r > 1 and p_c > 1
+        ragged = two_d and (m % (p_r * p_c) or n % (p_r * p_c)) and max(p_r, p_c) > 2
+        if ragged:
+            assert dw <= 2e-6 and dh <= 2e-6, (rank, dw, dh)
+        else:
+            assert eq, (rank, dw, dh)
         assert moved

@@ -165,10 +165,11 @@ def _child(port, q):
         native["odd_shapes"] = odd
         # --- the 2D entry points (dnmf_mu_{fro,kl}_step_2d: allreduce + allgather + reduce-scatter inside the library) on the
         #     one-rank communicator == the Python 2D choreography bit for bit; shapes on the 16-wide and 32-wide kernels, W_update
-        #     False, clamp; an uneven column slice is refused (the host then keeps the choreography)
+        #     False, clamp, column counts that are not whole vectors; slices off the grid's partition rule are refused
         two_d = True
         for (mm, nn, kk, nrm, wupd) in [(4096, 1024, 64, "fro", True), (4096, 1024, 64, "kl", True), (1000, 260, 5, "fro", True),
-                                        (513, 640, 16, "kl", True), (300, 128, 33, "kl", False), (2049, 512, 128, "fro", False)]:
+                                        (513, 640, 16, "kl", True), (300, 128, 33, "kl", False), (2049, 512, 128, "fro", False),
+                                        (64, 130, 8, "fro", True), (257, 131, 17, "kl", True)]:      # columns that are not whole vectors
             rq = np.random.RandomState(mm + nn + kk + 1)
             Aq = torch.from_numpy(rq.rand(mm, nn).astype(np.float32)).to(dev)
             Wq0, Hq0 = rq.rand(mm, kk).astype(np.float32), rq.rand(kk, nn).astype(np.float32)
@@ -188,8 +189,8 @@ def _child(port, q):
                 alg.update(clamp=(i == 0))
             two_d = two_d and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
         native["2d"] = two_d
-        Aq = torch.rand(64, 130, device=dev)                      # 130 columns: not whole 16-byte vectors
-        Wq, Hq = torch.rand(64, 8, device=dev), torch.rand(8, 130, device=dev)
+        Aq = torch.rand(64, 130, device=dev)                      # a W slice that is not the grid's share of the block's rows
+        Wq, Hq = torch.rand(63, 8, device=dev), torch.rand(8, 130, device=dev)
         assert not nc.step_2d_ok(Aq, Wq, Hq)
         try:
             nc.step_2d("fro", Aq, Wq, Hq, eps)
