@@ -136,6 +136,7 @@ class nmf_algorithms_1D(_Base):
         if nc.overlap_chunks != want:
             nc.set_overlap_chunks(want)
         nc.step_1d(self.norm, self.A_ij, self.W_i, self.H_j, self.eps, self.W_update, clamp)
+        nc.steps += 1
         return True
 
     # ---- Frobenius (dist_nmf.py:716-771)
@@ -323,6 +324,7 @@ class nmf_algorithms_2D(_Base):
         if not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
             return False
         nc.step_2d(self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
+        nc.steps += 1
         return True
 
     # ---- gathers (dist_nmf.py:163-165, :195-197, :268-291)

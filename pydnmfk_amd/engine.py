@@ -487,6 +487,7 @@ class NativeComm:
         self.device = torch.cuda.current_device()
         self._ws = None
         self.overlap_chunks = 1
+        self.steps = 0                 # whole steps the choreography handed to the library (tests read it)
 
     @classmethod
     def hosted(cls, size, rank, p_r, p_c, collective):
@@ -514,6 +515,7 @@ class NativeComm:
         self.device = torch.cuda.current_device()
         self._ws = None
         self.overlap_chunks = 1
+        self.steps = 0                 # whole steps the choreography handed to the library (tests read it)
         return self
 
     def close(self):

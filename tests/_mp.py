@@ -78,6 +78,9 @@ def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
             assert W.dtype == z["r%d_fit%d_W" % (rank, itr)].dtype and H.dtype == z["r%d_fit%d_H" % (rank, itr)].dtype
             out[itr] = (rel_fro(W, z["r%d_fit%d_W" % (rank, itr)]), rel_fro(H, z["r%d_fit%d_H" % (rank, itr)]),
                         abs(err - float(z["r0_fit%d_err" % itr])))
+            if (extra or {}).get("exchange") in ("native", "native-hosted"):      # the fit really ran inside the library
+                assert getattr(args, "_native_comm", None) is not None and args._native_comm.steps == itr, \
+                    (itr, getattr(getattr(args, "_native_comm", None), "steps", None))
         q.put((rank, out, None))
         if world > 1:
             dist.barrier()

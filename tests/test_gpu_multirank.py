@@ -30,6 +30,23 @@ def test_multirank_hip_matches_reference(name):
     run_case(name, use_hip=True, timeout=400)
 
 
+NATIVE_CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "swim_4x1_fro_float32", "swim_1x4_fro_float32",
+                "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
+                "t24x12_2x2_fro_float32", "r25x13_2x2_kl_float32", "swim_2x2_kl_float32", "swim_2x2_fro_float32",
+                "lr200x136k64_2x2_fro_float32", "lr136x100k32_2x2_kl_float32", "r50x39_4x2_fro_float32", "r50x39_4x2_kl_float32",
+                "r50x39_2x3_kl_float32", "r50x39_3x2_fro_float32", "r50x39_2x4_kl_float32", "lr200x136k64_4x2_kl_float32",
+                "lr150x140k128_4x2_kl_float32", "swim_4x2_kl_float32"]
+
+
+@pytest.mark.parametrize("name", NATIVE_CASES)
+def test_multirank_library_sequenced_steps_match_reference(name):
+    """The same golden fits with every MU step sequenced INSIDE the library (dnmf_mu_{fro,kl}_step_{1d,2d}: kernels, the
+    exchanges, kernels in one call; params.exchange = 'native-hosted' hands the collectives to gloo through
+    dnmf_comm_create_hosted) -- 1D and 2D grids, even and ragged blocks, against the reference's W, H and recon_err."""
+    from tests._mp import run_case
+    run_case(name, use_hip=True, timeout=400, extra={"exchange": "native-hosted"})
+
+
 @pytest.mark.parametrize("grid,method", [((2, 1), "hals"), ((1, 2), "mu"), ((2, 2), "hals")])
 def test_multirank_hip_bf16_storage(grid, method):
     """bf16-stored data blocks on a grid, real HIP kernels (the *_bf16a entry points), gloo transport."""
