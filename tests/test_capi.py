@@ -43,9 +43,11 @@ def test_argument_validation_without_gpu():
     assert lib.dnmf_comm_allreduce(None, None, 4, 0, None) == -1
     assert lib.dnmf_mu_fro_step_1d(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
     assert lib.dnmf_mu_kl_step_1d(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
-    # 2D steps: the workspace query is host arithmetic (0 where the grid does not divide the block), null arguments are refused
+    # 2D steps: the workspace query is host arithmetic (ragged grids included; 0 for a grid with more members than rows / columns
+    # or a bad grid), null arguments are refused
     assert lib.dnmf_ws_bytes_2d(32768, 32768, 128, 4, 2) >= lib.dnmf_ws_bytes(32768, 32768, 128) + 4 * 128 * (2 * 32768 + 2 * 32768)
-    assert lib.dnmf_ws_bytes_2d(1000, 1000, 8, 3, 1) == 0 and lib.dnmf_ws_bytes_2d(1000, 1024, 8, 2, 0) == 0
+    assert lib.dnmf_ws_bytes_2d(1000, 1000, 8, 3, 2) > lib.dnmf_ws_bytes(1000, 1000, 8)
+    assert lib.dnmf_ws_bytes_2d(2, 1000, 8, 2, 3) == 0 and lib.dnmf_ws_bytes_2d(1000, 1024, 8, 2, 0) == 0
     assert lib.dnmf_mu_fro_step_2d(None, 8, 8, 8, None, 8, 4, None, 8, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
     assert b"mu_fro_step_2d" in lib.dnmf_last_error()
     assert lib.dnmf_mu_kl_step_2d(None, 8, 8, 8, None, 8, 4, None, 8, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
