@@ -240,7 +240,8 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
 /* A communicator whose collectives the HOST performs (no RCCL in the process, or a transport of the host's own -- a GPU-aware
  * MPI under the reference's mpi4py driver; the multi-rank tests of this repository drive it with gloo):
  * every exchange of the step entry points calls fn(user, op, group, send, recv, count, stream) on the calling thread.
- *   op    DNMF_ALLREDUCE       recv == send: in-place SUM of `count` floats over the group (dist_nmf.py:114, :681, :707)
+ *   op    DNMF_ALLREDUCE       recv == send: in-place SUM of `count` floats over the group (dist_nmf.py:114, :681, :707);
+ *         DNMF_ALLREDUCE_F64 the same on doubles (the HALS steps only)
  *         DNMF_ALLGATHER       recv[q * count ...] = member q's `count` floats, members in group order (:163-165, :195-197)
  *         DNMF_REDUCE_SCATTER  send = members x count floats; recv = this member's block of the SUM (:169-171, :202)
  *   group 0 = all ranks, 1 = cart_1d_row (the p_r ranks of a grid column, ordered by grid row), 2 = cart_1d_column (the p_c
@@ -251,6 +252,7 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
 #define DNMF_ALLREDUCE 0
 #define DNMF_ALLGATHER 1
 #define DNMF_REDUCE_SCATTER 2
+#define DNMF_ALLREDUCE_F64 3   /* as DNMF_ALLREDUCE on `count` DOUBLES (send / recv point to doubles): the HALS column norms */
 typedef int (*dnmf_collective_fn)(void* user, int op, int group, const float* send, float* recv, size_t count, void* stream);
 int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collective_fn fn, void* user, dnmf_comm_t** comm);
 int dnmf_comm_destroy(dnmf_comm_t* comm);
@@ -299,6 +301,18 @@ int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, 
 /* KL_MU_update on the 2D grid (dist_nmf.py:351-407 with sum_axis :346-349, gather_W_H :268-291, UHT_glob :330-343, WTU_glob :294-318) */
 int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
                        int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
+
+/* HALS / Frobenius steps with the exchanges inside (FRO_HALS_update, dist_nmf.py:873-934 on 1D grids, :411-470 on the 2D grid):
+ * products and Gram matrices exchanged as in the MU steps above; the W sweep column by column -- where W's rows are spread over
+ * ranks (p_r > 1, and every 2D grid) the 8-byte sum of squares of each column is allreduced between the column kernels
+ * (utils.norm, utils.py:388-391); with local norms (1D, p_r == 1) it is dnmf_hals_sweep_w, or k column launches when
+ * `column_sweep` != 0 -- then the H sweep; `clamp` != 0: H = max(H, eps), W = max(W, eps) afterwards (pyDNMF.py:170-172).
+ * Workspaces: dnmf_ws_bytes_1d / dnmf_ws_bytes_2d. */
+int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                          float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* comm,
+                          void* stream);
+int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                          int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
 
 /* ---- measurement aid (no counterpart in the reference) ----
  * Which shader clock does the GPU hold right now?  Launches ONE wave on `stream` that writes `n` pairs {s_memtime (shader

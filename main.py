@@ -50,7 +50,7 @@ FLAGS = [
     ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
     ('gemm', str, 'fp32', False, 'arithmetic of the two big Frobenius contractions: fp32 (fp32 MFMA) or bf16x6 (six bf16 piece products, fp32-grade)'),
     ('rng', str, 'device', False, 'where random numbers are drawn: device (the data block goes to the GPU once, perturbations and the rand init are drawn there) or numpy (the reference\'s host stream: every fit draws and uploads host arrays)'),
-    ('exchange', str, 'torch', False, 'who sequences the exchanges of a multi-rank mu step: torch (torch.distributed between the kernel launches) or native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step)'),
+    ('exchange', str, 'torch', False, 'who sequences the exchanges of a multi-rank step: torch (torch.distributed between the kernel launches) or native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step)'),
     ('hals_sweep', str, 'persistent', False, 'W sweep of method hals on a rank with local norms: persistent (one launch; needs the GPU to itself) or columns'),
     # NMFk
     ('perturbations', int, 20, False, 'perturbed copies per rank'),

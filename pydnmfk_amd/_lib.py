@@ -93,9 +93,12 @@ SIGNATURES["dnmf_comm_set_null_exchange"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_allreduce"] = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
 SIGNATURES["dnmf_ws_bytes_1d"] = SIGNATURES["dnmf_ws_bytes"]
 SIGNATURES["dnmf_ws_bytes_2d"] = [c_long, c_long, c_int, c_int, c_int]
+SIGNATURES["dnmf_hals_fro_step_1d"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int, c_int,
+                                       c_int, c_void_p, c_size_t, c_void_p, c_void_p]
 for _n in ("fro", "kl"):      # A, m_l, n_l, lda, W, m_w, ldw, H, n_h, ldh, k, eps, w_update, clamp, ws, ws_bytes, comm, stream
     SIGNATURES["dnmf_mu_%s_step_2d" % _n] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
                                              c_int, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]
+SIGNATURES["dnmf_hals_fro_step_2d"] = SIGNATURES["dnmf_mu_fro_step_2d"]
 SIGNATURES["dnmf_mu_fro_step_1d"] = SIGNATURES["dnmf_mu_fro_step"][:-1] + [c_void_p, c_void_p]
 SIGNATURES["dnmf_mu_kl_step_1d"] = SIGNATURES["dnmf_mu_fro_step_1d"]
 SIGNATURES["dnmf_ws_bytes_hblocks"] = [c_long, c_long, c_int, c_long]

@@ -115,6 +115,41 @@ int allreduce_f32(dnmf_comm* cm, int g, float* buf, size_t count, hipStream_t st
     return DNMF_OK;
 }
 
+// in-place SUM of doubles (the column norms of the HALS W sweep, utils.py:388-391)
+int allreduce_f64(dnmf_comm* cm, int g, double* buf, size_t count, hipStream_t st) {
+    ncclComm_t c;
+    const int r = resolve(cm, g, &c, "allreduce");
+    if (r) return r < 0 ? r : DNMF_OK;
+    if (cm->hook)
+        return cm->hook(cm->hook_user, DNMF_ALLREDUCE_F64, g, reinterpret_cast<const float*>(buf), reinterpret_cast<float*>(buf), count, st)
+                   ? fail(DNMF_ECOMM, "allreduce: the host collective failed") : DNMF_OK;
+    NCCL_OK(rccl()->AllReduce(buf, buf, count, ncclFloat64, ncclSum, c, st), "allreduce");
+    return DNMF_OK;
+}
+
+// The W sweep of HALS with cross-rank column norms (dist_nmf.py:884-891 with utils.norm :388-391): column kernel, 8-byte
+// allreduce, next column (which first applies the pending normalisation), final scale.  ss2 = k device doubles.
+int hals_sweep_exchanged(dnmf_comm* cm, float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
+                         double* ss2, void* stream) {
+    hipStream_t st = S(stream);
+    HIP_OK(hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), st), "hals sweep: memset");
+    int rc;
+    for (int kk = 0; kk < k; ++kk) {
+        if ((rc = dnmf_hals_w_col(W, m, k, ldw, AH, ldah, G, kk, kk > 0 ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, stream))) return rc;
+        if ((rc = allreduce_f64(cm, G_WORLD, ss2 + kk, 1, st))) return rc;
+    }
+    return dnmf_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream);
+}
+// ... and with local norms: the persistent sweep (or its column form on request)
+int hals_sweep_local(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, int column_sweep,
+                     double* ss2, void* ws, size_t kws, void* stream) {
+    if (column_sweep) {
+        HIP_OK(hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), S(stream)), "hals sweep: memset");
+        return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);
+    }
+    return dnmf_hals_sweep_w(W, m, k, ldw, AH, ldah, G, eps, ws, kws, stream);
+}
+
 // equal blocks of `count` floats: recv[q * count ...] = member q's send (MPI Allgather, dist_nmf.py:163-165, :195-197)
 int allgather_f32(dnmf_comm* cm, int g, const float* send, float* recv, size_t count, hipStream_t st) {
     ncclComm_t c;
@@ -162,6 +197,7 @@ Ws2d ws2d_layout(long m_l, long n_l, int k, int p_r, int p_c) {
     const Split ws = split_of(m_l, p_c), hs = split_of(n_l, p_r);
     const long mw = ws.maxc(), nh = hs.maxc();
     size_t kws = std::max(dnmf_ws_bytes(m_l, n_l, k), dnmf_ws_bytes(m_l, std::max<long>(1, hs.base), k));
+    kws = std::max(kws, dnmf_ws_bytes(ws.maxc(), k, k));            // (the HALS W sweep on the rank's slice)
     if (hs.equal() && hs.base % 32 == 0) kws = std::max(kws, dnmf_ws_bytes_hblocks(m_l, n_l, k, hs.base));
     Ws2d w;
     size_t o = align256(kws);
@@ -178,7 +214,7 @@ Ws2d ws2d_layout(long m_l, long n_l, int k, int p_r, int p_c) {
     w.y_off = take((size_t)k * n_l);                            // full-width H-phase product
     w.yb_off = take((size_t)p_r * k * nh);                      // ... as member blocks
     w.sh_off = take((size_t)k * nh);
-    w.x_off = take(128);
+    w.x_off = take(128 + 2 * DNMF_MAX_K);                          // factor sums; k doubles for the HALS norms
     w.total = o;
     return w;
 }
@@ -303,7 +339,7 @@ struct Ws1d { size_t g_off, x_off, total; };
 Ws1d ws1d_layout(long m_l, long n_l, int k) {
     const int kp = 32 * kt_of(k);
     Ws1d w;
-    size_t kws = dnmf_ws_bytes(m_l, n_l, k);                      // kernel scratch: the whole block and every chunk width of the
+    size_t kws = std::max(dnmf_ws_bytes(m_l, n_l, k), dnmf_ws_bytes(m_l, k, k));   // kernel scratch: the whole block (and the HALS sweep's), every chunk width of the
     for (int nch = 2; nch <= MAX_CHUNKS; ++nch) {                 // overlapped H phase (the chunking of W^T A depends on the width)
         const long cw = (cdiv(n_l, nch) + 63) / 64 * 64;
         if (cw >= n_l) continue;
@@ -314,7 +350,7 @@ Ws1d ws1d_layout(long m_l, long n_l, int k) {
     w.x_off = w.g_off + align256((size_t)kp * kp * sizeof(float));
     const size_t big = std::max((size_t)k * n_l, (size_t)m_l * k);
     // one packed message [product | pad | KP x KP] or up to MAX_CHUNKS chunk messages, each padded to 64 floats
-    w.total = w.x_off + align256((pad64(big) + (size_t)MAX_CHUNKS * 64 + (size_t)kp * kp + 128) * sizeof(float));
+    w.total = w.x_off + align256((pad64(big) + (size_t)MAX_CHUNKS * 64 + (size_t)kp * kp + 128 + 2 * DNMF_MAX_K) * sizeof(float));   // (+ k doubles: HALS norms)
     return w;
 }
 
@@ -617,6 +653,96 @@ int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, l
     const long ldwtu = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
     if ((rc = dnmf_kl_update_h(H, k, n_h, ldh, WTU, ldwtu, x, eps, clamp, stream))) return rc;            // :389
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
+    return DNMF_OK;
+}
+
+// One HALS / Frobenius step of a rank of a 1D grid (FRO_HALS_update, dist_nmf.py:873-934): products and Gram matrices as in the
+// MU step (one packed allreduce per phase along the split axis), the W sweep column by column -- with row-sharded W (p_r > 1)
+// the 8-byte sum of squares of every column is allreduced between the column kernels (utils.py:388-391), with local norms
+// (p_r == 1) it is the persistent sweep, or k column launches when `column_sweep` != 0 -- then the H sweep.  `clamp`:
+// H = max(H, eps), W = max(W, eps) afterwards (pyDNMF.py:170-172).
+int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                          float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* c,
+                          void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1, "hals_fro_step_1d: bad arguments");
+    REQUIRE(c->p_r == 1 || c->p_c == 1, "hals_fro_step_1d: a %d x %d grid is 2D", c->p_r, c->p_c);
+    const int kp = 32 * kt;
+    const Ws1d L = ws1d_layout(m_l, n_l, k);
+    if (ws_bytes < L.total) return fail(DNMF_EWS, "hals_fro_step_1d: workspace %zu < %zu", ws_bytes, L.total);
+    char* base = (char*)ws;
+    const size_t kws = L.g_off;
+    float* X = (float*)(base + L.x_off);
+    const size_t big = std::max((size_t)k * n_l, (size_t)m_l * k);
+    double* ss2 = reinterpret_cast<double*>(X + pad64(big) + (size_t)MAX_CHUNKS * 64 + (size_t)kp * kp + 128);
+    hipStream_t st = S(stream);
+    int rc;
+    if (w_update) {                                               // FRO_HALS_update_W :873-891
+        const size_t off = pad64((size_t)m_l * k);
+        float* AH = X; float* Gx = X + off;
+        if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;                 // :882
+        if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
+        if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
+        if (c->p_r != 1 && c->nranks > 1) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, stream);   // :884-891
+        else rc = hals_sweep_local(W, m_l, k, ldw, AH, k, Gx, eps, column_sweep, ss2, ws, kws, stream);
+        if (rc) return rc;
+    }
+    const size_t off = pad64((size_t)k * n_l);                    // FRO_HALS_update_H :893-909
+    float* AtW = X; float* Gx = X + off;
+    if ((rc = dnmf_wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;   // :902-903
+    if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
+    if ((rc = dnmf_hals_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, stream))) return rc;           // :905-909
+    if (clamp) {
+        if ((rc = dnmf_clamp_min(H, k, n_l, ldh, eps, stream))) return rc;
+        return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
+    }
+    return DNMF_OK;
+}
+
+// The same on the 2D grid (FRO_HALS_update, dist_nmf.py:411-470): exchanges as dnmf_mu_fro_step_2d; the column norms of the W
+// sweep are summed over ALL ranks (every rank holds other rows of W).
+int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                          int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    const int kt = kt_of(k);
+    REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "hals_fro_step_2d: bad arguments");
+    Grid2d g;
+    int rc;
+    if ((rc = grid2d_init(g, "hals_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream))) return rc;
+    const int kp = 32 * kt;
+    const size_t kws = g.L.g_off;
+    float *G = g.at(g.L.g_off), *V = g.at(g.L.v_off), *Y = g.at(g.L.y_off), *Yb = g.at(g.L.yb_off);
+    double* ss2 = reinterpret_cast<double*>(g.at(g.L.x_off) + 128);
+    hipStream_t st = g.st;
+    if (w_update) {                                                // FRO_HALS_update_W :411-434
+        if ((rc = dnmf_gram_hht(H, k, n_h, ldh, G, ws, kws, stream))) return rc;
+        if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                          // :426
+        const float* Hop; long hb;
+        if ((rc = g.gather_h(H, &Hop, &hb))) return rc;
+        if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream);                 // AH_glob :427
+        else rc = dnmf_aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
+        if (rc) return rc;
+        const float* AH;
+        if ((rc = g.scatter_to_w(V, &AH))) return rc;
+        if (c->nranks > 1) rc = hals_sweep_exchanged(c, W, m_w, k, ldw, AH, k, G, eps, ss2, stream);      // :428-434
+        else rc = hals_sweep_local(W, m_w, k, ldw, AH, k, G, eps, 0, ss2, ws, kws, stream);
+        if (rc) return rc;
+    }
+    if ((rc = dnmf_gram_wtw(W, m_w, k, ldw, G, ws, kws, stream))) return rc;                              // FRO_HALS_update_H :436-452
+    if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;
+    const float* Wi;
+    if ((rc = g.gather_w(W, &Wi))) return rc;
+    if (g.sliced) {
+        for (int q = 0; q < c->p_r; ++q)
+            if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
+    } else if ((rc = dnmf_wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;          // ATW_glob :448
+    const float* AtW;
+    if ((rc = g.scatter_to_h(Y, &AtW))) return rc;
+    const long ldatw = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
+    if ((rc = dnmf_hals_update_h(H, k, n_h, ldh, AtW, ldatw, G, eps, stream))) return rc;                 // :449-452
+    if (clamp) {
+        if ((rc = dnmf_clamp_min(H, k, n_h, ldh, eps, stream))) return rc;
+        return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
+    }
     return DNMF_OK;
 }
 

@@ -123,8 +123,9 @@ class nmf_algorithms_1D(_Base):
         """`params.exchange = 'native'`: the whole MU step, exchanges included, is ONE library call (dnmf_mu_*_step_1d over
         the RCCL communicator inside libdnmf_hip.so) -- same kernels in the same order as the choreography below, no Python
         between the launches.  float32 data, the product's own operator set, more than one rank."""
-        if (self.p == 1 and not getattr(self.params, "native_always", False)) or self.method.upper() != 'MU' \
-                or self.norm.upper() not in ('FRO', 'KL'):
+        hals = self.method.upper() == 'HALS' and self.norm.upper() == 'FRO'
+        if (self.p == 1 and not getattr(self.params, "native_always", False)) or \
+                not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))):
             return False
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
@@ -132,6 +133,11 @@ class nmf_algorithms_1D(_Base):
             return False
         from .engine import native_comm_for
         nc = native_comm_for(self.params)
+        if hals:
+            nc.hals_step_1d(self.A_ij, self.W_i, self.H_j, self.eps, self.W_update, clamp,
+                            column_sweep=(getattr(self.params, "hals_sweep", None) == "columns"))
+            nc.steps += 1
+            return True
         want = self._overlap_chunks(self.A_ij.shape[1]) if self.norm.upper() == 'FRO' else 1
         if nc.overlap_chunks != want:
             nc.set_overlap_chunks(want)
@@ -315,7 +321,8 @@ class nmf_algorithms_2D(_Base):
         keep the choreography."""
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
-        if self.method.upper() != 'MU' or self.norm.upper() not in ('FRO', 'KL') or self.A_ij.dtype != torch.float32:
+        hals = self.method.upper() == 'HALS' and self.norm.upper() == 'FRO'
+        if not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))) or self.A_ij.dtype != torch.float32:
             return False
         if getattr(self.params, "_slice_counts", None) is not None:         # pruned factors: sizes no longer follow the grid
             return False
@@ -323,7 +330,7 @@ class nmf_algorithms_2D(_Base):
         nc = native_comm_for(self.params)
         if not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
             return False
-        nc.step_2d(self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
+        nc.step_2d("hals" if hals else self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
         nc.steps += 1
         return True
 

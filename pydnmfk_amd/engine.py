@@ -567,9 +567,20 @@ class NativeComm:
         check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
                  int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(), self.handle, _stream()))
 
+    def hals_step_1d(self, A, W, H, eps, w_update=True, clamp=False, column_sweep=False):
+        """One HALS / Frobenius step of this rank of a 1D grid, exchanges and column norms included (dnmf_hals_fro_step_1d)."""
+        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._workspace(m, n, k, A.device)
+        check(lib.dnmf_hals_fro_step_1d(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+                                        int(bool(w_update)), int(bool(clamp)), int(bool(column_sweep)), ws.data_ptr(), ws.numel(),
+                                        self.handle, _stream()))
+
 
     def step_2d(self, norm, A, W, H, eps, w_update=True, clamp=False):
-        """One MU step (norm 'fro' / 'kl') of this rank of a 2D grid, exchanges included (dnmf_mu_{fro,kl}_step_2d): W, H are the
+        """One step of this rank of a 2D grid, exchanges included -- MU (norm 'fro' / 'kl': dnmf_mu_{fro,kl}_step_2d) or HALS /
+        Frobenius (norm 'hals': dnmf_hals_fro_step_2d): W, H are the
         rank's SLICES (m_w x k, k x n_h), even or ragged per the partition rule.  Raises DnmfError (DNMF_EINVAL) on slices off that
         rule or strided -- `step_2d_ok` tells beforehand."""
         _req(A, "A"); _req(W, "W"); _req(H, "H")
@@ -580,7 +591,7 @@ class NativeComm:
             raise ValueError("step_2d: bad problem shape m=%d n=%d k=%d on %d x %d" % (m, n, k, self.p_r, self.p_c))
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != A.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
-        fn = lib.dnmf_mu_fro_step_2d if norm.lower() == "fro" else lib.dnmf_mu_kl_step_2d
+        fn = {"fro": lib.dnmf_mu_fro_step_2d, "kl": lib.dnmf_mu_kl_step_2d, "hals": lib.dnmf_hals_fro_step_2d}[norm.lower()]
         check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), W.shape[0], _ld(W), H.data_ptr(), H.shape[1], _ld(H), k, float(eps),
                  int(bool(w_update)), int(bool(clamp)), self._ws.data_ptr(), self._ws.numel(), self.handle, _stream()))
 
@@ -610,10 +621,10 @@ def _torch_hosted_collective(groups):
         n = comm.size
         torch.cuda.synchronize()                                    # everything that produces `send` has run
         dev = torch.device("cuda", torch.cuda.current_device())
-        t = torch.empty(count * (n if op == 2 else 1), dtype=torch.float32, device=dev)
-        if hip.hipMemcpy(t.data_ptr(), send, t.numel() * 4, D2D):
+        t = torch.empty(count * (n if op == 2 else 1), dtype=torch.float64 if op == 3 else torch.float32, device=dev)
+        if hip.hipMemcpy(t.data_ptr(), send, t.numel() * t.element_size(), D2D):
             return 1
-        if op == 0:
+        if op in (0, 3):
             out = comm.allreduce_(t)
         elif op == 1:
             out = torch.cat([b.reshape(-1) for b in comm.allgather_blocks(t, [(count,)] * n)])
@@ -621,7 +632,7 @@ def _torch_hosted_collective(groups):
             out = comm.reduce_scatter_rows(t.view(n, count), [1] * n).reshape(-1)
         out = out.contiguous()
         torch.cuda.synchronize()
-        if hip.hipMemcpy(recv, out.data_ptr(), out.numel() * 4, D2D):
+        if hip.hipMemcpy(recv, out.data_ptr(), out.numel() * out.element_size(), D2D):
             return 1
         return 0
     return collective

@@ -34,12 +34,14 @@ NATIVE_CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "swim_4x1_fro
                 "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
                 "t24x12_2x2_fro_float32", "r25x13_2x2_kl_float32", "swim_2x2_kl_float32", "swim_2x2_fro_float32",
                 "lr200x136k64_2x2_fro_float32", "lr136x100k32_2x2_kl_float32", "r50x39_4x2_fro_float32", "r50x39_4x2_kl_float32",
-                "r50x39_2x3_kl_float32", "lr150x140k128_4x2_kl_float32"]
+                "r50x39_2x3_kl_float32", "lr150x140k128_4x2_kl_float32",
+                "t24x12_2x1_hals_float32", "t24x12_2x2_hals_float32", "r25x13_3x1_hals_float32", "lr200x136k64_1x2_hals_float32",
+                "r50x39_4x2_hals_float32", "lr200x136k64_2x3_hals_float32", "swim_2x2_hals_float32"]
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
 def test_multirank_library_sequenced_steps_match_reference(name):
-    """The same golden fits with every MU step sequenced INSIDE the library (dnmf_mu_{fro,kl}_step_{1d,2d}: kernels, the
+    """The same golden fits with every MU / HALS step sequenced INSIDE the library (dnmf_mu_{fro,kl}_step_{1d,2d}, dnmf_hals_fro_step_{1d,2d}: kernels, the
     exchanges, kernels in one call; params.exchange = 'native-hosted' hands the collectives to gloo through
     dnmf_comm_create_hosted) -- 1D and 2D grids, even and ragged blocks, against the reference's W, H and recon_err."""
     from tests._mp import run_case

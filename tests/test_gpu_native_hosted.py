@@ -50,7 +50,7 @@ def _rank(rank, world, port, cfg, q):
             a = parse()
             a.comm1, a.comm, a.p_r, a.p_c, a.k, a.m, a.n = comms.comm, comms, p_r, p_c, k, m, n
             a.row_comm, a.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-            a.eps, a.W_update, a.norm, a.method = eps, w_update, norm, "mu"
+            a.eps, a.W_update, a.norm, a.method = eps, w_update, ("fro" if norm == "hals" else norm), ("hals" if norm == "hals" else "mu")
             a.overlap_min_cols, a.overlap_chunks = 64, chunks
             if exchange:
                 a.exchange = exchange
@@ -60,7 +60,10 @@ def _rank(rank, world, port, cfg, q):
         Wp, Hp = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (Wb, Hb))
         Wn, Hn = Wp.clone(), Hp.clone()
         took = 0
-        for it in range(3):
+        # (HALS on unstructured data is chaotic -- columns that collapse to eps are renormalised from rounding noise: a 1e-7
+        #  difference in ring order is 3e-2 after the third sweep of the ragged 2 x 3 case -- so its cases stop after two)
+        steps = 2 if norm == "hals" else 3
+        for it in range(steps):
             cls(A_ij, Wp, Hp, params=ap).update(clamp=(it == 1))
             alg = cls(A_ij, Wn, Hn, params=an)
             took += int(bool(alg._native_step(clamp=(it == 1))))
@@ -68,7 +71,7 @@ def _rank(rank, world, port, cfg, q):
         dw = float((Wp - Wn).norm() / Wp.norm())
         dh = float((Hp - Hn).norm() / Hp.norm())
         moved = float((Wp - torch.from_numpy(np.ascontiguousarray(Wb)).to(dev)).norm() / Wp.norm()) > 1e-3 or not w_update
-        q.put((rank, (took, eq, dw, dh, moved), None))
+        q.put((rank, (took == steps, eq, dw, dh, moved), None))
         dist.barrier()
         an._native_comm.close()
         dist.destroy_process_group()
@@ -88,6 +91,9 @@ CASES = [   # p_r, p_c, m, n, k, norm, W_update, overlap chunks of the 1D row gr
     (2, 2, 515, 262, 16, "fro", True, 1), (2, 2, 515, 262, 16, "kl", True, 1), (2, 2, 512, 264, 24, "kl", True, 1), (2, 2, 512, 136, 8, "fro", True, 1),
     (2, 3, 241, 199, 33, "fro", True, 1), (3, 2, 301, 197, 5, "kl", True, 1), (4, 2, 203, 259, 64, "fro", True, 1), (2, 4, 150, 140, 7, "kl", False, 1),
     (3, 1, 301, 260, 16, "fro", True, 1), (1, 3, 200, 385, 8, "kl", True, 1),
+    # HALS / Frobenius (dnmf_hals_fro_step_{1d,2d}): the column norms of the W sweep are 8-byte allreduces between the column kernels
+    (2, 1, 512, 256, 16, "hals", True, 1), (3, 1, 301, 260, 5, "hals", True, 1), (1, 2, 256, 512, 32, "hals", True, 1),
+    (2, 2, 512, 256, 16, "hals", True, 1), (2, 3, 241, 199, 33, "hals", True, 1), (4, 2, 200, 256, 64, "hals", False, 1),
 ]
 
 
@@ -108,7 +114,7 @@ def test_c_steps_over_a_hosted_transport_equal_the_choreography(cfg):
     for rank, out, err in res:
         assert err is None, "rank %d failed:\n%s" % (rank, err)
         took, eq, dw, dh, moved = out
-        assert took == 3, (rank, "the library's step entry point was not taken", out)
+        assert took, (rank, "the library's step entry point was not taken", out)
         p_r, p_c, m, n = cfg[:4]
         two_d = p_r > 1 and p_c > 1
         ragged = two_d and (m % (p_r * p_c) or n % (p_r * p_c)) and max(p_r, p_c) > 2
