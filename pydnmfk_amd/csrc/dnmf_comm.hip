@@ -683,7 +683,7 @@ int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W
         if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;                 // :882
         if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
         if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
-        if (c->p_r != 1 && c->nranks > 1) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, stream);   // :884-891
+        if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, stream);   // :884-891
         else rc = hals_sweep_local(W, m_l, k, ldw, AH, k, Gx, eps, column_sweep, ss2, ws, kws, stream);
         if (rc) return rc;
     }

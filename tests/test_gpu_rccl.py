@@ -189,6 +189,30 @@ def _child(port, q):
                 alg.update(clamp=(i == 0))
             two_d = two_d and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
         native["2d"] = two_d
+        # --- HALS / Frobenius in the library (dnmf_hals_fro_step_1d): with `always` the one-rank communicator runs the exchanged
+        #     W sweep -- column kernel, ncclAllReduce of ONE double, next column -- which must equal the column form of the
+        #     choreography bit for bit (the same column kernels; a one-rank sum is the identity)
+        hals = True
+        for (mm, nn, kk) in [(1000, 260, 5), (4096, 1024, 64), (513, 640, 16)]:
+            rq = np.random.RandomState(mm + nn + kk + 2)
+            Aq = torch.from_numpy(np.abs(rq.rand(mm, kk) @ rq.rand(kk, nn) + 0.01 * rq.randn(mm, nn)).astype(np.float32)).to(dev)
+            Wq0, Hq0 = rq.rand(mm, kk).astype(np.float32), rq.rand(kk, nn).astype(np.float32)
+            ap = parse()
+            ap.comm1, ap.comm, ap.p_r, ap.p_c, ap.k, ap.m, ap.n = world, comms, 4, 1, kk, mm, nn
+            ap.eps, ap.W_update, ap.norm, ap.method, ap.hals_sweep = eps, True, "fro", "hals", "columns"
+            an = parse()
+            an.__dict__.update(vars(ap))
+            an.exchange, an.native_always, an._native_comm = "native", True, nc
+            Wp, Hp = torch.from_numpy(Wq0).to(dev), torch.from_numpy(Hq0).to(dev)
+            Wn, Hn = Wp.clone(), Hp.clone()
+            TorchComm.always_collective = False
+            for i in range(2):
+                nmf_algorithms_1D(Aq, Wp, Hp, params=ap).update(clamp=(i == 0))
+            TorchComm.always_collective = True
+            for i in range(2):
+                nmf_algorithms_1D(Aq, Wn, Hn, params=an).update(clamp=(i == 0))
+            hals = hals and bool(torch.equal(Wp, Wn) and torch.equal(Hp, Hn))
+        native["hals_1d"] = hals
         Aq = torch.rand(64, 130, device=dev)                      # a W slice that is not the grid's share of the block's rows
         Wq, Hq = torch.rand(63, 8, device=dev), torch.rand(8, 130, device=dev)
         assert not nc.step_2d_ok(Aq, Wq, Hq)
@@ -231,4 +255,4 @@ def test_rccl_code_path_on_one_gpu():
     assert max(log["overlap"]) <= 2e-6, log
     assert log["fit"][0] <= 1e-4 and log["fit"][1] <= 1e-4 and log["fit"][2] <= 1e-5, log
     assert log["native"] == {"fro_1": True, "fro_2": True, "fro_4": True, "kl_1": True, "odd_shapes": True, "2d": True,
-                             "2d_refuses_uneven": True}, log
+                             "hals_1d": True, "2d_refuses_uneven": True}, log
