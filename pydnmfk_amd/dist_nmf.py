@@ -78,7 +78,8 @@ class _Base:
         call; with p_r > 1 the 8-byte sum of squares of every column is allreduced between the column kernels, where
         the reference calls utils.norm (utils.py:388-391)."""
         ops, eps, k = self.ops, self.eps, self.k
-        if not allreduce_norm or self.comm1.size == 1:
+        # (`params.hals_force_exchange`: measurement aid -- a one-rank group still runs the exchanged sweep, tools/rankbench.py)
+        if not allreduce_norm or (self.comm1.size == 1 and not getattr(self.params, "hals_force_exchange", False)):
             # `params.hals_sweep = 'columns'`: k column launches instead of the persistent sweep, whose workgroups wait for
             # each other and must all be resident (a GPU shared with another process or stream cannot promise that)
             if getattr(self.params, "hals_sweep", None) == "columns" and hasattr(ops, "hals_update_w_columns"):

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--rank", dest="k", type=int, default=64)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--norm", default="fro")
+    ap.add_argument("--method", default="mu", choices=["mu", "hals"],
+                    help="hals: the W sweep exchanges one 8-byte column norm per column (k allreduces per step on a row grid)")
     ap.add_argument("--no-collectives", action="store_true", help="same shard, single-GPU path (no RCCL calls)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
                     help="torch: dist.all_reduce between the launches; native: the library's own RCCL communicator, one C call per step")
@@ -48,7 +50,8 @@ def main():
     p.comm1, p.comm, p.k, p.m, p.n = comms.comm, comms, k, a.rows, n
     p.p_r, p.p_c = (1, 1) if a.no_collectives else (a.ranks, 1)
     p.row_comm, p.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-    p.norm, p.method, p.W_update, p.eps = a.norm, "mu", True, 1.1920929e-07
+    p.norm, p.method, p.W_update, p.eps = a.norm, a.method, True, 1.1920929e-07
+    p.hals_force_exchange = True          # (one rank standing in for a row grid: the column norms still go through the collective)
     if a.chunks is not None:
         p.overlap_chunks = a.chunks
     if a.exchange == "native" and not a.no_collectives:
@@ -74,7 +77,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = {"ranks_emulated": a.ranks, "rows_per_rank": m_l, "n": n, "k": k, "collectives": not a.no_collectives,
-           "exchange": a.exchange, "chunks": a.chunks,
+           "exchange": a.exchange, "chunks": a.chunks, "method": a.method,
            "ms_per_step": round(el / a.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 4)}
     print(json.dumps(out))
     if not a.no_collectives:
