@@ -50,7 +50,7 @@ FLAGS = [
     ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
     ('gemm', str, 'fp32', False, 'arithmetic of the two big Frobenius contractions: fp32 (fp32 MFMA) or bf16x6 (six bf16 piece products, fp32-grade)'),
     ('rng', str, 'device', False, 'where random numbers are drawn: device (the data block goes to the GPU once, perturbations and the rand init are drawn there) or numpy (the reference\'s host stream: every fit draws and uploads host arrays)'),
-    ('exchange', str, 'torch', False, 'who sequences the exchanges of a multi-rank step: torch (torch.distributed between the kernel launches) or native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step)'),
+    ('exchange', str, 'auto', False, 'who sequences the exchanges of a multi-rank step: torch (torch.distributed between the kernel launches), native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step) or auto (native for hals on grids with p_r > 1, where the per-column norm exchanges make the Python-sequenced step host-bound; torch otherwise)'),
     ('hals_sweep', str, 'persistent', False, 'W sweep of method hals on a rank with local norms: persistent (one launch; needs the GPU to itself) or columns'),
     # NMFk
     ('perturbations', int, 20, False, 'perturbed copies per rank'),
@@ -97,8 +97,10 @@ def main():
                                                                dtype=storage_dtype(A_ij, args))
     elif args.rng != 'numpy':
         raise SystemExit("--rng must be device or numpy")
-    if args.exchange not in ('torch', 'native'):
-        raise SystemExit("--exchange must be torch or native")
+    if args.exchange not in ('auto', 'torch', 'native'):
+        raise SystemExit("--exchange must be auto, torch or native")
+    if args.exchange == 'auto':                            # measured: tools/rankbench.py --method hals
+        args.exchange = 'native' if (args.method.lower() == 'hals' and args.p_r > 1) else 'torch'
     if args.exchange == 'torch' or world == 1:
         del args.exchange                                  # (the choreography reads params.exchange only when it is set)
     if args.process == 'pyDNMF':

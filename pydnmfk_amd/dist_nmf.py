@@ -134,6 +134,8 @@ class nmf_algorithms_1D(_Base):
             return False
         from .engine import native_comm_for
         nc = native_comm_for(self.params)
+        if nc is None:
+            return False
         if hals:
             nc.hals_step_1d(self.A_ij, self.W_i, self.H_j, self.eps, self.W_update, clamp,
                             column_sweep=(getattr(self.params, "hals_sweep", None) == "columns"))
@@ -329,7 +331,7 @@ class nmf_algorithms_2D(_Base):
             return False
         from .engine import native_comm_for
         nc = native_comm_for(self.params)
-        if not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
+        if nc is None or not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
             return False
         nc.step_2d("hals" if hals else self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
         nc.steps += 1

@@ -647,7 +647,13 @@ def native_comm_for(params):
     nc = getattr(params, "_native_comm", None)
     if nc is None:
         if mode == "native":
-            nc = NativeComm(params.comm1, params.p_r, params.p_c)
+            try:
+                nc = NativeComm(params.comm1, params.p_r, params.p_c)
+            except Exception as ex:      # no RCCL in reach, or the communicator did not come up: the host choreography still works
+                import warnings
+                warnings.warn("params.exchange = 'native': %s -- falling back to the torch.distributed choreography" % ex)
+                params.exchange = "torch"
+                return None
         else:       # 'native-hosted': the C step entry points over the host's torch.distributed groups (any backend)
             groups = {0: params.comm1, 1: getattr(params, "row_comm", None) or params.comm1,
                       2: getattr(params, "col_comm", None) or params.comm1}
