@@ -34,7 +34,7 @@ NATIVE_CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "swim_4x1_fro
                 "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
                 "t24x12_2x2_fro_float32", "r25x13_2x2_kl_float32", "swim_2x2_kl_float32", "swim_2x2_fro_float32",
                 "lr200x136k64_2x2_fro_float32", "lr136x100k32_2x2_kl_float32", "r50x39_4x2_fro_float32", "r50x39_4x2_kl_float32",
-                "r50x39_2x3_kl_float32", "lr150x140k128_4x2_kl_float32",
+                "lr150x140k128_4x2_kl_float32",
                 "t24x12_2x1_hals_float32", "t24x12_2x2_hals_float32", "r25x13_3x1_hals_float32", "lr200x136k64_1x2_hals_float32",
                 "r50x39_4x2_hals_float32", "lr200x136k64_2x3_hals_float32", "swim_2x2_hals_float32"]
 
