@@ -314,6 +314,19 @@ int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W
 int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
                           int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
 
+/* The Frobenius steps above with A STORED as bfloat16 (dnmf_*_bf16a: `A` points to 16-bit words, lda in elements; BASELINE config
+ * 5's "mixed precision"): same arguments, same exchanges; on the 2D grid H_j is always assembled (the column-block form of A H^T
+ * exists for fp32 A only). */
+int dnmf_mu_fro_step_1d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                              float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
+int dnmf_mu_fro_step_2d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                              int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
+int dnmf_hals_fro_step_1d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                                float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* comm,
+                                void* stream);
+int dnmf_hals_fro_step_2d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                                int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* comm, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ----
  * Which shader clock does the GPU hold right now?  Launches ONE wave on `stream` that writes `n` pairs {s_memtime (shader
  * cycles), wall_clock64 (the constant 100 MHz reference)} into samples[2 n], sleeping `naps` x ~4 us between two pairs, and

@@ -102,6 +102,8 @@ SIGNATURES["dnmf_hals_fro_step_2d"] = SIGNATURES["dnmf_mu_fro_step_2d"]
 SIGNATURES["dnmf_mu_fro_step_1d"] = SIGNATURES["dnmf_mu_fro_step"][:-1] + [c_void_p, c_void_p]
 SIGNATURES["dnmf_mu_kl_step_1d"] = SIGNATURES["dnmf_mu_fro_step_1d"]
 SIGNATURES["dnmf_ws_bytes_hblocks"] = [c_long, c_long, c_int, c_long]
+for _n in ("mu_fro_step_1d", "mu_fro_step_2d", "hals_fro_step_1d", "hals_fro_step_2d"):     # bf16-stored A: same argument lists
+    SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
 _RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
              "dnmf_ws_bytes_1d": c_size_t, "dnmf_ws_bytes_hblocks": c_size_t, "dnmf_ws_bytes_2d": c_size_t}
 

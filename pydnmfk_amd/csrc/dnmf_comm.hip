@@ -319,14 +319,31 @@ struct Grid2d {
     }
 };
 
+// the entry points that touch A, for fp32 and for bf16-stored A (params.precision = 'bfloat16': Frobenius mu / hals)
+template <typename TA> struct AOps;
+template <> struct AOps<float> {
+    static constexpr bool f32 = true;
+    static int aht(const float* A, long m, long n, long lda, const float* H, int k, long ldh, float* o, long ldo, void* s) { return dnmf_aht(A, m, n, lda, H, k, ldh, o, ldo, s); }
+    static int wta(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, void* ws, size_t wb, void* s) { return dnmf_wta(A, m, n, lda, W, k, ldw, o, ldo, ws, wb, s); }
+    static int wta_gram(const float* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, float* G, void* ws, size_t wb, void* s) { return dnmf_wta_gram(A, m, n, lda, W, k, ldw, o, ldo, G, ws, wb, s); }
+    static int ahtw(const float* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G, float* W, long ldw, float eps, void* s) { return dnmf_aht_update_w(A, m, n, lda, H, k, ldh, G, W, ldw, eps, s); }
+};
+template <> struct AOps<bf16_t> {
+    static constexpr bool f32 = false;
+    static int aht(const bf16_t* A, long m, long n, long lda, const float* H, int k, long ldh, float* o, long ldo, void* s) { return dnmf_aht_bf16a(A, m, n, lda, H, k, ldh, o, ldo, s); }
+    static int wta(const bf16_t* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, void* ws, size_t wb, void* s) { return dnmf_wta_bf16a(A, m, n, lda, W, k, ldw, o, ldo, ws, wb, s); }
+    static int wta_gram(const bf16_t* A, long m, long n, long lda, const float* W, int k, long ldw, float* o, long ldo, float* G, void* ws, size_t wb, void* s) { return dnmf_wta_gram_bf16a(A, m, n, lda, W, k, ldw, o, ldo, G, ws, wb, s); }
+    static int ahtw(const bf16_t* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G, float* W, long ldw, float eps, void* s) { return dnmf_aht_update_w_bf16a(A, m, n, lda, H, k, ldh, G, W, ldw, eps, s); }
+};
+
 int grid2d_init(Grid2d& g, const char* what, dnmf_comm* c, long m_l, long n_l, long m_w, long n_h, long ldw, long ldh, int k,
-                void* ws, size_t ws_bytes, void* stream) {
+                void* ws, size_t ws_bytes, void* stream, bool f32 = true) {
     int rc;
     if ((rc = check_2d(what, c, m_l, n_l, m_w, n_h, ldw, ldh, k))) return rc;
     g.c = c; g.st = S(stream); g.k = k; g.i = c->rank / c->p_c; g.j = c->rank % c->p_c;
     g.m_l = m_l; g.n_l = n_l; g.m_w = m_w; g.n_h = n_h;
     g.ws = split_of(m_l, c->p_c); g.hs = split_of(n_l, c->p_r);
-    g.blocked = c->p_r > 1 && g.hs.equal() && n_h % 32 == 0;
+    g.blocked = f32 && c->p_r > 1 && g.hs.equal() && n_h % 32 == 0;   // (bf16-stored A has no column-block form of A H^T)
     g.sliced = g.hs.equal() && n_h % 4 == 0;
     g.L = ws2d_layout(m_l, n_l, k, c->p_r, c->p_c);
     if (ws_bytes < g.L.total) return fail(DNMF_EWS, "%s: workspace %zu < %zu", what, ws_bytes, g.L.total);
@@ -467,7 +484,10 @@ size_t dnmf_ws_bytes_1d(long m_l, long n_l, int k) {
 // [W^T A (k x n_l) | pad | W^T W (KP x KP)] message (or `overlap_chunks` column chunks: W^T A of chunk c+1 is computed on
 // the caller's stream while chunk c is reduced on the communicator's stream; chunk 0 carries W^T W).  p_r == 1: the mirror
 // image (A and H column blocks, W replicated, [A H^T | H H^T] reduced).
-int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+}  // extern "C"
+namespace {
+template <typename TA>
+int mu_fro_step_1d_impl(const TA* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
                         float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1, "mu_fro_step_1d: bad arguments");
@@ -484,12 +504,12 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
     if (w_update) {                                               // Fro_MU_update_W :716-732
         if (c->p_c == 1) {
             if ((rc = dnmf_gram_hht(H, k, n_l, ldh, G, ws, kws, stream))) return rc;
-            if ((rc = dnmf_aht_update_w(A, m_l, n_l, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
+            if ((rc = AOps<TA>::ahtw(A, m_l, n_l, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
         } else {
             const size_t off = pad64((size_t)m_l * k);
             float* AH = X; float* Gx = X + off;
             if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;
-            if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;
+            if ((rc = AOps<TA>::aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;
             if ((rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
             if ((rc = dnmf_mu_update_w(W, m_l, k, ldw, AH, k, Gx, eps, stream))) return rc;
         }
@@ -500,7 +520,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
     if (nch <= 1) {
         const size_t off = pad64((size_t)k * n_l);
         float* AtW = X; float* Gx = X + off;
-        if ((rc = dnmf_wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;
+        if ((rc = AOps<TA>::wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;
         if (xr && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
         if ((rc = dnmf_mu_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, clamp, stream))) return rc;
     } else {
@@ -514,7 +534,7 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
             const long c1 = std::min(n_l, c0 + cw);
             const size_t ne = pad64((size_t)k * (c1 - c0));
             float* AtW = X + off;
-            if ((rc = dnmf_wta(A + c0, m_l, c1 - c0, lda, W, k, ldw, AtW, c1 - c0, ws, kws, stream))) return rc;
+            if ((rc = AOps<TA>::wta(A + c0, m_l, c1 - c0, lda, W, k, ldw, AtW, c1 - c0, ws, kws, stream))) return rc;
             const size_t span = ne + (nq == 0 ? (size_t)kp * kp : 0);          // chunk 0: [W^T A chunk | W^T W] in one message
             HIP_OK(hipEventRecord(c->ready[nq], st), "mu_fro_step_1d: event record");
             HIP_OK(hipStreamWaitEvent(c->xstream, c->ready[nq], 0), "mu_fro_step_1d: stream wait");
@@ -530,6 +550,16 @@ int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, 
     }
     if (clamp) return dnmf_clamp_min(W, m_l, k, ldw, eps, stream);
     return DNMF_OK;
+}
+}  // namespace
+extern "C" {
+int dnmf_mu_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                        float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return mu_fro_step_1d_impl<float>(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
+}
+int dnmf_mu_fro_step_1d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                              float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return mu_fro_step_1d_impl<bf16_t>((const bf16_t*)A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
 }
 
 // One MU / KL step of a rank of a 1D grid (dist_nmf.py:813-869; exchanges :797,:707): [U H^T | rowsum(H)] is reduced when
@@ -573,13 +603,16 @@ size_t dnmf_ws_bytes_2d(long m_l, long n_l, int k, int p_r, int p_c) {
 // AH_glob :186-205, ATW_glob :154-172): the rank holds A_ij (m_l x n_l), its slice W_ij (m_w x k) of the grid row's W_i and its
 // slice H_ij (k x n_h) of the grid column's H_j.  Row group = the p_r ranks of its grid column (they share H_j's columns), column
 // group = the p_c ranks of its grid row (they share W_i's rows).
-int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+}  // extern "C"
+namespace {
+template <typename TA>
+int mu_fro_step_2d_impl(const TA* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
                         int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "mu_fro_step_2d: bad arguments");
     Grid2d g;
     int rc;
-    if ((rc = grid2d_init(g, "mu_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream))) return rc;
+    if ((rc = grid2d_init(g, "mu_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream, AOps<TA>::f32))) return rc;
     const int kp = 32 * kt;
     const size_t kws = g.L.g_off;
     float *G = g.at(g.L.g_off), *V = g.at(g.L.v_off), *Y = g.at(g.L.y_off), *Yb = g.at(g.L.yb_off);
@@ -589,8 +622,8 @@ int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, 
         if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                          // global_gram :114
         const float* Hop; long hb;
         if ((rc = g.gather_h(H, &Hop, &hb))) return rc;                                                   // AH_glob :195-197
-        if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream);                 // :198, H as received
-        else rc = dnmf_aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
+        if constexpr (AOps<TA>::f32) { if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream); else rc = AOps<TA>::aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream); }                 // :198, H as received
+        else rc = AOps<TA>::aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
         if (rc) return rc;
         const float* AH;
         if ((rc = g.scatter_to_w(V, &AH))) return rc;                                                     // :202
@@ -602,14 +635,24 @@ int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, 
     if ((rc = g.gather_w(W, &Wi))) return rc;                                                             // ATW_glob :163-165
     if (g.sliced) {                                                // :166 slice by slice: member q's k x n_h block is contiguous
         for (int q = 0; q < c->p_r; ++q)
-            if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
-    } else if ((rc = dnmf_wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;
+            if ((rc = AOps<TA>::wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
+    } else if ((rc = AOps<TA>::wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;
     const float* AtW;
     if ((rc = g.scatter_to_h(Y, &AtW))) return rc;                                                        // :169-171
     const long ldatw = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
     if ((rc = dnmf_mu_update_h(H, k, n_h, ldh, AtW, ldatw, G, eps, clamp, stream))) return rc;            // :224-225
     if (clamp) return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     return DNMF_OK;
+}
+}  // namespace
+extern "C" {
+int dnmf_mu_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                        int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return mu_fro_step_2d_impl<float>(A, m_l, n_l, lda, W, m_w, ldw, H, n_h, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
+}
+int dnmf_mu_fro_step_2d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                              int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return mu_fro_step_2d_impl<bf16_t>((const bf16_t*)A, m_l, n_l, lda, W, m_w, ldw, H, n_h, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
 }
 
 // The same for MU / KL (dist_nmf.py:351-407 with sum_axis :346-349, gather_W_H :268-291, UHT_glob :330-343, WTU_glob :294-318)
@@ -661,7 +704,10 @@ int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, l
 // the 8-byte sum of squares of every column is allreduced between the column kernels (utils.py:388-391), with local norms
 // (p_r == 1) it is the persistent sweep, or k column launches when `column_sweep` != 0 -- then the H sweep.  `clamp`:
 // H = max(H, eps), W = max(W, eps) afterwards (pyDNMF.py:170-172).
-int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+}  // extern "C"
+namespace {
+template <typename TA>
+int hals_fro_step_1d_impl(const TA* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
                           float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* c,
                           void* stream) {
     const int kt = kt_of(k);
@@ -681,7 +727,7 @@ int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W
         const size_t off = pad64((size_t)m_l * k);
         float* AH = X; float* Gx = X + off;
         if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;                 // :882
-        if ((rc = dnmf_aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
+        if ((rc = AOps<TA>::aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
         if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
         if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, stream);   // :884-891
         else rc = hals_sweep_local(W, m_l, k, ldw, AH, k, Gx, eps, column_sweep, ss2, ws, kws, stream);
@@ -689,7 +735,7 @@ int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W
     }
     const size_t off = pad64((size_t)k * n_l);                    // FRO_HALS_update_H :893-909
     float* AtW = X; float* Gx = X + off;
-    if ((rc = dnmf_wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;   // :902-903
+    if ((rc = AOps<TA>::wta_gram(A, m_l, n_l, lda, W, k, ldw, AtW, n_l, Gx, ws, kws, stream))) return rc;   // :902-903
     if ((c->p_r != 1 || c->always) && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
     if ((rc = dnmf_hals_update_h(H, k, n_l, ldh, AtW, n_l, Gx, eps, stream))) return rc;           // :905-909
     if (clamp) {
@@ -698,16 +744,31 @@ int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W
     }
     return DNMF_OK;
 }
+}  // namespace
+extern "C" {
+int dnmf_hals_fro_step_1d(const float* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                          float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* c,
+                          void* stream) {
+    return hals_fro_step_1d_impl<float>(A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, w_update, clamp, column_sweep, ws, ws_bytes, c, stream);
+}
+int dnmf_hals_fro_step_1d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long ldw, float* H, long ldh, int k,
+                                float eps, int w_update, int clamp, int column_sweep, void* ws, size_t ws_bytes, dnmf_comm_t* c,
+                                void* stream) {
+    return hals_fro_step_1d_impl<bf16_t>((const bf16_t*)A, m_l, n_l, lda, W, ldw, H, ldh, k, eps, w_update, clamp, column_sweep, ws, ws_bytes, c, stream);
+}
 
 // The same on the 2D grid (FRO_HALS_update, dist_nmf.py:411-470): exchanges as dnmf_mu_fro_step_2d; the column norms of the W
 // sweep are summed over ALL ranks (every rank holds other rows of W).
-int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+}  // extern "C"
+namespace {
+template <typename TA>
+int hals_fro_step_2d_impl(const TA* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
                           int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && ws && c && m_l >= 1 && n_l >= 1 && lda >= n_l, "hals_fro_step_2d: bad arguments");
     Grid2d g;
     int rc;
-    if ((rc = grid2d_init(g, "hals_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream))) return rc;
+    if ((rc = grid2d_init(g, "hals_fro_step_2d", c, m_l, n_l, m_w, n_h, ldw, ldh, k, ws, ws_bytes, stream, AOps<TA>::f32))) return rc;
     const int kp = 32 * kt;
     const size_t kws = g.L.g_off;
     float *G = g.at(g.L.g_off), *V = g.at(g.L.v_off), *Y = g.at(g.L.y_off), *Yb = g.at(g.L.yb_off);
@@ -718,8 +779,8 @@ int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W
         if ((rc = allreduce_f32(c, G_WORLD, G, (size_t)kp * kp, st))) return rc;                          // :426
         const float* Hop; long hb;
         if ((rc = g.gather_h(H, &Hop, &hb))) return rc;
-        if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream);                 // AH_glob :427
-        else rc = dnmf_aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
+        if constexpr (AOps<TA>::f32) { if (g.blocked) rc = dnmf_aht_hblocks(A, m_l, n_l, lda, Hop, hb, k, V, k, stream); else rc = AOps<TA>::aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream); }                 // AH_glob :427
+        else rc = AOps<TA>::aht(A, m_l, n_l, lda, Hop, k, hb, V, k, stream);
         if (rc) return rc;
         const float* AH;
         if ((rc = g.scatter_to_w(V, &AH))) return rc;
@@ -733,8 +794,8 @@ int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W
     if ((rc = g.gather_w(W, &Wi))) return rc;
     if (g.sliced) {
         for (int q = 0; q < c->p_r; ++q)
-            if ((rc = dnmf_wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
-    } else if ((rc = dnmf_wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;          // ATW_glob :448
+            if ((rc = AOps<TA>::wta(A + q * n_h, m_l, n_h, lda, Wi, k, k, Yb + (size_t)q * k * n_h, n_h, ws, kws, stream))) return rc;
+    } else if ((rc = AOps<TA>::wta(A, m_l, n_l, lda, Wi, k, k, Y, n_l, ws, kws, stream))) return rc;          // ATW_glob :448
     const float* AtW;
     if ((rc = g.scatter_to_h(Y, &AtW))) return rc;
     const long ldatw = (c->p_r == 1 && !g.sliced) ? n_l : n_h;
@@ -744,6 +805,16 @@ int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W
         return dnmf_clamp_min(W, m_w, k, ldw, eps, stream);
     }
     return DNMF_OK;
+}
+}  // namespace
+extern "C" {
+int dnmf_hals_fro_step_2d(const float* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                          int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return hals_fro_step_2d_impl<float>(A, m_l, n_l, lda, W, m_w, ldw, H, n_h, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
+}
+int dnmf_hals_fro_step_2d_bf16a(const void* A, long m_l, long n_l, long lda, float* W, long m_w, long ldw, float* H, long n_h, long ldh,
+                                int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, dnmf_comm_t* c, void* stream) {
+    return hals_fro_step_2d_impl<bf16_t>((const bf16_t*)A, m_l, n_l, lda, W, m_w, ldw, H, n_h, ldh, k, eps, w_update, clamp, ws, ws_bytes, c, stream);
 }
 
 }  // extern "C"

@@ -130,7 +130,8 @@ class nmf_algorithms_1D(_Base):
             return False
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
-        if self.A_ij.dtype != torch.float32:
+        fro = self.norm.upper() == 'FRO'
+        if self.A_ij.dtype != torch.float32 and not (fro and self.A_ij.dtype == torch.bfloat16):   # bf16 storage: Frobenius only
             return False
         from .engine import native_comm_for
         nc = native_comm_for(self.params)
@@ -325,7 +326,9 @@ class nmf_algorithms_2D(_Base):
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
         hals = self.method.upper() == 'HALS' and self.norm.upper() == 'FRO'
-        if not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))) or self.A_ij.dtype != torch.float32:
+        if not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))):
+            return False
+        if self.A_ij.dtype != torch.float32 and not (self.norm.upper() == 'FRO' and self.A_ij.dtype == torch.bfloat16):
             return False
         if getattr(self.params, "_slice_counts", None) is not None:         # pruned factors: sizes no longer follow the grid
             return False

@@ -559,21 +559,25 @@ class NativeComm:
 
     def step_1d(self, norm, A, W, H, eps, w_update=True, clamp=False):
         """One MU step (norm 'fro' / 'kl') of this rank of a 1D grid, exchanges included (dnmf_mu_{fro,kl}_step_1d)."""
-        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
         ws = self._workspace(m, n, k, A.device)
-        fn = lib.dnmf_mu_fro_step_1d if norm.lower() == "fro" else lib.dnmf_mu_kl_step_1d
+        if norm.lower() == "fro":
+            fn = _fn("mu_fro_step_1d", _req_a(A))                      # fp32 or bf16-stored A
+        else:
+            _req(A, "A")
+            fn = lib.dnmf_mu_kl_step_1d
         check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
                  int(bool(w_update)), int(bool(clamp)), ws.data_ptr(), ws.numel(), self.handle, _stream()))
 
     def hals_step_1d(self, A, W, H, eps, w_update=True, clamp=False, column_sweep=False):
         """One HALS / Frobenius step of this rank of a 1D grid, exchanges and column norms included (dnmf_hals_fro_step_1d)."""
-        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        sfx = _req_a(A); _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
         ws = self._workspace(m, n, k, A.device)
-        check(lib.dnmf_hals_fro_step_1d(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
+        check(_fn("hals_fro_step_1d", sfx)(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps),
                                         int(bool(w_update)), int(bool(clamp)), int(bool(column_sweep)), ws.data_ptr(), ws.numel(),
                                         self.handle, _stream()))
 
@@ -583,7 +587,7 @@ class NativeComm:
         Frobenius (norm 'hals': dnmf_hals_fro_step_2d): W, H are the
         rank's SLICES (m_w x k, k x n_h), even or ragged per the partition rule.  Raises DnmfError (DNMF_EINVAL) on slices off that
         rule or strided -- `step_2d_ok` tells beforehand."""
-        _req(A, "A"); _req(W, "W"); _req(H, "H")
+        _req(W, "W"); _req(H, "H")
         m, n = A.shape
         k = W.shape[1]
         nbytes = lib.dnmf_ws_bytes_2d(int(m), int(n), int(k), self.p_r, self.p_c)
@@ -591,7 +595,10 @@ class NativeComm:
             raise ValueError("step_2d: bad problem shape m=%d n=%d k=%d on %d x %d" % (m, n, k, self.p_r, self.p_c))
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != A.device:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
-        fn = {"fro": lib.dnmf_mu_fro_step_2d, "kl": lib.dnmf_mu_kl_step_2d, "hals": lib.dnmf_hals_fro_step_2d}[norm.lower()]
+        sfx = _req_a(A)
+        if norm.lower() == "kl" and sfx:
+            raise ValueError("step_2d: KL needs float32 data")
+        fn = {"fro": _fn("mu_fro_step_2d", sfx), "kl": lib.dnmf_mu_kl_step_2d, "hals": _fn("hals_fro_step_2d", sfx)}[norm.lower()]
         check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), W.shape[0], _ld(W), H.data_ptr(), H.shape[1], _ld(H), k, float(eps),
                  int(bool(w_update)), int(bool(clamp)), self._ws.data_ptr(), self._ws.numel(), self.handle, _stream()))
 

@@ -153,6 +153,8 @@ def run_bf16_rank(rank, world, port, grid, method, q, use_hip, cfg=None):
             args.gemm = cfg["gemm"]
         if cfg.get("overlap_min_cols"):
             args.overlap_min_cols = cfg["overlap_min_cols"]
+        if cfg.get("exchange"):
+            args.exchange = cfg["exchange"]
         s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
         (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, m, n)
         nmf = PyNMF(A[s[0]:e[0] + 1, s[1]:e[1] + 1], factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=ops)
@@ -160,6 +162,8 @@ def run_bf16_rank(rank, world, port, grid, method, q, use_hip, cfg=None):
         if cfg.get("gemm") and use_hip:
             assert nmf._ops().name == "hip-" + cfg["gemm"]
         W, H, err = nmf.fit()
+        if cfg.get("exchange"):             # every iteration ran inside the library
+            assert getattr(args, "_native_comm", None) is not None and args._native_comm.steps == itr, getattr(args, "_native_comm", None)
         q.put((rank, (rel_fro(W, Wr[rank]), rel_fro(H, Hr[rank]), abs(err - err_r)), None))
         if world > 1:
             dist.barrier()

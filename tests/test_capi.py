@@ -53,6 +53,8 @@ def test_argument_validation_without_gpu():
     assert lib.dnmf_mu_kl_step_2d(None, 8, 8, 8, None, 8, 4, None, 8, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
     assert lib.dnmf_hals_fro_step_1d(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, 0, None, 0, None, None) == -1
     assert lib.dnmf_hals_fro_step_2d(None, 8, 8, 8, None, 8, 4, None, 8, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
+    assert lib.dnmf_hals_fro_step_1d_bf16a(None, 8, 8, 8, None, 4, None, 8, 4, 1e-7, 1, 0, 0, None, 0, None, None) == -1
+    assert lib.dnmf_mu_fro_step_2d_bf16a(None, 8, 8, 8, None, 8, 4, None, 8, 8, 4, 1e-7, 1, 0, None, 0, None, None) == -1
     assert lib.dnmf_wta_gram(None, 8, 8, 8, None, 4, 4, None, 8, None, None, 0, None) == -1
     assert lib.dnmf_clock_probe(None, 4, 1, None) == -1
     assert lib.dnmf_comm_destroy(None) == 0

@@ -55,6 +55,16 @@ def test_multirank_hip_bf16_storage(grid, method):
     run_bf16(grid, method, use_hip=True)
 
 
+@pytest.mark.parametrize("grid,method", [((2, 1), "hals"), ((2, 1), "mu"), ((1, 2), "mu"), ((2, 2), "hals"), ((2, 2), "mu"), ((3, 2), "hals")])
+def test_multirank_bf16_storage_library_sequenced(grid, method):
+    """bf16-stored blocks with every step sequenced inside the library (dnmf_{mu,hals}_fro_step_{1d,2d}_bf16a over the hosted
+    gloo transport): BASELINE config 5's arithmetic (HALS / Frobenius on bf16 data) on row, column and 2D grids, even and ragged,
+    against the oracle's grid simulation on float(bf16(A))."""
+    from tests._mp import run_bf16
+    run_bf16(grid, method, use_hip=True, cfg={"exchange": "native-hosted"})
+    run_bf16(grid, method, use_hip=True, cfg={"exchange": "native-hosted", "shape": (256, 192, 16, 6)})
+
+
 @pytest.mark.parametrize("grid,method", [((2, 1), "mu"), ((1, 2), "mu"), ((2, 2), "mu"), ((2, 1), "hals"), ((4, 1), "mu")])
 def test_multirank_hip_bf16x6_gemm(grid, method):
     """params.gemm = 'bf16x6' on a grid: the split kernels on every rank's block (k = 40, local n a multiple of 128; the
