@@ -471,7 +471,8 @@ class NativeComm:
     """The grid's RCCL communicators INSIDE libdnmf_hip.so (csrc/dnmf_comm.hip) and the whole-step entry points on top of
     them: one library call enqueues kernels -> allreduce -> kernels, no Python between the launches.  Built from the host's
     existing communicator (`comm`: a dist_comm.TorchComm over all ranks), which only carries the 128-byte RCCL id from rank 0
-    to the others.  `params.exchange = 'native'` makes nmf_algorithms_1D use it (PyNMF / bench.py create it)."""
+    to the others.  `params.exchange = 'native'` makes nmf_algorithms_1D / _2D use it for MU (Frobenius, KL) and HALS steps, fp32
+    and bf16-stored data (created on first use; `NativeComm.hosted` builds one whose collectives the host performs)."""
 
     def __init__(self, comm, p_r, p_c):
         import ctypes
