@@ -330,11 +330,25 @@ class nmf_algorithms_2D(_Base):
             return False
         if self.A_ij.dtype != torch.float32 and not (self.norm.upper() == 'FRO' and self.A_ij.dtype == torch.bfloat16):
             return False
-        if getattr(self.params, "_slice_counts", None) is not None:         # pruned factors: sizes no longer follow the grid
-            return False
         from .engine import native_comm_for
         nc = native_comm_for(self.params)
-        if nc is None or not nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij):
+        if nc is None:
+            return False
+        ok = nc.step_2d_ok(self.A_ij, self.W_ij, self.H_ij)
+        if getattr(self.params, "_slice_counts", None) is not None:
+            # pruning is on (the reference's default): the slice sizes were exchanged, and the library's steps apply only if
+            # EVERY rank's slices still follow the partition rule of its pruned block -- decided once per shape by all ranks
+            # together (a rank-local decision would let the grid split between the two sequencings)
+            key = (tuple(self.A_ij.shape), tuple(map(tuple, self.params._slice_counts)))
+            cache = self.params.__dict__.setdefault("_native_2d_ok", {})
+            if key not in cache:
+                m_l, n_l = self.A_ij.shape
+                rule = ([m_l // self.p_c + (1 if q < m_l % self.p_c else 0) for q in range(self.p_c)],
+                        [n_l // self.p_r + (1 if q < n_l % self.p_r else 0) for q in range(self.p_r)])
+                mine = ok and [list(self.params._slice_counts[0]), list(self.params._slice_counts[1])] == [rule[0], rule[1]]
+                cache[key] = int(self.comm1.allreduce(0 if mine else 1)) == 0
+            ok = cache[key]
+        if not ok:
             return False
         nc.step_2d("hals" if hals else self.norm, self.A_ij, self.W_ij, self.H_ij, self.eps, self.W_update, clamp)
         nc.steps += 1

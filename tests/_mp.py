@@ -226,6 +226,8 @@ def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
             args.gemm = cfg[3]
         if len(cfg) > 4:
             args.perturbations = cfg[4]
+        if os.environ.get("DNMF_TEST_EXCHANGE"):          # ad-hoc: the same sweep with library-sequenced steps (native-hosted)
+            args.exchange = os.environ["DNMF_TEST_EXCHANGE"]
         tmp = [tempfile.mkdtemp() if rank == 0 else None]
         dist.broadcast_object_list(tmp, src=0)
         args.results_path = tmp[0] + "/"
@@ -235,6 +237,8 @@ def run_swim_nmfk_rank(rank, world, port, cfg, q, use_hip):
         nmfk = PyNMFk(A_ij, factors=None, params=args, ops=ops)
         nopt = nmfk.fit()
         sil = {k: float(np.min(v["clusterSilhouetteCoefficients"])) for k, v in nmfk.stats.items()}
+        if os.environ.get("DNMF_TEST_EXCHANGE"):
+            assert getattr(args, "_native_comm", None) is not None and args._native_comm.steps > 0
         q.put((rank, (int(nopt), sil, time.time() - t0), None))
         dist.barrier()
         dist.destroy_process_group()

@@ -240,3 +240,18 @@ def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):
     sil = outs[0][1]
     assert sil[17] < 0.3 and sil[16] > sil[17], sil
     print("swim 2x2 KL short (%s): nopt" % gemm, outs[0][0], "min silhouettes", sil, "seconds", round(outs[0][2], 1))
+
+
+def test_swim_2x2_kl_nmfk_through_library_sequenced_steps(monkeypatch):
+    """The NMFk driver on the 2 x 2 grid with every 2D KL step sequenced inside the library (exchange = 'native-hosted': the C
+    steps over the hosted gloo transport).  Pruning is on (the reference's default), so the ranks first agree that the pruned
+    slices still follow the partition rule; the sweep must then give the choreography's estimate and silhouettes exactly --
+    same kernels, same order, same sums."""
+    from tests._mp import run_swim_nmfk
+    cfg = (16, 17, 100, "fp32", 3)
+    ref = run_swim_nmfk(cfg, use_hip=True, timeout=300)
+    monkeypatch.setenv("DNMF_TEST_EXCHANGE", "native-hosted")
+    outs = run_swim_nmfk(cfg, use_hip=True, timeout=300)          # (each rank asserts that steps ran inside the library)
+    assert [o[0] for o in outs] == [o[0] for o in ref]
+    for o, r in zip(outs, ref):
+        assert o[1] == r[1], (o[1], r[1])
