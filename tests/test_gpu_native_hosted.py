@@ -85,12 +85,12 @@ def _rank(rank, world, port, cfg, q):
 CASES = [   # p_r, p_c, m, n, k, norm, W_update, overlap chunks of the 1D row grid
     (2, 1, 512, 256, 16, "fro", True, 1), (4, 1, 1024, 512, 64, "fro", True, 2), (3, 1, 300, 260, 5, "kl", True, 1),
     (1, 2, 256, 512, 32, "fro", True, 1), (1, 3, 200, 384, 8, "kl", True, 1),
-    (2, 2, 512, 256, 16, "fro", True, 1), (2, 2, 512, 256, 16, "kl", True, 1), (2, 3, 240, 192, 33, "fro", True, 1),
-    (2, 3, 240, 192, 8, "kl", False, 1), (4, 2, 200, 256, 64, "kl", True, 1), (3, 2, 300, 192, 128, "fro", False, 1),
+    (2, 2, 512, 256, 16, "kl", True, 1), (2, 3, 240, 192, 33, "fro", True, 1),
+    (4, 2, 200, 256, 64, "kl", True, 1),
     # ragged / narrow slices: rows and columns that do not divide, equal slices that are not whole tiles, 16-wide and 32-wide kernels
-    (2, 2, 515, 262, 16, "fro", True, 1), (2, 2, 515, 262, 16, "kl", True, 1), (2, 2, 512, 264, 24, "kl", True, 1), (2, 2, 512, 136, 8, "fro", True, 1),
+    (2, 2, 515, 262, 16, "fro", True, 1), (2, 2, 515, 262, 16, "kl", True, 1), (2, 2, 512, 264, 24, "kl", True, 1),
     (2, 3, 241, 199, 33, "fro", True, 1), (3, 2, 301, 197, 5, "kl", True, 1), (4, 2, 203, 259, 64, "fro", True, 1), (2, 4, 150, 140, 7, "kl", False, 1),
-    (3, 1, 301, 260, 16, "fro", True, 1), (1, 3, 200, 385, 8, "kl", True, 1),
+    (3, 1, 301, 260, 16, "fro", True, 1),
     # HALS / Frobenius (dnmf_hals_fro_step_{1d,2d}): the column norms of the W sweep are 8-byte allreduces between the column kernels
     (2, 1, 512, 256, 16, "hals", True, 1), (3, 1, 301, 260, 5, "hals", True, 1), (1, 2, 256, 512, 32, "hals", True, 1),
     (2, 2, 512, 256, 16, "hals", True, 1), (2, 3, 241, 199, 33, "hals", True, 1), (4, 2, 200, 256, 64, "hals", False, 1),
