@@ -16,13 +16,18 @@ from .pyDNMFk import PyNMFk
 class pyDNMFk_Runner:
     def __init__(self, init="rand", itr=5000, norm="kl", method="mu", verbose=False, checkpoint=False,
                  timing_stats=False, prune=False, precision="float32", perturbations=20, noise_var=0.015,
-                 sill_thr=0.6, sampling="uniform", process="pyDNMF", rng="device"):
+                 sill_thr=0.6, sampling="uniform", process="pyDNMF", rng="device", exchange="auto"):
         self.init, self.itr, self.norm, self.method = init, itr, norm, method
         self.verbose, self.checkpoint, self.timing_stats, self.prune = verbose, checkpoint, timing_stats, prune
         self.precision = precision
         self.perturbations, self.noise_var, self.sill_thr, self.sampling = perturbations, noise_var, sill_thr, sampling
         self.process = process
         self.rng = rng      # 'device': the block is uploaded once, random numbers are drawn on the GPU; 'numpy': the reference's host stream
+        # who sequences the exchanges of a multi-rank step: 'torch' (torch.distributed between the launches), 'native' (whole steps
+        # inside libdnmf_hip.so over its own RCCL communicators) or 'auto' (native for hals on grids with p_r > 1: main.py)
+        if exchange not in ("auto", "torch", "native"):
+            raise ValueError("exchange should be auto, torch or native")
+        self._exchange_request = exchange
         self.fpath = self.ftype = self.fname = self.results_path = None
         self.k_range = self.step_k = None
         if self.process not in ["pyDNMFk", "pyDNMF"]:
@@ -41,6 +46,13 @@ class pyDNMFk_Runner:
         if len(grid) != 2 or len(k_range) != 2:
             raise ValueError("grid and k_range needs to be a list sized 2")
         self.p_r, self.p_c = grid[0], grid[1]
+        ex = self._exchange_request
+        if ex == "auto":
+            ex = "native" if (str(self.method).lower() == "hals" and self.p_r > 1) else "torch"
+        if ex == "native" and self.main_comm.size > 1:
+            self.exchange = "native"
+        elif hasattr(self, "exchange"):
+            del self.exchange
         self.start_k, self.end_k = k_range[0], k_range[1]
         self.fpath, self.ftype, self.fname, self.results_path = fpath, ftype, fname, results_path
         self.results_paths = results_path
