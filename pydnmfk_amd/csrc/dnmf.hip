@@ -223,9 +223,7 @@ size_t partial_bytes(long m, long n, int k) {
     }
     {   // kl_uht column-split slabs
         const long rowtiles = cdiv(m, 128);
-        long ns = std::min<long>(std::max<long>(1, cdiv(1536, rowtiles)), std::max<long>(1, n / 256));
-        const long cps = round_up(cdiv(n, ns), BK);
-        const int nsp = (int)cdiv(n, cps);
+        const int nsp = plan_uht(m, n, kt).nsplit;
         if (nsp > 1) b = std::max(b, (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes(nsp, (int)m, k));
         if (k <= 16) {   // kl_uht16: 16-wide slabs, also for a single split (ranks below 16 go through the slab)
             const long ns16 = std::min<long>(std::max<long>(1, 1024 / rowtiles), std::max<long>(1, n / 256));

@@ -137,7 +137,10 @@ Tn16Plan plan_wtu16(long m, long n) {
 
 inline int tn_nt(int kt) { return kt == 4 ? 2 : 4; }  // column sets per wave in TN form
 
-inline int kl_nt(int kt) { return kt == 1 ? 4 : 2; }  // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
+inline int kl_nt(int kt) {   // column sets per wave in kl_wtu (three live tiles: out, S/U, A)
+    static const int nt1 = (int)tune("DNMF_WTU_NT1", 4);
+    return kt == 1 ? nt1 : 2;
+}
 
 // zero-padded factor images of the KL products (see pad_factors)
 size_t pad_bytes(long m, long n, int kp) {
@@ -196,12 +199,26 @@ bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k,
 
 struct UhtPlan { int nsplit; long cols_per_split; };
 
-UhtPlan plan_uht(long m, long n) {
+// Column splits of kl_uht (rowtiles x nsplit workgroups).  Round 4: the grid is cut to WHOLE resident rounds -- the pipelined
+// kernel (csrc/dnmf_kluht.h) holds 2 / 3 / 4 workgroups per CU at k = 128 / 64 / 32, and a last round that fills half the
+// chip costs as much as a full one (32768 x 16384, k = 32: 1536 workgroups on 1024 slots were 1.5 rounds).  Model: time ~
+// rounds x (column tiles per split + 3 tiles' worth of prologue / epilogue); fewest splits among the best (fewer slabs to
+// write and reduce); every split keeps at least 8 column tiles.
+inline int uht_wgs_per_cu(int kt) { return kt == 4 ? 2 : (kt == 2 ? 3 : 4); }
+UhtPlan plan_uht(long m, long n, int kt) {
     UhtPlan u;
-    const long rowtiles = cdiv(m, 128);
-    long ns = std::max<long>(1, cdiv(1536, rowtiles));           // aim at >= 1536 workgroups (2 resident per CU)
-    ns = std::min<long>(ns, std::max<long>(1, n / 256));         // at least 8 column tiles per split
-    u.cols_per_split = round_up(cdiv(n, ns), 32);          // 32 = BK, the column tile of the NT-shaped kernels
+    const long rowtiles = cdiv(m, 128), slots = 256L * uht_wgs_per_cu(kt), coltiles = cdiv(n, 32);
+    const long max_ns = std::min<long>(32, std::max<long>(1, n / 256));
+    long best_ns = 1;
+    double best_t = 0;
+    for (long ns = 1; ns <= max_ns; ++ns) {
+        const long cps = round_up(cdiv(n, ns), 32);
+        const long nsp = cdiv(n, cps);
+        const double t = (double)cdiv(rowtiles * nsp, slots) * (double)(cps / 32 + 3);
+        if (ns == 1 || t < best_t * 0.97) { best_t = t; best_ns = ns; }
+    }
+    (void)coltiles;
+    u.cols_per_split = round_up(cdiv(n, best_ns), 32);          // 32 = BK, the column tile of the NT-shaped kernels
     u.nsplit = (int)cdiv(n, u.cols_per_split);
     return u;
 }

@@ -14,6 +14,12 @@ __attribute__((visibility("hidden"))) int dnmf_kl16_wtu_(const float* A, long m,
                                                          const float* H, long ldh, int k, float eps, float* WTU, long ldo,
                                                          void* ws, size_t ws_bytes, void* stream);
 
+// the software-pipelined U H^T for whole 128-row tiles (csrc/dnmf_kluht.hip)
+__attribute__((visibility("hidden"))) int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const float* W, long ldw,
+                                                            const float* H, long ldh, long hblk, long hextra, int kt, float eps,
+                                                            float* out, long ldo, long split_stride, long cols_per_split,
+                                                            int nsplit, void* stream);
+
 extern "C" {
 
 static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
@@ -160,7 +166,7 @@ int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long l
     const int kp = 32 * kt;
     const int k_out = k;                                   // columns of UHT the caller gets
     if (int rc16 = dnmf_kl16_uht_(A, m, n, lda, W, ldw, H, ldh, hblk, k, eps, UHT, ldo, ws, ws_bytes, stream); rc16 != 1) return rc16;
-    UhtPlan u = plan_uht(m, n);
+    UhtPlan u = plan_uht(m, n, kt);
     if (hblk) {                                            // a column split must not straddle a block: cols_per_split divides hblk
         const long nb = n / hblk;
         long s = std::max<long>(1, (u.nsplit + nb / 2) / nb);
@@ -187,9 +193,23 @@ int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long l
     const long ldout = split ? kp : ldo;
     const int out_cols = split ? kp : k_out;
     const bool fast = nn_fast(A, n, lda, W, ldw, H, ldh, k) && aligned16(out) && ldout % 4 == 0;
-    const dim3 grid((unsigned)cdiv(m, 128), (unsigned)u.nsplit), block(256);
-    const size_t lds = 2ul * kp * BK * sizeof(float);
     hipStream_t st = S(stream);
+    // Whole 128-row tiles of a friendly problem (aligned rows, k = KP or padded to it, whole 32-column tiles, 2 GiB descriptor
+    // windows) go to the software-pipelined kernel; a ragged last row tile -- or everything else -- to kl_uht_kernel.  Same
+    // arithmetic in the same order: the two are bit identical.
+    static const int pipe_on = (int)tune("DNMF_KLUHT_PIPE", 1);
+    auto window = [](long rows, long ld, long cols) { return (rows * ld + cols) * 4 < 0x7fffffffL; };
+    long rowtile0 = 0;
+    if (pipe_on && fast && k == kp && m >= 128 && n % BK == 0 && u.cols_per_split % BK == 0 && out_cols >= kp &&
+        window(128, lda, u.cols_per_split) && window(kp, ldh, u.cols_per_split)) {
+        rowtile0 = m / 128;
+        if (int rcp = dnmf_kl_uht_pipe_(A, rowtile0, n, lda, W, ldw, H, ldh, hblk, a.hextra, kt, eps, out, ldout, (long)m * kp,
+                                        u.cols_per_split, u.nsplit, stream); rcp) return rcp;
+    }
+    a.rowtile0 = rowtile0;
+    const dim3 grid((unsigned)(cdiv(m, 128) - rowtile0), (unsigned)u.nsplit), block(256);
+    const size_t lds = 2ul * kp * BK * sizeof(float);
+    if (grid.x > 0) {
 #define UH_CASE(KT_)                                                                                                  \
     if (kt == KT_) {                                                                                                  \
         if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
@@ -199,6 +219,7 @@ int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long l
     }
     UH_CASE(1) UH_CASE(2) UH_CASE(4)
 #undef UH_CASE
+    }
     int rc = check_launch("kl_uht");
     if (rc || !split) return rc;
     return launch_reduce((const float*)ws, (long)m * kp, kp, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
@@ -218,7 +239,7 @@ size_t dnmf_ws_bytes_hblocks(long m, long n, int k, long nh) {
     if (kt < 0 || m < 1 || n < 1 || nh < 1 || n % nh) return 0;
     const int kp = 32 * kt;
     // a column split never straddles a block: at least n / nh splits, at most twice the planner's count
-    const UhtPlan u = plan_uht(m, n);
+    const UhtPlan u = plan_uht(m, n, kt);
     const long nb = n / nh, nsp = nb * std::max<long>(1, (u.nsplit + nb / 2) / nb);
     const size_t slabs = (size_t)nsp * m * kp * sizeof(float) + reduce_scratch_bytes((int)nsp, (int)m, k);
     return std::max(dnmf_ws_bytes(m, n, k), align256(slabs) + pad_bytes(m, n, kp));
@@ -258,7 +279,16 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
         if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
         else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
     }
+#ifdef DNMF_TUNING
+    static const long wvar = tune("DNMF_WTU_VAR", 0);          // A/B: 10 * nt + waves per SIMD for kt = 1; 100 + waves per SIMD for kt = 2
+#define WV(KT_, NT_, OCC_, VAR_) if (kt == KT_ && nt == NT_ && wvar == VAR_ && fast) { \
+        hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true, OCC_>), grid, block, lds, st, a, rowblks_per_chunk); } else
+    WV(1, 2, 2, 22) WV(1, 2, 3, 23) WV(1, 4, 1, 41) WV(2, 2, 1, 101) WV(2, 2, 2, 102)
+#undef WV
+#endif
+    {
     WU_CASE(1, 4) WU_CASE(2, 2) WU_CASE(4, 2)
+    }
 #undef WU_CASE
     int rc = check_launch("kl_wtu");
     if (rc) return rc;

@@ -25,6 +25,8 @@ struct NnArgs {
                                                      // hblk = 0: one k x n matrix.  A column split never straddles a block.
     int kreal;                                       // NN_KL_*: the rank before zero padding to KP: S = W H skips the MFMA steps whose 8
                                                      // contraction indices are all padding (k <= 16: half of that product's matrix work)
+    long rowtile0;                                   // kl_uht: first 128-row tile of this launch (the full tiles below it went to
+                                                     // kl_uht_pipe_kernel, csrc/dnmf_kluht.h)
 };
 
 // S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
@@ -321,7 +323,7 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
 // -- and each register set is refilled in the phase after the one that consumed it, so nothing is double buffered.
 // With predicated loads (kl_wtu_block) hipcc drains vmcnt(0) at every one of the 48 loads of a block and the single
 // wave per SIMD waits out each latency: MFMA busy 51 % at a 2.39 GHz clock (32768 x 32768, k = 128).
-template <int KT, int NT>
+template <int KT, int NT, bool SKIP>
 __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const NnArgs& p, const float* smem, long rb0,
                                                   long rb1, long col0, int li, int h) {
     constexpr int CW = 32 * NT;
@@ -365,8 +367,9 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
                 for (int e = 0; e < 4; ++e) load_vec_raw<NT>(hb[(s + 1) & 1][e], &smem[(8 * (s + 1) + 4 * h + e) * CW + NT * li]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (KT > 1 || 8 * s < p.kreal) {                     // wave uniform; the loads above stay unconditional (pipeline).  KT = 1 only:
-                                                                 // at KT = 2 the branches cost the kernel its register allocation (104 spills)
+            if (!SKIP || 8 * s < p.kreal) {                      // wave uniform; the loads above stay unconditional (pipeline).  SKIP: KT = 1
+                                                                 // with a rank of at most 24 only (round 4: the test itself -- a scalar
+                                                                 // branch per step -- cut the block into basic blocks hipcc schedules one by one)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -391,8 +394,8 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
     }
 }
 
-template <int KT, int NT, bool FAST>
-__global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
+template <int KT, int NT, bool FAST, int OCC = (KT == 2 ? 2 : 1)>
+__global__ __launch_bounds__(256, OCC) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = 32 * KT, CW = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(256, KT == 2 ? 2 : 1) void kl_wtu_kernel(NnArgs p, 
     const long rb0 = chunk * rowblks_per_chunk;
     if (FAST && p.pipe && p.k == KP && col0 + CW <= p.n && rb1 * 32 <= p.m &&
         buf_window_ok((rb1 - rb0 + 1) * 32, p.lda, CW) && buf_window_ok((rb1 - rb0 + 1) * 32, p.ldw, KP)) {   // (one descriptor per chunk)
-        kl_wtu_chunk_pipe<KT, NT>(out, p, smem, rb0, rb1, col0, li, h);
+        if (KT == 1 && p.kreal <= 24) kl_wtu_chunk_pipe<KT, NT, KT == 1>(out, p, smem, rb0, rb1, col0, li, h);
+        else kl_wtu_chunk_pipe<KT, NT, false>(out, p, smem, rb0, rb1, col0, li, h);
     } else {
         for (long rb = rb0; rb < rb1; ++rb) kl_wtu_block<KT, NT, FAST, false>(out, p, smem, rb * 32, col0, li, h);
     }
@@ -458,7 +462,8 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
                                             long cols_per_split, int out_cols, float* smem) {
     constexpr int KP = 32 * KT, T = 256, STAGE = KP * BK, NY = KP / (T / 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-    const long arow = (long)blockIdx.x * 128 + wave * 32 + li;
+    const long rtile = (long)blockIdx.x + p.rowtile0;
+    const long arow = rtile * 128 + wave * 32 + li;
     const bool rok = arow < p.m;
     const long cbeg = (long)blockIdx.y * cols_per_split;
     long cend = cbeg + cols_per_split;
@@ -471,7 +476,7 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
     i32x4 rsa = {0, 0, 0, 0}, rsh = {0, 0, 0, 0};
     int va = 0, vh[NY];
     if constexpr (INTERIOR) {
-        rsa = buf_rsrc(p.A + (long)blockIdx.x * 128 * p.lda + cbeg);
+        rsa = buf_rsrc(p.A + rtile * 128 * p.lda + cbeg);
         rsh = buf_rsrc(Hb + cbeg);
         va = (int)((wave * 32 + li) * p.lda * 4) + 16 * h;
         stage_offsets<KP, T>(vh, p.ldh, tid);
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, 
                                                         long split_stride, long cols_per_split, int out_cols) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block-uniform: all 128 rows in bounds and no rank padding -> branch-free W / A / output accesses
-    const bool interior = FAST && p.k == 32 * KT && ((long)blockIdx.x + 1) * 128 <= p.m && out_cols >= 32 * KT;
+    const bool interior = FAST && p.k == 32 * KT && ((long)blockIdx.x + p.rowtile0 + 1) * 128 <= p.m && out_cols >= 32 * KT;
     if (interior) kl_uht_body<KT, FAST, true>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
     else kl_uht_body<KT, FAST, false>(p, out_base, ldo, split_stride, cols_per_split, out_cols, smem);
 }
