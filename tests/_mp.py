@@ -259,3 +259,82 @@ def run_swim_nmfk(cfg, use_hip=True, timeout=3600):
     for rank, out, err in res:
         assert err is None, "rank %d failed:\n%s" % (rank, err)
     return [out for _, out, _ in sorted(res, key=lambda r: r[0])]
+
+
+def run_nmfk_golden_rank(rank, world, port, fixture, q, use_hip, extra):
+    """PyNMFk on the problem, grid and parameters of a reference-generated NMFk fixture (tests/golden/make_golden_nmfk.py:
+    nmfk_2x1.npz, nmfk_hals_1x1.npz, nmfk_hals_2x1.npz).  numpy input: every rank consumes the reference's numpy stream
+    (every MPI rank of the reference seeds its own process-global generator alike, pyDNMFk.py:31-32)."""
+    try:
+        import json
+        import tempfile
+        import numpy as np
+        import torch.distributed as dist
+        from pydnmfk_amd.dist_comm import MPI_comm
+        from pydnmfk_amd.pyDNMFk import PyNMFk
+        from pydnmfk_amd.utils import determine_block_params, parse
+        from tests._golden import GOLDEN
+
+        torch.set_num_threads(1)
+        if use_hip:
+            torch.cuda.set_device(0)
+            ops = None
+        else:
+            from tests._ops_double import OracleOps
+            ops = OracleOps()
+        if world > 1:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        z = np.load(os.path.join(GOLDEN, fixture))
+        meta = json.loads(str(z["meta"]))
+        A = z["A"]
+        p_r, p_c = meta["grid"]
+        comms = MPI_comm(None, p_r, p_c)
+        args = parse()
+        args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = world, rank, comms.comm, comms, p_r, p_c
+        args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        tmp = [tempfile.mkdtemp() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(tmp, src=0)
+        args.fpath, args.fname, args.ftype = tmp[0] + "/", "synth", "npy"
+        args.start_k, args.end_k, args.step_k = meta["start_k"], meta["end_k"], 1
+        args.sill_thr, args.itr, args.init, args.verbose = meta["sill_thr"], meta["itr"], "rand", False
+        args.norm, args.method, args.prune = meta["norm"], meta["method"], False
+        args.perturbations, args.noise_var, args.checkpoint = meta["perturbations"], meta["noise_var"], False
+        args.results_path = tmp[0] + "/results/"
+        for key, val in (extra or {}).items():
+            setattr(args, key, val)
+        s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+        A_ij = np.ascontiguousarray(A[s[0]:e[0] + 1, s[1]:e[1] + 1])
+        nmfk = PyNMFk(A_ij, factors=None, params=args, ops=ops)
+        nopt = nmfk.fit()
+        stats = {k: {key: np.asarray(val) for key, val in st.items()} for k, st in nmfk.stats.items()}
+        if (extra or {}).get("exchange") in ("native", "native-hosted"):
+            assert getattr(args, "_native_comm", None) is not None and args._native_comm.steps > 0
+        q.put((rank, (int(nopt), stats), None))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+def run_nmfk_golden(fixture, use_hip=False, timeout=600, extra=None):
+    """-> [(nopt, {k: statistics}) per rank]"""
+    import json
+    import numpy as np
+    from tests._golden import GOLDEN
+    grid = json.loads(str(np.load(os.path.join(GOLDEN, fixture))["meta"]))["grid"]
+    world = grid[0] * grid[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_nmfk_golden_rank, args=(r, world, port, fixture, q, use_hip, extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, err in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+    return [out for _, out, _ in sorted(res, key=lambda r: r[0])]

@@ -8,6 +8,14 @@ of latent features (3 Gaussian bumps + noise, 48 x 40), k = 1..5, 6 perturbation
 init='rand', on grids 1x1 and 2x1, and records per k: min / mean silhouettes, average reconstruction error, the
 regression error and the column-error vector, plus the estimated k.  Output: tests/golden/nmfk_<grid>.npz.
 (matplotlib plotting in the reference's fit() is redirected to the Agg backend.)
+
+Round 4 -- BASELINE config 5's method and multi-rank NMFk: `hals3` (the same problem with method='hals', 1x1 and 2x1) and
+`fro3` on 2x1.  The reference seeds and draws from numpy's PROCESS-GLOBAL generator (pyDNMFk.py:31-32,42,50;
+pyDNMF.py:112-126); under mpirun every rank is a process with a generator of its own, all seeded alike.  The mpi4py
+stand-in runs ranks as threads of one process, so this script gives every rank thread a private
+numpy.random.RandomState behind np.random.seed / rand / random_sample / poisson (`per_rank_numpy_rng`) -- the legacy
+functions are methods of one global RandomState, so a private instance seeded the same way yields the same stream a
+separate process would see.  The reference itself is untouched.
 """
 import json
 import os
@@ -34,6 +42,22 @@ from pyDNMFk.pyDNMFk import PyNMFk  # noqa: E402
 from pyDNMFk.utils import determine_block_params, parse  # noqa: E402
 
 
+def per_rank_numpy_rng():
+    """np.random.{seed,rand,random_sample,poisson} -> a RandomState private to the calling thread (= simulated rank)."""
+    import threading
+    tls = threading.local()
+
+    def rs():
+        if not hasattr(tls, "rs"):
+            tls.rs = np.random.RandomState()
+        return tls.rs
+
+    np.random.seed = lambda seed=None: rs().seed(seed)
+    np.random.rand = lambda *a: rs().rand(*a)
+    np.random.random_sample = lambda size=None: rs().random_sample(size)
+    np.random.poisson = lambda lam=1.0, size=None: rs().poisson(lam, size)
+
+
 def dataset():
     rs = np.random.RandomState(11)
     m, n, k = 48, 40, 3
@@ -53,14 +77,16 @@ def dataset_kl5():
     return (W @ H + 0.01 * rs.rand(m, n)).astype(np.float32)
 
 
-CASES = {   # name -> (dataset, start_k, end_k, norm, itr, output stem)
+CASES = {   # name -> (dataset, start_k, end_k, norm, itr, output stem[, method])
     "fro3": (dataset, 1, 5, "fro", 300, "nmfk"),
     "kl5": (dataset_kl5, 3, 7, "kl", 400, "nmfk_kl5"),
+    "hals3": (dataset, 1, 5, "fro", 100, "nmfk_hals", "hals"),
 }
 
 
 def run(grid, case="fro3"):
-    make, k0, k1, norm, itr, stem = CASES[case]
+    make, k0, k1, norm, itr, stem = CASES[case][:6]
+    method = CASES[case][6] if len(CASES[case]) > 6 else "mu"
     A = make()
     p_r, p_c = grid
     tmp = tempfile.mkdtemp()
@@ -75,7 +101,7 @@ def run(grid, case="fro3"):
         args.fpath, args.fname, args.ftype = tmp + "/", "synth", "npy"
         args.start_k, args.end_k, args.step_k = k0, k1, 1
         args.sill_thr, args.itr, args.init, args.verbose = 0.8, itr, "rand", False
-        args.norm, args.method, args.prune = norm, "mu", False
+        args.norm, args.method, args.prune = norm, method, False
         args.perturbations, args.noise_var, args.checkpoint = 6, 0.03, False
         args.results_path = tmp + "/results/"
         s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
@@ -90,7 +116,7 @@ def run(grid, case="fro3"):
                 out["k%d_%s" % (k, key)] = np.array(hf[key])
     out["A"] = A
     out["meta"] = np.array(json.dumps(dict(grid=list(grid), start_k=k0, end_k=k1, perturbations=6, noise_var=0.03,
-                                           itr=itr, sill_thr=0.8, norm=norm, method="mu")))
+                                           itr=itr, sill_thr=0.8, norm=norm, method=method)))
     np.savez_compressed(os.path.join(HERE, "%s_%dx%d.npz" % ((stem,) + tuple(grid))), **out)
     shutil.rmtree(tmp, ignore_errors=True)
     print(grid, "nopt =", res, {k: (round(float(out["k%d_clusterSilhouetteCoefficients" % k].min()), 3),
@@ -119,11 +145,16 @@ def checkpoint_fixture():
 
 
 if __name__ == "__main__":
-    # Only the single-rank run is kept as a fixture: `sample` seeds the process-global numpy RNG (pyDNMFk.py:31-32),
-    # and the thread-simulated ranks of the mpi4py stand-in share that RNG, so multi-rank draws interleave
-    # nondeterministically here (real MPI ranks are separate processes).  run((2, 1)) is still useful as a smoke check.
+    # Rounds 1-3 kept only single-rank fixtures (thread-simulated ranks shared the process-global numpy RNG); round 4 gives
+    # every rank thread its own generator (per_rank_numpy_rng), which makes multi-rank runs deterministic and equal to what
+    # separate MPI processes draw.  `multirank` writes nmfk_2x1.npz, nmfk_hals_1x1.npz, nmfk_hals_2x1.npz.
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
         checkpoint_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "multirank":
+        per_rank_numpy_rng()
+        run((1, 1), "hals3")
+        run((2, 1), "hals3")
+        run((2, 1), "fro3")
     elif len(sys.argv) > 1 and sys.argv[1] in CASES:
         run((1, 1), sys.argv[1])
     else:

@@ -30,6 +30,19 @@ def test_nmfk_kl_on_gpu_matches_reference_statistics(tmp_path, golden_dir):
     check_against_golden_kl5(nmfk, nmfk.fit(), z)
 
 
+@pytest.mark.parametrize("fixture,exchange", [("nmfk_hals_1x1.npz", None), ("nmfk_2x1.npz", None), ("nmfk_hals_2x1.npz", None),
+                                              ("nmfk_hals_2x1.npz", "native-hosted")])
+def test_nmfk_hals_and_two_rank_fixtures_on_gpu(fixture, exchange, golden_dir):
+    """BASELINE config 5's method pinned to the REFERENCE: the NMFk sweep with HALS inside every fit, on one
+    rank and on a 2 x 1 grid (two processes on the one GPU), against statistics the unmodified reference wrote for the same
+    data, seeds and parameters -- and once more with every HALS step sequenced inside the library (dnmf_hals_fro_step_1d over
+    the hosted transport)."""
+    from tests._mp import run_nmfk_golden
+    from tests.test_nmfk_cpu import check_nmfk_fixture
+    outs = run_nmfk_golden(fixture, use_hip=True, timeout=600, extra={"exchange": exchange} if exchange else None)
+    check_nmfk_fixture(outs, np.load(golden_dir + "/" + fixture), tight=False)
+
+
 def test_nmfk_device_resident_input(tmp_path, golden_dir):
     """CUDA-tensor input: perturbations are drawn on the device (different stream, same distribution) -> the estimate
     and the error levels still match, silhouettes are compared loosely."""

@@ -108,6 +108,51 @@ def test_nmfk_kl_matches_reference_statistics(tmp_path, golden_dir):
     check_against_golden_kl5(nmfk, nmfk.fit(), z, tight=True)
 
 
+def check_nmfk_fixture(outs, z, tight):
+    """Rank outputs of tests/_mp.run_nmfk_golden against a round-4 fixture (nmfk_2x1 / nmfk_hals_1x1 / nmfk_hals_2x1:
+    the 3-feature problem, k = 1..5, 6 perturbations; reference: pyDNMFk.py:169-258 over dist_nmf.py:873-934 / 716-751 and
+    the clustering allreduces of dist_clustering.py:84-160).  tight = the float64-accumulating checker back end, which
+    follows the reference's fp32 numpy run to 1e-4 on every silhouette -- unstable clusterings included -- and to 1e-6 on
+    the errors; the fp32 MFMA kernels are held to the reference's statistics where the clustering is stable (k <= 3) and to
+    the levels above it."""
+    import json
+    meta = json.loads(str(z["meta"]))
+    assert [o[0] for o in outs] == [int(z["nopt"])] * len(outs) == [3] * len(outs)
+    for o in outs[1:]:                       # every rank ends with the same statistics
+        for k in o[1]:
+            for key in ("clusterSilhouetteCoefficients", "avgErr", "AIC", "L_errDist"):
+                assert np.allclose(o[1][k][key], outs[0][1][k][key], rtol=1e-6, atol=1e-9), (k, key)
+    for k in range(meta["start_k"], meta["end_k"] + 1):
+        st = outs[0][1][k]
+        ref = {key: np.asarray(z["k%d_%s" % (k, key)], dtype=np.float64) for key in
+               ("clusterSilhouetteCoefficients", "avgSilhouetteCoefficients", "avgErr", "L_errDist", "L_err", "AIC")}
+        sil = np.asarray(st["clusterSilhouetteCoefficients"], dtype=np.float64)
+        assert sil.shape == ref["clusterSilhouetteCoefficients"].shape == (k,)
+        stable = ref["clusterSilhouetteCoefficients"].min() > 0.5
+        if tight:
+            assert np.allclose(sil, ref["clusterSilhouetteCoefficients"], atol=5e-4), (k, sil, ref["clusterSilhouetteCoefficients"])
+            assert abs(float(st["avgErr"]) / float(ref["avgErr"]) - 1) < 2e-6, k
+            assert abs(float(st["AIC"]) / float(ref["AIC"]) - 1) < 1e-6, k
+        else:
+            if stable:
+                assert np.allclose(sil, ref["clusterSilhouetteCoefficients"], atol=0.08), (k, sil, ref["clusterSilhouetteCoefficients"])
+            else:
+                assert sil.min() < 0.6, (k, sil)
+            assert abs(float(st["avgErr"]) / float(ref["avgErr"]) - 1) < 5e-3, k
+            assert abs(float(st["AIC"]) / float(ref["AIC"]) - 1) < 1e-3, k
+        if k <= 3:      # the regression fit starts from the reference's stacked H (hall_layout = 'reference')
+            assert abs(float(st["L_errDist"]) / float(ref["L_errDist"]) - 1) < (1e-5 if tight else 2e-3), k
+            assert np.allclose(st["L_err"], ref["L_err"], rtol=1e-3 if tight else 5e-3, atol=1e-5), k
+
+
+@pytest.mark.parametrize("fixture", ["nmfk_hals_1x1.npz", "nmfk_2x1.npz", "nmfk_hals_2x1.npz"])
+def test_nmfk_hals_and_two_rank_fixtures(fixture, golden_dir):
+    """BASELINE config 5's method (HALS) and NMFk on more than one rank against the reference itself: fixtures written by the
+    unmodified reference on 1 x 1 and 2 x 1 grids (make_golden_nmfk.py multirank), our host code over the checker back end."""
+    from tests._mp import run_nmfk_golden
+    check_nmfk_fixture(run_nmfk_golden(fixture, use_hip=False, timeout=600), np.load(golden_dir + "/" + fixture), tight=True)
+
+
 def test_sample_follows_reference_stream():
     """pyDNMFk.py:26-49: X * (1 + nv + 2 nv U) with the global numpy RNG seeded per perturbation."""
     from pydnmfk_amd.pyDNMFk import sample
