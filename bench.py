@@ -27,6 +27,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   cpu_baseline : the numpy oracle (port of the reference's path) in the reference's process model -- P = min(8, cores)
                  single-thread processes, each on its 1/P row slab of X -- timed on the host (N=1 only)
 With no flags: N = 1 and 500 timed steps (about 2.3 s of GPU time).
+
+--config {2,3,4,5} (round 4) selects the BASELINE configuration that is measured; 3 (the headline) is the default and is
+unchanged.  2 = MU/FRO 65536 x 4096, k = 32 (the same step on the smaller problem).  4 = MU/KL 131072 x 65536, k = 128 on the
+2D grid the rank count gives (8 ranks: 4 x 2) through nmf_algorithms_2D -- `--emulate-ranks 8` runs ONE rank's 32768 x 32768
+block on one GPU with the real collective calls on one-rank groups; roofline = the KL W-side product.  5 = the NMFk sweep
+k = 2..16 x 20 perturbations, HALS/FRO on bf16-stored X (a "step" is one whole sweep; value = fits per second).
 """
 import argparse
 import json
@@ -49,12 +55,20 @@ MEASURED_STREAM_GBS = 6760.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", dest="m", type=int, default=262144)
-    ap.add_argument("--cols", dest="n", type=int, default=8192)
-    ap.add_argument("--rank", dest="k", type=int, default=64)
-    ap.add_argument("--norm", default="fro")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration: 3 = the headline (default); 2 = MU/FRO 65536x4096 k=32; 4 = MU/KL 131072x65536 "
+                         "k=128 on the 2D grid; 5 = NMFk sweep k=2..16 x 20 perturbations, HALS/FRO, bf16-stored X")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per config: 500 / 2000 / 30 / 1)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--rows", dest="m", type=int, default=None)
+    ap.add_argument("--cols", dest="n", type=int, default=None)
+    ap.add_argument("--rank", dest="k", type=int, default=None)
+    ap.add_argument("--norm", default=None)
+    ap.add_argument("--grid", default=None, help="config 4 / 5: process grid 'RxC' (default: 8 ranks 4x2, 4: 2x2, 2: 2x1 for config 4; 1xN for config 5)")
+    ap.add_argument("--perturbations", type=int, default=20, help="config 5")
+    ap.add_argument("--itr", type=int, default=100, help="config 5: HALS iterations per fit")
+    ap.add_argument("--start-k", type=int, default=2, help="config 5")
+    ap.add_argument("--end-k", type=int, default=16, help="config 5")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -74,7 +88,21 @@ def parse_args():
     ap.add_argument("--overlap-chunks", default="auto",
                     help="N > 1: column chunks of the H phase's overlapped exchange; 'auto' (default) times 1 / 2 / 4 in "
                          "the warm-up and uses the fastest")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = CONFIGS[a.config]
+    for key in ("m", "n", "k", "norm", "steps", "warmup"):
+        if getattr(a, key) is None:
+            setattr(a, key, dflt[key])
+    return a
+
+
+# BASELINE.json `configs` (1 = the reference's own CPU case: a parity test, tests/test_gpu_parity.py, not a bench line)
+CONFIGS = {
+    2: dict(m=65536, n=4096, k=32, norm="fro", steps=2000, warmup=20, label="BASELINE config 2"),
+    3: dict(m=262144, n=8192, k=64, norm="fro", steps=500, warmup=5, label="BASELINE config 3"),
+    4: dict(m=131072, n=65536, k=128, norm="kl", steps=30, warmup=3, label="BASELINE config 4"),
+    5: dict(m=65536, n=4096, k=16, norm="fro", steps=1, warmup=1, label="BASELINE config 5"),
+}
 
 
 def flush_c_stdio():
@@ -312,6 +340,476 @@ def count_gpus():
     return torch.cuda.device_count()
 
 
+class Job:
+    """What every configuration's timed region needs: the ranks, the barrier and the max-over-ranks clock of the contract."""
+
+    def __init__(self, a, world, rank, local, dev, ctl, emu, rccl_ranks_seen):
+        self.a, self.world, self.rank, self.local, self.dev, self.ctl = a, world, rank, local, dev, ctl
+        self.emu, self.rccl_ranks_seen = emu, rccl_ranks_seen
+
+    def barrier(self):
+        import torch.distributed as dist
+        if self.a.backend == "nccl":
+            dist.barrier(device_ids=[self.local])
+        else:
+            dist.barrier()
+
+    def max_over_ranks(self, x):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=self.ctl)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed(self, nsteps, step):
+        """EXACTLY nsteps steps between barrier + device sync on both sides; max over ranks."""
+        import torch
+        if self.world > 1:
+            self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.barrier()
+        torch.cuda.synchronize()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+def parse_grid(text, world, default):
+    if not text:
+        return default
+    r, c = (int(x) for x in text.lower().split("x"))
+    if r * c != world:
+        sys.exit("bench.py: --grid %s needs %d ranks, the job has %d" % (text, r * c, world))
+    return r, c
+
+
+def _cpu_kl_rank(rank, rows_s, n_l, k, steps, q):
+    """One rank of the reference's process model for config 4 (single BLAS thread, main.py:3): the oracle's MU/KL step
+    (dist_nmf.py:806-849) on a ROW SLAB of the rank's block -- the step is linear in the rows."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    from oracle import nmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except ImportError:
+        ctx = None
+    rng = np.random.default_rng(1234 + rank)
+    A = rng.random((rows_s, n_l), dtype=np.float32)
+    W = rng.random((rows_s, k), dtype=np.float32)
+    H = np.random.default_rng(99).random((k, n_l), dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    orc.kl_mu_step_local(A, W, H, eps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.kl_mu_step_local(A, W, H, eps)
+    q.put((rank, (time.perf_counter() - t0) / steps))
+    del ctx
+
+
+def _cpu_hals_rank(rank, m_l, n_l, ks, steps, q):
+    """One rank of the reference's process model for config 5: the oracle's HALS/FRO step (dist_nmf.py:873-934) on the rank's
+    block (float32: numpy has no bfloat16) for a few ranks k."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    from oracle import nmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except ImportError:
+        ctx = None
+    rng = np.random.default_rng(1234 + rank)
+    A = rng.random((m_l, n_l), dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    res = {}
+    for k in ks:
+        W = rng.random((m_l, k), dtype=np.float32)
+        H = rng.random((k, n_l), dtype=np.float32)
+        orc.fro_hals_step_local(A, W, H, eps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            orc.fro_hals_step_local(A, W, H, eps)
+        res[k] = (time.perf_counter() - t0) / steps
+    q.put((rank, res))
+    del ctx
+
+
+def _cpu_pool(target, argsets, timeout=600):
+    """P single-thread processes, one result each (rank, value); None when any of them fails."""
+    import multiprocessing as mp
+    import queue
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=tuple(args) + (q,)) for args in argsets]
+    for pr in procs:
+        pr.start()
+    got, deadline = {}, time.time() + timeout
+    try:
+        while len(got) < len(procs) and time.time() < deadline:
+            try:
+                r, v = q.get(timeout=2)
+                got[r] = v
+            except queue.Empty:
+                if any(pr.exitcode not in (None, 0) for pr in procs):
+                    break
+    finally:
+        for pr in procs:
+            pr.join(timeout=5)
+            if pr.is_alive():
+                pr.kill()
+    return got if len(got) == len(procs) else None
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return os.cpu_count() or 1, model
+
+
+def run_config4(a, job):
+    """BASELINE config 4: MU/KL, X = 131072 x 65536 fp32, k = 128, on the p_r x p_c grid of the job (8 ranks: 4 x 2; reference
+    dist_nmf.py:268-407 over the grid of dist_comm.py:16-56).  Strong scaling: the global X is fixed.  A step = one
+    nmf_algorithms_2D(...).update() (1D class on 1 x 1 / N x 1 grids), clamp on every 10th; `--emulate-ranks R` = this
+    process is rank 0 of the R-rank grid on one GPU, its sub-communicators EmulatedGroup objects (dist_comm.py)."""
+    import torch
+    import torch.distributed as dist
+    from pydnmfk_amd.dist_comm import EmulatedGroup, MPI_comm, NullExchange
+    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
+    from pydnmfk_amd.engine import ops_for
+    from pydnmfk_amd.utils import determine_block_params, parse
+
+    world, rank, dev, emu = job.world, job.rank, job.dev, job.emu
+    nr = emu or world
+    p_r, p_c = parse_grid(a.grid, nr, {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(nr, (nr, 1)))
+    m, n, k = a.m, a.n, a.k
+    two_d = p_r > 1 and p_c > 1
+    p = parse()
+    if emu:
+        base = MPI_comm(None, 1, 1)
+        p.comm1, p.comm = base.comm, base
+        p.row_comm, p.col_comm = EmulatedGroup(base.comm, p_r), EmulatedGroup(base.comm, p_c)
+    else:
+        comms = MPI_comm(None, p_r, p_c)
+        p.comm1, p.comm, p.row_comm, p.col_comm = comms.comm, comms, comms.cart_1d_row(), comms.cart_1d_column()
+    p.p_r, p.p_c, p.k, p.m, p.n = p_r, p_c, k, m, n
+    p.norm, p.method, p.W_update, p.eps, p.gemm = a.norm, "mu", True, 1.1920929e-07, "fp32"
+    ops = ops_for(p)
+    i, j = divmod(rank, p_c)
+    m_l, n_l = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_shape_asymm()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    A = torch.rand(m_l, n_l, device=dev, generator=g)
+    if two_d:      # the rank's SLICES of the factors (utils.py:99-103): W_ij = rows of W_i split over the p_c ranks of grid row i
+        m_w = determine_block_params(j, (p_c, 1), (m_l, k)).determine_block_shape_asymm()[0]
+        n_h = determine_block_params(i, (1, p_r), (k, n_l)).determine_block_shape_asymm()[1]
+    else:          # 1D (and 1 x 1): the sharded factor whole, the other one replicated
+        m_w, n_h = m_l, n_l
+    g.manual_seed(4321 + rank)
+    W = torch.rand(m_w, k, device=dev, generator=g)
+    g.manual_seed(99 + (rank if two_d else (j if p_c > 1 else 0)))
+    H = torch.rand(k, n_h, device=dev, generator=g)
+    if not two_d and world > 1:
+        H = p.comm1.bcast(H, root=0) if p_c == 1 else H
+        W = p.comm1.bcast(W, root=0) if p_r == 1 else W
+    cls = nmf_algorithms_2D if two_d else nmf_algorithms_1D
+
+    def step(it, params=p):
+        cls(A, W, H, params=params).update(clamp=(it % 10 == 0))
+
+    multi = world > 1 or emu > 1
+    mg = None
+    if multi:
+        mg = {"rccl_ranks_seen": job.rccl_ranks_seen, "backend": a.backend, "grid": [p_r, p_c]}
+        if emu:
+            mg["emulated"] = ("rank 0 of a %d x %d grid on a single GPU: its own %d x %d block, real kernels and launches, the collectives of the "
+                              "step issued on one-rank groups (EmulatedGroup: no wire time; the library-sequenced step needs the real grid)" % (p_r, p_c, m_l, n_l))
+        modes = ["torch"] if a.exchange in ("auto", "torch") else []
+        if world > 1 and a.backend == "nccl" and a.exchange in ("auto", "native"):
+            p.exchange = "native"
+            from pydnmfk_amd.engine import native_comm_for
+            ok = 1
+            try:
+                ok = int(native_comm_for(p) is not None)           # collective-safe: raises / returns None on every rank together
+                if ok:
+                    step(1)
+                    torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                ok, mg["native_exchange_unavailable"] = 0, repr(exc)
+            if int(-job.max_over_ranks(-float(ok))):
+                modes.append("native")
+            p.exchange = "torch"
+        if not modes:
+            sys.exit("bench.py: --exchange %s is not available (backend %s%s)" % (a.exchange, a.backend, ", emulated" if emu else ""))
+        if len(modes) > 1:
+            ab, nab = {}, max(3, min(10, a.steps))
+            for mode in modes:
+                p.exchange = mode
+                for it in range(2):
+                    step(it)
+                ab[mode] = job.timed(nab, step) / nab * 1e3
+            mg["exchange_ab_ms_per_step"], mg["exchange_ab_steps"] = ab, nab
+            p.exchange = min(ab, key=ab.get)
+        else:
+            p.exchange = modes[0]
+        mg["exchange_used"] = p.exchange
+
+    for it in range(a.warmup):
+        step(it)
+    elapsed = job.timed(a.steps, step)
+    assert torch.isfinite(W).all() and torch.isfinite(H).all()
+    ms = elapsed / a.steps * 1e3
+
+    if multi:      # the same step with every exchange stubbed out (timing only): this rank's compute
+        pn = parse()
+        pn.__dict__.update(vars(p))
+        native_used = p.exchange == "native"
+        if native_used:
+            p._native_comm.set_null_exchange(True)
+        else:
+            pn.comm1, pn.row_comm, pn.col_comm = NullExchange(p.comm1), NullExchange(p.row_comm), NullExchange(p.col_comm)
+        keep = (W.clone(), H.clone())
+        for it in range(2):
+            step(it, pn)
+        nn = max(3, min(20, a.steps))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(nn):
+            step(it, pn)
+        torch.cuda.synchronize()
+        mine = (time.perf_counter() - t0) / nn * 1e3
+        if native_used:
+            p._native_comm.set_null_exchange(False)
+        per = [mine]
+        if world > 1:
+            per = [None] * world
+            dist.all_gather_object(per, mine)
+        W.copy_(keep[0]); H.copy_(keep[1])
+        del keep
+        mg["compute_only_ms_per_rank"], mg["compute_only_ms"] = per, max(per)
+        mg["full_step_ms"], mg["exposed_comm_ms"] = ms, ms - max(per)
+        kb = 4 * k
+        mg["exchange_bytes_per_step"] = {"allgather_H_recv": kb * n_l if p_r > 1 else 0, "allgather_W_recv": 2 * kb * m_l if p_c > 1 else 0,
+                                         "reduce_scatter_W_send": kb * m_l if p_c > 1 else 0, "reduce_scatter_H_send": kb * n_l if p_r > 1 else 0,
+                                         "allreduce_k_vectors": 2 * kb}
+        mg["note"] = ("compute_only = the same step with every exchange stubbed out (NullExchange / the library's null mode; timing only); "
+                      "exposed_comm_ms = full step - slowest rank's compute-only step")
+
+    out = None
+    flops_iter = 8.0 * m * n * k + 6.0 * (m + n) * k                  # SURVEY 8d, whole job
+    if rank == 0:
+        out = {
+            "metric": "mu_iterations_per_sec", "value": a.steps / elapsed, "unit": "iter/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, %s grid p_r=%d p_c=%d (%s)%s" % (
+                a.norm.upper(), m, n, k, "2D" if two_d else "1D", p_r, p_c, CONFIGS[4]["label"],
+                " -- EMULATED: one rank's block on one GPU, not a whole-job number" if emu else ""),
+                "m": m, "n": n, "k": k, "block_per_gpu": [m_l, n_l], "gemm": "fp32",
+                "parallelism": ("%d x %d blocks of X; per step: allreduce of k-vectors, allgather of the H / W slices in the size-p_r / size-p_c "
+                                "groups, reduce-scatter of U H^T / W^T U over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend + " (host staged)"))
+                if multi else "single GPU"},
+            "step_tflops_per_gpu": flops_iter / nr / (ms * 1e-3) / 1e12,
+            "step_mfma_frac": flops_iter / nr / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "step_algorithmic_hbm_gbs_per_gpu": 4.0 * m_l * n_l / (ms * 1e-3) / 1e9,          # ONE read of the block (SURVEY 8d; the step makes two)
+        }
+        if mg is not None:
+            out["multi_gpu"] = mg
+
+    if not a.no_kernel_timing:
+        # the two KL products in situ (HIP events on the stream the launches go to), on this rank's block with the gathered factors
+        W_i = torch.rand(m_l, k, device=dev, generator=g)
+        H_j = torch.rand(k, n_l, device=dev, generator=g)
+        V = torch.empty(m_l, k, device=dev)
+        Y = torch.empty(k, n_l, device=dev)
+        t_uht, _ = event_time_ms(lambda: ops.kl_uht(A, W_i, H_j, p.eps, V), reps=10, warm=3)
+        t_wtu, _ = event_time_ms(lambda: ops.kl_wtu(A, W_i, H_j, p.eps, Y), reps=10, warm=3)
+        del W_i, H_j, V, Y
+        if rank == 0:
+            fl = 4.0 * m_l * n_l * k
+            kt = max(1, (k + 31) // 32)
+            pipe = k > 16 and m_l >= 128 and n_l % 32 == 0
+
+            def entry(kernel, ms_, role):
+                ach = fl / ms_ / 1e9
+                e = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": fl, "ms_per_launch": ms_,
+                     "algorithmic_bytes_per_launch": 4.0 * m_l * n_l}
+                tr = pmc_traffic(role, "kl") if (m_l, n_l, k) == (32768, 32768, 128) else None
+                if tr is not None:
+                    e["traffic"] = tr["bytes"]
+                    e["traffic_note"] = ("HBM bytes per launch from the committed PMC pass %s, kernel %s (FETCH_SIZE x2 + WRITE_SIZE); a "
+                                         "constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
+                return e
+
+            r_uht = entry(("kl_uht_pipe_kernel<KT=%d>" if pipe else "kl_uht_kernel<KT=%d>") % kt +
+                          " + reduce_partials (dnmf_kl_uht: U H^T, the W phase's product, dist_nmf.py:806,810)", t_uht,
+                          "kl_uht_pipe_kernel<4" if pipe else "kl_uht_kernel<4")
+            r_wtu = entry("kl_wtu_kernel<KT=%d> + reduce_partials (dnmf_kl_wtu: W^T U, the H phase's product, dist_nmf.py:806,808)" % kt,
+                          t_wtu, "kl_wtu_kernel<4")
+            out["roofline"], out["rooflines"] = r_uht, [r_uht, r_wtu]
+            out["kernels"] = {"dnmf_kl_uht": {"ms": t_uht, "tflops": fl / t_uht / 1e9}, "dnmf_kl_wtu": {"ms": t_wtu, "tflops": fl / t_wtu / 1e9},
+                              "rest_of_step_ms": ms - t_uht - t_wtu}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the reference's process model for this config: the 4 x 2 grid = 8 ranks x 1 BLAS thread, each with a 32768 x 32768 block;
+        # bounded sample = a row slab of every rank's block (the KL step is linear in the rows)
+        cores, model = host_cpu()
+        P = min(8, cores)
+        pr_, pc_ = (4, 2) if P == 8 else (P, 1)
+        mb, nb = m // pr_, n // pc_
+        rows_s = max(32, min(mb, int(2.4e10 / (8.0 * nb * k))))            # ~1-2 s per slab step on one core
+        got = _cpu_pool(_cpu_kl_rank, [(r, rows_s, nb, k, 2) for r in range(P)])
+        if got is None:
+            out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": P, "kind": "port", "sample": "FAILED: a CPU rank died or timed out"}
+        else:
+            t_slab = max(got.values())
+            t_it = t_slab * (mb / rows_s)
+            out["cpu_baseline"] = {
+                "value": 1.0 / t_it, "unit": "iter/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
+                "seconds_per_iter": t_it, "gflops_whole_job": flops_iter / t_it / 1e9,
+                "sample": "oracle kl_mu_step_local in the reference's process model: %d processes x 1 BLAS thread = the ranks of a %d x %d grid, "
+                          "each on a %d x %d row slab of its %d x %d block, k=%d, 1 warm-up + 2 timed steps; slab step %.2f s (slowest rank) x %.0f "
+                          "= %.1f s per iteration (the step is linear in the rows); no exchange simulated" % (
+                              P, pr_, pc_, rows_s, nb, mb, nb, k, t_slab, mb / rows_s, t_it)}
+    if multi and getattr(p, "_native_comm", None) is not None:
+        p._native_comm.close()
+    return out
+
+
+def run_config5(a, job):
+    """BASELINE config 5: the NMFk sweep k = 2..16, 20 perturbations, HALS / Frobenius on bf16-STORED X (reference
+    pyDNMFk.py:169-258 over dist_nmf.py:873-934, clustering dist_clustering.py:84-160).  X = 65536 x 4096 of planted rank 6
+    (+ 1 % noise), per-rank blocks of the 1 x N grid (the grid for HALS: W is replicated there, its column norms are local).
+    A "step" is one WHOLE sweep: (end_k - start_k + 1) x perturbations fits of `itr` HALS iterations + the regression fit,
+    clustering and statistics of every k, device resident (params.rng = 'device'); value = fits per second."""
+    import contextlib
+    import torch
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.engine import ops_for
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from pydnmfk_amd.utils import determine_block_params, parse
+
+    world, rank, dev = job.world, job.rank, job.dev
+    p_r, p_c = parse_grid(a.grid, world, (1, world))
+    m, n = a.m, a.n
+    comms = MPI_comm(None, p_r, p_c)
+    s, e = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_index_range_asymm()
+    # planted rank 6, identifiable (the recipe of tests/test_gpu_nmfk_sweep.py at this size): six Gaussian bumps along the rows,
+    # sparse uniform mixing, 0.5 % noise -- the sweep must come back with estimated_k = 6
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)                                                   # the planted factors: the same on every rank
+    x = torch.arange(m, device=dev, dtype=torch.float32)[:, None]
+    cen = torch.linspace(0.075 * m, m - 0.075 * m, 6, device=dev)[None, :]
+    Wt = torch.exp(-(x - cen) ** 2 / (2 * (0.044 * m) ** 2))
+    Ht = torch.rand(6, n, device=dev, generator=g) * (torch.rand(6, n, device=dev, generator=g) < 0.7)
+    g.manual_seed(1234 + rank)
+    X = (Wt[s[0]:e[0] + 1] @ Ht[:, s[1]:e[1] + 1])
+    X += 0.005 * torch.rand(X.shape, device=dev, generator=g)
+    del x, cen
+    Xb = X.to(torch.bfloat16)
+    del X, Wt, Ht
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dnmf_c5_") if rank == 0 else None
+    tmp = comms.comm.bcast(tmp, root=0) if world > 1 else tmp
+
+    def params(start_k, end_k, pert, itr):
+        q = parse()
+        q.comm1, q.comm, q.p_r, q.p_c = comms.comm, comms, p_r, p_c
+        q.row_comm, q.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+        q.size, q.rank = world, rank
+        q.norm, q.method, q.init, q.itr, q.verbose, q.prune = "fro", "hals", "rand", itr, False, False
+        q.start_k, q.end_k, q.step_k, q.fname, q.checkpoint = start_k, end_k, 1, "c5", False
+        q.perturbations, q.noise_var, q.sampling, q.sill_thr = pert, 0.03, "uniform", 0.8
+        q.precision, q.results_path, q.timing_stats, q.rng = "bfloat16", tmp + "/", False, "device"
+        return q
+
+    nopt = [None]
+
+    def sweep(_i, small=False):
+        q = params(2, 3, 2, 10) if small else params(a.start_k, a.end_k, a.perturbations, a.itr)
+        with contextlib.redirect_stdout(sys.stderr):                   # PyNMFk reports progress on stdout: the JSON line stays alone there
+            nopt[0] = PyNMFk(Xb, factors=None, params=q).fit()
+
+    for i in range(max(1, a.warmup)):
+        sweep(i, small=True)                                           # loads every kernel class of the sweep; not a full sweep
+    elapsed = job.timed(a.steps, sweep)
+    nk = a.end_k - a.start_k + 1
+    fits = nk * a.perturbations
+    ms = elapsed / a.steps * 1e3
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "nmfk_fits_per_sec", "value": fits * a.steps / elapsed, "unit": "fits/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 storage of X, f32 arithmetic and factors", "data": "synthetic",
+            "config": {"workload": "NMFk k=%d..%d x %d perturbations, HALS/FRO %d iterations per fit, X=%dx%d stored bf16 (planted rank 6: estimated_k must be 6), "
+                                   "%d x %d grid (%s); a step = one whole sweep (fits + regression fit + clustering per k)" % (
+                                       a.start_k, a.end_k, a.perturbations, a.itr, m, n, p_r, p_c, CONFIGS[5]["label"]),
+                       "m": m, "n": n, "k_range": [a.start_k, a.end_k], "perturbations": a.perturbations, "itr": a.itr,
+                       "block_per_gpu": [e[0] - s[0] + 1, e[1] - s[1] + 1],
+                       "parallelism": "single GPU" if world == 1 else "%d x %d blocks of X over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend)},
+            "fits_per_step": fits, "estimated_k": int(nopt[0]), "seconds_per_sweep": elapsed / a.steps,
+            "hals_iterations_per_sec": (fits + nk) * a.itr * a.steps / elapsed,
+        }
+    if not a.no_kernel_timing:
+        # the kernel the sweep spends most of its time in: A H^T on the bf16-stored block at the top rank of the sweep (HBM bound)
+        ops = ops_for(None)
+        kk = min(16, a.end_k)
+        m_l, n_l = Xb.shape
+        Hk = torch.rand(kk, n_l, device=dev, generator=g)
+        Wk = torch.rand(m_l, kk, device=dev, generator=g)
+        V = torch.empty(m_l, kk, device=dev)
+        Y = torch.empty(kk, n_l, device=dev)
+        t_nt, _ = event_time_ms(lambda: ops.aht(Xb, Hk, V), reps=20, warm=5)
+        t_tn, _ = event_time_ms(lambda: ops.wta(Xb, Wk, Y), reps=20, warm=5)
+        if rank == 0:
+            by = 2.0 * m_l * n_l
+
+            def entry(kernel, ms_):
+                ach = by / ms_ / 1e6
+                return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                        "traffic": None, "bytes_per_launch": by, "ms_per_launch": ms_, "measured_ceiling": MEASURED_STREAM_GBS,
+                        "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS, "note": "algorithmic bytes = one read of the bf16 block"}
+            out["roofline"] = entry("nt16_kernel<bf16 X> (dnmf_aht_bf16a, k=%d: A H^T of the HALS W phase, dist_nmf.py:884)" % kk, t_nt)
+            out["rooflines"] = [out["roofline"], entry("tn16_kernel<bf16 X> + reduce_partials (dnmf_wta_bf16a, k=%d: W^T A of the H phase, dist_nmf.py:903)" % kk, t_tn)]
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cores, model = host_cpu()
+        P = min(8, cores)
+        ks = sorted({a.start_k, (a.start_k + a.end_k) // 2, a.end_k})
+        got = _cpu_pool(_cpu_hals_rank, [(r, m, n // P, ks, 3) for r in range(P)])
+        if got is None:
+            out["cpu_baseline"] = {"value": None, "unit": "fits/s", "cores": P, "kind": "port", "sample": "FAILED: a CPU rank died or timed out"}
+        else:
+            import numpy as np
+            t_k = {k_: max(v[k_] for v in got.values()) for k_ in ks}                      # iteration time = slowest rank
+            t_all = np.interp(np.arange(a.start_k, a.end_k + 1), ks, [t_k[k_] for k_ in ks])
+            t_sweep = float(np.sum(t_all) * (a.perturbations + 1) * a.itr)
+            out["cpu_baseline"] = {
+                "value": fits / t_sweep, "unit": "fits/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
+                "seconds_per_sweep": t_sweep,
+                "sample": "oracle fro_hals_step_local (float32: numpy has no bfloat16) in the reference's process model: %d processes x 1 BLAS "
+                          "thread = the ranks of a 1 x %d grid, each on its %d x %d column block; 1 warm-up + 3 timed HALS iterations at k = %s "
+                          "(%s s, slowest rank), interpolated over k = %d..%d and multiplied by (%d perturbations + 1 regression fit) x %d "
+                          "iterations = %.0f s per sweep; no exchange, no clustering counted" % (
+                              P, P, m, n // P, ks, [round(t_k[k_], 4) for k_ in ks], a.start_k, a.end_k, a.perturbations, a.itr, t_sweep)}
+    import shutil
+    if rank == 0:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -363,6 +861,18 @@ def main():
             sys.stderr.write("bench.py: %s did not come up on rank %d (%s)\n" % (a.backend, rank, exc))
             sys.stderr.flush()
             os._exit(3)
+
+    if a.config in (4, 5):
+        job = Job(a, world, rank, local, dev, ctl, emu, rccl_ranks_seen)
+        out = run_config4(a, job) if a.config == 4 else run_config5(a, job)
+        if rank == 0:
+            flush_c_stdio()
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            job.barrier()
+        if world > 1 or emu:
+            dist.destroy_process_group()
+        return
 
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -568,8 +1078,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if a.gemm == "fp32" else "f32 operands as 3 bf16 pieces, 6 bf16 MFMA products per fp32 product, fp32 accumulation",
             "data": "synthetic",
-            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (BASELINE config 3)%s" % (
-                a.norm.upper(), m, n, k, grid_r, " -- EMULATED: one rank's share on one GPU, not a whole-job number" if emu else ""), "m": m, "n": n, "k": k, "rows_per_gpu": m_l, "gemm": a.gemm,
+            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, 1D row grid p_r=%d p_c=1 (%s)%s" % (
+                a.norm.upper(), m, n, k, grid_r, CONFIGS[a.config]["label"], " -- EMULATED: one rank's share on one GPU, not a whole-job number" if emu else ""), "m": m, "n": n, "k": k, "rows_per_gpu": m_l, "gemm": a.gemm,
                 "parallelism": ("row-sharded X, allreduce[W^T A | W^T W] over %s" % ("RCCL" if a.backend == "nccl" else a.backend + " (host staged)")) if world > 1 else "single GPU"},
             "step_tflops_per_gpu": flops_iter / world / (ms * 1e-3) / 1e12,
             "step_mfma_frac": (flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if a.gemm == "fp32" else None,

@@ -209,9 +209,8 @@ size_t partial_bytes(long m, long n, int k) {
     {   // wta / kl_wtu: A [m x n]
         TnPlan p = plan_tn(m, n, kt, tn_nt(kt));
         b = std::max(b, (size_t)p.nchunks * p.chunk_stride * sizeof(float) + reduce_scratch_bytes(p.nchunks, k, n));
-        TnPlan q = plan_tn(m, n, kt, kl_nt(kt));
-        const long klc = cdiv(cdiv(m, 32), std::max<long>(1, q.rows_per_chunk / 32));
-        b = std::max(b, (size_t)klc * q.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)klc, k, n));
+        const KlWtuPlan q = plan_kl_wtu(m, n, kt);
+        b = std::max(b, (size_t)q.nchunks * q.tn.ldp * kp * sizeof(float) + reduce_scratch_bytes((int)q.nchunks, k, n));
     }
     {   // gram W^T W: Y = W [m x k]
         TnPlan p = plan_tn(m, kp, kt, kt == 4 ? 2 : kt, gram_min_rows(m));

@@ -142,6 +142,24 @@ inline int kl_nt(int kt) {   // column sets per wave in kl_wtu (three live tiles
     return kt == 1 ? nt1 : 2;
 }
 
+// Row chunking of kl_wtu_kernel: plan_tn's round of waves, with the chunk capped so that ONE 2 GiB buffer descriptor covers a
+// chunk's rows of A (the pipelined path of the kernel addresses a chunk through MUBUF; a chunk beyond the window fell back to
+// the predicated blocks -- round 4: the whole 131072 x 65536 matrix of BASELINE config 4 on one GPU ran W^T U at 43 TFLOP/s
+// that way, 139 with the cap).  n stands in for the leading dimension (column slices of a wider block keep the plan of their
+// own width and may still leave the window: they take the slower path, correctly).
+struct KlWtuPlan { int nt; long rowblks_per_chunk; long nchunks; TnPlan tn; };
+KlWtuPlan plan_kl_wtu(long m, long n, int kt) {
+    KlWtuPlan q;
+    q.nt = kl_nt(kt);
+    q.tn = plan_tn(m, n, kt, q.nt);
+    const long cap_rows = ((0x7fffffffL / 4 - 32 * q.nt) / std::max<long>(n, 1) - 33) / 32 * 32;       // (rows + 32) * n + CW floats < 2^31 bytes
+    long rpc = std::max<long>(1, q.tn.rows_per_chunk / 32);
+    if (cap_rows >= 32) rpc = std::min<long>(rpc, cap_rows / 32);
+    q.rowblks_per_chunk = rpc;
+    q.nchunks = cdiv(cdiv(m, 32), rpc);
+    return q;
+}
+
 // zero-padded factor images of the KL products (see pad_factors)
 size_t pad_bytes(long m, long n, int kp) {
     return align256((size_t)m * kp * sizeof(float)) + align256((size_t)kp * round_up(n, 4) * sizeof(float));

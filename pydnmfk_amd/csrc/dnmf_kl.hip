@@ -256,10 +256,11 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
     const int kp = 32 * kt;
-    const int nt = kl_nt(kt);
-    TnPlan p = plan_tn(m, n, kt, nt);
-    const long rowblks_per_chunk = std::max<long>(1, p.rows_per_chunk / 32);
-    const long nchunks = cdiv(cdiv(m, 32), rowblks_per_chunk);
+    const KlWtuPlan plan = plan_kl_wtu(m, n, kt);
+    const int nt = plan.nt;
+    const TnPlan& p = plan.tn;
+    const long rowblks_per_chunk = plan.rowblks_per_chunk;
+    const long nchunks = plan.nchunks;
     const size_t pbytes = (size_t)nchunks * p.ldp * kp * sizeof(float);
     const size_t need = pbytes + reduce_scratch_bytes((int)nchunks, k, n);
     if (ws_bytes < need) return fail(DNMF_EWS, "kl_wtu: workspace %zu < %zu", ws_bytes, need);

@@ -229,8 +229,79 @@ class NullExchange:
     def allreduce(self, x, op=None):
         return x
 
+    def allgather_blocks(self, x, shapes):
+        """every member's block = a copy of this rank's (right sizes for the kernels that follow, no exchange)"""
+        if self.size == 1:
+            return [x]
+        mx = max(int(np.prod(sh)) for sh in shapes)
+        send = x.reshape(-1)
+        rc = send.new_empty(self.size * mx)
+        for q in range(self.size):
+            rc[q * mx: q * mx + send.numel()].copy_(send)
+        return [rc[q * mx: q * mx + int(np.prod(shapes[q]))].view(*shapes[q]) for q in range(self.size)]
+
+    def reduce_scatter_rows(self, full, counts):
+        if self.size == 1:
+            return full
+        off = sum(counts[: self.rank])
+        return full[off: off + counts[self.rank]].contiguous()
+
+    def bcast(self, x, root=0):
+        return x
+
     def barrier(self):
         pass
+
+
+class EmulatedGroup:
+    """MEASUREMENT ONLY (bench.py --config 4 --emulate-ranks R): one member's view of a `size`-member sub-communicator on a
+    box with one GPU.  Every collective issues the REAL torch.distributed call on the one-rank group `comm` (the call's fixed
+    costs -- launch, stream ordering against the kernels -- are real; there is no wire) and hands back buffers of the sizes a
+    real group would: the other members' allgather blocks are copies of this rank's, a reduce-scatter returns this member's
+    block.  Results are not a factorisation of anything."""
+
+    def __init__(self, comm, size, rank=0):
+        self.inner, self.size, self.rank = comm, int(size), int(rank)
+        self.ranks, self.backend, self.device, self.group = list(range(self.size)), comm.backend, comm.device, comm.group
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def allreduce_(self, t):
+        return self.inner.allreduce_(t)
+
+    def allreduce_begin(self, t):
+        return self.inner.allreduce_begin(t)
+
+    def allreduce(self, x, op=None):
+        return self.inner.allreduce(x)
+
+    def bcast(self, x, root=0):
+        return self.inner.bcast(x, root=0)
+
+    def barrier(self):
+        self.inner.barrier()
+
+    def allgather_blocks(self, x, shapes):
+        mx = max(int(np.prod(sh)) for sh in shapes)
+        send = x.reshape(-1)
+        if send.numel() < mx:
+            send = torch.cat([send, send.new_zeros(mx - send.numel())])
+        rc = send.new_empty(self.size * mx)
+        dist.all_gather_into_tensor(rc[:mx], send.contiguous(), group=self.inner.group)      # this member's block, really gathered
+        for q in range(1, self.size):
+            rc[q * mx: (q + 1) * mx].copy_(rc[:mx])
+        return [rc[q * mx: q * mx + int(np.prod(shapes[q]))].view(*shapes[q]) for q in range(self.size)]
+
+    def reduce_scatter_rows(self, full, counts):
+        c = full.shape[1]
+        out = full.new_empty(counts[self.rank], c)
+        off = sum(counts[: self.rank])
+        dist.reduce_scatter_tensor(out, full[off: off + counts[self.rank]].contiguous(), group=self.inner.group)
+        return out
 
 
 def COMM_WORLD():

@@ -77,8 +77,12 @@ class DistSVD:
                 # are rounding noise of A^T A applied in float32 and cannot settle further).  A test against lam_max alone
                 # accepted trailing vectors (s_k / s_1 < 1e-3) that had not converged.
                 w, wp = lam[-kk:], lam_prev[-kk:]                       # (eigvalsh ascends: the last kk are the wanted ones)
-                tol = torch.clamp(1e-7 * w.abs(), min=1e-7 * 1e-7 * float(lam.abs().max()))
-                floor = w.abs() <= 1e-7 * float(lam.abs().max())
+                # (the Ritz values come from A^T A B applied in float32, whose noise is ~6e-8 lam_max ABSOLUTE for every
+                # component -- a component with 1e-7 < lam_i / lam_max << 1 cannot settle to 1e-7 lam_i and the loop ran all its
+                # passes; hence the absolute term 4 eps lam_max in the tolerance)
+                lam_max = float(lam.abs().max())
+                tol = torch.clamp(1e-7 * w.abs(), min=4 * 1.1920929e-07 * lam_max)
+                floor = w.abs() <= 1e-7 * lam_max
                 if bool((((w - wp).abs() <= tol) | floor).all()):
                     break
             lam_prev = lam

@@ -478,12 +478,32 @@ class NativeComm:
         import ctypes
         if not torch.cuda.is_available():
             raise RuntimeError("NativeComm: needs a GPU (RCCL communicators live on the current HIP device)")
+        # Bring-up is COLLECTIVE-SAFE: rank 0 always takes part in the broadcast -- it sends the id or an error
+        # marker -- and after dnmf_comm_create every rank learns whether ALL ranks hold a communicator; any failure raises
+        # on every rank together, so callers that fall back to the torch.distributed choreography do so on every rank.
         idbuf = ctypes.create_string_buffer(128)
+        payload = None
         if comm.rank == 0:
-            check(lib.dnmf_comm_unique_id(idbuf))
-        raw = comm.bcast(bytes(idbuf.raw), root=0)
+            try:
+                check(lib.dnmf_comm_unique_id(idbuf))
+                payload = ("id", bytes(idbuf.raw))
+            except Exception as ex:  # noqa: BLE001
+                payload = ("error", repr(ex))
+        kind, raw = comm.bcast(payload, root=0)
+        if kind != "id":
+            raise RuntimeError("NativeComm: rank 0 could not create the RCCL id (%s)" % raw)
         h = ctypes.c_void_p()
-        check(lib.dnmf_comm_create(raw, int(comm.size), int(comm.rank), int(p_r), int(p_c), ctypes.byref(h)))
+        mine = None
+        try:
+            check(lib.dnmf_comm_create(raw, int(comm.size), int(comm.rank), int(p_r), int(p_c), ctypes.byref(h)))
+        except Exception as ex:  # noqa: BLE001
+            mine = ex
+        nbad = int(comm.allreduce(1 if mine is not None else 0)) if comm.size > 1 else (1 if mine is not None else 0)
+        if nbad:
+            if mine is None:
+                lib.dnmf_comm_destroy(h)
+            raise RuntimeError("NativeComm: dnmf_comm_create failed on %d of %d ranks%s" % (
+                nbad, comm.size, " (here: %s)" % mine if mine is not None else ""))
         self.handle, self.size, self.rank, self.p_r, self.p_c = h, int(comm.size), int(comm.rank), int(p_r), int(p_c)
         self.device = torch.cuda.current_device()
         self._ws = None
@@ -653,11 +673,17 @@ def native_comm_for(params):
     if mode not in ("native", "native-hosted"):
         return None
     nc = getattr(params, "_native_comm", None)
+    if nc is not None and (nc.p_r, nc.p_c, nc.size) != (int(params.p_r), int(params.p_c), int(params.comm1.size)):
+        # the bag was reused with another grid (pyDNMFk_Runner.run(grid=...) twice): every rank sees the same mismatch, so
+        # the rebuild below is collective
+        nc.close()
+        nc = params._native_comm = None
     if nc is None:
         if mode == "native":
             try:
                 nc = NativeComm(params.comm1, params.p_r, params.p_c)
-            except Exception as ex:      # no RCCL in reach, or the communicator did not come up: the host choreography still works
+            except Exception as ex:      # no RCCL in reach, or the communicator did not come up -- on EVERY rank (the
+                # constructor agrees on that before it raises): the host choreography still works
                 import warnings
                 warnings.warn("params.exchange = 'native': %s -- falling back to the torch.distributed choreography" % ex)
                 params.exchange = "torch"

@@ -199,9 +199,20 @@ class PyNMF:
                     self.W_ij, self.H_ij = self.normalize_features(self.W_ij, self.H_ij)
                 else:
                     self.W_i, self.H_j = self.normalize_features(self.W_i, self.H_j)
-                self.relative_err()
                 if self.method.lower() == 'hals' and hasattr(ops, "hals_check"):
-                    ops.hals_check()                                # a persistent W sweep that lost its co-residency raises here
+                    # a persistent W sweep that lost its co-residency raises here -- BEFORE the error's allreduce sees NaN
+                    # factors, and on EVERY rank (the word is per device: the ranks agree on it first, or the others would
+                    # walk into the next collective alone)
+                    bad = None
+                    try:
+                        ops.hals_check()
+                    except Exception as ex:  # noqa: BLE001
+                        bad = ex
+                    nbad = int(self.params.comm1.allreduce(1 if bad is not None else 0))
+                    if nbad:
+                        raise bad if bad is not None else RuntimeError(
+                            "HALS W sweep timed out on %d other rank(s) (params.hals_sweep = 'columns' selects the per-column sweep)" % nbad)
+                self.relative_err()
                 if self.verbose is True and self.rank == 0:
                     print('relative error is:', self.recon_err)
                 W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)

@@ -67,8 +67,11 @@ def test_two_ranks_on_one_gpu_gloo(cols):
 @pytest.mark.gpu
 def test_launcher_refuses_more_ranks_than_gpus_over_rccl():
     """One GPU on the box: `--gpus 2` over RCCL must be refused by the parent (one line, exit 2), not fail inside RCCL."""
-    r = _run(["--gpus", "2", "--steps", "2"], timeout=120)
-    assert r.returncode == 2 and "--gpus 2" in r.stderr, (r.returncode, r.stderr)
+    sys.path.insert(0, ROOT)
+    import bench
+    ng = bench.count_gpus() + 1            # one more than the node has (the box of the GPU tier has one; any node works)
+    r = _run(["--gpus", str(ng), "--steps", "2"], timeout=120)
+    assert r.returncode == 2 and ("--gpus %d" % ng) in r.stderr, (r.returncode, r.stderr)
 
 
 @pytest.mark.gpu
@@ -93,3 +96,58 @@ def test_emulated_rank_runs_the_rccl_exchange_paths():
     assert set(mg["exchange_ab_ms_per_step"]) == {"%s/chunks=%d" % (t, c) for t in ("torch", "native") for c in (1, 2, 4)}
     assert mg["exchange_used"] in ("torch", "native") and mg["overlap_chunks_used"] in (1, 2, 4)
     assert mg["compute_only_ms"] > 0 and mg["allreduce_alone_ms"] > 0
+
+
+# ---- round 4: every BASELINE configuration is launchable as typed
+@pytest.mark.gpu
+def test_config4_emulated_rank_of_the_4x2_grid():
+    """`--config 4 --emulate-ranks 8` on the one GPU: rank 0 of the 4 x 2 grid steps its own block through nmf_algorithms_2D
+    with the real collective calls on one-rank groups; the line names the configuration and carries the KL roofline."""
+    r = _run(["--config", "4", "--emulate-ranks", "8", "--rows", "8192", "--cols", "4096", "--steps", "4", "--warmup", "1",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["metric"] == "mu_iterations_per_sec" and out["n_gpus"] == 1 and out["value"] > 0
+    assert "BASELINE config 4" in out["config"]["workload"] and "EMULATED" in out["config"]["workload"]
+    assert out["config"]["block_per_gpu"] == [2048, 2048] and out["config"]["k"] == 128
+    mg = out["multi_gpu"]
+    assert mg["grid"] == [4, 2] and mg["exchange_used"] == "torch" and mg["rccl_ranks_seen"] == 1
+    assert mg["compute_only_ms"] > 0 and abs(mg["exposed_comm_ms"] - (mg["full_step_ms"] - mg["compute_only_ms"])) < 1e-9
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["kernel"].startswith("kl_uht_pipe_kernel<KT=4>") and 0 < rf["frac"] < 1
+    assert rf["flops_per_launch"] == 4.0 * 2048 * 2048 * 128 and "cpu_baseline" not in out
+
+
+@pytest.mark.gpu
+def test_config4_on_a_2x2_grid_stacked_on_one_gpu():
+    """`--config 4 --gpus 4` over gloo with the four ranks stacked on the one GPU: the whole N > 1 path of config 4 (2 x 2
+    grid, sub-communicators, allgather / reduce-scatter between the kernels, compute-only leg)."""
+    r = _run(["--config", "4", "--gpus", "4", "--backend", "gloo", "--rows", "2048", "--cols", "1024", "--rank", "32", "--steps", "3",
+              "--warmup", "1", "--no-kernel-timing"], env_extra={"DNMF_BENCH_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["config"]["block_per_gpu"] == [1024, 512]
+    mg = out["multi_gpu"]
+    assert mg["grid"] == [2, 2] and mg["rccl_ranks_seen"] == 4 and len(mg["compute_only_ms_per_rank"]) == 4
+    assert "2D grid p_r=2 p_c=2" in out["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_config5_sweep_line_small():
+    """`--config 5` cut down (k = 2..5, 3 perturbations x 20 HALS iterations on 4096 x 512): one sweep = one step, fits/s."""
+    r = _run(["--config", "5", "--rows", "4096", "--cols", "512", "--end-k", "5", "--perturbations", "3", "--itr", "20",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["metric"] == "nmfk_fits_per_sec" and out["unit"] == "fits/s" and out["fits_per_step"] == 12 and out["value"] > 0
+    assert "BASELINE config 5" in out["config"]["workload"] and out["dtype"].startswith("bf16")
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel"].startswith("nt16_kernel<bf16 X>")
+
+
+@pytest.mark.gpu
+def test_config2_line_small_steps():
+    r = _run(["--config", "2", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-sustained"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert "BASELINE config 2" in out["config"]["workload"] and (out["config"]["m"], out["config"]["n"], out["config"]["k"]) == (65536, 4096, 32)
+    assert out["roofline"]["bound"] == "mfma" and out["value"] > 500
