@@ -160,6 +160,10 @@ int dnmf_sqnorm(const float* A, long m, long n, long lda, double* out, void* str
 /* *out (double, device) = sum (A - W H)^2 without materialising the residual (pyDNMF.py:207,215) */
 int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                       int k, double* out, void* stream);
+/* the same with a workspace (dnmf_ws_bytes(m, n, k) is enough; NULL = dnmf_resid_sqnorm): ranks that are not a whole number of
+ * 32-wide tiles (every k an NMFk sweep visits) are evaluated on zero-padded factor images in it by the LDS-staged kernel */
+int dnmf_resid_sqnorm_ws(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                         int k, double* out, void* ws, size_t ws_bytes, void* stream);
 /* per-column pieces of PyNMF.column_err (pyDNMF.py:221-239) over this rank's rows: num[c] += sum_i (A - W H)[i][c]^2,
  * den[c] += sum_i A[i][c]^2 (device doubles, n each, ACCUMULATED: the caller zeroes them; A - W H is never materialised) */
 int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
@@ -182,6 +186,8 @@ int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, lo
 int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void* stream);
 int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H,
                             long ldh, int k, double* out, void* stream);
+int dnmf_resid_sqnorm_ws_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H,
+                               long ldh, int k, double* out, void* ws, size_t ws_bytes, void* stream);
 int dnmf_column_err_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                           int k, double* num, double* den, void* stream);
 

@@ -66,8 +66,9 @@ SIGNATURES = {
     "dnmf_resid_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,
                           c_void_p],
 }
+SIGNATURES["dnmf_resid_sqnorm_ws"] = SIGNATURES["dnmf_resid_sqnorm"][:-1] + [c_void_p, c_size_t, c_void_p]
 # bf16 storage of A: same argument lists as the fp32 twins (A is passed as a device pointer either way)
-for _n in ("aht", "wta", "wta_gram", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "column_err"):
+for _n in ("aht", "wta", "wta_gram", "aht_update_w", "mu_fro_step", "sqnorm", "resid_sqnorm", "resid_sqnorm_ws", "column_err"):
     SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
 # bf16x6 contractions: the fp32 argument lists, aht / aht_update_w with a workspace added
 SIGNATURES["dnmf_ws_bytes_bf16x6"] = SIGNATURES["dnmf_ws_bytes"]

@@ -88,6 +88,14 @@ inline long round_up(long a, long b) { return cdiv(a, b) * b; }
 // RULE: a store of more than 8 bytes must not use the SGPR offset (pass 0 and add constants to the VGPR offset, they
 // fold into the immediate): with an SGPR offset the gfx950 hardware may still be reading the data registers when the
 // next VALU write hits them, and hipcc pads that hazard only for the immediate form (see update_w_seq_tile).
+// HAZARD 2 (round 4, measured): an MFMA reads its C operand DURING its passes (64 cycles for 32x32x2), and neither the hardware
+// nor hipcc's hazard recognizer protects those registers against the write-back of an LDS / global LOAD issued after it (only
+// VALU writes are padded).  When the C operand is a register block that dies with that MFMA -- eps as the initial value of an
+// accumulator chain: `acc = MFMA(a, b, epsv)` -- the allocator may hand the block to the next ds_read / buffer_load, and
+// data that returns within the MFMA's passes corrupts the upper accumulator rows.  Kernels that start a chain from eps therefore
+// pin the order [loads of the step] sched_barrier [the step's MFMAs, at least two on that chain] sched_barrier [next loads]:
+// the second MFMA cannot issue before the first has finished reading C (dnmf_kluht.h, kl_wtu_chunk_pipe, kl_uht_body);
+// loops without barriers start from zero (an inline constant, no registers) and add eps in the epilogue.
 constexpr int BUF_OOB = (int)0x80000000u;
 
 // descriptor for `base` (wave-uniform): raw buffer (stride 0), 2 GiB window, gfx9 data format word

@@ -40,13 +40,19 @@ static bool nn_fast(const float* A, long n, long lda, const float* W, long ldw, 
 
 }  // extern "C"
 namespace {
+// ws (optional): with room for the zero-padded factor images (pad_bytes: every dnmf_ws_bytes workspace has it) a rank that is
+// not a whole number of 32-wide tiles -- every k an NMFk sweep visits -- runs the LDS-staged kernel on [m x KP] / [KP x n]
+// images instead of the predicated one-tile-per-wave kernel (round 4: 0.645 -> ~0.39 ms at 32768 x 16384, k = 16; zero
+// columns of W / rows of H add nothing to W H).
 template <typename TA>
 int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
-                      int k, double* out, void* stream) {
+                      int k, double* out, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
     hipStream_t st = S(stream);
     if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
+    if (ws && a_aligned(A) && lda % 4 == 0 && n % 4 == 0 && n >= 128 && m >= 4096)
+        pad_factors(W, ldw, H, ldh, k, m, n, 32 * kt, ws, ws_bytes, 0, st);      // (no-op for friendly factors)
     NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
     a.out = out;
     const bool fast = a_aligned(A) && nn_fast(W, n, lda, W, ldw, H, ldh, k);
@@ -96,6 +102,14 @@ int dnmf_resid_sqnorm(const float* A, long m, long n, long lda, const float* W, 
 int dnmf_resid_sqnorm_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                             int k, double* out, void* stream) {
     return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream);
+}
+int dnmf_resid_sqnorm_ws(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                         int k, double* out, void* ws, size_t ws_bytes, void* stream) {
+    return resid_sqnorm_impl<float>(A, m, n, lda, W, ldw, H, ldh, k, out, stream, ws, ws_bytes);
+}
+int dnmf_resid_sqnorm_ws_bf16a(const void* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
+                               int k, double* out, void* ws, size_t ws_bytes, void* stream) {
+    return resid_sqnorm_impl<bf16_t>((const bf16_t*)A, m, n, lda, W, ldw, H, ldh, k, out, stream, ws, ws_bytes);
 }
 
 }  // extern "C"

@@ -281,7 +281,8 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
 #pragma unroll
     for (int ne = 0; ne < NT; ++ne)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ne][r] = p.eps;        // S + eps: eps is the accumulators' initial value (no add per element)
+        for (int r = 0; r < 16; ++r) acc[ne][r] = 0.f;          // (eps is added in the quotient below: this block has no scheduling
+                                                                // barriers -- HAZARD 2 in dnmf_common.h; the pipelined chunk keeps the eps start)
     const long wrow = row0 + li;
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {  // S = W H: contraction jj = 8s + 4h + e
@@ -299,7 +300,7 @@ __device__ __forceinline__ void kl_wtu_block(f32x16 (&out)[KT][NT], const NnArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = kl_quot(areg[r][ne], acc[ne][r]);  // U (dist_nmf.py:806)
+        for (int ne = 0; ne < NT; ++ne) acc[ne][r] = kl_quot(areg[r][ne], acc[ne][r] + p.eps);  // U (dist_nmf.py:806)
     // out[ke][ne] += sum_i W[i][KT*li + ke] * U[i][c]: A-operand lane (li, h) holds W[row0 + crow(r,h)][KT*li + ke]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -24,6 +24,17 @@ namespace {
 // still contract over them.  All global accesses are buffer loads / stores (dnmf_common.h): one offset register per
 // lane for the whole tile, edge lanes switched off through the offset.
 
+// s / d for d = (product) + eps > 0 (round 4): numerator times v_rcp_f32 -- 2 vector instructions (+ the add of eps) where
+// hipcc's IEEE division sequence (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) is 10.  On gfx950 every fp32 vector
+// instruction costs matrix-pipe time (tools/coissue.hip), and these kernels carry one division per factor element beside
+// k / 32 MFMAs per element-row: at k = 64 the epilogue was ~30 % of a tile's cycles.  <= 1.5 ulp from the correctly rounded
+// quotient -- the same form as the KL products (dnmf_nn.h kl_quot); a step's parity budget is 1e-5.
+// eps is ADDED here, not used as the accumulators' initial value as in the KL kernels: these loops carry no scheduling
+// barriers, and hipcc then reused the dead 16-register block that held eps (the C operand of the first MFMA) as the
+// destination of the next ds_read_b128 -- whose data lands while that MFMA is still reading C (HAZARD 2 in dnmf_common.h;
+// found as 5 % errors in the last 16 factor columns of test_mu_updates[300-260-32]).
+__device__ __forceinline__ float mu_quot(float s, float d) { return s * __builtin_amdgcn_rcpf(d); }
+
 // waves per SIMD asked of the compiler for the kernels that contain the edge tile code (per-row offset selects: ~40 more
 // registers) or the dword form of the W tile: what they hold without spilling
 constexpr int edge_occ(int kt, int occ) { return kt == 4 ? 2 : (occ < 4 ? occ : 4); }
@@ -71,7 +82,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
             const int ju = (r & 3) + 8 * (r >> 2);
             buf_load<NT, AUXL>(sreg[r], srs[ob], vo(soff, 32 * ob + ju), ju * lds4);
         }
-        f32x16 acc[NT];
+        f32x16 acc[NT];                 // (zero, not eps, as the initial value: see mu_quot)
 #pragma unroll
         for (int ne = 0; ne < NT; ++ne)
 #pragma unroll
@@ -96,7 +107,7 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
             float o[NT];
 #pragma unroll
             for (int ne = 0; ne < NT; ++ne) {
-                const float q = sreg[r][ne] / (acc[ne][r] + eps);
+                const float q = mu_quot(sreg[r][ne], acc[ne][r] + eps);
                 float v = hreg[ob][r][ne] * q;
                 if (clamp) v = fmaxf(v, eps);
                 o[ne] = v;
@@ -203,7 +214,7 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (MODE == UW_HALS_T) o[e] = sreg[g][e] - out[4 * g + e];
-                else o[e] = wreg[4 * jt + g][e] * (sreg[g][e] / (out[4 * g + e] + eps));
+                else o[e] = wreg[4 * jt + g][e] * mu_quot(sreg[g][e], out[4 * g + e] + eps);
             }
             st4(o, trs, toff, 4 * jt + g);
         }

@@ -357,8 +357,9 @@ class HipOps:
     def resid_sqnorm(self, A, W, H):
         sfx = _req_a(A); _req(W, "W"); _req(H, "H")
         out = torch.empty(1, dtype=torch.float64, device=A.device)
-        check(_fn("resid_sqnorm", sfx)(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), W.data_ptr(), _ld(W), H.data_ptr(),
-                                    _ld(H), W.shape[1], out.data_ptr(), _stream()))
+        ws = workspace(A.shape[0], A.shape[1], W.shape[1], A.device)      # room for the zero-padded factor images (ragged ranks)
+        check(_fn("resid_sqnorm_ws", sfx)(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), W.data_ptr(), _ld(W), H.data_ptr(),
+                                       _ld(H), W.shape[1], out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def column_err_sums(self, A, W, H):
