@@ -340,6 +340,26 @@ def count_gpus():
     return torch.cuda.device_count()
 
 
+def rccl_record():
+    """What the N > 1 line says about the transport: the RCCL the library bound (version code, where it was found) and the
+    NCCL_* / RCCL_* environment in effect (algorithm / protocol overrides change what an allreduce of 2 MiB costs)."""
+    rec = {"env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) or k == "HSA_ENABLE_IPC_MODE_LEGACY"}}
+    try:
+        import ctypes
+        from pydnmfk_amd._lib import lib
+        v, buf = ctypes.c_int(0), ctypes.create_string_buffer(256)
+        if lib.dnmf_comm_rccl_version(ctypes.byref(v), buf, 256) == 0:
+            rec["version_code"], rec["found"] = int(v.value), buf.value.decode()
+    except Exception as exc:  # noqa: BLE001
+        rec["version_error"] = repr(exc)
+    try:
+        import torch
+        rec["torch_nccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        pass
+    return rec
+
+
 class Job:
     """What every configuration's timed region needs: the ranks, the barrier and the max-over-ranks clock of the contract."""
 
@@ -530,7 +550,8 @@ def run_config4(a, job):
     multi = world > 1 or emu > 1
     mg = None
     if multi:
-        mg = {"rccl_ranks_seen": job.rccl_ranks_seen, "backend": a.backend, "grid": [p_r, p_c]}
+        mg = {"rccl_ranks_seen": job.rccl_ranks_seen, "backend": a.backend, "grid": [p_r, p_c],
+              "rccl": rccl_record() if a.backend == "nccl" else None}
         if emu:
             mg["emulated"] = ("rank 0 of a %d x %d grid on a single GPU: its own %d x %d block, real kernels and launches, the collectives of the "
                               "step issued on one-rank groups (EmulatedGroup: no wire time; the library-sequenced step needs the real grid)" % (p_r, p_c, m_l, n_l))
@@ -945,7 +966,7 @@ def main():
     # max-over-ranks times and therefore picks the same winner.
     mg = None
     if multi:
-        mg = {"rccl_ranks_seen": rccl_ranks_seen, "backend": a.backend}
+        mg = {"rccl_ranks_seen": rccl_ranks_seen, "backend": a.backend, "rccl": rccl_record() if a.backend == "nccl" else None}
         if emu:
             mg["emulated"] = ("ONE rank's share of a %d-GPU row grid on a single GPU: real kernels, launches and collective calls on a "
                               "one-rank group, no wire time" % emu)

@@ -259,8 +259,12 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
 #define DNMF_ALLGATHER 1
 #define DNMF_REDUCE_SCATTER 2
 #define DNMF_ALLREDUCE_F64 3   /* as DNMF_ALLREDUCE on `count` DOUBLES (send / recv point to doubles): the HALS column norms */
-typedef int (*dnmf_collective_fn)(void* user, int op, int group, const float* send, float* recv, size_t count, void* stream);
+/* send / recv are untyped: the element type is the op's (float32 for ops 0-2, float64 for DNMF_ALLREDUCE_F64) */
+typedef int (*dnmf_collective_fn)(void* user, int op, int group, const void* send, void* recv, size_t count, void* stream);
 int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collective_fn fn, void* user, dnmf_comm_t** comm);
+/* the RCCL this library bound at run time: *version = ncclGetVersion's code (e.g. 22604; 0 if the symbol is absent), `origin` =
+ * how it was found ("already in the process" = the host framework's copy, or the library name that was loaded).  For run records. */
+int dnmf_comm_rccl_version(int* version, char* origin, size_t origin_bytes);
 int dnmf_comm_destroy(dnmf_comm_t* comm);
 int dnmf_comm_info(const dnmf_comm_t* comm, int* nranks, int* rank, int* p_r, int* p_c);
 /* column chunks of the overlapped H phase of dnmf_mu_fro_step_1d on a row grid (1 = one packed allreduce; <= 8) */

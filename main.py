@@ -101,6 +101,14 @@ def main():
         raise SystemExit("--exchange must be auto, torch or native")
     if args.exchange == 'auto':                            # measured: tools/rankbench.py --method hals
         args.exchange = 'native' if (args.method.lower() == 'hals' and args.p_r > 1) else 'torch'
+    if args.method.lower() == 'hals' and args.p_r > 1 and args.rank == 0:
+        # the W sweep's column norms are global when W's rows are spread over ranks (dist_nmf.py:889, utils.py:388-391): k
+        # dependent 8-byte allreduces per iteration -- said once, with the grid that avoids them
+        print("note: method=hals on a %d x %d grid exchanges one column norm per factor column: k dependent 8-byte allreduces "
+              "per iteration (k = %s%s).  On a 1 x %d grid W is replicated and its column norms are local -- prefer "
+              "--p_r=1 --p_c=%d for HALS / NMFk sweeps when the matrix shape allows it."
+              % (args.p_r, args.p_c, getattr(args, 'k', None) if args.process == 'pyDNMF' else "%s..%s" % (args.start_k, args.end_k),
+                 ", sequenced inside the library: --exchange=%s" % args.exchange, world, world), flush=True)
     if args.exchange == 'torch' or world == 1:
         del args.exchange                                  # (the choreography reads params.exchange only when it is set)
     if args.process == 'pyDNMF':

@@ -27,6 +27,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;                  // optional
     const char* origin = "";
 };
 
@@ -45,10 +46,14 @@ Rccl* rccl() {
         r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym)); \
         if (!r.field) return nullptr;
         BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
-        BIND(CommSplit, "ncclCommSplit") BIND(AllReduce, "ncclAllReduce") BIND(AllGather, "ncclAllGather")
+        BIND(AllReduce, "ncclAllReduce") BIND(AllGather, "ncclAllGather")
         BIND(ReduceScatter, "ncclReduceScatter") BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
         BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
+        // optional symbols (round 4): ncclCommSplit is needed by 2D grids only -- a 1D grid must not lose the in-library exchange
+        // to an RCCL without it; ncclGetVersion feeds dnmf_comm_rccl_version
+        r.CommSplit = reinterpret_cast<decltype(r.CommSplit)>(dlsym(r.handle, "ncclCommSplit"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
         return &r;
     }();
     return inst;
@@ -121,7 +126,7 @@ int allreduce_f64(dnmf_comm* cm, int g, double* buf, size_t count, hipStream_t s
     const int r = resolve(cm, g, &c, "allreduce");
     if (r) return r < 0 ? r : DNMF_OK;
     if (cm->hook)
-        return cm->hook(cm->hook_user, DNMF_ALLREDUCE_F64, g, reinterpret_cast<const float*>(buf), reinterpret_cast<float*>(buf), count, st)
+        return cm->hook(cm->hook_user, DNMF_ALLREDUCE_F64, g, buf, buf, count, st)
                    ? fail(DNMF_ECOMM, "allreduce: the host collective failed") : DNMF_OK;
     NCCL_OK(rccl()->AllReduce(buf, buf, count, ncclFloat64, ncclSum, c, st), "allreduce");
     return DNMF_OK;
@@ -393,6 +398,10 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
     if (!r) return fail(DNMF_ECOMM, "comm_create: no RCCL library found (librccl.so.1)");
     dnmf_comm* c = new dnmf_comm();
     c->nranks = nranks; c->rank = rank; c->p_r = p_r; c->p_c = p_c;
+    if (p_r > 1 && p_c > 1 && !r->CommSplit) {
+        delete c;
+        return fail(DNMF_ECOMM, "comm_create: this RCCL (%s) has no ncclCommSplit: a %d x %d grid needs it (1D grids do not)", r->origin, p_r, p_c);
+    }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclResult_t e = r->CommInitRank(&c->world, nranks, id, rank);
@@ -408,6 +417,16 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
         if (hipEventCreateWithFlags(&c->ready[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->done[q], hipEventDisableTiming) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create: events"); }
     *out = c;
+    return DNMF_OK;
+}
+
+int dnmf_comm_rccl_version(int* version, char* origin, size_t origin_bytes) {
+    Rccl* r = rccl();
+    if (!r) return fail(DNMF_ECOMM, "comm_rccl_version: no RCCL library found (librccl.so.1)");
+    int v = 0;
+    if (r->GetVersion && r->GetVersion(&v) != ncclSuccess) v = 0;
+    if (version) *version = v;
+    if (origin && origin_bytes) snprintf(origin, origin_bytes, "%s", r->origin);
     return DNMF_OK;
 }
 
