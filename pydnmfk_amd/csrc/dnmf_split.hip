@@ -74,24 +74,12 @@ int cut_wt(const float* W, long m, int k, int kp, long ldw, bf16_t* img, SplitOp
 template <int KT, int MODE, typename TX, int NW = 4>
 int launch_ntx_kt(const NtArgs& a, const SplitOperand& ys, hipStream_t st) {
     // two stages [A tile, 32 NW rows x 128 bytes | H tile bf16 pieces (32 indices per row for fp32 A, 64 for bf16 A)]; >= the W.G loop's LDS
-    // (the wave-private form of dnmf_split_nt2.h needs 48 KiB at KT = 2: less)
     constexpr size_t lds = 2 * (32 * NW * 128 + 3 * 32 * KT * (std::is_same<TX, bf16_t>::value ? 128 : 64));
-    static_assert(KT != 2 || lds >= nt2_lds_bytes<2>(), "LDS of the second A H^T main loop");
     static bool once = false;
     // A is touched once: stream it past the caches when it cannot stay in them anyway
     const bool nt = (double)a.nrows * a.ncols * sizeof(TX) >= 256.0 * (1 << 20) && tune("DNMF_SPLIT_NT", 1) != 0;
     if (!once) { allow_lds(ntx_kernel<KT, MODE, 0, TX, NW>, lds); allow_lds(ntx_kernel<KT, MODE, 2, TX, NW>, lds); once = true; }
     const dim3 grid((unsigned)cdiv(a.nrows, 32 * NW), 1);
-#ifdef DNMF_TUNING      // A/B: the second main loop (A cut before LDS, wave-private piece tiles: dnmf_split_nt2.h)
-    if constexpr (KT == 2 && std::is_same<TX, float>::value && NW == 4) {
-        if (tune("DNMF_NTX_ML", 0) == 1) {
-            static bool once1 = false;
-            if (!once1) { allow_lds(ntx_kernel<KT, MODE, 2, TX, NW, 4, 1>, lds); once1 = true; }
-            hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2, TX, NW, 4, 1>), grid, dim3(64 * NW), lds, st, a, ys);
-            return check_launch("ntx_kernel");
-        }
-    }
-#endif
     if (nt) hipLaunchKernelGGL((ntx_kernel<KT, MODE, 2, TX, NW>), grid, dim3(64 * NW), lds, st, a, ys);
     else hipLaunchKernelGGL((ntx_kernel<KT, MODE, 0, TX, NW>), grid, dim3(64 * NW), lds, st, a, ys);
     return check_launch("ntx_kernel");

@@ -674,7 +674,9 @@ def native_comm_for(params):
     if mode not in ("native", "native-hosted"):
         return None
     nc = getattr(params, "_native_comm", None)
-    if nc is not None and (nc.p_r, nc.p_c, nc.size) != (int(params.p_r), int(params.p_c), int(params.comm1.size)):
+    stale = nc is not None and (nc.size != int(params.comm1.size) or (
+        int(params.p_r) * int(params.p_c) == nc.size and (nc.p_r, nc.p_c) != (int(params.p_r), int(params.p_c))))
+    if stale:      # (a grid that does not multiply to the communicator's size is an emulated share -- bench.py, tests -- and is left alone)
         # the bag was reused with another grid (pyDNMFk_Runner.run(grid=...) twice): every rank sees the same mismatch, so
         # the rebuild below is collective
         nc.close()

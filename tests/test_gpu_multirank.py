@@ -5,6 +5,7 @@ What this does not cover is the RCCL transport itself (the 8-GPU runs are the dr
 import pytest
 
 torch = pytest.importorskip("torch")
+from tests.conftest import long_param  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 CASES = ["t24x12_2x1_fro_float32", "t24x12_1x2_kl_float32", "t24x12_2x2_fro_float32", "r25x13_3x1_fro_float32",
@@ -54,7 +55,8 @@ def test_multirank_hip_bf16_storage(grid, method):
     run_bf16(grid, method, use_hip=True)
 
 
-@pytest.mark.parametrize("grid,method", [((2, 1), "hals"), ((2, 1), "mu"), ((1, 2), "mu"), ((2, 2), "hals"), ((2, 2), "mu"), ((3, 2), "hals")])
+@pytest.mark.parametrize("grid,method", [((2, 1), "hals"), long_param((2, 1), "mu"), long_param((1, 2), "mu"), long_param((2, 2), "hals"),
+                                         ((2, 2), "mu"), long_param((3, 2), "hals")])
 def test_multirank_bf16_storage_library_sequenced(grid, method):
     """bf16-stored blocks with every step sequenced inside the library (dnmf_{mu,hals}_fro_step_{1d,2d}_bf16a over the hosted
     gloo transport): BASELINE config 5's arithmetic (HALS / Frobenius on bf16 data) on row, column and 2D grids, even and ragged,
@@ -65,7 +67,7 @@ def test_multirank_bf16_storage_library_sequenced(grid, method):
         run_bf16(grid, method, use_hip=True, cfg={"exchange": "native-hosted", "shape": (256, 192, 16, 6)})
 
 
-@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), ((1, 2), "mu"), ((2, 2), "mu"), ((2, 1), "hals"), ((4, 1), "mu")])
+@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), long_param((1, 2), "mu"), ((2, 2), "mu"), long_param((2, 1), "hals"), long_param((4, 1), "mu")])
 def test_multirank_hip_bf16x6_gemm(grid, method):
     """params.gemm = 'bf16x6' on a grid: the split kernels on every rank's block (k = 40, local n a multiple of 128; the
     4 x 1 grid takes the overlapped H phase on column halves of A), checked against the oracle's grid simulation at the fp32
@@ -75,14 +77,14 @@ def test_multirank_hip_bf16x6_gemm(grid, method):
                                               "overlap_min_cols": 128})
 
 
-@pytest.mark.parametrize("grid", [(2, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("grid", [long_param((2, 1)), long_param((1, 2)), (2, 2)])
 def test_multirank_hip_bf16x6_kl(grid):
     """KL updates with params.gemm = 'bf16x6' on a grid (k = 12: the split KL kernels on every block, 2D slices included)."""
     from tests._mp import run_bf16
     run_bf16(grid, "mu", use_hip=True, cfg={"shape": (512, 512, 12, 8), "precision": "float32", "gemm": "bf16x6", "norm": "kl"})
 
 
-@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), ((2, 2), "hals")])
+@pytest.mark.parametrize("grid,method", [((2, 1), "mu"), long_param((2, 2), "hals")])
 def test_multirank_hip_bf16_storage_with_bf16x6(grid, method):
     """bf16-stored blocks AND params.gemm = 'bf16x6' on a grid: the three-product kernels against the oracle on float(bf16(A))."""
     from tests._mp import run_bf16

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
+from tests.conftest import long_param  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
@@ -97,7 +98,18 @@ CASES = [   # p_r, p_c, m, n, k, norm, W_update, overlap chunks of the 1D row gr
 ]
 
 
-@pytest.mark.parametrize("cfg", CASES, ids=["%dx%d_%dx%d_k%d_%s%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "" if c[6] else "_noW") for c in CASES])
+# the default tier keeps one case of every family (row / column / 2D grids, overlapped chunks, ragged slices, W_update off, HALS
+# 1D and 2D); the rest runs with DNMF_LONG_TESTS=1
+DEFAULT = {(2, 1, 512, 256, 16, "fro"), (4, 1, 1024, 512, 64, "fro"), (1, 2, 256, 512, 32, "fro"), (2, 2, 512, 256, 16, "kl"),
+           (4, 2, 200, 256, 64, "kl"), (2, 3, 241, 199, 33, "fro"), (3, 2, 301, 197, 5, "kl"), (2, 4, 150, 140, 7, "kl"),
+           (2, 1, 512, 256, 16, "hals"), (2, 3, 241, 199, 33, "hals"), (4, 2, 200, 256, 64, "hals")}
+
+
+def _id(c):
+    return "%dx%d_%dx%d_k%d_%s%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "" if c[6] else "_noW")
+
+
+@pytest.mark.parametrize("cfg", [pytest.param(c, id=_id(c)) if tuple(c[:6]) in DEFAULT else long_param(c, id=_id(c)) for c in CASES])
 def test_c_steps_over_a_hosted_transport_equal_the_choreography(cfg):
     import torch.multiprocessing as mp
     from tests._mp import free_port

@@ -3,6 +3,8 @@ PyNMFk (tests/golden/nmfk_1x1.npz): same data, seeds, parameters; numpy input ->
 import numpy as np
 import pytest
 
+from tests.conftest import LONG, long_param
+
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
@@ -176,6 +178,7 @@ def test_wtsi_known_answer(tmp_path, golden_dir):
     assert PyNMFk(A, factors=None, params=args).fit() == 4
 
 
+@LONG       # 28 s; the fp32 known answer above and the bf16 / HALS sweep against the checker (test_gpu_nmfk_sweep.py) stay
 def test_wtsi_known_answer_with_bf16_storage(tmp_path, golden_dir):
     """The same known answer with the data held as bfloat16 (params.precision, BASELINE config 5) and HALS: the rank
     estimate of the wtsi example must survive the 8-bit rounding of X (nopt == 4)."""
@@ -238,8 +241,8 @@ def test_swim_kl_known_answer_on_one_rank(tmp_path, golden_dir):
     assert sil[16] > 0.6 and sil[17] < 0.6, sil
 
 
-@pytest.mark.parametrize("gemm", ["fp32", "bf16x6"])
-def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):
+@pytest.mark.parametrize("gemm", [long_param("fp32"), long_param("bf16x6")])   # (65 s + 31 s: the 2 x 2 KL sweep stays in the default
+def test_swim_2x2_kl_nmfk_short(tmp_path, gemm):                               #  tier through ..._through_library_sequenced_steps below)
     """The same example cut to what fits the regular GPU tier (k = 16..17, 800 iterations): every rank of the 2 x 2 grid
     runs the 2D KL choreography inside NMFk, the four ranks agree on the estimate and on the silhouettes, and the
     clustering of k = 17 (one feature too many for the 16 swimmer limbs) is unstable.  The known answer itself needs the

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
+from tests.conftest import long_param  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 EPS = float(np.finfo(np.float32).eps)
@@ -241,7 +242,7 @@ def test_kl_split_steps_are_bitwise_reproducible():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", [0, 1] + [long_param(x) for x in range(2, 6)])
 def test_random_shapes_split_vs_fp32(seed):
     """Ragged row counts, every rank tile, column views with a pitch: each split product against its fp32 twin (both within
     rounding of the exact result, so they agree to a few 1e-6 of the largest entry)."""

@@ -1,3 +1,4 @@
+// tools/dnmf_split_nt2.h (round 4: moved out of pydnmfk_amd/csrc -- an experiment that measured no gain, kept for tools/ntxproto.hip)
 // dnmf_split_nt2.h -- A H^T in the bf16x6 arithmetic, second main loop: A is cut BEFORE it goes to LDS, into a tile that is
 // private to the wave that owns its 32 rows.
 //

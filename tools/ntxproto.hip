@@ -1,7 +1,8 @@
 // ntxproto.hip -- prototype bench for the bf16x6 A H^T kernel (ntx_kernel of csrc/dnmf_split.h) against candidate main loops.
-// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ipydnmfk_amd/csrc -o tools/_build/ntxproto tools/ntxproto.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Ipydnmfk_amd/csrc -Itools -o tools/_build/ntxproto tools/ntxproto.hip
 // Run on the GPU box: tools/_build/ntxproto [m n]   (k = 64; outputs are compared bit for bit with the library kernel)
 #define NT2_CLOCKS 1
+#define DNMF_NTX2 1      // pulls tools/dnmf_split_nt2.h into dnmf_split.h (not part of the library any more)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
