@@ -409,11 +409,12 @@ int launch_update_w_seq(float* W, long m, int k, long ldw, const float* AH, long
     if (!once) { allow_lds(update_w_seq_kernel<KT, V, OCC, false>, lds); allow_lds(update_w_seq_kernel<KT, V, OCC, true>, lds); once = true; }
     // one tile per wave (the kernel's tile loop only matters beyond 2^31 workgroups): measured on the 3.2 GB pass at
     // k = 64, workgroups that loop over tiles (256 x OCC of them, G staged once each) 4.5 TB/s, one tile per wave 4.75
-    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(m, 32), 4), tune("DNMF_UPD_GRID", 1L << 30));
+    const unsigned grid = upd_grid(cdiv(m, 32), KT);
+    constexpr unsigned T = 64 * upd_waves(KT);
     if (k == 32 * KT && m % 32 == 0)
-        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, false>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, false>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps);
     else
-        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, true>), dim3(grid), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, true>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps);
     return check_launch("mu_update_w");
 }
 }  // namespace
@@ -541,7 +542,8 @@ int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, lon
     constexpr size_t lds = (size_t)(32 * KT) * (32 * KT + 4) * sizeof(float);
     static bool once = false;
     if (!once) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false>, lds); allow_lds(update_h_seq_kernel<KT, NT, OCC, true>, lds); once = true; }
-    const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32 * NT), 4), tune("DNMF_UPD_GRID", 1L << 30));
+    const unsigned grid = upd_grid(cdiv(n, 32 * NT), KT);
+    constexpr unsigned T = 64 * upd_waves(KT);
     if constexpr (NT == 2 && KT <= 2) {
         // a long H that cannot stay cached (>= 64 MiB) streams with nontemporal loads and stores: 4.87 -> 5.07 TB/s at
         // 64 x 2^22 (each line is touched by exactly one instruction here; the W-side kernel touches a line four times
@@ -549,14 +551,14 @@ int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, lon
         if (k == 32 * KT && n % (32 * NT) == 0 && (double)k * n * sizeof(float) >= 64.0 * (1 << 20)) {
             static bool once2 = false;
             if (!once2) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>, lds); once2 = true; }
-            hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+            hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
             return check_launch("mu_update_h");
         }
     }
     if (k == 32 * KT && n % (32 * NT) == 0)
-        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     else
-        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, true>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, true>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     return check_launch("mu_update_h");
 }
 }  // namespace

@@ -99,13 +99,14 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
             allow_lds(update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>, lds1);
             once = true;
         }
-        const unsigned g1 = (unsigned)cdiv(cdiv(m, 32), 4);
+        const unsigned g1 = upd_grid(cdiv(m, 32), KT);
+        constexpr unsigned T1 = 64 * upd_waves(KT);
         if (vecw && k == KP && m % 32 == 0)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         else if (vecw)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         else
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(256), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         int rc = check_launch("hals_sweep_w(transform)");
         if (rc) return rc;
     }

@@ -120,21 +120,34 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
 // Workgroups walk the column tiles grid-stride (G is staged once per workgroup, not once per tile).  EDGE = false is the
 // kernel for k == KP and n a whole number of tiles: it contains the interior tile code only (the edge tile's per-row offset
 // selects cost ~40 registers, i.e. one to two waves per SIMD).
-template <int KT, int NT, int OCC, bool EDGE, bool MMA = true, int AUXL = 0, int AUXS = 0>
-__global__ __launch_bounds__(256, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_seq_kernel(float* __restrict__ H, int k, long n, long ldh,
+// Round 4, k = 128: the staged G is 66 KiB there, so the 160 KiB of LDS hold TWO workgroups per CU (2 waves per SIMD whatever the
+// registers allow), and with one tile per wave every workgroup staged its 64 KiB of G for four tiles: MFMA busy 50 % at an
+// unthrottled 2.28 GHz (profiles/r04b_elt128_*).  The launch now caps the grid at 1024 workgroups (two resident rounds), each
+// walking its share of the tiles with ONE staging of G: 3.55 -> 4.25 TB/s (H), 4.14 -> 4.46 TB/s (W) on the 6.4 GB pass.
+// NWV = waves per workgroup (a template parameter since then): 8-wave workgroups sharing one G measured the same for H and
+// 3-8 % slower for W than the capped 4-wave grid, so 4 stays.
+constexpr int upd_waves(int /*kt*/) { return 4; }
+// workgroups for `tiles` wave tiles: one tile per wave at k <= 64 (measured best: G is at most 16 KiB), capped at k = 128
+inline unsigned upd_grid(long tiles, int kt) {
+    const long cap = tune("DNMF_UPD_GRID", kt == 4 ? 1024 : (1L << 30));
+    return (unsigned)std::min<long>(cdiv(tiles, upd_waves(kt)), cap);
+}
+
+template <int KT, int NT, int OCC, bool EDGE, bool MMA = true, int AUXL = 0, int AUXS = 0, int NWV = upd_waves(KT)>
+__global__ __launch_bounds__(64 * NWV, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_seq_kernel(float* __restrict__ H, int k, long n, long ldh,
                                                                 const float* __restrict__ Sm, long lds_,
                                                                 const float* __restrict__ G, float eps, int clamp) {
     constexpr int KP = 32 * KT, GP = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float gs[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 64 * NWV) {
         const int gr = idx / (KP / 4), gc = (idx % (KP / 4)) * 4;
         *reinterpret_cast<f32x4*>(&gs[gr * GP + gc]) = *reinterpret_cast<const f32x4*>(G + gr * KP + gc);
     }
     __syncthreads();
     const long ntiles = cdiv(n, 32 * NT);
-    for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
+    for (long t = (long)blockIdx.x * NWV + wid; t < ntiles; t += (long)gridDim.x * NWV) {
         const long col0 = t * 32 * NT;
         if constexpr (!EDGE) update_h_seq_tile<KT, NT, true, MMA, AUXL, AUXS>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
         else if (k == KP && col0 + 32 * NT <= n) update_h_seq_tile<KT, NT, true>(H, k, n, ldh, Sm, lds_, gs, eps, clamp, col0, li, h);
@@ -221,8 +234,8 @@ __device__ __forceinline__ void update_w_seq_tile(float* __restrict__ W, long m,
     }
 }
 
-template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU, int AUX = 0>
-__global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) void update_w_seq_kernel(float* __restrict__ W, long m, int k, long ldw,
+template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU, int AUX = 0, int NWV = upd_waves(KT)>
+__global__ __launch_bounds__(64 * NWV, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) void update_w_seq_kernel(float* __restrict__ W, long m, int k, long ldw,
                                                                 const float* __restrict__ Sm, long lds_,
                                                                 const float* __restrict__ G, float eps,
                                                                 float* __restrict__ T = nullptr, long ldt = 0) {
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) vo
     extern __shared__ __attribute__((aligned(16))) float gs[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 64 * NWV) {
         const int gr = idx / (KP / 4), gc = (idx % (KP / 4)) * 4;
         f32x4 g = *reinterpret_cast<const f32x4*>(G + gr * KP + gc);
         if constexpr (MODE == UW_HALS_T) {      // gs[j][l] feeds output column j with contraction index l: keep l > j
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) vo
     }
     __syncthreads();
     const long ntiles = cdiv(m, 32);
-    for (long t = (long)blockIdx.x * 4 + wid; t < ntiles; t += (long)gridDim.x * 4) {
+    for (long t = (long)blockIdx.x * NWV + wid; t < ntiles; t += (long)gridDim.x * NWV) {
         const long row0 = t * 32;
         if constexpr (!EDGE) update_w_seq_tile<KT, V, true, MODE, AUX>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
         else if (k == KP && row0 + 32 <= m) update_w_seq_tile<KT, V, true, MODE>(W, m, k, ldw, Sm, lds_, gs, eps, row0, li, h, T, ldt);
