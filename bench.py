@@ -992,6 +992,30 @@ def main():
             ok = int(-max_over_ranks(-float(ok)))                  # usable only if every rank has it
             if ok:
                 modes.append("native")
+                # third arm: the direct two-shot allreduce over IPC peer buffers for the packed
+                # message -- eligible only if every rank connected AND its sum agrees with RCCL's on a test vector here
+                if world > 1 and a.exchange == "auto":
+                    try:
+                        kp_ = 32 if k <= 32 else (64 if k <= 64 else 128)
+                        nmsg = max(k * n, m_l * k) + 8 * 64 + kp_ * kp_ + 1024
+                        good = p._native_comm.enable_direct(comms.comm, nmsg)
+                        if good:
+                            xt = torch.rand(k * n + kp_ * kp_, device=dev) - 0.25
+                            y_ring = p._native_comm.allreduce_(xt.clone())
+                            y_dir = p._native_comm.allreduce_direct_(xt.clone())
+                            torch.cuda.synchronize()
+                            err_d = float((y_dir - y_ring).abs().max() / y_ring.abs().max())
+                            good = err_d < 1e-5 and not p._native_comm.direct_timed_out()
+                            mg["direct_vs_rccl_max_rel_diff"] = err_d
+                        good = int(-max_over_ranks(-float(bool(good))))
+                    except Exception as exc:  # noqa: BLE001
+                        good = 0
+                        mg["direct_exchange_unavailable"] = repr(exc)
+                        good = int(-max_over_ranks(-float(good)))
+                    if good:
+                        modes.append("native-direct")
+                    else:
+                        mg.setdefault("direct_exchange_unavailable", "not connected on every rank, or its sum disagreed with RCCL's")
             else:
                 mg["native_exchange_unavailable"] = why or "another rank could not create the library communicator"
         if not modes:
@@ -1000,7 +1024,9 @@ def main():
         if len(modes) * len(chunks) > 1:
             ab, nab = {}, max(5, min(40, a.steps))
             for mode in modes:
-                p.exchange = mode
+                p.exchange = "native" if mode.startswith("native") else mode
+                if mode.startswith("native"):
+                    p._native_comm.set_direct(mode == "native-direct")
                 for c in chunks:
                     p.overlap_chunks = c
                     for i in range(3):
@@ -1011,7 +1037,9 @@ def main():
             mg["exchange_ab_steps"] = nab
         else:
             best = (modes[0], chunks[0])
-        p.exchange, p.overlap_chunks = best
+        p.exchange, p.overlap_chunks = ("native" if best[0].startswith("native") else best[0]), best[1]
+        if best[0].startswith("native"):
+            p._native_comm.set_direct(best[0] == "native-direct")
         mg["exchange_used"], mg["overlap_chunks_used"] = best
         p6.overlap_chunks = p.overlap_chunks
 

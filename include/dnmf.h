@@ -265,6 +265,24 @@ int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collect
 /* the RCCL this library bound at run time: *version = ncclGetVersion's code (e.g. 22604; 0 if the symbol is absent), `origin` =
  * how it was found ("already in the process" = the host framework's copy, or the library name that was loaded).  For run records. */
 int dnmf_comm_rccl_version(int* version, char* origin, size_t origin_bytes);
+/* ---- direct (two-shot) allreduce over IPC peer buffers -- an alternative to RCCL's ring for the small packed message of a 1D
+ * step (2 MiB at BASELINE config 3; SURVEY section 5 "measure both").  Every rank exports a region of device memory, the host
+ * moves the 64-byte handles (allgather over whatever it has), every rank maps its peers' regions.  One node, at most
+ * DNMF_DIRECT_MAX_RANKS ranks, messages of an even number of floats.  Rank-ordered sums with one owner per element: every rank
+ * ends with identical bits.  Works on RCCL and on hosted communicators alike (it needs neither). ---- */
+#define DNMF_DIRECT_MAX_RANKS 16
+#define DNMF_DIRECT_HANDLE_BYTES 64
+/* allocate this rank's region for messages of up to max_floats floats; handle_out receives DNMF_DIRECT_HANDLE_BYTES bytes */
+int dnmf_comm_direct_init(dnmf_comm_t* comm, size_t max_floats, void* handle_out);
+/* handles = nranks x DNMF_DIRECT_HANDLE_BYTES bytes in rank order (this rank's own entry is ignored) */
+int dnmf_comm_direct_connect(dnmf_comm_t* comm, const void* handles);
+/* on != 0: allreduces over ALL ranks that fit the regions (the packed exchange of the 1D steps, dnmf_comm_allreduce with
+ * group 0) take the direct path; everything else stays on RCCL / the hosted function */
+int dnmf_comm_set_direct(dnmf_comm_t* comm, int on);
+/* in-place SUM allreduce of `count` floats over all ranks through the peer regions, on `stream` */
+int dnmf_comm_allreduce_direct(dnmf_comm_t* comm, float* buf, size_t count, void* stream);
+/* *timed_out != 0: a wait of a direct allreduce saw no progress for ~2 s and gave up (a peer is gone): results are invalid */
+int dnmf_comm_direct_status(dnmf_comm_t* comm, int* timed_out);
 int dnmf_comm_destroy(dnmf_comm_t* comm);
 int dnmf_comm_info(const dnmf_comm_t* comm, int* nranks, int* rank, int* p_r, int* p_c);
 /* column chunks of the overlapped H phase of dnmf_mu_fro_step_1d on a row grid (1 = one packed allreduce; <= 8) */

@@ -88,6 +88,11 @@ COLLECTIVE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_void_p, c_void
 SIGNATURES["dnmf_comm_create_hosted"] = [c_int, c_int, c_int, c_int, COLLECTIVE_FN, c_void_p, ctypes.POINTER(c_void_p)]
 SIGNATURES["dnmf_comm_destroy"] = [c_void_p]
 SIGNATURES["dnmf_comm_rccl_version"] = [ctypes.POINTER(c_int), c_void_p, c_size_t]
+SIGNATURES["dnmf_comm_direct_init"] = [c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_comm_direct_connect"] = [c_void_p, c_void_p]
+SIGNATURES["dnmf_comm_set_direct"] = [c_void_p, c_int]
+SIGNATURES["dnmf_comm_allreduce_direct"] = [c_void_p, c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_comm_direct_status"] = [c_void_p, ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_info"] = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_set_overlap_chunks"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_set_always_exchange"] = [c_void_p, c_int]

@@ -551,6 +551,44 @@ class NativeComm:
         if not sys.is_finalizing():
             self.close()
 
+    def enable_direct(self, host_comm, max_floats):
+        """Set up the direct two-shot allreduce over IPC peer buffers (dnmf_comm_direct_*; include/dnmf.h): every rank exports a
+        region for messages of up to `max_floats` floats, `host_comm` (a dist_comm.TorchComm over the same ranks) carries the
+        64-byte handles.  Collective; returns True when EVERY rank is connected (the ranks agree before anybody uses it), else
+        False on every rank.  `set_direct(True)` then routes the world allreduces that fit through it."""
+        import ctypes
+        hbuf = ctypes.create_string_buffer(64)
+        ok = 1
+        try:
+            check(lib.dnmf_comm_direct_init(self.handle, int(max_floats), hbuf))
+        except Exception:  # noqa: BLE001
+            ok = 0
+        handles = host_comm.allgather(bytes(hbuf.raw))
+        if ok:
+            try:
+                check(lib.dnmf_comm_direct_connect(self.handle, b"".join(handles)))
+            except Exception:  # noqa: BLE001
+                ok = 0
+        nbad = int(host_comm.allreduce(0 if ok else 1)) if host_comm.size > 1 else (0 if ok else 1)
+        self.direct_ready = nbad == 0
+        return self.direct_ready
+
+    def set_direct(self, on=True):
+        check(lib.dnmf_comm_set_direct(self.handle, int(bool(on))))
+
+    def allreduce_direct_(self, t):
+        _req(t, "t", t.dim())
+        if not t.is_contiguous():
+            raise ValueError("allreduce_direct_: contiguous tensors only")
+        check(lib.dnmf_comm_allreduce_direct(self.handle, t.data_ptr(), t.numel(), _stream()))
+        return t
+
+    def direct_timed_out(self):
+        import ctypes
+        w = ctypes.c_int(0)
+        check(lib.dnmf_comm_direct_status(self.handle, ctypes.byref(w)))
+        return bool(w.value)
+
     def set_overlap_chunks(self, n):
         check(lib.dnmf_comm_set_overlap_chunks(self.handle, int(n)))
         self.overlap_chunks = int(n)
@@ -695,6 +733,18 @@ def native_comm_for(params):
             groups = {0: params.comm1, 1: getattr(params, "row_comm", None) or params.comm1,
                       2: getattr(params, "col_comm", None) or params.comm1}
             nc = NativeComm.hosted(params.comm1.size, params.comm1.rank, params.p_r, params.p_c, _torch_hosted_collective(groups))
+        if getattr(params, "direct_allreduce", False) and params.comm1.size > 1:
+            # params.direct_allreduce: the world allreduces of the library-sequenced 1D steps (the packed [W^T A | W^T W] message)
+            # go through the two-shot form over IPC peer buffers instead of RCCL / the hosted function (one node; collective set-up;
+            # every rank falls back together when any rank cannot connect)
+            kk = int(getattr(params, "end_k", None) or getattr(params, "k", None) or 128)
+            kp = 32 if kk <= 32 else (64 if kk <= 64 else 128)
+            nmax = kk * max(int(params.m), int(params.n)) + 8 * 64 + kp * kp + 2048
+            if nc.enable_direct(params.comm1, nmax):
+                nc.set_direct(True)
+            else:
+                import warnings
+                warnings.warn("params.direct_allreduce: the peer regions could not be connected on every rank -- staying on the communicator's own allreduce")
         params._native_comm = nc
     return nc
 

@@ -81,6 +81,8 @@ def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
             if (extra or {}).get("exchange") in ("native", "native-hosted"):      # the fit really ran inside the library
                 assert getattr(args, "_native_comm", None) is not None and args._native_comm.steps == itr, \
                     (itr, getattr(getattr(args, "_native_comm", None), "steps", None))
+                if (extra or {}).get("direct_allreduce"):                         # ... with its world allreduce over the peer regions
+                    assert getattr(args._native_comm, "direct_ready", False) and not args._native_comm.direct_timed_out()
         q.put((rank, out, None))
         if world > 1:
             dist.barrier()

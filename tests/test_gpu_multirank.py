@@ -48,6 +48,15 @@ def test_multirank_library_sequenced_steps_match_reference(name):
     run_case(name, use_hip=True, timeout=400, extra={"exchange": "native-hosted"})
 
 
+@pytest.mark.parametrize("name", ["swim_4x1_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32"])
+def test_multirank_direct_allreduce_matches_reference(name):
+    """Reference golden fits on 1D grids with every step inside the library AND its packed exchange through the direct two-shot
+    allreduce over IPC peer buffers (params.direct_allreduce; csrc/dnmf_comm.hip): four / two ranks stacked on the one GPU map
+    each other's regions; W, H and recon_err against the reference at the usual tolerances."""
+    from tests._mp import run_case
+    run_case(name, use_hip=True, timeout=400, extra={"exchange": "native-hosted", "direct_allreduce": True})
+
+
 @pytest.mark.parametrize("grid,method", [((2, 1), "hals"), ((1, 2), "mu"), ((2, 2), "hals")])
 def test_multirank_hip_bf16_storage(grid, method):
     """bf16-stored data blocks on a grid, real HIP kernels (the *_bf16a entry points), gloo transport."""
