@@ -60,6 +60,70 @@ __global__ __launch_bounds__(256) void mix_kernel(const f32x4* __restrict__ buf,
     if (s == 123.456f) out[0] = s;
 }
 
+// the same mix on v_mfma_f32_16x16x4_f32 (2048 flop per instruction, 4 accumulator registers: per flop 40 % less register-file
+// traffic than 32x32x2 -- does the power-shared ceiling move?  round 4)
+template <int MFMAS, int LOADS>
+__global__ __launch_bounds__(256) void mix16_kernel(const f32x4* __restrict__ buf, long n4, long trips, float* out) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    float a = 1.0f + lane * 1e-6f, b = 0.5f;
+    f32x4 v[LOADS > 0 ? LOADS : 1];
+    long idx = (gw * 64 + lane) % n4;
+    const long stride = nw * 64;
+    if constexpr (LOADS > 0) {
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) { v[l] = __builtin_nontemporal_load(buf + idx); idx += stride; if (idx >= n4) idx -= n4; }
+    }
+    for (long t = 0; t < trips; ++t) {
+        f32x4 nv[LOADS > 0 ? LOADS : 1];
+        if constexpr (LOADS > 0) {
+#pragma unroll
+            for (int l = 0; l < LOADS; ++l) { nv[l] = __builtin_nontemporal_load(buf + idx); idx += stride; if (idx >= n4) idx -= n4; }
+        }
+#pragma unroll
+        for (int i = 0; i < MFMAS; ++i) {
+            float aa = a;
+            if constexpr (LOADS > 0) aa += v[i % LOADS][i & 3] * 1e-30f;
+            acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, b, acc[i & 7], 0, 0, 0);
+        }
+        if constexpr (LOADS > 0) {
+#pragma unroll
+            for (int l = 0; l < LOADS; ++l) v[l] = nv[l];
+        }
+    }
+    float s = a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int MFMAS, int LOADS>
+void run16(const char* name, const f32x4* buf, long n4, float* out, long trips, int wg_per_cu = 2) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int grid = 256 * wg_per_cu, block = 256;
+    trips = trips * 2 / wg_per_cu;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((mix16_kernel<MFMAS, LOADS>), dim3(grid), dim3(block), 0, 0, buf, n4, trips / 8, out);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((mix16_kernel<MFMAS, LOADS>), dim3(grid), dim3(block), 0, 0, buf, n4, trips, out);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double waves = (double)grid * block / 64;
+    const double flops = waves * trips * MFMAS * 2048.0, bytes = waves * trips * LOADS * 1024.0;
+    printf("%-30s %2d waves/CU %8.3f ms  %7.1f TFLOP/s (%3.0f %% of 157.3)  %6.2f TB/s  [16x16x4: %d B of HBM per 4096 flop]\n", name, 4 * wg_per_cu, best,
+           flops / best / 1e9, 100.0 * flops / best / 1e9 / 157.3, bytes / best / 1e9, MFMAS ? LOADS * 2048 / MFMAS : 0);
+}
+
 template <int MFMAS, int LOADS>
 void run(const char* name, const f32x4* buf, long n4, float* out, long trips, int wg_per_cu = 2) {
     hipEvent_t e0, e1;
@@ -97,6 +161,13 @@ int main() {
         run<32, 4>("mfma + stream (k=64 ratio)", buf, n4, out, 20000, w);
         run<16, 4>("mfma + stream (k=32 ratio)", buf, n4, out, 20000, w);
         run<8, 4>("mfma + stream (k=16 ratio)", buf, n4, out, 20000, w);
+    }
+    // round 4: the same ceilings on the 16x16x4 instruction (twice the instructions for the same flops and bytes)
+    run16<64, 0>("16x16x4 mfma only", buf, n4, out, 20000);
+    for (int w = 2; w <= 3; ++w) {
+        run16<64, 2>("16x16x4 + stream (k=128)", buf, n4, out, 20000, w);
+        run16<64, 4>("16x16x4 + stream (k=64)", buf, n4, out, 20000, w);
+        run16<32, 4>("16x16x4 + stream (k=32)", buf, n4, out, 20000, w);
     }
     return 0;
 }
