@@ -620,9 +620,11 @@ def run_config4(a, job):
         mg["compute_only_ms_per_rank"], mg["compute_only_ms"] = per, max(per)
         mg["full_step_ms"], mg["exposed_comm_ms"] = ms, ms - max(per)
         kb = 4 * k
-        mg["exchange_bytes_per_step"] = {"allgather_H_recv": kb * n_l if p_r > 1 else 0, "allgather_W_recv": 2 * kb * m_l if p_c > 1 else 0,
-                                         "reduce_scatter_W_send": kb * m_l if p_c > 1 else 0, "reduce_scatter_H_send": kb * n_l if p_r > 1 else 0,
-                                         "allreduce_k_vectors": 2 * kb}
+        if two_d:
+            mg["exchange_bytes_per_step"] = {"allgather_H_recv": kb * n_l, "allgather_W_recv": 2 * kb * m_l, "reduce_scatter_W_send": kb * m_l,
+                                             "reduce_scatter_H_send": kb * n_l, "allreduce_k_vectors": 2 * kb}
+        else:      # 1D grid: the sharded factor's phase is local, the replicated one's product is allreduced (dist_nmf.py:776-869)
+            mg["exchange_bytes_per_step"] = {"allreduce_product": kb * (n_l if p_c == 1 else m_l), "allreduce_k_vectors": 2 * kb}
         mg["note"] = ("compute_only = the same step with every exchange stubbed out (NullExchange / the library's null mode; timing only); "
                       "exposed_comm_ms = full step - slowest rank's compute-only step")
 
