@@ -44,7 +44,7 @@ template <int KT> struct KlUhtOcc { static constexpr int value = KT == 4 ? 2 : (
 // A2: the A pieces of tile t+1 land in a second register set requested at the top of tile t (a whole tile of latency);
 // otherwise they refill the one set right after the quotient consumed it (second product + next first product of latency).
 // ABL (tuning build only, tools/kluht_ab.py): ablations that give wrong results but tell where the time goes -- 1: no
-// barrier, 2: no quotient, 4: A pieces loaded once, 8: H tile loaded / staged once, 16: no second product, 32: no first product
+// barrier, 2: no quotient, 4: A pieces loaded once, 8: H tile loaded / staged once, 16: no second product, 32: no first product, 64: line-coalesced A requests, 128: one LDS read per product and tile
 template <int KT, bool A2, int OCC = KlUhtOcc<KT>::value, int ABL = 0, int AUXA = 0>
 __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,11 +102,13 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p) {
     };
     auto read_hv = [&](float (&v)[4], const float* Hs, auto S) {
         constexpr int s = decltype(S)::value;
+        if constexpr ((ABL & 128) != 0) { if (s != 0) return; }        // (ablation: the first step's values for every step)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = Hs[ax[2 * (s & 1) + (e >> 1)] + (8 * s + e) * BK];
     };
     auto read_hh = [&](f32x4& v, const float* Hs, auto Q) {
         constexpr int q = decltype(Q)::value, g = q / KT, jt = q % KT;
+        if constexpr ((ABL & 128) != 0) { if (q != 0) return; }
         v = *reinterpret_cast<const f32x4*>(&Hs[ay[g] + jt * 32 * BK]);
     };
 

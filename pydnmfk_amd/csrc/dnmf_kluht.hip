@@ -32,7 +32,7 @@ int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const flo
             hipLaunchKernelGGL((kl_uht_pipe_kernel<KT_, A2_, OCC_, 0, AUX_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
         KA(1, true, 4, 0) KA(2, true, 3, 0) KA(4, false, 2, 0) KA(1, true, 4, 1) KA(2, true, 3, 1) KA(4, false, 2, 1)
 #undef KA
-        KV(1, true, 4, 1) KV(1, true, 4, 2) KV(1, true, 4, 4) KV(1, true, 4, 8) KV(1, true, 4, 16) KV(1, true, 4, 32) KV(1, true, 4, 12) KV(1, true, 4, 15) KV(1, true, 4, 64) KV(2, true, 3, 64)
+        KV(1, true, 4, 1) KV(1, true, 4, 2) KV(1, true, 4, 4) KV(1, true, 4, 8) KV(1, true, 4, 16) KV(1, true, 4, 32) KV(1, true, 4, 12) KV(1, true, 4, 15) KV(1, true, 4, 64) KV(2, true, 3, 64) KV(1, true, 4, 128) KV(2, true, 3, 128) KV(1, true, 4, 136) KV(1, true, 4, 129)
         KV(2, true, 3, 1) KV(2, true, 3, 2) KV(2, true, 3, 4) KV(2, true, 3, 8) KV(2, true, 3, 12) KV(2, true, 3, 15)
 #undef KV
     }
