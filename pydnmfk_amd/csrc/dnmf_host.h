@@ -222,10 +222,10 @@ struct UhtPlan { int nsplit; long cols_per_split; };
 // chip costs as much as a full one (32768 x 16384, k = 32: 1536 workgroups on 1024 slots were 1.5 rounds).  Model: time ~
 // rounds x (column tiles per split + 3 tiles' worth of prologue / epilogue); fewest splits among the best (fewer slabs to
 // write and reduce); every split keeps at least 8 column tiles.
-inline int uht_wgs_per_cu(int kt) { return kt == 4 ? 2 : (kt == 2 ? 3 : 4); }
+inline int uht_wgs_per_cu(int kt) { return kt == 4 ? 2 : (kt == 2 ? 3 : 4); }      // = KlUhtOcc<KT> of csrc/dnmf_kluht.h
 UhtPlan plan_uht(long m, long n, int kt) {
     UhtPlan u;
-    const long rowtiles = cdiv(m, 128), slots = 256L * uht_wgs_per_cu(kt), coltiles = cdiv(n, 32);
+    const long rowtiles = cdiv(m, 128), slots = 256L * uht_wgs_per_cu(kt);
     const long max_ns = std::min<long>(32, std::max<long>(1, n / 256));
     long best_ns = 1;
     double best_t = 0;
@@ -235,7 +235,6 @@ UhtPlan plan_uht(long m, long n, int kt) {
         const double t = (double)cdiv(rowtiles * nsp, slots) * (double)(cps / 32 + 3);
         if (ns == 1 || t < best_t * 0.97) { best_t = t; best_ns = ns; }
     }
-    (void)coltiles;
     u.cols_per_split = round_up(cdiv(n, best_ns), 32);          // 32 = BK, the column tile of the NT-shaped kernels
     u.nsplit = (int)cdiv(n, u.cols_per_split);
     return u;

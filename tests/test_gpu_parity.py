@@ -227,6 +227,37 @@ def test_config4_block_kl_checksums():
     assert d1 < d0
 
 
+def test_config4_whole_matrix_kl_checksums_on_one_gpu():
+    """ALL of BASELINE config 4 on one GPU (131072 x 65536 fp32 = 34 GB, 8.6e9 elements: element indices beyond 2^32, row
+    chunks beyond the 2 GiB descriptor window -- round 4: the chunk of `W^T U` had left the window and silently taken the slow
+    path) -- what `bench.py --config 4` steps at N = 1.  The same identities as on the block: <U H^T, W> = <W^T U, H> ~= sum(A),
+    plus a far-corner spike that must reach both products."""
+    from pydnmfk_amd.engine import HIP_OPS as ops
+    m, n, k = 131072, 65536, 128
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2**30:
+        pytest.skip("needs 36 GB of device memory")
+    EPS = float(np.finfo(np.float32).eps)
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(12)
+    A = torch.rand(m, n, device=dev, generator=g)
+    W = torch.rand(m, k, device=dev, generator=g)
+    H = torch.rand(k, n, device=dev, generator=g)
+    UHT = ops.kl_uht(A, W, H, EPS, torch.empty(m, k, device=dev))
+    WTU = ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, device=dev))
+    lhs, rhs = float((UHT.double() * W.double()).sum()), float((WTU.double() * H.double()).sum())
+    sa = sum(float(A[r0:r0 + 8192].double().sum()) for r0 in range(0, m, 8192))
+    assert abs(lhs - rhs) / abs(rhs) < 1e-6
+    assert abs(lhs - sa) / sa < 1e-5
+    # the last element of the matrix (linear index 2^33 - 1): raise it and watch the last row of U H^T / last column of W^T U move
+    wh = float(W[m - 1].double() @ H[:, n - 1].double()) + EPS
+    A[m - 1, n - 1] += 1000.0
+    UHT2 = ops.kl_uht(A, W, H, EPS, torch.empty(m, k, device=dev))
+    WTU2 = ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, device=dev))
+    assert torch.allclose(UHT2[m - 1] - UHT[m - 1], (1000.0 / wh) * H[:, n - 1], rtol=2e-3, atol=1e-2)
+    assert torch.allclose(WTU2[:, n - 1] - WTU[:, n - 1], (1000.0 / wh) * W[m - 1], rtol=2e-3, atol=1e-2)
+    assert torch.equal(UHT2[: m - 1], UHT[: m - 1]) and torch.equal(WTU2[:, : n - 1], WTU[:, : n - 1])
+
+
 @pytest.mark.parametrize("k", [16, 9, 32])
 def test_headline_size_kl_checksums_small_rank(k):
     """The KL products at the full 262144 x 8192 (8 GiB: offsets beyond 2^32 bytes, MUBUF windows re-based per chunk / per
