@@ -281,6 +281,10 @@ int dnmf_comm_direct_connect(dnmf_comm_t* comm, const void* handles);
 int dnmf_comm_set_direct(dnmf_comm_t* comm, int on);
 /* in-place SUM allreduce of `count` floats over all ranks through the peer regions, on `stream` */
 int dnmf_comm_allreduce_direct(dnmf_comm_t* comm, float* buf, size_t count, void* stream);
+/* the ONE-launch form for 1..8 doubles (the column norms of the HALS W sweep: k dependent 8-byte allreduces per iteration on
+ * p_r > 1, pure latency): every rank pushes its values into its peers' regions, sums in rank order.  With dnmf_comm_set_direct
+ * the HALS step entry points use it for their norm exchanges. */
+int dnmf_comm_allreduce_direct_f64(dnmf_comm_t* comm, double* buf, size_t count, void* stream);
 /* *timed_out != 0: a wait of a direct allreduce saw no progress for ~2 s and gave up (a peer is gone): results are invalid */
 int dnmf_comm_direct_status(dnmf_comm_t* comm, int* timed_out);
 int dnmf_comm_destroy(dnmf_comm_t* comm);

@@ -92,6 +92,7 @@ SIGNATURES["dnmf_comm_direct_init"] = [c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_direct_connect"] = [c_void_p, c_void_p]
 SIGNATURES["dnmf_comm_set_direct"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_allreduce_direct"] = [c_void_p, c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_comm_allreduce_direct_f64"] = [c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_direct_status"] = [c_void_p, ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_info"] = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
 SIGNATURES["dnmf_comm_set_overlap_chunks"] = [c_void_p, c_int]

@@ -77,7 +77,7 @@ struct dnmf_comm {
     int direct_on = 0;
     size_t direct_cap = 0;                                       // floats per message
     char* direct_peer[DNMF_DIRECT_MAX_RANKS] = {};               // [rank] = the own region
-    unsigned long long direct_seq = 0;
+    unsigned long long direct_seq = 0, direct_small_seq = 0;
 };
 
 namespace {
@@ -130,7 +130,7 @@ int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
 // call).  A wait that sees no progress for about two seconds sets the region's status word (dnmf_comm_direct_status) and gives up.
 // NOT measured on more than one GPU (this pool has none): bench.py treats it as a third arm of its warm-up A/B and only after
 // its result has matched RCCL's on the warm-up step.
-constexpr size_t DIRECT_HDR = 4096;
+constexpr size_t DIRECT_HDR = 8192;       // flag1 @0, flag2 @1024, status @2048, small-message flags @3072, small-message slots @4096
 struct DirectArgs {
     char* peer[DNMF_DIRECT_MAX_RANKS];
     int P, rank, par;
@@ -207,6 +207,54 @@ int direct_allreduce(dnmf_comm* cm, float* buf, size_t count, hipStream_t st) {
     return check_launch("allreduce(direct)");
 }
 
+// ONE-shot form for a few doubles (the column norms of the HALS W sweep, utils.py:388-391: k DEPENDENT 8-byte allreduces per
+// iteration when W's rows are spread over ranks -- pure latency): a single launch of one wave.  Thread q pushes this rank's
+// values into slot [parity][rank] of peer q's region and then raises its flag there; when all P flags of the own region have
+// arrived the values are summed in rank order -- identical bits everywhere.  Same parity argument as above.
+constexpr int DIRECT_SMALL_MAX = 8;
+__global__ __launch_bounds__(64) void direct_small_f64_kernel(DirectArgs a, double* __restrict__ buf, int count) {
+    const int q = threadIdx.x;
+    double mine[DIRECT_SMALL_MAX];
+#pragma unroll
+    for (int i = 0; i < DIRECT_SMALL_MAX; ++i) mine[i] = i < count ? buf[i] : 0.0;
+    __threadfence_system();
+    if (q < a.P) {
+        double* slot = reinterpret_cast<double*>(a.peer[q] + 4096) + ((size_t)a.par * DNMF_DIRECT_MAX_RANKS + a.rank) * DIRECT_SMALL_MAX;
+        for (int i = 0; i < count; ++i)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot) + i, (unsigned long long)__double_as_longlong(mine[i]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.peer[q] + 3072) + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(a.peer[a.rank] + 3072) + q;
+        long spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 25)) {
+                __hip_atomic_store(d_flags(a.peer[a.rank], 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (q < count) {
+        const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(a.peer[a.rank] + 4096) + (size_t)a.par * DNMF_DIRECT_MAX_RANKS * DIRECT_SMALL_MAX;
+        double s = 0.0;
+        for (int r = 0; r < a.P; ++r)
+            s += __longlong_as_double((long long)__hip_atomic_load(slots + (size_t)r * DIRECT_SMALL_MAX + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        buf[q] = s;
+    }
+}
+
+int direct_allreduce_small_f64(dnmf_comm* cm, double* buf, size_t count, hipStream_t st) {
+    DirectArgs a{};
+    for (int q = 0; q < cm->nranks; ++q) a.peer[q] = cm->direct_peer[q];
+    a.P = cm->nranks; a.rank = cm->rank; a.cap = cm->direct_cap; a.count = count;
+    a.seq = ++cm->direct_small_seq;
+    a.par = (int)(a.seq & 1);
+    hipLaunchKernelGGL(direct_small_f64_kernel, dim3(1), dim3(64), 0, st, a, buf, (int)count);
+    return check_launch("allreduce(direct, small)");
+}
+
 // in-place SUM over the group
 int allreduce_f32(dnmf_comm* cm, int g, float* buf, size_t count, hipStream_t st) {
     if (cm->direct_on && g == G_WORLD && cm->nranks > 1 && !cm->null_exchange && count <= cm->direct_cap && count % 2 == 0 &&
@@ -222,6 +270,8 @@ int allreduce_f32(dnmf_comm* cm, int g, float* buf, size_t count, hipStream_t st
 
 // in-place SUM of doubles (the column norms of the HALS W sweep, utils.py:388-391)
 int allreduce_f64(dnmf_comm* cm, int g, double* buf, size_t count, hipStream_t st) {
+    if (cm->direct_on && g == G_WORLD && cm->nranks > 1 && !cm->null_exchange && count >= 1 && count <= DIRECT_SMALL_MAX)
+        return direct_allreduce_small_f64(cm, buf, count, st);
     ncclComm_t c;
     const int r = resolve(cm, g, &c, "allreduce");
     if (r) return r < 0 ? r : DNMF_OK;
@@ -602,6 +652,13 @@ int dnmf_comm_allreduce_direct(dnmf_comm_t* c, float* buf, size_t count, void* s
     for (int q = 0; q < c->nranks; ++q) REQUIRE(c->direct_peer[q], "comm_allreduce_direct: rank %d is not connected", q);
     if (c->nranks == 1) return DNMF_OK;
     return direct_allreduce(c, buf, count, S(stream));
+}
+
+int dnmf_comm_allreduce_direct_f64(dnmf_comm_t* c, double* buf, size_t count, void* stream) {
+    REQUIRE(c && buf && count >= 1 && count <= DIRECT_SMALL_MAX, "comm_allreduce_direct_f64: 1 <= count <= %d doubles", DIRECT_SMALL_MAX);
+    for (int q = 0; q < c->nranks; ++q) REQUIRE(c->direct_peer[q], "comm_allreduce_direct_f64: rank %d is not connected", q);
+    if (c->nranks == 1) return DNMF_OK;
+    return direct_allreduce_small_f64(c, buf, count, S(stream));
 }
 
 int dnmf_comm_destroy(dnmf_comm_t* c) {

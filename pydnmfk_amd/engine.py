@@ -583,6 +583,12 @@ class NativeComm:
         check(lib.dnmf_comm_allreduce_direct(self.handle, t.data_ptr(), t.numel(), _stream()))
         return t
 
+    def allreduce_direct_f64_(self, t):
+        if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or not 1 <= t.numel() <= 8:
+            raise ValueError("allreduce_direct_f64_: 1..8 contiguous float64 values on the GPU")
+        check(lib.dnmf_comm_allreduce_direct_f64(self.handle, t.data_ptr(), t.numel(), _stream()))
+        return t
+
     def direct_timed_out(self):
         import ctypes
         w = ctypes.c_int(0)

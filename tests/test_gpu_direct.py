@@ -43,6 +43,22 @@ def _rank(rank, world, port, q):
                 y = nc.allreduce_direct_(x.clone())
                 torch.cuda.synchronize()
                 out[(n, rep)] = bool(torch.equal(y, ref))
+        # the one-launch form for a few doubles (the HALS column norms): rank-ordered float64 sum, bit for bit
+        for cnt in (1, 3, 8):
+            for rep in range(4):
+                g = torch.Generator(device=dev)
+                g.manual_seed(77 * cnt + rep + 1000 * rank)
+                x = torch.rand(cnt, device=dev, generator=g, dtype=torch.float64) * 1e3
+                parts = comms.comm.allgather_blocks(x.float(), [(cnt,)] * world)      # (transport for the check only; fp32 view)
+                xs = [None] * world
+                import torch.distributed as dist2
+                dist2.all_gather_object(xs, x.cpu())
+                ref = xs[0].clone()
+                for p in xs[1:]:
+                    ref += p
+                y = nc.allreduce_direct_f64_(x.clone())
+                torch.cuda.synchronize()
+                out[("f64", cnt, rep)] = bool(torch.equal(y.cpu(), ref))
         assert not nc.direct_timed_out()
         # a whole 1D step inside the library: the packed exchange through the direct path vs through the hosted transport
         rs = np.random.RandomState(5)
@@ -62,6 +78,19 @@ def _rank(rank, world, port, q):
             out["step"] = bool(torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]))
         else:                # gloo sums four ranks in its own order, the direct form in rank order: equal to fp32 rounding
             out["step"] = bool(torch.allclose(res[0][0], res[1][0], rtol=2e-6, atol=1e-7) and torch.allclose(res[0][1], res[1][1], rtol=2e-6, atol=1e-7))
+        # HALS: the k column norms of the W sweep go through the one-launch form when direct is on
+        res = []
+        for direct in (False, True):
+            nc.set_direct(direct)
+            dA, dW, dH = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (A[r0:r1], W0[r0:r1], H0))
+            for it in range(3):
+                nc.hals_step_1d(dA, dW, dH, 1.1920929e-07, True, it == 0)
+            torch.cuda.synchronize()
+            res.append((dW.cpu(), dH.cpu()))
+        # (two ranks: the same sums in either order; four: gloo's order against rank order, and a HALS sweep amplifies the last
+        #  bits of every norm -- its per-step parity budget is 5e-5, tests/_mp.py)
+        tol = dict(rtol=5e-6, atol=1e-7) if world == 2 else dict(rtol=2e-4, atol=2e-5)
+        out["hals_step"] = bool(torch.allclose(res[0][0], res[1][0], **tol) and torch.allclose(res[0][1], res[1][1], **tol))
         q.put((rank, out, None))
         dist.barrier()
         nc.close()

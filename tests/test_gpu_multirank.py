@@ -48,7 +48,8 @@ def test_multirank_library_sequenced_steps_match_reference(name):
     run_case(name, use_hip=True, timeout=400, extra={"exchange": "native-hosted"})
 
 
-@pytest.mark.parametrize("name", ["swim_4x1_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32"])
+@pytest.mark.parametrize("name", ["swim_4x1_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
+                                  "t24x12_2x1_hals_float32", "r25x13_3x1_hals_float32"])     # (HALS: the column norms take the one-launch form)
 def test_multirank_direct_allreduce_matches_reference(name):
     """Reference golden fits on 1D grids with every step inside the library AND its packed exchange through the direct two-shot
     allreduce over IPC peer buffers (params.direct_allreduce; csrc/dnmf_comm.hip): four / two ranks stacked on the one GPU map
