@@ -544,7 +544,7 @@ int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, lon
     if (!once) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false>, lds); allow_lds(update_h_seq_kernel<KT, NT, OCC, true>, lds); once = true; }
     const unsigned grid = upd_grid(cdiv(n, 32 * NT), KT);
     constexpr unsigned T = 64 * upd_waves(KT);
-    if constexpr (NT == 2 && KT <= 2) {
+    if constexpr (NT == 2) {
         // a long H that cannot stay cached (>= 64 MiB) streams with nontemporal loads and stores: 4.87 -> 5.07 TB/s at
         // 64 x 2^22 (each line is touched by exactly one instruction here; the W-side kernel touches a line four times
         // and loses a factor of two with the same hint, so it keeps the default policy)
@@ -577,12 +577,15 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
     // k = 128: 14 -> 3.44, 23 -> 2.58.  Two columns per lane (256 B per row and wave) stream better but need 8-byte
     // aligned rows, and a short H (fewer than 1024 such tiles: a latency chain on a few CUs) keeps 32-column tiles.
     static const int var0 = (int)tune("DNMF_UPD_H", 0);
-    int var = var0 ? var0 : ((kt <= 2 && even && k == 32 * kt && n % 64 == 0 && n / 64 >= 1024) ? 23 : 14);
+    // k = 128 (round 4): LDS holds two workgroups per CU there whatever the registers allow (66 KiB of G each), so the two-column
+    // tile at TWO waves per SIMD (200 registers, no spills) costs no occupancy and halves the accesses per byte: 4.25 -> 4.5 TB/s on
+    // the 6.4 GB pass (variant 23 spills there: 2.4 TB/s)
+    int var = var0 ? var0 : ((even && k == 32 * kt && n % 64 == 0 && n / 64 >= 1024) ? (kt == 4 ? 22 : 23) : 14);
     if (var >= 20 && !even) var = 14;
 #define UHS(KT_, NT_, OCC_)                                                                                       \
     if (kt == KT_ && var == 10 * NT_ + OCC_)                                                                      \
         return launch_update_h_seq<KT_, NT_, OCC_>(H, k, n, ldh, AtW, ldatw, G, eps, clamp, st);
-    UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4) UHS(1, 2, 3) UHS(2, 2, 3)
+    UHS(1, 1, 4) UHS(2, 1, 4) UHS(4, 1, 4) UHS(1, 2, 3) UHS(2, 2, 3) UHS(4, 2, 2)
 #ifdef DNMF_TUNING
     if (var >= 91 && var <= 93 && kt == 2 && k == 64 && n % 64 == 0 && even) {   // cache-policy variants of the k = 64, NT = 2 kernel
         constexpr size_t lds = 64 * 68 * sizeof(float);
@@ -599,7 +602,7 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
         return check_launch("mu_update_h(nomma)");
     }
     UHS(1, 1, 5) UHS(2, 1, 5) UHS(1, 1, 6) UHS(2, 1, 6) UHS(1, 1, 8) UHS(4, 1, 3) UHS(4, 1, 5)
-    UHS(1, 2, 4) UHS(2, 2, 4) UHS(4, 2, 2) UHS(4, 2, 3) UHS(1, 2, 5) UHS(1, 2, 6)
+    UHS(1, 2, 4) UHS(2, 2, 4) UHS(4, 2, 3) UHS(1, 2, 5) UHS(1, 2, 6)
 #endif
 #undef UHS
     return fail(DNMF_EINVAL, "mu_update_h: no kernel for k tile %d / variant %d", kt, var);

@@ -123,7 +123,8 @@ __device__ __forceinline__ void update_h_seq_tile(float* __restrict__ H, int k, 
 // Round 4, k = 128: the staged G is 66 KiB there, so the 160 KiB of LDS hold TWO workgroups per CU (2 waves per SIMD whatever the
 // registers allow), and with one tile per wave every workgroup staged its 64 KiB of G for four tiles: MFMA busy 50 % at an
 // unthrottled 2.28 GHz (profiles/r04b_elt128_*).  The launch now caps the grid at 1024 workgroups (two resident rounds), each
-// walking its share of the tiles with ONE staging of G: 3.55 -> 4.25 TB/s (H), 4.14 -> 4.46 TB/s (W) on the 6.4 GB pass.
+// walking its share of the tiles with ONE staging of G: 3.55 -> 4.25 TB/s (H; 4.55 with the two-column tile at two waves per
+// SIMD, csrc/dnmf.hip dnmf_mu_update_h), 4.14 -> 4.46 TB/s (W) on the 6.4 GB pass.
 // NWV = waves per workgroup (a template parameter since then): 8-wave workgroups sharing one G measured the same for H and
 // 3-8 % slower for W than the capped 4-wave grid, so 4 stays.
 constexpr int upd_waves(int /*kt*/) { return 4; }
