@@ -169,6 +169,12 @@ int dnmf_resid_sqnorm_ws(const float* A, long m, long n, long lda, const float* 
 int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                     int k, double* num, double* den, void* stream);
 
+/* NMFk perturbation (pyDNMFk.py:42-44, sample.randM): X_per = X * (1 + noise_var + 2 noise_var U), U ~ U[0,1) per element from a
+ * counter-based generator keyed by `seed` and the element's position (stateless: the same (seed, position) gives the same value).
+ * One pass; bf16 != 0: X and X_per are bfloat16 (scaled in fp32, rounded once).  cols % 8 == 0, 16-byte aligned rows. */
+int dnmf_perturb_uniform(const void* X, void* X_per, long rows, long cols, long ldx, long ldo, float noise_var,
+                         unsigned long long seed, int bf16, void* stream);
+
 /* ---- bf16 STORAGE of the data matrix (BASELINE config 5, "mixed precision"; no reference counterpart: numpy has no
  * bf16).  A is bfloat16 in device memory (pointer to 16-bit words, lda in elements, rows 8-byte aligned for the vector
  * path), widened exactly to fp32 in registers; W, H, every product and every accumulation stay fp32, so each call equals

@@ -61,6 +61,7 @@ SIGNATURES = {
     "dnmf_scale_rows_mul": [c_void_p, c_int, c_long, c_long, c_void_p, c_void_p],
     "dnmf_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p],
     "dnmf_clock_probe": [c_void_p, c_int, c_int, c_void_p],
+    "dnmf_perturb_uniform": [c_void_p, c_void_p, c_long, c_long, c_long, c_long, c_float, ctypes.c_ulonglong, c_int, c_void_p],
     "dnmf_column_err": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_void_p,
                         c_void_p],
     "dnmf_resid_sqnorm": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p,

@@ -5,6 +5,58 @@
 
 namespace {
 
+// =============================================================================================== NMFk perturbation
+// X_per = X * (1 + nv + 2 nv U), U ~ U[0,1) per element (reference pyDNMFk.py:42-44, `sample.randM`: the perturbed copy every
+// one of the 20 fits per k of an NMFk sweep starts from).  ONE pass: 8 elements per thread are read in their storage type (fp32
+// or bf16), scaled in fp32 and written back rounded once; the uniforms come from a counter-based generator -- the splitmix64
+// finaliser of (seed, element-pair index), 24 bits per element -- so there is no state, no second buffer, and the result
+// depends only on (seed, position).  Round 4: the torch expression this replaces made five passes over fp32 temporaries of
+// the data's shape (about 9 GB of traffic per fit at 65536 x 4096 against 1 GB here).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void perturb_uniform_kernel(const TA* __restrict__ X, TA* __restrict__ out, long rows, long cols,
+                                                              long ldx, long ldo, float nv, unsigned long long seed) {
+    const long cvecs = cols / 8;                            // 8 elements per thread (cols % 8 == 0: checked by the host)
+    const long total = rows * cvecs;
+    const unsigned long long key = mix64(seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / cvecs, c = (idx % cvecs) * 8;
+        float v[8];
+        load_vec_raw<4>(reinterpret_cast<float (&)[4]>(v[0]), X + r * ldx + c);
+        load_vec_raw<4>(reinterpret_cast<float (&)[4]>(v[4]), X + r * ldx + c + 4);
+        const unsigned long long base = ((unsigned long long)r * (unsigned long long)cols + (unsigned long long)c) >> 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long h = mix64(key + (base + q) * 0x9E3779B97F4A7C15ull);
+            const float u0 = (float)((unsigned)(h >> 40)) * (1.0f / 16777216.0f);          // 24 bits each: [0, 1)
+            const float u1 = (float)((unsigned)(h >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
+            v[2 * q] *= fmaf(2.0f * nv, u0, 1.0f + nv);
+            v[2 * q + 1] *= fmaf(2.0f * nv, u1, 1.0f + nv);
+        }
+        if constexpr (std::is_same<TA, float>::value) {
+            *reinterpret_cast<f32x4*>(out + r * ldo + c) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(out + r * ldo + c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {                                            // round to nearest even, as torch's .to(bfloat16) does
+            unsigned int w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned int lo = __float_as_uint(v[2 * q]), hi = __float_as_uint(v[2 * q + 1]);
+                lo = (lo + 0x7fffu + ((lo >> 16) & 1u)) >> 16;
+                hi = (hi + 0x7fffu + ((hi >> 16) & 1u)) & 0xffff0000u;
+                w[q] = lo | hi;
+            }
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4*>(out + r * ldo + c) = u32x4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
 // =============================================================================================== element-wise passes
 // clamp / column- and row-scaling / the KL multiply-divide: one read-modify-write pass over a rows x cols matrix, at most
 // one streamed operand S beside it and a k-vector x indexed by row or by column.  HBM-bound, so what matters is 16-byte

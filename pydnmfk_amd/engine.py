@@ -348,6 +348,20 @@ class HipOps:
         _req(H, "H"); _req(s, "s", 1)
         check(lib.dnmf_scale_rows_mul(H.data_ptr(), H.shape[0], H.shape[1], _ld(H), s.data_ptr(), _stream()))
 
+    def perturb_uniform(self, X, noise_var, seed):
+        """X * (1 + nv + 2 nv U[0,1)) element-wise in ONE pass (NMFk's `sample.randM`, pyDNMFk.py:42-44), in X's storage type
+        (float32 or bfloat16).  None when the shape does not fit the kernel (the caller keeps its torch expression)."""
+        if not (X.is_cuda and X.dim() == 2 and X.dtype in (torch.float32, torch.bfloat16) and X.stride(1) == 1):
+            return None
+        rows, cols = X.shape
+        ld = _ld(X)
+        if cols % 8 or ld % 8 or X.data_ptr() % 16:
+            return None
+        out = torch.empty(rows, cols, dtype=X.dtype, device=X.device)
+        check(lib.dnmf_perturb_uniform(X.data_ptr(), out.data_ptr(), rows, cols, ld, cols, float(noise_var), int(seed) & (2**64 - 1),
+                                       int(X.dtype == torch.bfloat16), _stream()))
+        return out
+
     def sqnorm(self, A):
         sfx = _req_a(A)
         out = torch.empty(1, dtype=torch.float64, device=A.device)

@@ -43,6 +43,12 @@ class sample:
     def randM(self):
         nv = self.noise_var
         if isinstance(self.X, torch.Tensor):
+            if self.X.is_cuda:      # one fused pass with a counter-based generator (dnmf_perturb_uniform): 1 GB of traffic per fit at
+                from .engine import HIP_OPS        # 65536 x 4096 bf16 where the torch expression below moves about 9 GB
+                out = HIP_OPS.perturb_uniform(self.X, nv, 0 if self.seed is None else int(self.seed))
+                if out is not None:
+                    self.X_per = out
+                    return
             g = torch.Generator(device=self.X.device)
             g.manual_seed(0 if self.seed is None else int(self.seed))
             M = torch.rand(self.X.shape, dtype=torch.float32, device=self.X.device, generator=g)

@@ -431,3 +431,40 @@ def test_wta_gram_is_wta_plus_gram(m, n, k, bf16):
     G2 = torch.full_like(G, 5.0)
     ops.wta_gram(A, W, torch.empty(k, n, device=dev), G2)
     assert torch.equal(G, G2)                             # run-to-run bit reproducible
+
+
+def test_perturb_uniform_is_the_reference_distribution(ops):
+    """dnmf_perturb_uniform = NMFk's `sample.randM` (pyDNMFk.py:42-44) in one pass: X * (1 + nv + 2 nv U), U ~ U[0,1) from a counter-based
+    generator.  The ratio X_per / X must be uniform on [1 + nv, 1 + 3 nv) (range, mean, variance, no correlation between
+    neighbours), a function of (seed, position) only, and the bf16 form must equal the fp32 form rounded once."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(3)
+    m, n, nv = 2048, 1024, 0.03
+    X = torch.rand(m, n, device=dev, generator=g) + 0.5
+    Y = ops.perturb_uniform(X, nv, 1000)
+    assert Y is not None and Y.dtype == torch.float32 and Y.shape == X.shape
+    ratio = (Y.double() / X.double())
+    u = (ratio - 1 - nv) / (2 * nv)                                   # should be U[0, 1)
+    assert float(u.min()) > -1e-5 and float(u.max()) < 1 + 1e-5
+    N = u.numel()
+    assert abs(float(u.mean()) - 0.5) < 5 * (1 / 12) ** 0.5 / N ** 0.5
+    assert abs(float(u.var()) - 1 / 12) < 5e-4
+    uc = u - u.mean()
+    for a, b in ((uc[:, :-1], uc[:, 1:]), (uc[:-1], uc[1:])):        # neighbours along a row / down a column
+        assert abs(float((a * b).mean()) / float(uc.var())) < 5e-3
+    hist = torch.histc(u.float(), bins=64, min=0.0, max=1.0)
+    assert float((hist - N / 64).abs().max()) < 6 * (N / 64) ** 0.5
+    assert torch.equal(Y, ops.perturb_uniform(X, nv, 1000))           # a function of (seed, position)
+    Y2 = ops.perturb_uniform(X, nv, 2000)
+    assert float((Y2 != Y).float().mean()) > 0.99
+    # a view with a row pitch reads the same values as its contiguous copy (the uniforms are keyed by position in the matrix)
+    big = torch.zeros(m, n + 64, device=dev)
+    big[:, :n] = X
+    assert torch.equal(ops.perturb_uniform(big[:, :n], nv, 1000), Y)
+    # bf16 storage: the same uniforms, scaled in fp32, rounded once to nearest even
+    Xb = X.to(torch.bfloat16)
+    Yb = ops.perturb_uniform(Xb, nv, 1000)
+    assert Yb.dtype == torch.bfloat16
+    assert torch.equal(Yb, ops.perturb_uniform(Xb.float(), nv, 1000).to(torch.bfloat16))
+    # shapes the kernel does not take are left to the caller
+    assert ops.perturb_uniform(X[:, :1001], nv, 1) is None
