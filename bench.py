@@ -996,7 +996,8 @@ def main():
                 modes.append("native")
                 # third arm: the direct two-shot allreduce over IPC peer buffers for the packed
                 # message -- eligible only if every rank connected AND its sum agrees with RCCL's on a test vector here
-                if world > 1 and a.exchange == "auto":
+                # (DNMF_BENCH_NO_DIRECT=1 leaves this arm out)
+                if world > 1 and a.exchange == "auto" and not os.environ.get("DNMF_BENCH_NO_DIRECT"):
                     try:
                         kp_ = 32 if k <= 32 else (64 if k <= 64 else 128)
                         nmsg = max(k * n, m_l * k) + 8 * 64 + kp_ * kp_ + 1024
