@@ -22,8 +22,8 @@ SINGLE = [c for c in case_names() if "_1x1_" in c and c.endswith(("float32", "fl
 def _tols(meta):
     """(per-step, fit factors, fit error): HALS sweeps subtract nearly equal terms, so fp32 trajectories are only
     reproducible to ~1e-3 after 10 sweeps (even between two numpy builds: tests/test_oracle_golden.py::test_fit)."""
-    if meta.get("method") == "hals":
-        return 5e-5, 2e-3, 5e-5
+    if meta.get("method") == "hals":      # (round 4, observed on the GPU over the single-rank HALS goldens -- tools/dbg/hals_dev.py:
+        return 5e-5, 2e-3, 1e-5           #  W <= 1.05e-3 (k = 128, over-parameterised), H <= 1.1e-4, recon_err <= 1.4e-6)
     return 1e-5, 1e-4, 1e-5
 
 
@@ -50,7 +50,7 @@ def test_fit_matches_reference_golden(name):
         # numpy in -> numpy out, in the dtype the reference hands back (float64 after unprune, utils.py:195,198)
         assert isinstance(W, np.ndarray) and W.dtype == z["r0_fit%d_W" % itr].dtype and H.dtype == z["r0_fit%d_H" % itr].dtype
         assert rel_fro(W, z["r0_fit%d_W" % itr]) <= tol_fit, itr
-        assert rel_fro(H, z["r0_fit%d_H" % itr]) <= tol_fit, itr
+        assert rel_fro(H, z["r0_fit%d_H" % itr]) <= (5e-4 if meta.get("method") == "hals" else tol_fit), itr   # (H carries no column cancellation)
         ref = float(z["r0_fit%d_err" % itr])
         assert abs(err - ref) <= tol_err * max(1.0, abs(ref)), itr
 
