@@ -23,7 +23,8 @@ def _tols(meta):
     """(per-step, fit factors, fit error): HALS sweeps subtract nearly equal terms, so fp32 trajectories are only
     reproducible to ~1e-3 after 10 sweeps (even between two numpy builds: tests/test_oracle_golden.py::test_fit)."""
     if meta.get("method") == "hals":      # (round 4, observed on the GPU over the single-rank HALS goldens -- tools/dbg/hals_dev.py:
-        return 5e-5, 2e-3, 1e-5           #  W <= 1.05e-3 (k = 128, over-parameterised), H <= 1.1e-4, recon_err <= 1.4e-6)
+        # W <= 1.05e-3 (k = 128, over-parameterised), H <= 1.1e-4, recon_err <= 1.4e-6; regression mode (W fixed, err ~ 30): 3e-5 relative)
+        return 5e-5, 2e-3, (1e-5 if meta.get("W_update", True) else 5e-5)
     return 1e-5, 1e-4, 1e-5
 
 

@@ -7,7 +7,7 @@ from tests.test_gpu_parity import _args
 from pydnmfk_amd.pyDNMF import PyNMF
 worst = (0, 0, 0)
 for name in case_names():
-    if "_1x1_" not in name or "hals" not in name or not name.endswith("float32"): continue
+    if "_1x1_" not in name or "hals" not in name or not name.endswith(("float32", "float32_noW", "float32_prune")): continue
     meta, A, W0, H0, z = load_case(name)
     for itr in meta["itrs"]:
         W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"], "hals", meta.get("prune", False))).fit()
