@@ -27,7 +27,7 @@ int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const flo
         static const long var = tune("DNMF_KLUHT_VAR", 0), abl = tune("DNMF_KLUHT_ABL", 0);
 #define KV(KT_, A2_, OCC_, ABL_) if (kt == KT_ && var == 100 * OCC_ + 10 * A2_ && abl == ABL_) { \
             hipLaunchKernelGGL((kl_uht_pipe_kernel<KT_, A2_, OCC_, ABL_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
-        KV(1, true, 3, 0) KV(1, false, 4, 0) KV(1, true, 2, 0) KV(2, true, 2, 0) KV(2, false, 3, 0) KV(4, false, 1, 0)
+        KV(1, true, 3, 0) KV(1, false, 4, 0) KV(1, true, 2, 0) KV(2, true, 2, 0) KV(2, false, 3, 0) KV(4, false, 1, 0) KV(4, true, 2, 0)
 #define KA(KT_, A2_, OCC_, AUX_) if (kt == KT_ && var == 100 * OCC_ + 10 * A2_ + 1 + AUX_ && abl == 0) { \
             hipLaunchKernelGGL((kl_uht_pipe_kernel<KT_, A2_, OCC_, 0, AUX_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
         KA(1, true, 4, 0) KA(2, true, 3, 0) KA(4, false, 2, 0) KA(1, true, 4, 1) KA(2, true, 3, 1) KA(4, false, 2, 1)
