@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if constexpr (!(ABL & 2)) st[4 * g + e] = klu_quot(ac[g][e], st[4 * g + e]);   // U^T (dist_nmf.py:806)
-                else if (g == 0 && e == 0) st[0] += ac[0][0] + ac[1][1] + ac[2][2] + ac[3][3];
+            for (int e = 0; e < 4; e += 2)
+                if constexpr (!(ABL & 2)) {                                   // U^T (dist_nmf.py:806): two reciprocals, ONE packed multiply
+                    const f32x2 r = {__builtin_amdgcn_rcpf(st[4 * g + e]), __builtin_amdgcn_rcpf(st[4 * g + e + 1])};
+                    const f32x2 q = f32x2{ac[g][e], ac[g][e + 1]} * r;
+                    st[4 * g + e] = q[0]; st[4 * g + e + 1] = q[1];
+                } else if (g == 0 && e == 0) st[0] += ac[0][0] + ac[1][1] + ac[2][2] + ac[3][3];
         if constexpr (!A2 && !(ABL & 4)) load_a(ac, so);
         static_for<0, NG>([&](auto Q) {
             constexpr int q = decltype(Q)::value, g = q / KT, jt = q % KT;
