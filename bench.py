@@ -976,11 +976,17 @@ def main():
         # library's own communicator, where a whole step -- kernels, allreduce, kernels -- is ONE C call (no Python between
         # the launches; csrc/dnmf_comm.hip).  Both run the same kernels in the same order.
         modes = ["torch"] if a.exchange in ("auto", "torch") else []
-        if a.backend == "nccl" and a.exchange in ("auto", "native") and a.gemm == "fp32":
+        hosted = a.backend != "nccl" and bool(os.environ.get("DNMF_BENCH_HOSTED"))   # (tests: the library-sequenced arms over gloo,
+        if (a.backend == "nccl" or hosted) and a.exchange in ("auto", "native") and a.gemm == "fp32":   #  ranks stacked on one GPU)
             ok, why = 1, None
             try:
-                from pydnmfk_amd.engine import NativeComm
-                p._native_comm = NativeComm(comms.comm, world, 1)
+                from pydnmfk_amd.engine import NativeComm, _torch_hosted_collective
+                if hosted:
+                    p._native_comm = NativeComm.hosted(world, rank, world, 1, _torch_hosted_collective(
+                        {0: comms.comm, 1: comms.cart_1d_row(), 2: comms.cart_1d_column()}))
+                    mg["native_transport"] = "hosted over " + a.backend
+                else:
+                    p._native_comm = NativeComm(comms.comm, world, 1)
                 if emu:                                            # a one-rank communicator that still issues its RCCL calls
                     p._native_comm.set_always_exchange(True)
                     p.native_always = True

@@ -151,3 +151,17 @@ def test_config2_line_small_steps():
     out = _json_line(r.stdout)
     assert "BASELINE config 2" in out["config"]["workload"] and (out["config"]["m"], out["config"]["n"], out["config"]["k"]) == (65536, 4096, 32)
     assert out["roofline"]["bound"] == "mfma" and out["value"] > 500
+
+
+@pytest.mark.gpu
+def test_three_exchange_arms_over_gloo_with_a_hosted_library_communicator():
+    """The warm-up A/B of an N > 1 run with all THREE arms -- torch.distributed between the launches, the library-sequenced step, and
+    the library-sequenced step with its packed allreduce over IPC peer buffers (`native-direct`) -- on two ranks stacked on the
+    one GPU: the library's communicator is a hosted one over gloo here (DNMF_BENCH_HOSTED=1; on a node it is RCCL)."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--rows", "8192", "--cols", "1024", "--steps", "6", "--warmup", "2", "--no-kernel-timing",
+              "--no-sustained"], env_extra={"DNMF_BENCH_OVERSUBSCRIBE": "1", "DNMF_BENCH_HOSTED": "1"})
+    assert r.returncode == 0, r.stderr[-4000:]
+    mg = _json_line(r.stdout)["multi_gpu"]
+    assert set(mg["exchange_ab_ms_per_step"]) == {"%s/chunks=%d" % (t, c) for t in ("torch", "native", "native-direct") for c in (1, 2, 4)}
+    assert mg["direct_vs_rccl_max_rel_diff"] < 1e-5 and mg["exchange_used"] in ("torch", "native", "native-direct")
+    assert mg["native_transport"] == "hosted over gloo"
