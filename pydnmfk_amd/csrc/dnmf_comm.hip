@@ -148,10 +148,10 @@ __global__ __launch_bounds__(64) void direct_signal_wait_kernel(DirectArgs a, in
     if (q < a.P) __hip_atomic_store(d_flags(a.peer[q], which) + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (q < a.P) {
         const unsigned long long* mine = d_flags(a.peer[a.rank], which) + q;
-        long spins = 0;
+        const unsigned long long t0 = wall_clock64();             // (100 MHz, independent of the shader clock)
         while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 24)) {                            // ~2 s: a peer is gone -- say so instead of hanging the GPU
+            if (wall_clock64() - t0 > 200000000ull) {              // 2 s: a peer is gone -- say so instead of hanging the GPU
                 __hip_atomic_store(d_flags(a.peer[a.rank], 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -226,10 +226,10 @@ __global__ __launch_bounds__(64) void direct_small_f64_kernel(DirectArgs a, doub
         __threadfence_system();
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.peer[q] + 3072) + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(a.peer[a.rank] + 3072) + q;
-        long spins = 0;
+        const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1L << 25)) {
+            if (wall_clock64() - t0 > 200000000ull) {
                 __hip_atomic_store(d_flags(a.peer[a.rank], 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
