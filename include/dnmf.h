@@ -236,6 +236,36 @@ int dnmf_kl_wtu_bf16x6(const float* A, long m, long n, long lda, const float* W,
 int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
                            int k, float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- Whole fits on one rank (PyNMF.fit, pyDNMF.py:138-182 with p_r = p_c = 1): `itr` update steps with the clamp to eps
+ * after the steps i % 10 == 0 (:155-157, :170-172), then normalize_features (:185-194) and the two squared norms of
+ * relative_err (:205-218) -- everything enqueued on `stream` by ONE call: no host code between the launches, nothing
+ * synchronises.  sq_out (device doubles) receives {sum (A - W H)^2, sum A^2} per problem; recon_err = sqrt of their ratio.
+ * `batch` > 1: that many INDEPENDENT problems of one shape in every launch (blockIdx.z = problem) -- the perturbation fits of an
+ * NMFk sweep (pyDNMFk.py:226-231), which the reference runs one after another.  Problem b's operands live at A + b a_stride,
+ * W + b w_stride, H + b h_stride (strides in ELEMENTS, multiples of 16 bytes, each spanning at least one problem: e.g. stacked
+ * [batch][m][lda] arrays) and its scratch at ws + b (ws_bytes_fit / batch); sq_out is [batch][2].  Problem b of a batched fit
+ * runs the same kernels on the same operands as a fit of its own: results are bit-identical to `batch` single fits (strides
+ * are ignored for batch == 1).  `ws` >= dnmf_ws_bytes_fit(m, n, k, batch).  The persistent HALS W sweep then needs the
+ * workgroups of ALL problems resident together (it takes the column launches otherwise); `column_sweep` != 0 forces those.
+ * After a HALS fit dnmf_hals_sweep_status tells whether a persistent sweep timed out. */
+size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch);
+int dnmf_mu_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
+                    int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
+                    void* stream);
+int dnmf_mu_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
+                   int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
+                   void* stream);
+int dnmf_hals_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                      int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
+                      void* ws, size_t ws_bytes, void* stream);
+/* the Frobenius fits with A STORED as bfloat16 (dnmf_*_bf16a above; a_stride in bf16 elements) */
+int dnmf_mu_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                          int w_update, int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws,
+                          size_t ws_bytes, void* stream);
+int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                            int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride,
+                            double* sq_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Grid exchanges inside the library (RCCL over xGMI; replaces MPI_comm, dist_comm.py:16-56, and the mpi4py calls of
  * global_gram / global_mm, dist_nmf.py:681,707).  RCCL is bound at run time (dlopen; an RCCL already in the process -- the
  * PyTorch host's -- is preferred), so the library loads without it; these entry points then return DNMF_ECOMM.

@@ -113,7 +113,16 @@ SIGNATURES["dnmf_mu_kl_step_1d"] = SIGNATURES["dnmf_mu_fro_step_1d"]
 SIGNATURES["dnmf_ws_bytes_hblocks"] = [c_long, c_long, c_int, c_long]
 for _n in ("mu_fro_step_1d", "mu_fro_step_2d", "hals_fro_step_1d", "hals_fro_step_2d"):     # bf16-stored A: same argument lists
     SIGNATURES["dnmf_%s_bf16a" % _n] = SIGNATURES["dnmf_" + _n]
-_RESTYPES = {"dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
+# whole fits (csrc/dnmf_fit.hip): A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, [column_sweep,] batch, a_stride, w_stride, h_stride,
+# sq_out, ws, ws_bytes, stream
+SIGNATURES["dnmf_ws_bytes_fit"] = [c_long, c_long, c_int, c_int]
+SIGNATURES["dnmf_mu_fro_fit"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int, c_int,
+                                 c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p]
+SIGNATURES["dnmf_mu_kl_fit"] = SIGNATURES["dnmf_mu_fro_fit"]
+SIGNATURES["dnmf_mu_fro_fit_bf16a"] = SIGNATURES["dnmf_mu_fro_fit"]
+SIGNATURES["dnmf_hals_fro_fit"] = SIGNATURES["dnmf_mu_fro_fit"][:12] + [c_int] + SIGNATURES["dnmf_mu_fro_fit"][12:]
+SIGNATURES["dnmf_hals_fro_fit_bf16a"] = SIGNATURES["dnmf_hals_fro_fit"]
+_RESTYPES = {"dnmf_ws_bytes_fit": c_size_t, "dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
              "dnmf_ws_bytes_1d": c_size_t, "dnmf_ws_bytes_hblocks": c_size_t, "dnmf_ws_bytes_2d": c_size_t}
 
 

@@ -30,6 +30,11 @@ char* dnmf_errbuf_() {
     return buf;
 }
 
+BatchCtx* dnmf_batch_() {
+    static thread_local BatchCtx ctx = {1, {}};
+    return &ctx;
+}
+
 namespace {
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF, typename TX>
@@ -40,7 +45,7 @@ int launch_nt_pf(const NtArgs& a, int nsplit, hipStream_t st) {
     constexpr size_t lds = std::is_same<TX, bf16_t>::value ? (lds16 > lds32 ? lds16 : lds32) : lds32;
     static bool once = false;
     if (!once) { allow_lds(nt_kernel<KT, MT, NW, KS, FAST, MODE, PF, TX>, lds); once = true; }
-    hipLaunchKernelGGL((nt_kernel<KT, MT, NW, KS, FAST, MODE, PF, TX>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
+    DNMF_LAUNCH((nt_kernel<KT, MT, NW, KS, FAST, MODE, PF, TX>), dim3((unsigned)cdiv(a.nrows, BM), (unsigned)nsplit),
                        dim3(64 * NW), lds, st, a);
     return check_launch("nt_kernel");
 }
@@ -124,9 +129,9 @@ int launch_tn(int kt, bool fast, const TnArgs& a, hipStream_t st) {
     static const bool nty = tune("DNMF_TN_NT", 1) != 0;
 #define TN_CASE(KT_, NT_)                                                                                \
     if (kt == KT_) {                                                                                     \
-        if (fast && nty) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, true, TY>), grid, block, 0, st, a); \
-        else if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, MODE, false, TY>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, MODE, false, TY>), grid, block, 0, st, a);          \
+        if (fast && nty) DNMF_LAUNCH((tn_kernel<KT_, NT_, true, MODE, true, TY>), grid, block, 0, st, a); \
+        else if (fast) DNMF_LAUNCH((tn_kernel<KT_, NT_, true, MODE, false, TY>), grid, block, 0, st, a);  \
+        else DNMF_LAUNCH((tn_kernel<KT_, NT_, false, MODE, false, TY>), grid, block, 0, st, a);          \
         return check_launch("tn_kernel");                                                                \
     }
     TN_CASE(1, 4)
@@ -169,11 +174,11 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
         // step are re-read by the next kernel) keep the default policy.  DNMF_EW_NT = 0 / 1 forces it in the tuning build.
         const long ntp_dflt = (double)rows * cols * sizeof(float) >= 256.0 * (1 << 20);
         if (vec && tune("DNMF_EW_NT", ntp_dflt)) {
-            hipLaunchKernelGGL((ew_kernel<OP, 4, true, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+            DNMF_LAUNCH((ew_kernel<OP, 4, true, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
             return check_launch(what);
         }
-        if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
-        else hipLaunchKernelGGL((ew_kernel<OP, 1, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+        if (vec) DNMF_LAUNCH((ew_kernel<OP, 4, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
+        else DNMF_LAUNCH((ew_kernel<OP, 1, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, 0);
         return check_launch(what);
     }
     if (cvecs > 256) return fail(DNMF_EINVAL, "%s: %ld rows x %ld columns: neither a long-row nor a patch shape", what, rows, cols);
@@ -182,11 +187,11 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
     const long TY = 256 >> txs;
     const dim3 grid((unsigned)cdiv(rows, TY * U));
     if (vec && tune("DNMF_EW_NT", (double)rows * cols * sizeof(float) >= 256.0 * (1 << 20))) {
-        hipLaunchKernelGGL((ew_kernel<OP, 4, false, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+        DNMF_LAUNCH((ew_kernel<OP, 4, false, true>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
         return check_launch(what);
     }
-    if (vec) hipLaunchKernelGGL((ew_kernel<OP, 4, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
-    else hipLaunchKernelGGL((ew_kernel<OP, 1, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+    if (vec) DNMF_LAUNCH((ew_kernel<OP, 4, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
+    else DNMF_LAUNCH((ew_kernel<OP, 1, false>), grid, dim3(256), 0, st, X, rows, cols, ldx, Sm, lds_, x, eps, clamp, txs);
     return check_launch(what);
 }
 
@@ -313,8 +318,8 @@ int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, s
     hipStream_t st = S(stream);
 #define GRAM_CASE(KT_, NT_)                                                                          \
     if (kt == KT_) {                                                                                 \
-        if (fast) hipLaunchKernelGGL((tn_kernel<KT_, NT_, true, TN_PARTIAL>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((tn_kernel<KT_, NT_, false, TN_PARTIAL>), grid, block, 0, st, a);    \
+        if (fast) DNMF_LAUNCH((tn_kernel<KT_, NT_, true, TN_PARTIAL>), grid, block, 0, st, a); \
+        else DNMF_LAUNCH((tn_kernel<KT_, NT_, false, TN_PARTIAL>), grid, block, 0, st, a);    \
     }
     GRAM_CASE(1, 1) GRAM_CASE(2, 2) GRAM_CASE(4, 2)
 #undef GRAM_CASE
@@ -334,7 +339,7 @@ template <int MODE, typename TA>
 int try_nt16(const NtArgs& a, bool fast, long n, int k, hipStream_t st) {
     constexpr bool b16 = std::is_same<TA, bf16_t>::value;
     if (!(k <= 16 && fast && k16_on() && n % (b16 ? BKH : BK) == 0)) return 1;
-    hipLaunchKernelGGL((nt16_kernel<TA, MODE>), dim3((unsigned)cdiv(a.nrows, 128)), dim3(256), nt16_lds_bytes(b16), st, a);
+    DNMF_LAUNCH((nt16_kernel<TA, MODE>), dim3((unsigned)cdiv(a.nrows, 128)), dim3(256), nt16_lds_bytes(b16), st, a);
     return check_launch("nt16_kernel");
 }
 
@@ -412,9 +417,9 @@ int launch_update_w_seq(float* W, long m, int k, long ldw, const float* AH, long
     const unsigned grid = upd_grid(cdiv(m, 32), KT);
     constexpr unsigned T = 64 * upd_waves(KT);
     if (k == 32 * KT && m % 32 == 0)
-        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, false>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        DNMF_LAUNCH((update_w_seq_kernel<KT, V, OCC, false>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps, (float*)nullptr, 0L);
     else
-        hipLaunchKernelGGL((update_w_seq_kernel<KT, V, OCC, true>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        DNMF_LAUNCH((update_w_seq_kernel<KT, V, OCC, true>), dim3(grid), dim3(T), lds, st, W, m, k, ldw, AH, ldah, G, eps, (float*)nullptr, 0L);
     return check_launch("mu_update_w");
 }
 }  // namespace
@@ -441,7 +446,7 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
         constexpr size_t lds = 64 * 68 * sizeof(float);
         static bool once = false;
         if (!once) { allow_lds(update_w_seq_kernel<2, 4, 5, false, UW_MU, 2>, lds); once = true; }
-        hipLaunchKernelGGL((update_w_seq_kernel<2, 4, 5, false, UW_MU, 2>), dim3((unsigned)cdiv(cdiv(m, 32), 4)), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps);
+        DNMF_LAUNCH((update_w_seq_kernel<2, 4, 5, false, UW_MU, 2>), dim3((unsigned)cdiv(cdiv(m, 32), 4)), dim3(256), lds, st, W, m, k, ldw, AH, ldah, G, eps, (float*)nullptr, 0L);
         return check_launch("mu_update_w(nt)");
     }
     UWS(1, 3) UWS(2, 3) UWS(4, 3) UWS(1, 4) UWS(2, 4) UWS(4, 5) UWS(1, 6) UWS(2, 6) UWS(1, 8) UWS(2, 2) UWS(4, 2)
@@ -480,9 +485,9 @@ int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long 
                 const dim3 grid16((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4));
                 if (ride) {
                     a.Pg = (float*)((char*)ws + pb);
-                    hipLaunchKernelGGL((tn16_kernel<TA, true>), grid16, dim3(256), 0, st, a);
+                    DNMF_LAUNCH((tn16_kernel<TA, true>), grid16, dim3(256), 0, st, a);
                 } else {
-                    hipLaunchKernelGGL((tn16_kernel<TA>), grid16, dim3(256), 0, st, a);
+                    DNMF_LAUNCH((tn16_kernel<TA>), grid16, dim3(256), 0, st, a);
                 }
                 if ((rc = check_launch("tn16_kernel"))) return rc;
                 const GramTail gt{a.Pg, G, 16, k, kp, q.nchunks};
@@ -551,14 +556,14 @@ int launch_update_h_seq(float* H, int k, long n, long ldh, const float* AtW, lon
         if (k == 32 * KT && n % (32 * NT) == 0 && (double)k * n * sizeof(float) >= 64.0 * (1 << 20)) {
             static bool once2 = false;
             if (!once2) { allow_lds(update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>, lds); once2 = true; }
-            hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+            DNMF_LAUNCH((update_h_seq_kernel<KT, NT, OCC, false, true, 2, 2>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
             return check_launch("mu_update_h");
         }
     }
     if (k == 32 * KT && n % (32 * NT) == 0)
-        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        DNMF_LAUNCH((update_h_seq_kernel<KT, NT, OCC, false>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     else
-        hipLaunchKernelGGL((update_h_seq_kernel<KT, NT, OCC, true>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        DNMF_LAUNCH((update_h_seq_kernel<KT, NT, OCC, true>), dim3(grid), dim3(T), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
     return check_launch("mu_update_h");
 }
 }  // namespace
@@ -590,15 +595,15 @@ int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long l
     if (var >= 91 && var <= 93 && kt == 2 && k == 64 && n % 64 == 0 && even) {   // cache-policy variants of the k = 64, NT = 2 kernel
         constexpr size_t lds = 64 * 68 * sizeof(float);
         const unsigned grid = (unsigned)cdiv(cdiv(n, 64), 4);
-        if (var == 91) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 2, 0>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
-        if (var == 92) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 0, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
-        if (var == 93) hipLaunchKernelGGL((update_h_seq_kernel<2, 2, 3, false, true, 2, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        if (var == 91) DNMF_LAUNCH((update_h_seq_kernel<2, 2, 3, false, true, 2, 0>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        if (var == 92) DNMF_LAUNCH((update_h_seq_kernel<2, 2, 3, false, true, 0, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        if (var == 93) DNMF_LAUNCH((update_h_seq_kernel<2, 2, 3, false, true, 2, 2>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
         return check_launch("mu_update_h(aux)");
     }
     if (var == 99 && kt == 2 && k == 64 && n % 32 == 0) {   // memory pattern of the k = 64 kernel without its matrix work
         constexpr size_t lds = 64 * 68 * sizeof(float);
         const unsigned grid = (unsigned)std::min<long>(cdiv(cdiv(n, 32), 4), tune("DNMF_UPD_GRID", 1024L));
-        hipLaunchKernelGGL((update_h_seq_kernel<2, 1, 4, false, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
+        DNMF_LAUNCH((update_h_seq_kernel<2, 1, 4, false, false>), dim3(grid), dim3(256), lds, st, H, k, n, ldh, AtW, ldatw, G, eps, clamp);
         return check_launch("mu_update_h(nomma)");
     }
     UHS(1, 1, 5) UHS(2, 1, 5) UHS(1, 1, 6) UHS(2, 1, 6) UHS(1, 1, 8) UHS(4, 1, 3) UHS(4, 1, 5)
@@ -640,12 +645,12 @@ template <typename TA>
 int sqnorm_impl(const TA* A, long m, long n, long lda, double* out, void* stream) {
     REQUIRE(A && out && m >= 1 && n >= 1 && lda >= n, "sqnorm: bad arguments");
     hipStream_t st = S(stream);
-    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "sqnorm: memset failed");
+    if (batch_memset(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "sqnorm: memset failed");
     const bool fast = a_aligned(A) && lda % 4 == 0 && n % 4 == 0;
     const long work = fast ? m * (n / 4) : m * n;
     const unsigned grid = (unsigned)std::min<long>(cdiv(work, 256), 2048);
-    if (fast) hipLaunchKernelGGL((sqnorm_kernel<true, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
-    else hipLaunchKernelGGL((sqnorm_kernel<false, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    if (fast) DNMF_LAUNCH((sqnorm_kernel<true, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
+    else DNMF_LAUNCH((sqnorm_kernel<false, TA>), dim3(grid), dim3(256), 0, st, A, m, n, lda, out);
     return check_launch("sqnorm");
 }
 }  // namespace
@@ -679,7 +684,7 @@ int dnmf_clock_probe(unsigned long long* samples, int n, int naps, void* stream)
 
 int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream) {
     REQUIRE(H && x && k >= 1 && n >= 1 && ldh >= n, "rowsum: bad arguments");
-    hipLaunchKernelGGL(rowsum_kernel, dim3(k), dim3(1024), 0, S(stream), H, n, ldh, x);
+    DNMF_LAUNCH(rowsum_kernel, dim3(k), dim3(1024), 0, S(stream), H, n, ldh, x);
     return check_launch("rowsum");
 }
 
@@ -692,8 +697,8 @@ int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, siz
     const long rows_per_blk = std::max<long>(128, round_up(cdiv(m, 1024), 8));
     const int nblk = (int)cdiv(m, rows_per_blk);
     if (ws_bytes < (size_t)nblk * kp * sizeof(float)) return fail(DNMF_EWS, "colsum: workspace too small");
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, S(stream), W, m, k, ldw, rows_per_blk, (float*)ws, kp);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, S(stream), (const float*)ws, nblk, kp, k, x);
+    DNMF_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, S(stream), W, m, k, ldw, rows_per_blk, (float*)ws, kp);
+    DNMF_LAUNCH(colsum_final_kernel, dim3(1), dim3(1024), 0, S(stream), (const float*)ws, nblk, kp, k, x);
     return check_launch("colsum");
 }
 

@@ -43,6 +43,45 @@ __device__ void buf_st_f32(float v, i32x4 rsrc, int voff, int soff, int aux) __a
 __device__ void buf_st_f32x2(f32x2 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
+// ----------------------------------------------------------------------------------------------- batched launches
+// B independent problems of ONE shape in one launch: blockIdx.z = problem (the perturbations of an NMFk sweep,
+// include/dnmf.h "whole fits").  The host lays everything out for problem 0 exactly as for a single problem -- same plans,
+// same grids, same workspace offsets -- and hands every kernel this table: up to four operand families (the data blocks,
+// the W factors, the H factors, the workspaces), each the byte extent [lo, hi) of problem 0's member and the byte distance to
+// the next problem's.  A kernel's first statement moves each of its pointers into its own problem (`rebase`): whatever
+// family the pointer falls in, + blockIdx.z x that family's stride.  Everything after that line is the single-problem code,
+// so problem z of a batched launch executes the instructions of a single launch on the same operands -- bit-identical results.
+// n = 0 (and gridDim.z = 1) outside a batched fit: the rebase then adds zero.  Strides are multiples of 16 bytes, so the
+// host's alignment decisions for problem 0 hold for every problem.
+struct BatchFam { unsigned long lo, hi; long stride; };
+struct BatchTab { int n; int pad_; BatchFam f[4]; };
+// the calling thread's batch state (csrc/dnmf.hip owns it; set by the *_fit entry points around their launch sequence)
+struct BatchCtx { int B; BatchTab tab; };
+__attribute__((visibility("hidden"))) BatchCtx* dnmf_batch_();
+
+__device__ __forceinline__ long batch_off(const void* p, const BatchTab& bt) {
+    const unsigned long a = (unsigned long)p;
+    long d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < bt.n && a >= bt.f[i].lo && a < bt.f[i].hi) d = bt.f[i].stride;
+    return d * (long)blockIdx.z;
+}
+// pointer arithmetic, not integer arithmetic: the kernel-argument pointer keeps its global address space through it
+template <typename T>
+__device__ __forceinline__ void rebase(T*& p, const BatchTab& bt) { p = (T*)((char*)p + batch_off((const void*)p, bt)); }
+// the same for a __restrict__-qualified kernel parameter (a reference to it would drop the qualifier)
+#define REBASE(p) (p) = (decltype(p))((char*)(p) + batch_off((const void*)(p), bt))
+
+// every kernel of the batched paths is launched through this: grid.z = problems, the table as the last argument
+#define DNMF_LAUNCH(kernel, grid, block, lds, st, ...)                                           \
+    do {                                                                                         \
+        const BatchCtx* bc_ = dnmf_batch_();                                                     \
+        dim3 g_ = (grid);                                                                        \
+        g_.z = (unsigned)bc_->B;                                                                 \
+        hipLaunchKernelGGL(kernel, g_, block, lds, st, __VA_ARGS__, bc_->tab);                   \
+    } while (0)
+
 // persistent HALS W sweep (csrc/dnmf_hals.h); the workspace query (csrc/dnmf.hip) sizes its slot slab from these
 constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
 constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
@@ -73,6 +112,24 @@ inline long tune(const char* name, long dflt) { const char* v = getenv(name); re
 #else
 constexpr long tune(const char*, long dflt) { return dflt; }
 #endif
+
+// host twins of `rebase`: problem z's copy of a pointer laid out for problem 0, and a memset of every problem's copy
+inline void* batch_ptr(const void* p, int z) {
+    const BatchCtx* bc = dnmf_batch_();
+    const unsigned long a = (unsigned long)p;
+    long d = 0;
+    for (int i = 0; i < bc->tab.n; ++i)
+        if (a >= bc->tab.f[i].lo && a < bc->tab.f[i].hi) d = bc->tab.f[i].stride;
+    return (char*)p + d * z;
+}
+inline hipError_t batch_memset(void* p, int value, size_t bytes, hipStream_t st) {
+    const int B = dnmf_batch_()->B;
+    for (int z = 0; z < B; ++z) {
+        const hipError_t e = hipMemsetAsync(batch_ptr(p, z), value, bytes, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 __host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }

@@ -1,0 +1,172 @@
+// dnmf_fit.hip -- whole fits on one rank: `itr` update steps, the final normalisation and the two squared norms of the
+// relative error in ONE library call, for one problem or for a batch of same-shape problems (blockIdx.z = problem).
+// Replaces the Python loop of PyNMF.fit (reference pyDNMF.py:138-182 with p_r = p_c = 1) and, batched, the sequential
+// perturbation fits of an NMFk sweep (reference pyDNMFk.py:226-231).  No kernel of its own: every launch below is a launch
+// of the per-step entry points, in the order the per-step callers issue them -- problem z of a batch runs the instructions
+// a single fit runs, on the same operands (csrc/dnmf_common.h "batched launches").
+#include "dnmf_common.h"
+
+// csrc/dnmf.hip: offsets of the step workspace {G, S, x, partials, total}
+__attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]);
+
+namespace {
+
+enum { FIT_MU_FRO = 0, FIT_MU_KL = 1, FIT_HALS_FRO = 2 };
+
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// per-problem workspace: [ step workspace | s: KP floats (column sums of W) | ss2: KP doubles | sq: 2 doubles ]
+struct FitWs { size_t g_off, s_off, part_off, step_total, cs_off, ss2_off, sq_off, total; };
+
+FitWs fit_layout(long m, long n, int k) {
+    size_t o[5];
+    dnmf_ws_offsets_(m, n, k, o);
+    const int kp = dnmf_kp(k);
+    FitWs f;
+    f.g_off = o[0]; f.s_off = o[1]; f.part_off = o[3];
+    // the partial area also serves the calls made on the factor alone (the persistent HALS W sweep and the column sums of W ask
+    // for dnmf_ws_bytes(m, k, k))
+    f.step_total = std::max(o[4], o[3] + al256(dnmf_ws_bytes(m, k, k)));
+    f.cs_off = al256(f.step_total);
+    f.ss2_off = f.cs_off + al256((size_t)kp * sizeof(float));
+    f.sq_off = f.ss2_off + al256((size_t)kp * sizeof(double));
+    f.total = f.sq_off + 256;
+    return f;
+}
+
+struct BatchGuard {      // the batch state of this thread is set for the duration of one fit call, whatever the exit path
+    BatchCtx* c;
+    explicit BatchGuard(BatchCtx* ctx) : c(ctx) {}
+    ~BatchGuard() { c->B = 1; c->tab.n = 0; }
+};
+
+bool overlap(const BatchFam& a, const BatchFam& b) { return a.lo < b.hi && b.lo < a.hi; }
+
+template <bool BF>
+int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
+              int clamp, int column_sweep, char* ws, const FitWs& f, void* stream) {
+    float* G = (float*)(ws + f.g_off);
+    float* Sb = (float*)(ws + f.s_off);
+    void* part = ws + f.part_off;
+    const size_t part_bytes = f.step_total - f.part_off;
+    int rc;
+    if (w_update) {                                                                   // FRO_HALS_update_W, dist_nmf.py:873-891
+        if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;                  // :882
+        if ((rc = BF ? dnmf_aht_bf16a(A, m, n, lda, H, k, ldh, Sb, k, stream)
+                     : dnmf_aht((const float*)A, m, n, lda, H, k, ldh, Sb, k, stream))) return rc;       // :883
+        if (column_sweep) rc = dnmf_hals_update_w(W, m, k, ldw, Sb, k, G, eps, (double*)(ws + f.ss2_off), stream);
+        else rc = dnmf_hals_sweep_w(W, m, k, ldw, Sb, k, G, eps, part, part_bytes, stream);              // :884-891
+        if (rc) return rc;
+    }
+    if ((rc = BF ? dnmf_wta_gram_bf16a(A, m, n, lda, W, k, ldw, Sb, n, G, part, part_bytes, stream)      // :902-903
+                 : dnmf_wta_gram((const float*)A, m, n, lda, W, k, ldw, Sb, n, G, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_hals_update_h(H, k, n, ldh, Sb, n, G, eps, stream))) return rc;                       // :905-909
+    if (clamp) {                                                                                         // pyDNMF.py:170-172
+        if ((rc = dnmf_clamp_min(H, k, n, ldh, eps, stream))) return rc;
+        return dnmf_clamp_min(W, m, k, ldw, eps, stream);
+    }
+    return DNMF_OK;
+}
+
+int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+             int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
+             void* ws, size_t ws_bytes, void* stream) {
+    const int kp = dnmf_kp(k);
+    if (kp < 0 || !A || !W || !H || !sq_out || !ws || m < 1 || n < 1 || itr < 0 || batch < 1 || lda < n || ldw < k || ldh < n)
+        return fail(DNMF_EINVAL, "fit: bad arguments (m=%ld n=%ld k=%d itr=%d batch=%d)", m, n, k, itr, batch);
+    if (bf && method == FIT_MU_KL) return fail(DNMF_EINVAL, "fit: bfloat16 storage of A is for the Frobenius updates");
+    const FitWs f = fit_layout(m, n, k);
+    if (ws_bytes < (size_t)batch * f.total) return fail(DNMF_EWS, "fit: workspace %zu < %d x %zu", ws_bytes, batch, f.total);
+    BatchCtx* ctx = dnmf_batch_();
+    if (ctx->B != 1) return fail(DNMF_EINVAL, "fit: called inside a batched fit");
+    BatchGuard guard(ctx);
+    const size_t ea = bf ? 2 : 4;
+    if (batch > 1) {
+        BatchFam fam[4] = {{(unsigned long)A, (unsigned long)A + ((size_t)(m - 1) * lda + n) * ea, (long)(a_stride * (long)ea)},
+                           {(unsigned long)W, (unsigned long)W + ((size_t)(m - 1) * ldw + k) * 4, w_stride * 4},
+                           {(unsigned long)H, (unsigned long)H + ((size_t)(k - 1) * ldh + n) * 4, h_stride * 4},
+                           {(unsigned long)ws, (unsigned long)ws + f.total, (long)f.total}};
+        for (int i = 0; i < 4; ++i) {
+            if (fam[i].stride % 16 != 0 || (unsigned long)(fam[i].stride < 0 ? -fam[i].stride : fam[i].stride) < fam[i].hi - fam[i].lo)
+                return fail(DNMF_EINVAL, "fit: stride of operand %d (%ld bytes) must be a multiple of 16 bytes and span one problem (%lu bytes)",
+                            i, fam[i].stride, fam[i].hi - fam[i].lo);
+            for (int j = 0; j < i; ++j)
+                if (overlap(fam[i], fam[j])) return fail(DNMF_EINVAL, "fit: operands %d and %d overlap", j, i);
+            ctx->tab.f[i] = fam[i];
+        }
+        ctx->tab.n = 4;
+        ctx->B = batch;
+    }
+    char* base = (char*)ws;
+    int rc = DNMF_OK;
+    for (int i = 0; i < itr && !rc; ++i) {                                            // pyDNMF.py:151-172
+        const int clamp = (i % 10 == 0);
+        if (method == FIT_MU_FRO)
+            rc = bf ? dnmf_mu_fro_step_bf16a(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream)
+                    : dnmf_mu_fro_step((const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream);
+        else if (method == FIT_MU_KL)
+            rc = dnmf_mu_kl_step((const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream);
+        else
+            rc = bf ? hals_step<true>(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, column_sweep, base, f, stream)
+                    : hals_step<false>(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, column_sweep, base, f, stream);
+    }
+    if (rc) return rc;
+    // normalize_features (pyDNMF.py:185-194): s = column sums of W; W /= s + eps; H *= s^T
+    float* s = (float*)(base + f.cs_off);
+    void* part = base + f.part_off;
+    const size_t part_bytes = f.step_total - f.part_off;
+    if ((rc = dnmf_colsum(W, m, k, ldw, s, part, part_bytes, stream))) return rc;
+    if ((rc = dnmf_scale_cols_div(W, m, k, ldw, s, eps, stream))) return rc;
+    if ((rc = dnmf_scale_rows_mul(H, k, n, ldh, s, stream))) return rc;
+    // relative_err (pyDNMF.py:205-218): sum (A - W H)^2 and sum A^2; the caller takes the square roots
+    double* sq = (double*)(base + f.sq_off);
+    if ((rc = bf ? dnmf_resid_sqnorm_ws_bf16a(A, m, n, lda, W, ldw, H, ldh, k, sq, ws, f.step_total, stream)
+                 : dnmf_resid_sqnorm_ws((const float*)A, m, n, lda, W, ldw, H, ldh, k, sq, ws, f.step_total, stream))) return rc;
+    if ((rc = bf ? dnmf_sqnorm_bf16a(A, m, n, lda, sq + 1, stream) : dnmf_sqnorm((const float*)A, m, n, lda, sq + 1, stream))) return rc;
+    if (hipMemcpy2DAsync(sq_out, 2 * sizeof(double), sq, f.total, 2 * sizeof(double), (size_t)batch, hipMemcpyDeviceToDevice,
+                         reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(DNMF_EHIP, "fit: copy of the squared norms failed");
+    return DNMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch) {
+    if (dnmf_kp(k) < 0 || m < 1 || n < 1 || batch < 1) return 0;
+    return (size_t)batch * fit_layout(m, n, k).total;
+}
+
+int dnmf_mu_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
+                    int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
+                    void* stream) {
+    return fit_impl(FIT_MU_FRO, false, A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, 0, batch, a_stride, w_stride, h_stride,
+                    sq_out, ws, ws_bytes, stream);
+}
+int dnmf_mu_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                          int w_update, int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws,
+                          size_t ws_bytes, void* stream) {
+    return fit_impl(FIT_MU_FRO, true, A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, 0, batch, a_stride, w_stride, h_stride,
+                    sq_out, ws, ws_bytes, stream);
+}
+int dnmf_mu_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
+                   int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
+                   void* stream) {
+    return fit_impl(FIT_MU_KL, false, A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, 0, batch, a_stride, w_stride, h_stride,
+                    sq_out, ws, ws_bytes, stream);
+}
+int dnmf_hals_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                      int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return fit_impl(FIT_HALS_FRO, false, A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, column_sweep, batch, a_stride, w_stride,
+                    h_stride, sq_out, ws, ws_bytes, stream);
+}
+int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
+                            int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride,
+                            double* sq_out, void* ws, size_t ws_bytes, void* stream) {
+    return fit_impl(FIT_HALS_FRO, true, A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, column_sweep, batch, a_stride, w_stride,
+                    h_stride, sq_out, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void hals_w_col_kernel(float* __restrict__ W, 
                                                         const float* __restrict__ AH, long ldah,
                                                         const float* __restrict__ G, int kp, int kk,
                                                         const double* __restrict__ prev_ss2, float eps,
-                                                        double* __restrict__ ss2_out) {
+                                                        double* __restrict__ ss2_out, BatchTab bt) {
+    REBASE(W); REBASE(AH); REBASE(G); REBASE(prev_ss2); REBASE(ss2_out);
     __shared__ float gcol[DNMF_MAX_K];
     for (int j = threadIdx.x; j < k; j += blockDim.x) gcol[j] = G[(long)j * kp + kk];
     __syncthreads();
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void hals_w_col_kernel(float* __restrict__ W, 
 
 // final normalisation of one column: W[i][col] /= sqrt(*ss2) (skipped when 0)
 __global__ __launch_bounds__(256) void hals_w_scale_kernel(float* __restrict__ W, long m, long ldw, int col,
-                                                          const double* __restrict__ ss2) {
+                                                          const double* __restrict__ ss2, BatchTab bt) {
+    REBASE(W); REBASE(ss2);
     const float ss = (float)sqrt(*ss2);
     if (!(ss > 0.f)) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long)gridDim.x * blockDim.x)
@@ -54,7 +56,8 @@ __global__ __launch_bounds__(256) void hals_w_scale_kernel(float* __restrict__ W
 template <int KP>
 __global__ __launch_bounds__(256) void hals_h_kernel(float* __restrict__ H, int k, long n, long ldh,
                                                     const float* __restrict__ AtW, long ldatw,
-                                                    const float* __restrict__ G, float eps) {
+                                                    const float* __restrict__ G, float eps, BatchTab bt) {
+    REBASE(H); REBASE(AtW); REBASE(G);
     extern __shared__ __attribute__((aligned(16))) float gs[];
     for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 256)
         *reinterpret_cast<f32x4*>(&gs[idx * 4]) = *reinterpret_cast<const f32x4*>(G + idx * 4);
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(256) void hals_h_kernel(float* __restrict__ H, int 
 // workgroup: hs[j][lane], G rows broadcast from LDS).
 __global__ __launch_bounds__(64) void hals_h_kernel_lds(float* __restrict__ H, int k, long n, long ldh,
                                                        const float* __restrict__ AtW, long ldatw,
-                                                       const float* __restrict__ G, int kp, float eps) {
+                                                       const float* __restrict__ G, int kp, float eps, BatchTab bt) {
+    REBASE(H); REBASE(AtW); REBASE(G);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* gs = sm;                 // kp * kp
     float* hs = sm + kp * kp;       // kp * 64
@@ -293,7 +297,8 @@ __device__ __forceinline__ void hals_sweep_all(float (&t)[KP], float& u, int k, 
 template <int KP, bool VEC>
 __global__ __launch_bounds__(HALS_WG, KP <= 64 ? 4 : 2) void hals_w_sweep_kernel(
     float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ T, long ldt, const float* __restrict__ G,
-    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out, int dbg) {
+    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out, int dbg, BatchTab bt) {
+    REBASE(W); REBASE(T); REBASE(G); REBASE(slab); REBASE(ss2_out);
     __shared__ double red[HALS_WG / 64];
     // G (KP x KP, zero padded, symmetric) staged once per workgroup: every use is a row segment G[r][c0 .. c0+3] at a
     // wave-uniform address = a broadcast ds_read_b128

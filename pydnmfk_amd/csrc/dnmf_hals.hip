@@ -14,9 +14,9 @@ static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH,
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
     hipStream_t st = S(stream);
-    if (zero && hipMemsetAsync(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
+    if (zero && batch_memset(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
     const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
-    hipLaunchKernelGGL(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
+    DNMF_LAUNCH(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
                        eps, ss2_out);
     return check_launch("hals_w_col");
 }
@@ -29,14 +29,14 @@ int dnmf_hals_w_col(float* W, long m, int k, long ldw, const float* AH, long lda
 int dnmf_hals_w_scale(float* W, long m, long ldw, int col, const double* ss2, void* stream) {
     REQUIRE(W && ss2 && m >= 1 && col >= 0 && ldw > col, "hals_w_scale: bad arguments");
     const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
-    hipLaunchKernelGGL(hals_w_scale_kernel, dim3(grid), dim3(256), 0, S(stream), W, m, ldw, col, ss2);
+    DNMF_LAUNCH(hals_w_scale_kernel, dim3(grid), dim3(256), 0, S(stream), W, m, ldw, col, ss2);
     return check_launch("hals_w_scale");
 }
 
 int dnmf_hals_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                        double* ss2, void* stream) {
     REQUIRE(ss2 != nullptr && k >= 1, "hals_update_w: ss2 scratch (k doubles) required");
-    if (hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "hals_update_w: memset failed");
+    if (batch_memset(ss2, 0, (size_t)k * sizeof(double), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "hals_update_w: memset failed");
     for (int kk = 0; kk < k; ++kk) {   // one launch per column: the column norm is a grid-wide dependency
         int rc = hals_w_col_launch(W, m, k, ldw, AH, ldah, G, kk, kk ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, false, stream);
         if (rc) return rc;
@@ -86,9 +86,9 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
             have[dev] = true;
         }
     }
-    if (grid > HALS_MAX_WG || grid > (vec ? cap_v[dev] : cap_s[dev])) return 1;   // not applicable: the caller takes the column path
+    if (grid > HALS_MAX_WG || grid * dnmf_batch_()->B > (vec ? cap_v[dev] : cap_s[dev])) return 1;   // not applicable: the caller takes the column path
     if (ldw >= (1L << 23) || ldah >= (1L << 23)) return 1;                        // beyond the 32-bit tile offsets of pass 1: column path
-    if (hipMemsetAsync(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
+    if (batch_memset(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
         return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
     {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
         constexpr size_t lds1 = (size_t)KP * (KP + 4) * sizeof(float);
@@ -102,17 +102,17 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
         const unsigned g1 = upd_grid(cdiv(m, 32), KT);
         constexpr unsigned T1 = 64 * upd_waves(KT);
         if (vecw && k == KP && m % 32 == 0)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            DNMF_LAUNCH((update_w_seq_kernel<KT, 4, OCC, false, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         else if (vecw)
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            DNMF_LAUNCH((update_w_seq_kernel<KT, 4, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         else
-            hipLaunchKernelGGL((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
+            DNMF_LAUNCH((update_w_seq_kernel<KT, 1, OCC, true, UW_HALS_T>), dim3(g1), dim3(T1), lds1, st, W, m, k, ldw, AH, ldah, G, eps, T, ldt);
         int rc = check_launch("hals_sweep_w(transform)");
         if (rc) return rc;
     }
     static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
-    if (vec) hipLaunchKernelGGL((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
-    else hipLaunchKernelGGL((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    if (vec) DNMF_LAUNCH((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
+    else DNMF_LAUNCH((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
     return check_launch("hals_sweep_w");
 }
 }  // namespace
@@ -164,7 +164,7 @@ int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long
 #define HH_CASE(KT_)                                                                                              \
     if (kt == KT_) {                                                                                              \
         const size_t lds = (size_t)(32 * KT_) * (32 * KT_) * sizeof(float);                                        \
-        hipLaunchKernelGGL((hals_h_kernel<32 * KT_>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps);     \
+        DNMF_LAUNCH((hals_h_kernel<32 * KT_>), grid, block, lds, st, H, k, n, ldh, AtW, ldatw, G, eps);     \
     }
     HH_CASE(1) HH_CASE(2)
 #undef HH_CASE
@@ -173,7 +173,7 @@ int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long
         const size_t lds = (size_t)(kp * kp + kp * 64) * sizeof(float);   // 96 KiB
         static bool once = false;
         if (!once) { allow_lds(hals_h_kernel_lds, lds); once = true; }
-        hipLaunchKernelGGL(hals_h_kernel_lds, dim3((unsigned)cdiv(n, 64)), dim3(64), lds, st, H, k, n, ldh, AtW, ldatw, G, kp, eps);
+        DNMF_LAUNCH(hals_h_kernel_lds, dim3((unsigned)cdiv(n, 64)), dim3(64), lds, st, H, k, n, ldh, AtW, ldatw, G, kp, eps);
     }
     return check_launch("hals_update_h");
 }

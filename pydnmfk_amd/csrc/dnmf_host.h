@@ -56,18 +56,18 @@ int launch_reduce(const float* P, long stride, long ldp, int nsplit, float* out,
     static const bool wide = tune("DNMF_REDUCE_WIDE", 1) != 0;
     if (wide && ny == 1 && rows == rows_out && cols == cols_out && cols % 4 == 0 && cols >= 4096 && ldo % 4 == 0 &&
         aligned16(out) && aligned16(P) && ldp % 4 == 0 && stride % 4 == 0) {
-        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256) + extra), dim3(256), 0, st, P, stride, ldp,
+        DNMF_LAUNCH(reduce_partials_wide_kernel, dim3((unsigned)cdiv(total, 256) + extra), dim3(256), 0, st, P, stride, ldp,
                            nsplit, out, ldo, rows, cols, gt);
         return check_launch("reduce_partials_wide");
     }
     if (ny == 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx + extra, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
+        DNMF_LAUNCH(reduce_partials_kernel, dim3(gx + extra, 1), dim3(256), 0, st, P, stride, ldp, nsplit, nsplit, out, ldo,
                            0L, rows, cols, rows_out, cols_out, gt);
     } else {
         const long ld2 = round_up(cols_out, 4), ys = (long)rows_out * ld2;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, ny), dim3(256), 0, st, P, stride, ldp, nsplit, REDUCE_SLICE,
+        DNMF_LAUNCH(reduce_partials_kernel, dim3(gx, ny), dim3(256), 0, st, P, stride, ldp, nsplit, REDUCE_SLICE,
                            scratch, ld2, ys, rows, cols, rows_out, cols_out, gt);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, ys, ld2, ny, ny, out,
+        DNMF_LAUNCH(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, ys, ld2, ny, ny, out,
                            ldo, 0L, rows_out, cols_out, rows_out, cols_out, gt);
     }
     return check_launch("reduce_partials");
@@ -177,7 +177,8 @@ size_t pad_bytes(long m, long n, int kp) {
 // 9 % of a KL step at the NMFk sweep shape, 65536 x 4096, k = 8.)
 __global__ __launch_bounds__(256) void pad_factors_kernel(const float* __restrict__ W, long ldw, long m, int k, float* __restrict__ Wp,
                                                           int kp, const float* __restrict__ H, long ldh, long n,
-                                                          float* __restrict__ Hp, long ldhp) {
+                                                          float* __restrict__ Hp, long ldhp, BatchTab bt) {
+    REBASE(W); REBASE(Wp); REBASE(H); REBASE(Hp);
     const long wq = m * (kp / 4), hq = (long)kp * (ldhp / 4);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < wq + hq; idx += (long)gridDim.x * 256) {
         float d[4];
@@ -209,7 +210,7 @@ bool pad_factors(const float*& W, long& ldw, const float*& H, long& ldh, int& k,
     float* Hp = (float*)(base + align256((size_t)m * kp * sizeof(float)));
     const long quads = m * (kp / 4) + (long)kp * (ldhp / 4);
     const unsigned grid = (unsigned)std::min<long>(cdiv(quads, 256), 4096);
-    hipLaunchKernelGGL(pad_factors_kernel, dim3(grid), dim3(256), 0, st, W, ldw, m, k, Wp, kp, H, ldh, n, Hp, ldhp);
+    DNMF_LAUNCH(pad_factors_kernel, dim3(grid), dim3(256), 0, st, W, ldw, m, k, Wp, kp, H, ldh, n, Hp, ldhp);
     if (hipGetLastError() != hipSuccess) return false;
     W = Wp; ldw = kp; H = Hp; ldh = ldhp; k = kp;
     return true;

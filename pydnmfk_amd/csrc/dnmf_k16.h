@@ -23,8 +23,9 @@ namespace {
 // free (nt_mainloop_p2).  Fragment of sub-tile rs, group s in {0, 1}: lane (i16, kq) reads the 16-byte chunk 4s + kq of
 // X row rs*16 + i16 and the matching contraction range of Y row i16.
 template <typename TX, int MODE>
-__global__ __launch_bounds__(256) void nt16_kernel(NtArgs p) {
+__global__ __launch_bounds__(256) void nt16_kernel(NtArgs p, BatchTab bt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    rebase_args(p, bt);
     constexpr bool B16 = std::is_same<TX, bf16_t>::value;
     constexpr int BKE = B16 ? BKH : BK;          // contraction indices per k-tile
     constexpr int EPC = B16 ? 8 : 4;             // X elements per 16-byte chunk
@@ -248,7 +249,8 @@ __device__ __forceinline__ void tn16_body(const TnArgs& p, long chunk, long colb
 }
 
 template <typename TY, bool GRAM = false>
-__global__ __launch_bounds__(256) void tn16_kernel(TnArgs p) {
+__global__ __launch_bounds__(256) void tn16_kernel(TnArgs p, BatchTab bt) {
+    rebase_args(p, bt);
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long gw = (long)blockIdx.x * 4 + wid;
     const long chunk = gw / p.ncolblk, colblk = gw % p.ncolblk;

@@ -50,7 +50,7 @@ int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, lon
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
     hipStream_t st = S(stream);
-    if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
+    if (batch_memset(out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "resid_sqnorm: memset failed");
     if (ws && a_aligned(A) && lda % 4 == 0 && n % 4 == 0 && n >= 128 && m >= 4096)
         pad_factors(W, ldw, H, ldh, k, m, n, 32 * kt, ws, ws_bytes, 0, st);      // (no-op for friendly factors)
     NnArgs a = nn_args(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, 0.f);
@@ -76,7 +76,7 @@ int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, lon
         if (kt == KT_) {                                                                             \
             static bool once = false;                                                                \
             if (!once) { allow_lds(resid_lds_kernel<KT_, true, TA>, lds); once = true; }              \
-            hipLaunchKernelGGL((resid_lds_kernel<KT_, true, TA>), grid2, block2, lds, stq, a, rpc);  \
+            DNMF_LAUNCH((resid_lds_kernel<KT_, true, TA>), grid2, block2, lds, stq, a, rpc);  \
         }
         RL_CASE(1) RL_CASE(2) RL_CASE(4)
 #undef RL_CASE
@@ -85,8 +85,8 @@ int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, lon
     const dim3 grid((unsigned)cdiv(a.nrowblk * a.ncolblk, 4)), block(256);
 #define RS_CASE(KT_)                                                                   \
     if (kt == KT_) {                                                                   \
-        if (fast) hipLaunchKernelGGL((resid_kernel<KT_, true, TA>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((resid_kernel<KT_, false, TA>), grid, block, 0, st, a);    \
+        if (fast) DNMF_LAUNCH((resid_kernel<KT_, true, TA>), grid, block, 0, st, a); \
+        else DNMF_LAUNCH((resid_kernel<KT_, false, TA>), grid, block, 0, st, a);    \
     }
     RS_CASE(1) RS_CASE(2) RS_CASE(4)
 #undef RS_CASE
@@ -128,8 +128,8 @@ int column_err_impl(const TA* A, long m, long n, long lda, const float* W, long 
     const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
 #define CE_CASE(KT_)                                                                             \
     if (kt == KT_) {                                                                             \
-        if (fast) hipLaunchKernelGGL((colerr_kernel<KT_, true, TA>), grid, block, 0, st, a, num, den, rpc); \
-        else hipLaunchKernelGGL((colerr_kernel<KT_, false, TA>), grid, block, 0, st, a, num, den, rpc);    \
+        if (fast) DNMF_LAUNCH((colerr_kernel<KT_, true, TA>), grid, block, 0, st, a, num, den, rpc); \
+        else DNMF_LAUNCH((colerr_kernel<KT_, false, TA>), grid, block, 0, st, a, num, den, rpc);    \
     }
     CE_CASE(1) CE_CASE(2) CE_CASE(4)
 #undef CE_CASE
@@ -226,9 +226,9 @@ int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long l
     if (grid.x > 0) {
 #define UH_CASE(KT_)                                                                                                  \
     if (kt == KT_) {                                                                                                  \
-        if (fast) hipLaunchKernelGGL((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
+        if (fast) DNMF_LAUNCH((kl_uht_kernel<KT_, true>), grid, block, lds, st, a, out, ldout, (long)m * kp,    \
                                      u.cols_per_split, out_cols);                                                     \
-        else hipLaunchKernelGGL((kl_uht_kernel<KT_, false>), grid, block, lds, st, a, out, ldout, (long)m * kp,        \
+        else DNMF_LAUNCH((kl_uht_kernel<KT_, false>), grid, block, lds, st, a, out, ldout, (long)m * kp,        \
                                 u.cols_per_split, out_cols);                                                          \
     }
     UH_CASE(1) UH_CASE(2) UH_CASE(4)
@@ -291,13 +291,13 @@ int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long l
     hipStream_t st = S(stream);
 #define WU_CASE(KT_, NT_)                                                                                         \
     if (kt == KT_) {                                                                                              \
-        if (fast) hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
-        else hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
+        if (fast) DNMF_LAUNCH((kl_wtu_kernel<KT_, NT_, true>), grid, block, lds, st, a, rowblks_per_chunk); \
+        else DNMF_LAUNCH((kl_wtu_kernel<KT_, NT_, false>), grid, block, lds, st, a, rowblks_per_chunk);    \
     }
 #ifdef DNMF_TUNING
     static const long wvar = tune("DNMF_WTU_VAR", 0);          // A/B: 10 * nt + waves per SIMD for kt = 1; 100 + waves per SIMD for kt = 2
 #define WV(KT_, NT_, OCC_, VAR_) if (kt == KT_ && nt == NT_ && wvar == VAR_ && fast) { \
-        hipLaunchKernelGGL((kl_wtu_kernel<KT_, NT_, true, OCC_>), grid, block, lds, st, a, rowblks_per_chunk); } else
+        DNMF_LAUNCH((kl_wtu_kernel<KT_, NT_, true, OCC_>), grid, block, lds, st, a, rowblks_per_chunk); } else
     WV(1, 2, 2, 22) WV(1, 2, 3, 23) WV(1, 4, 1, 41) WV(2, 2, 1, 101) WV(2, 2, 2, 102)
 #undef WV
 #endif

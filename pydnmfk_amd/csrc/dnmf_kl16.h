@@ -42,6 +42,9 @@ struct Kl16Args {
     long cols_per_split;                             // uht16 (multiple of 32)
     long hblk; long hextra;                          // uht16: H as column blocks [n / hblk][16][hblk] (see NnArgs in dnmf_nn.h); 0 = plain
 };
+__device__ __forceinline__ void rebase_args(Kl16Args& p, const BatchTab& bt) {
+    rebase(p.A, bt); rebase(p.W, bt); rebase(p.H, bt); rebase(p.P, bt);
+}
 
 // a / d for d = S + eps > 0: v_rcp_f32 (1 ulp) times a -- at most 1.5 ulp from the exact quotient.  Every further vector
 // instruction costs 3.3 matrix-pipe cycles per lane here (the residual correction that makes the quotient correctly rounded
@@ -57,7 +60,8 @@ __device__ __forceinline__ float div16(float a, float d) { return a * __builtin_
 // (register r <-> row 4 kq + r, lane <-> column), U = A / (S + eps) in place, and U is then the B operand of W^T U as it
 // stands (the contraction index -- the row -- is the C/D row index, i.e. kk = kq with step r).  Two blocks in flight: the
 // loads of block b+1 are issued before the products of block b.
-__global__ __launch_bounds__(256) void kl_wtu16_kernel(Kl16Args p) {
+__global__ __launch_bounds__(256) void kl_wtu16_kernel(Kl16Args p, BatchTab bt) {
+    rebase_args(p, bt);
     const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long gw = (long)blockIdx.x * 4 + wid;
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(256) void kl_wtu16_kernel(Kl16Args p) {
 // as the B operand and four scalar LDS reads of H as the A operand, U^T replaces it in place and feeds the second product
 // (U H^T)^T[j][i] = sum_c H[j][c] U^T[c][i] as its B operand, whose A operand H[j = i16][16 s + 4 kq + e] is one 16-byte
 // LDS read.  blockIdx.y splits the columns; partial slabs are summed by reduce_partials.
-__global__ __launch_bounds__(256) void kl_uht16_kernel(Kl16Args p) {
+__global__ __launch_bounds__(256) void kl_uht16_kernel(Kl16Args p, BatchTab bt) {
+    rebase_args(p, bt);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = 128, XT = BM * BK, YT = 16 * BK, STAGE = XT + YT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kq = lane >> 4;

@@ -57,7 +57,7 @@ int dnmf_kl16_uht_(const float* A, long m, long n, long lda, const float* W, lon
     a.P = direct ? UHT : (float*)ws; a.ldp = direct ? ldo : 16; a.chunk_stride = direct ? 0 : m * 16;
     a.cols_per_split = u.cols_per_split;
     a.hblk = hblk; a.hextra = hblk ? (long)16 * hblk - hblk : 0;
-    hipLaunchKernelGGL(kl_uht16_kernel, dim3((unsigned)cdiv(m, 128), (unsigned)u.nsplit), dim3(256), kl_uht16_lds_bytes(), st, a);
+    DNMF_LAUNCH(kl_uht16_kernel, dim3((unsigned)cdiv(m, 128), (unsigned)u.nsplit), dim3(256), kl_uht16_lds_bytes(), st, a);
     int rc = check_launch("kl_uht16");
     if (rc || direct) return rc;
     return launch_reduce((const float*)ws, m * 16, 16, u.nsplit, UHT, ldo, (int)m, k_out, (int)m, k_out,
@@ -80,7 +80,7 @@ int dnmf_kl16_wtu_(const float* A, long m, long n, long lda, const float* W, lon
     a.A = A; a.lda = lda; a.m = m; a.n = n; a.W = W; a.ldw = ldw; a.H = H; a.ldh = ldh; a.eps = eps;
     a.P = (float*)ws; a.ldp = n; a.chunk_stride = 16 * n;
     a.rows_per_chunk = q.rows_per_chunk; a.nchunks = q.nchunks; a.ncolblk = q.ncolblk;
-    hipLaunchKernelGGL(kl_wtu16_kernel, dim3((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4)), dim3(256), 0, st, a);
+    DNMF_LAUNCH(kl_wtu16_kernel, dim3((unsigned)cdiv((long)q.nchunks * q.ncolblk, 4)), dim3(256), 0, st, a);
     int rc = check_launch("kl_wtu16");
     if (rc) return rc;
     return launch_reduce((const float*)ws, 16 * n, n, q.nchunks, WTU, ldo, k_out, n, k_out, n, (float*)((char*)ws + pb16), st);

@@ -31,6 +31,9 @@ struct KlUhtArgs {
     long hblk; long hextra;              // H as column blocks (see NnArgs in dnmf_nn.h); 0 = one k x n matrix
     float* out; long ldo; long split_stride; long cols_per_split;
 };
+__device__ __forceinline__ void rebase_args(KlUhtArgs& p, const BatchTab& bt) {
+    rebase(p.A, bt); rebase(p.W, bt); rebase(p.H, bt); rebase(p.out, bt);
+}
 
 __device__ __forceinline__ float klu_quot(float a, float d) { return a * __builtin_amdgcn_rcpf(d); }
 
@@ -46,7 +49,8 @@ template <int KT> struct KlUhtOcc { static constexpr int value = KT == 4 ? 2 : (
 // ABL (tuning build only, tools/kluht_ab.py): ablations that give wrong results but tell where the time goes -- 1: no
 // barrier, 2: no quotient, 4: A pieces loaded once, 8: H tile loaded / staged once, 16: no second product, 32: no first product, 64: line-coalesced A requests, 128: one LDS read per product and tile
 template <int KT, bool A2, int OCC = KlUhtOcc<KT>::value, int ABL = 0, int AUXA = 0>
-__global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p) {
+__global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, BatchTab bt) {
+    rebase_args(p, bt);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = 32 * KT, STAGE = KP * BK, NY = KP / 32, NG = 4 * KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;

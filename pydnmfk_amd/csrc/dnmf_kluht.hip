@@ -26,10 +26,10 @@ int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const flo
     {   // A/B variants: DNMF_KLUHT_VAR = 100 * waves per SIMD + 10 * A2 + ... , DNMF_KLUHT_ABL = ablation bits (wrong results)
         static const long var = tune("DNMF_KLUHT_VAR", 0), abl = tune("DNMF_KLUHT_ABL", 0);
 #define KV(KT_, A2_, OCC_, ABL_) if (kt == KT_ && var == 100 * OCC_ + 10 * A2_ && abl == ABL_) { \
-            hipLaunchKernelGGL((kl_uht_pipe_kernel<KT_, A2_, OCC_, ABL_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
+            DNMF_LAUNCH((kl_uht_pipe_kernel<KT_, A2_, OCC_, ABL_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
         KV(1, true, 3, 0) KV(1, false, 4, 0) KV(1, true, 2, 0) KV(2, true, 2, 0) KV(2, false, 3, 0) KV(4, false, 1, 0) KV(4, true, 2, 0)
 #define KA(KT_, A2_, OCC_, AUX_) if (kt == KT_ && var == 100 * OCC_ + 10 * A2_ + 1 + AUX_ && abl == 0) { \
-            hipLaunchKernelGGL((kl_uht_pipe_kernel<KT_, A2_, OCC_, 0, AUX_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
+            DNMF_LAUNCH((kl_uht_pipe_kernel<KT_, A2_, OCC_, 0, AUX_>), grid, block, lds, st, a); return check_launch("kl_uht(pipe var)"); }
         KA(1, true, 4, 0) KA(2, true, 3, 0) KA(4, false, 2, 0) KA(1, true, 4, 1) KA(2, true, 3, 1) KA(4, false, 2, 1)
 #undef KA
         KV(1, true, 4, 1) KV(1, true, 4, 2) KV(1, true, 4, 4) KV(1, true, 4, 8) KV(1, true, 4, 16) KV(1, true, 4, 32) KV(1, true, 4, 12) KV(1, true, 4, 15) KV(1, true, 4, 64) KV(2, true, 3, 64) KV(1, true, 4, 128) KV(2, true, 3, 128) KV(1, true, 4, 136) KV(1, true, 4, 129)
@@ -37,8 +37,8 @@ int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const flo
 #undef KV
     }
 #endif
-    if (kt == 1) hipLaunchKernelGGL((kl_uht_pipe_kernel<1, true>), grid, block, lds, st, a);
-    else if (kt == 2) hipLaunchKernelGGL((kl_uht_pipe_kernel<2, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((kl_uht_pipe_kernel<4, false>), grid, block, lds, st, a);
+    if (kt == 1) DNMF_LAUNCH((kl_uht_pipe_kernel<1, true>), grid, block, lds, st, a);
+    else if (kt == 2) DNMF_LAUNCH((kl_uht_pipe_kernel<2, true>), grid, block, lds, st, a);
+    else DNMF_LAUNCH((kl_uht_pipe_kernel<4, false>), grid, block, lds, st, a);
     return check_launch("kl_uht(pipe)");
 }

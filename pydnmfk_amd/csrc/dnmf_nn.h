@@ -28,6 +28,9 @@ struct NnArgs {
     long rowtile0;                                   // kl_uht: first 128-row tile of this launch (the full tiles below it went to
                                                      // kl_uht_pipe_kernel, csrc/dnmf_kluht.h)
 };
+__device__ __forceinline__ void rebase_args(NnArgs& p, const BatchTab& bt) {
+    rebase(p.A, bt); rebase(p.W, bt); rebase(p.H, bt); rebase(p.out, bt); rebase(p.P, bt);
+}
 
 // S tile for rows [row0, row0 + 32) x cols [col0, col0 + 32*NT): acc[ne] over contraction j in [0, KP)
 template <int KT, int NT, bool FAST, bool INTERIOR>
@@ -87,7 +90,8 @@ __device__ __forceinline__ float resid_tile(const NnArgs& p, long row0, long col
 
 // TA = storage type of A (float, or bf16_t: p.A then carries the bf16 pointer reinterpreted)
 template <int KT, bool FAST, typename TA = float>
-__global__ __launch_bounds__(256) void resid_kernel(NnArgs p) {
+__global__ __launch_bounds__(256) void resid_kernel(NnArgs p, BatchTab bt) {
+    rebase_args(p, bt);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long gw = (long)blockIdx.x * 4 + wid;
@@ -175,7 +179,8 @@ __device__ __forceinline__ double resid_chunk_pipe(const NnArgs& p, const float*
 }
 
 template <int KT, bool FAST, typename TA = float>
-__global__ __launch_bounds__(256, 1) void resid_lds_kernel(NnArgs p, long rowblks_per_chunk) {   // one wave per SIMD: 224+ live registers (two waves spill)
+__global__ __launch_bounds__(256, 1) void resid_lds_kernel(NnArgs p, long rowblks_per_chunk, BatchTab bt) {
+    rebase_args(p, bt);   // one wave per SIMD: 224+ live registers (two waves spill)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = 32 * KT, CW = 128;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256, 1) void resid_lds_kernel(NnArgs p, long rowblk
 // the global fp64 arrays (atomics: these are statistics, like the norms of pyDNMF.py:205-218).
 template <int KT, bool FAST, typename TA = float>
 __global__ __launch_bounds__(256) void colerr_kernel(NnArgs p, double* __restrict__ num, double* __restrict__ den,
-                                                     long rowblks_per_chunk) {
+                                                     long rowblks_per_chunk, BatchTab bt) {
+    rebase_args(p, bt); REBASE(num); REBASE(den);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long gw = (long)blockIdx.x * 4 + wid;
@@ -396,7 +402,8 @@ __device__ __forceinline__ void kl_wtu_chunk_pipe(f32x16 (&out)[KT][NT], const N
 }
 
 template <int KT, int NT, bool FAST, int OCC = (KT == 2 ? 2 : 1)>
-__global__ __launch_bounds__(256, OCC) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk) {
+__global__ __launch_bounds__(256, OCC) void kl_wtu_kernel(NnArgs p, long rowblks_per_chunk, BatchTab bt) {
+    rebase_args(p, bt);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = 32 * KT, CW = 32 * NT;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -586,7 +593,8 @@ __device__ __forceinline__ void kl_uht_body(const NnArgs& p, float* __restrict__
 
 template <int KT, bool FAST>
 __global__ __launch_bounds__(256, KT == 4 ? 1 : 2) void kl_uht_kernel(NnArgs p, float* __restrict__ out_base, long ldo,
-                                                        long split_stride, long cols_per_split, int out_cols) {
+                                                        long split_stride, long cols_per_split, int out_cols, BatchTab bt) {
+    rebase_args(p, bt); REBASE(out_base);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block-uniform: all 128 rows in bounds and no rank padding -> branch-free W / A / output accesses
     const bool interior = FAST && p.k == 32 * KT && ((long)blockIdx.x + p.rowtile0 + 1) * 128 <= p.m && out_cols >= 32 * KT;

@@ -35,6 +35,9 @@ struct NtArgs {
     int wfast;                                              // NT_FUSED_W: rows of W are 16-byte aligned (k, ldw % 4 == 0)
     YBlk yb;                                                // Y as column blocks (zero = one matrix)
 };
+__device__ __forceinline__ void rebase_args(NtArgs& p, const BatchTab& bt) {
+    rebase(p.X, bt); rebase(p.Y, bt); rebase(p.out, bt); rebase(p.W, bt); rebase(p.G, bt);
+}
 
 // Stage a tile of R rows x BK floats: thread t owns 16-B chunk (t & 7) of rows (t >> 3) + it * T/8.
 // INTERIOR (compile time): the whole tile is in bounds -> plain loads with no exec-masked branches, so hipcc can
@@ -625,8 +628,9 @@ __device__ __forceinline__ void nt_mainloop_b16(f32x16 (&acc)[MT][KT], const bf1
 }
 
 template <int KT, int MT, int NW, int KS, bool FAST, int MODE, int PF, typename TX = float>
-__global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p) {
+__global__ __launch_bounds__(64 * NW) void nt_kernel(NtArgs p, BatchTab bt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    rebase_args(p, bt);
     constexpr int NRG = NW / KS, BM = 32 * MT * NRG;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int wave = (threadIdx.x >> 6) % NRG, ks = (threadIdx.x >> 6) / NRG;   // row group, contraction slice

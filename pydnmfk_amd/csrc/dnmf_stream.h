@@ -72,7 +72,8 @@ enum { EW_CLAMP = 0, EW_COLS_DIV = 1, EW_ROWS_MUL = 2, EW_KL_BYROW = 3, EW_KL_BY
 template <int OP, int V, bool LONG, bool NTP = false>
 __global__ __launch_bounds__(256) void ew_kernel(float* __restrict__ X, long rows, long cols, long ldx,
                                                  const float* __restrict__ Sm, long lds_, const float* __restrict__ x,
-                                                 float eps, int clamp, int txs) {
+                                                 float eps, int clamp, int txs, BatchTab bt) {
+    REBASE(X); REBASE(Sm); REBASE(x);
     constexpr bool HAS_S = OP == EW_KL_BYROW || OP == EW_KL_BYCOL;
     constexpr bool BYCOL = OP == EW_COLS_DIV || OP == EW_KL_BYCOL;
     constexpr bool BYROW = OP == EW_ROWS_MUL || OP == EW_KL_BYROW;
@@ -165,7 +166,8 @@ __device__ __forceinline__ void block_atomic_sum(double v, double* out) {
 
 // sum of squares of an m x n matrix; fp32 products, fp64 accumulation
 template <bool FAST, typename TA = float>
-__global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, long m, long n, long lda, double* out) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, long m, long n, long lda, double* out, BatchTab bt) {
+    REBASE(A); REBASE(out);
     double acc = 0.0;
     if constexpr (FAST) {
         // four independent nontemporal 4-element loads in flight per lane and trip; a matrix without row padding is
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const TA* __restrict__ A, l
 
 // x[j] = sum_c H[j][c]  -- one 16-wave workgroup per row, 16-byte loads where the row allows, fp64 accumulation in a fixed
 // order (per-thread stride, wave butterfly, waves in order)
-__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ H, long n, long ldh, float* x) {
+__global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ H, long n, long ldh, float* x, BatchTab bt) {
+    REBASE(H); REBASE(x);
     const float* row = H + (long)blockIdx.x * ldh;
     double acc = 0.0;
     const bool vec = ((uintptr_t)row & 15) == 0;
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(1024) void rowsum_kernel(const float* __restrict__ 
 
 // stage 1 of x[j] = sum_i W[i][j]: partial[blk][j] over a slab of rows (coalesced along j)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ W, long m, int k, long ldw,
-                                                             long rows_per_blk, float* partial, int kp) {
+                                                             long rows_per_blk, float* partial, int kp, BatchTab bt) {
+    REBASE(W); REBASE(partial);
     __shared__ float red[256];
     const int j = threadIdx.x % kp, g = threadIdx.x / kp, ng = 256 / kp;
     const long r0 = (long)blockIdx.x * rows_per_blk;
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // in order, the G sums of a column are combined in fixed order through LDS -> deterministic.  (One thread per column walking
 // all slabs was a 60 us latency chain at 256 slabs: 4 % of a KL step.)
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int kp, int k,
-                                                            float* __restrict__ x) {
+                                                            float* __restrict__ x, BatchTab bt) {
+    REBASE(partial); REBASE(x);
     __shared__ double red[1024];
     const int j = threadIdx.x % kp, g = threadIdx.x / kp, G = 1024 / kp;
     double acc = 0.0;

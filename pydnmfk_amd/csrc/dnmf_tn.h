@@ -15,6 +15,9 @@ struct TnArgs {
     float* P; long chunk_stride; long ldp;   // P[chunk][KP][ldp]
     float* Pg;                               // tn16_kernel<., GRAM>: partial X^T X per chunk [chunk][16][16]
 };
+__device__ __forceinline__ void rebase_args(TnArgs& p, const BatchTab& bt) {
+    rebase(p.X, bt); rebase(p.Y, bt); rebase(p.P, bt); rebase(p.Pg, bt);
+}
 
 template <int KT, int NT, bool FAST, int U, typename TY>
 __device__ __forceinline__ void tn_load(float (&a)[U][KT], float (&b)[U][NT], const float* __restrict__ X, long ldx,
@@ -189,7 +192,8 @@ __device__ __forceinline__ void tn_mainloop(f32x16 (&acc)[KT][NT], const float* 
 }
 
 template <int KT, int NT, bool FAST, int MODE, bool NTY = false, typename TY = float>
-__global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p) {
+__global__ __launch_bounds__(256, 2) void tn_kernel(TnArgs p, BatchTab bt) {
+    rebase_args(p, bt);
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     // wave-uniform quantities kept provably scalar (readfirstlane) so row bases live in SGPRs
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -263,8 +267,9 @@ __device__ __forceinline__ void gram_tail(const GramTail& t, int b) {
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, long stride, long ldp,
                                                               int nsplit, int splits_per_y, float* __restrict__ out,
                                                               long ldo, long y_stride, int rows, long cols,
-                                                              int rows_out, long cols_out, GramTail gt) {
+                                                              int rows_out, long cols_out, GramTail gt, BatchTab bt) {
     __shared__ f32x4 red[256];
+    REBASE(P); REBASE(out); rebase(gt.Pg, bt); rebase(gt.G, bt);
     if (gt.Pg && (int)blockIdx.x >= (int)gridDim.x - (gt.k * gt.k + 255) / 256) {     // (single-stage launches only: gridDim.y == 1)
         gram_tail(gt, (int)blockIdx.x - ((int)gridDim.x - (gt.k * gt.k + 255) / 256));
         return;
@@ -300,7 +305,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // association; single stage only (nsplit <= 64).
 __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ P, long stride, long ldp,
                                                                    int nsplit, float* __restrict__ out, long ldo, int rows,
-                                                                   long cols, GramTail gt) {
+                                                                   long cols, GramTail gt, BatchTab bt) {
+    REBASE(P); REBASE(out); rebase(gt.Pg, bt); rebase(gt.G, bt);
     if (gt.Pg && (int)blockIdx.x >= (int)gridDim.x - (gt.k * gt.k + 255) / 256) {
         gram_tail(gt, (int)blockIdx.x - ((int)gridDim.x - (gt.k * gt.k + 255) / 256));
         return;

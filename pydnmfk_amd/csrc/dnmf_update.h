@@ -137,7 +137,8 @@ inline unsigned upd_grid(long tiles, int kt) {
 template <int KT, int NT, int OCC, bool EDGE, bool MMA = true, int AUXL = 0, int AUXS = 0, int NWV = upd_waves(KT)>
 __global__ __launch_bounds__(64 * NWV, EDGE ? edge_occ(KT, OCC) : OCC) void update_h_seq_kernel(float* __restrict__ H, int k, long n, long ldh,
                                                                 const float* __restrict__ Sm, long lds_,
-                                                                const float* __restrict__ G, float eps, int clamp) {
+                                                                const float* __restrict__ G, float eps, int clamp, BatchTab bt) {
+    REBASE(H); REBASE(Sm); REBASE(G);
     constexpr int KP = 32 * KT, GP = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float gs[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -239,7 +240,8 @@ template <int KT, int V, int OCC, bool EDGE, int MODE = UW_MU, int AUX = 0, int 
 __global__ __launch_bounds__(64 * NWV, (EDGE || V == 1) ? edge_occ(KT, OCC) : OCC) void update_w_seq_kernel(float* __restrict__ W, long m, int k, long ldw,
                                                                 const float* __restrict__ Sm, long lds_,
                                                                 const float* __restrict__ G, float eps,
-                                                                float* __restrict__ T = nullptr, long ldt = 0) {
+                                                                float* __restrict__ T, long ldt, BatchTab bt) {
+    REBASE(W); REBASE(Sm); REBASE(G); REBASE(T);
     constexpr int KP = 32 * KT, GP = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float gs[];
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;

@@ -88,6 +88,14 @@ def workspace(m, n, k, device):
     return _scratch(nbytes, device)
 
 
+def stack_alloc(B, rows, cols, dtype, device):
+    """[B][rows][cols] with contiguous members whose distance is a multiple of 16 bytes -- the layout the batched whole-fit
+    entry points take (include/dnmf.h: every problem then has problem 0's alignment)."""
+    per = 16 // torch.empty(0, dtype=dtype).element_size()
+    stride = -(-(rows * cols) // per) * per
+    return torch.empty(B * stride, dtype=dtype, device=device).as_strided((B, rows, cols), (stride, cols, 1))
+
+
 def new_gram(k, device):
     return torch.zeros(kp(k), kp(k), dtype=torch.float32, device=device)
 
@@ -348,16 +356,18 @@ class HipOps:
         _req(H, "H"); _req(s, "s", 1)
         check(lib.dnmf_scale_rows_mul(H.data_ptr(), H.shape[0], H.shape[1], _ld(H), s.data_ptr(), _stream()))
 
-    def perturb_uniform(self, X, noise_var, seed):
+    def perturb_uniform(self, X, noise_var, seed, out=None):
         """X * (1 + nv + 2 nv U[0,1)) element-wise in ONE pass (NMFk's `sample.randM`, pyDNMFk.py:42-44), in X's storage type
-        (float32 or bfloat16).  None when the shape does not fit the kernel (the caller keeps its torch expression)."""
+        (float32 or bfloat16).  None when the shape does not fit the kernel (the caller keeps its torch expression).  `out`:
+        a contiguous destination of X's shape and type (else a new tensor)."""
         if not (X.is_cuda and X.dim() == 2 and X.dtype in (torch.float32, torch.bfloat16) and X.stride(1) == 1):
             return None
         rows, cols = X.shape
         ld = _ld(X)
         if cols % 8 or ld % 8 or X.data_ptr() % 16:
             return None
-        out = torch.empty(rows, cols, dtype=X.dtype, device=X.device)
+        if out is None or out.shape != X.shape or out.dtype != X.dtype or not out.is_contiguous() or out.data_ptr() % 16:
+            out = torch.empty(rows, cols, dtype=X.dtype, device=X.device)
         check(lib.dnmf_perturb_uniform(X.data_ptr(), out.data_ptr(), rows, cols, ld, cols, float(noise_var), int(seed) & (2**64 - 1),
                                        int(X.dtype == torch.bfloat16), _stream()))
         return out
@@ -384,6 +394,46 @@ class HipOps:
         check(_fn("column_err", sfx)(A.data_ptr(), A.shape[0], n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H),
                                   W.shape[1], out[0].data_ptr(), out[1].data_ptr(), _stream()))
         return out[0], out[1]
+
+    # ---- whole fits (csrc/dnmf_fit.hip)
+    def fit(self, method, norm, A, W, H, eps, w_update, itr, column_sweep=False):
+        """`itr` update steps (clamp after the steps i % 10 == 0), normalize_features and the squared norms of relative_err in
+        ONE library call (dnmf_{mu_fro,mu_kl,hals_fro}_fit; pyDNMF.py:138-182 on one rank).  A, W, H are matrices -- one
+        problem -- or stacks [B][m][n], [B][m][k], [B][k][n] of B same-shape problems that every launch then covers together
+        (blockIdx.z = problem; bit-identical to B single fits).  W, H are updated in place; returns the device tensor
+        [B][2] of {sum (A - W H)^2, sum A^2}."""
+        method, norm = method.lower(), norm.lower()
+        batched = A.dim() == 3
+        if W.dim() != A.dim() or H.dim() != A.dim():
+            raise ValueError("fit: A, W, H must all be matrices or all be stacks")
+        A3, W3, H3 = (A, W, H) if batched else (A[None], W[None], H[None])
+        sfx = _req_a(A3[0]); _req(W3[0], "W"); _req(H3[0], "H")
+        B, m, n = A3.shape
+        k = W3.shape[2]
+        if W3.shape != (B, m, k) or H3.shape != (B, k, n):
+            raise ValueError("fit: shapes A %s, W %s, H %s do not match" % (tuple(A3.shape), tuple(W3.shape), tuple(H3.shape)))
+        if (norm, method) == ("kl", "mu"):
+            if sfx:
+                raise TypeError("fit: KL needs float32 data")
+            fn, extra = lib.dnmf_mu_kl_fit, ()
+        elif (norm, method) == ("fro", "mu"):
+            fn, extra = _fn("mu_fro_fit", sfx), ()
+        elif (norm, method) == ("fro", "hals"):
+            fn, extra = _fn("hals_fro_fit", sfx), (int(bool(column_sweep)),)
+        else:
+            raise ValueError("fit: no whole-fit entry point for method %r / norm %r" % (method, norm))
+        nbytes = lib.dnmf_ws_bytes_fit(int(m), int(n), int(k), int(B))
+        if nbytes == 0:
+            raise ValueError("fit: bad problem shape m=%d n=%d k=%d batch=%d" % (m, n, k, B))
+        ws = _scratch(nbytes, A.device)
+        sq = torch.empty(B, 2, dtype=torch.float64, device=A.device)
+        for t, name in ((A3, "A"), (W3, "W"), (H3, "H")):
+            if t.stride(2) != 1 and t.numel():
+                raise ValueError("fit: %s must have unit inner stride" % name)
+        check(fn(A3.data_ptr(), m, n, _ld(A3[0]), W3.data_ptr(), _ld(W3[0]), H3.data_ptr(), _ld(H3[0]), k, float(eps),
+                 int(bool(w_update)), int(itr), *extra, int(B), A3.stride(0), W3.stride(0), H3.stride(0), sq.data_ptr(),
+                 ws.data_ptr(), ws.numel(), _stream()))
+        return sq
 
     # ---- allocation helpers used by the choreography
     def empty(self, shape, like):

@@ -47,6 +47,10 @@ def storage_dtype(A_ij, params):
     return torch.float32
 
 
+_MASKS = ("row_zero_idx_x", "col_zero_idx_x", "row_zero_idx_w", "col_zero_idx_h")
+_NATIVE_FITS = (("mu", "fro"), ("mu", "kl"), ("hals", "fro"))
+
+
 class PyNMF:
     """Reference pyDNMF.py:6-239 (the MU path of it)."""
 
@@ -111,6 +115,9 @@ class PyNMF:
             else:
                 self.A_ij, self.W_ij, self.H_ij = self.data_op.prune_all(self.W_ij, self.H_ij)
             self.m_loc, self.n_loc = self.A_ij.shape
+            # the keep-masks live on the (shared) params bag: this fit's own copy, for fits that are set up together and
+            # finished later (fit_batch)
+            self._masks = tuple(getattr(self.params, n_) for n_ in _MASKS)
             if self.topo == '2d':   # pruned slices are ragged: exchange the actual sizes once per fit
                 self.params._slice_counts = (
                     [int(c) for c in self.cart_1d_column.allgather(int(self.W_ij.shape[0]))],
@@ -186,6 +193,12 @@ class PyNMF:
         if self.method.lower() not in ('mu', 'hals'):
             raise NotImplementedError("method '%s' is not part of the MI355X engine (mu / hals)" % self.method)
         ops = self._ops()
+        if self._whole_fit_ok(ops):
+            # one rank: the whole loop below -- steps, clamps, normalisation, both squared norms -- is ONE library call
+            # (dnmf_*_fit, csrc/dnmf_fit.hip): no Python, no ctypes call and no host synchronisation inside the fit
+            sq = ops.fit(self.method, self.norm, self.A_ij, self.W_i, self.H_j, self.eps, self.W_update, self.itr,
+                         column_sweep=(getattr(self.params, "hals_sweep", None) == "columns"))
+            return self._finish(sq[0])
         for i in range(self.itr):
             clamp = (i % 10 == 0)                                   # :155 / :170, fused into the step
             if self.topo == '2d':
@@ -199,29 +212,96 @@ class PyNMF:
                     self.W_ij, self.H_ij = self.normalize_features(self.W_ij, self.H_ij)
                 else:
                     self.W_i, self.H_j = self.normalize_features(self.W_i, self.H_j)
-                if self.method.lower() == 'hals' and hasattr(ops, "hals_check"):
-                    # a persistent W sweep that lost its co-residency raises here -- BEFORE the error's allreduce sees NaN
-                    # factors, and on EVERY rank (the word is per device: the ranks agree on it first, or the others would
-                    # walk into the next collective alone)
-                    bad = None
-                    try:
-                        ops.hals_check()
-                    except Exception as ex:  # noqa: BLE001
-                        bad = ex
-                    nbad = int(self.params.comm1.allreduce(1 if bad is not None else 0))
-                    if nbad:
-                        raise bad if bad is not None else RuntimeError(
-                            "HALS W sweep timed out on %d other rank(s) (params.hals_sweep = 'columns' selects the per-column sweep)" % nbad)
-                self.relative_err()
-                if self.verbose is True and self.rank == 0:
-                    print('relative error is:', self.recon_err)
-                W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
-                if self.prune:                                      # :166,:180-181 (before the save here, so that the
-                    W, H = self.data_op.unprune_factors(W, H)       # saved blocks have the un-pruned shapes)
-                if self.save_factors:
-                    from .data_io import data_write
-                    data_write(self.params).save_factors([W.cpu().numpy(), H.cpu().numpy()])
-                return self._out(W), self._out(H), self.recon_err
+                return self._finish(None)
+
+    def _whole_fit_ok(self, ops):
+        """One rank, the product's own fp32-MFMA operator set, a method / norm pair the library has a whole-fit entry point for
+        (anything else keeps the step loop, which raises the reference's messages for invalid pairs).  `params.fit_loop =
+        'python'` keeps the step loop (A/B runs, tests of the per-step API)."""
+        return (self.p == 1 and self.topo == '1d' and self.itr >= 1 and getattr(ops, "name", "") == "hip" and hasattr(ops, "fit")
+                and (str(self.method).lower(), str(self.norm).lower()) in _NATIVE_FITS
+                and getattr(self.params, "fit_loop", None) != "python"
+                and not getattr(self.params, "native_always", False))
+
+    def _finish(self, sq):
+        """The end of the last iteration (pyDNMF.py:158-166, :173-181): error, un-pruning, save.  `sq`: the device pair
+        {sum (A - W H)^2, sum A^2} a whole-fit call left (None: evaluate them here)."""
+        ops = self._ops()
+        if self.method.lower() == 'hals' and hasattr(ops, "hals_check"):
+            # a persistent W sweep that lost its co-residency raises here -- BEFORE the error's allreduce sees NaN
+            # factors, and on EVERY rank (the word is per device: the ranks agree on it first, or the others would
+            # walk into the next collective alone)
+            bad = None
+            try:
+                ops.hals_check()
+            except Exception as ex:  # noqa: BLE001
+                bad = ex
+            nbad = int(self.params.comm1.allreduce(1 if bad is not None else 0))
+            if nbad:
+                raise bad if bad is not None else RuntimeError(
+                    "HALS W sweep timed out on %d other rank(s) (params.hals_sweep = 'columns' selects the per-column sweep)" % nbad)
+        self.relative_err(sq)
+        if self.verbose is True and self.rank == 0:
+            print('relative error is:', self.recon_err)
+        W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
+        if self.prune:                                      # :166,:180-181 (before the save here, so that the
+            for n_, v in zip(_MASKS, getattr(self, "_masks", ())):
+                setattr(self.params, n_, v)                 # (this fit's masks: the bag may have served another fit since)
+            W, H = self.data_op.unprune_factors(W, H)       # saved blocks have the un-pruned shapes)
+        if self.save_factors:
+            from .data_io import data_write
+            data_write(self.params).save_factors([W.cpu().numpy(), H.cpu().numpy()])
+        return self._out(W), self._out(H), self.recon_err
+
+    @staticmethod
+    def fit_batch(fits):
+        """Fit several independent problems TOGETHER: `fits` are PyNMF objects set up one after another (each has drawn
+        its perturbation and its initial factors in the reference's order); the result is the list of their `fit()`
+        results.  Same-shape problems on one rank run as ONE batched whole-fit call -- every kernel launch covers all of
+        them (blockIdx.z = problem), each problem on the same kernels and operands as a fit of its own: the results are
+        bit-identical to fitting them one by one (pyDNMFk.py:226-231 runs them one by one).  Anything the batched entry
+        points do not cover falls back to exactly that."""
+        from .engine import stack_alloc
+        fits = list(fits)
+        f0 = fits[0] if fits else None
+
+        def same(f):
+            return (f._whole_fit_ok(f._ops()) and f._ops() is f0._ops() and f.A_ij.shape == f0.A_ij.shape
+                    and f.A_ij.dtype == f0.A_ij.dtype and f.A_ij.device == f0.A_ij.device and f.W_i.shape == f0.W_i.shape
+                    and f.H_j.shape == f0.H_j.shape and (f.method, f.norm, f.itr, f.W_update, f.eps, f.k) ==
+                    (f0.method, f0.norm, f0.itr, f0.W_update, f0.eps, f0.k))
+        if len(fits) < 2 or not all(same(f) for f in fits):
+            return [f.fit() for f in fits]
+        if f0.method.lower() not in ('mu', 'hals'):
+            raise NotImplementedError("method '%s' is not part of the MI355X engine (mu / hals)" % f0.method)
+        A = getattr(f0, "_stack", None)
+        if A is None or A.shape[0] != len(fits) or any(getattr(f, "_stack", None) is not A or f.A_ij.data_ptr() != A[b].data_ptr()
+                                                       for b, f in enumerate(fits)):
+            A = stack_alloc(len(fits), f0.A_ij.shape[0], f0.A_ij.shape[1], f0.A_ij.dtype, f0.A_ij.device)
+            for b, f in enumerate(fits):                    # (callers that adopt_stack() as they go never get here)
+                f.adopt_stack(A, b)
+        W = stack_alloc(len(fits), f0.W_i.shape[0], f0.W_i.shape[1], f0.W_i.dtype, f0.W_i.device)
+        H = stack_alloc(len(fits), f0.H_j.shape[0], f0.H_j.shape[1], f0.H_j.dtype, f0.H_j.device)
+        for b, f in enumerate(fits):
+            W[b].copy_(f.W_i)
+            H[b].copy_(f.H_j)
+        sq = f0._ops().fit(f0.method, f0.norm, A, W, H, f0.eps, f0.W_update, f0.itr,
+                           column_sweep=(getattr(f0.params, "hals_sweep", None) == "columns"))
+        out = []
+        sq_host = sq.cpu()                                  # ONE synchronisation for the whole batch
+        for b, f in enumerate(fits):
+            f.W_i, f.H_j = W[b], H[b]
+            out.append(f._finish(sq_host[b]))
+        return out
+
+    def adopt_stack(self, stack, b):
+        """Hold this fit's data block as slice `b` of `stack` ([B][m][n], the layout fit_batch hands to the library): copied
+        there unless it already is that slice (NMFk perturbs straight into it), the block's own buffer is released."""
+        if self.A_ij.data_ptr() != stack[b].data_ptr():
+            stack[b].copy_(self.A_ij)
+        self.A_ij = stack[b]
+        self.data_op.ten = self.A_ij
+        self._stack = stack
 
     def normalize_features(self, Wall, Hall):
         """pyDNMF.py:185-194: s = column sums of W (allreduced iff 2D or p_r != 1); W /= s + eps; H *= s^T."""
@@ -239,13 +319,15 @@ class PyNMF:
         self.H_j = alg.gather_H()
         self.W_i = alg.gather_W()
 
-    def relative_err(self):
-        """pyDNMF.py:205-218: ||A - W H||_F / ||A||_F; squared norms are summed over ranks, then sqrt."""
+    def relative_err(self, sq=None):
+        """pyDNMF.py:205-218: ||A - W H||_F / ||A||_F; squared norms are summed over ranks, then sqrt.  `sq`: the pair of
+        squared norms when a whole-fit call has already evaluated them (one rank: nothing to sum)."""
         ops = self._ops()
-        if self.topo == '2d':
-            self.cart_2d_collect_factors()
-        sq = torch.cat([ops.resid_sqnorm(self.A_ij, self.W_i, self.H_j), ops.sqnorm(self.A_ij)])
-        self.comm1.allreduce_(sq)
+        if sq is None:
+            if self.topo == '2d':
+                self.cart_2d_collect_factors()
+            sq = torch.cat([ops.resid_sqnorm(self.A_ij, self.W_i, self.H_j), ops.sqnorm(self.A_ij)])
+            self.comm1.allreduce_(sq)
         num, den = (float(v) for v in sq.cpu())
         self.glob_norm_err, self.glob_norm_A = float(np.sqrt(num)), float(np.sqrt(den))
         self.recon_err = self.glob_norm_err / self.glob_norm_A

@@ -31,8 +31,9 @@ class sample:
     CUDA tensors are perturbed on the device with a torch generator seeded the same way (same distribution,
     different stream)."""
 
-    def __init__(self, data, noise_var, method, seed=None):
+    def __init__(self, data, noise_var, method, seed=None, out=None):
         self.X = data
+        self.out = out          # optional destination of the perturbed copy (a slice of the stack an NMFk batch is fitted from)
         self.noise_var = noise_var
         self.seed = seed
         if self.seed is not None:
@@ -45,7 +46,7 @@ class sample:
         if isinstance(self.X, torch.Tensor):
             if self.X.is_cuda:      # one fused pass with a counter-based generator (dnmf_perturb_uniform): 1 GB of traffic per fit at
                 from .engine import HIP_OPS        # 65536 x 4096 bf16 where the torch expression below moves about 9 GB
-                out = HIP_OPS.perturb_uniform(self.X, nv, 0 if self.seed is None else int(self.seed))
+                out = HIP_OPS.perturb_uniform(self.X, nv, 0 if self.seed is None else int(self.seed), out=self.out)
                 if out is not None:
                     self.X_per = out
                     return
@@ -148,15 +149,40 @@ class PyNMFk:
         if self.rank == 0:
             print('*************Computing for k=', self.k, '************')
         perturbation = 0
-        for perturbation in range(self.perturbations):
-            if self.rank == 0 and self.verbose:
-                print('Current perturbation =', perturbation)
-            data = sample(data=self.A_ij, noise_var=self.noise_var, method=self.sampling, seed=perturbation * 1000).fit()
-            self.params.W_update = True
-            if getattr(self.params, "rng", None) == "device":       # device-drawn init: one seed per (perturbation, k)
-                self.params.init_seed = perturbation * 1000 + self.k
-            results.append(PyNMF(data, factors=None, params=self.params, ops=self.ops).fit())          # :230
-            self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+        # The perturbations are independent fits of one shape (:226-231 runs them one after another).  On one rank they are
+        # set up in the reference's order -- perturbation p draws its data and then its initial factors from the stream
+        # seeded p * 1000 -- and then fitted TOGETHER, `nb` at a time: one batched whole-fit call in which every kernel launch
+        # covers all of them (PyNMF.fit_batch; bit-identical to the one-by-one fits, which nb = 1 still runs).
+        from .engine import stack_alloc
+        nb = self._batch_size()
+        for p0 in range(0, self.perturbations, nb):
+            fits, stack = [], None
+            for perturbation in range(p0, min(self.perturbations, p0 + nb)):
+                if self.rank == 0 and self.verbose:
+                    print('Current perturbation =', perturbation)
+                b = perturbation - p0
+                if nb > 1 and stack is None and isinstance(self.A_ij, torch.Tensor) and self.A_ij.is_cuda and self.A_ij.dim() == 2:
+                    stack = stack_alloc(min(nb, self.perturbations - p0), self.A_ij.shape[0], self.A_ij.shape[1], self.A_ij.dtype,
+                                        self.A_ij.device)            # the perturbed copies are written straight into it
+                data = sample(data=self.A_ij, noise_var=self.noise_var, method=self.sampling, seed=perturbation * 1000,
+                              out=None if stack is None else stack[b]).fit()
+                self.params.W_update = True
+                if getattr(self.params, "rng", None) == "device":       # device-drawn init: one seed per (perturbation, k)
+                    self.params.init_seed = perturbation * 1000 + self.k
+                f = PyNMF(data, factors=None, params=self.params, ops=self.ops)                          # :230
+                if nb > 1:
+                    if stack is None or tuple(stack.shape[1:]) != tuple(f.A_ij.shape) or stack.dtype != f.A_ij.dtype:
+                        if b == 0:           # (host data, bf16 storage of fp32 input, pruned shapes: the stack takes the fit's block)
+                            stack = stack_alloc(min(nb, self.perturbations - p0), f.A_ij.shape[0], f.A_ij.shape[1], f.A_ij.dtype,
+                                                f.A_ij.device)
+                    if stack is not None and tuple(stack.shape[1:]) == tuple(f.A_ij.shape) and stack.dtype == f.A_ij.dtype:
+                        f.adopt_stack(stack, b)
+                fits.append(f)
+                del data
+            results.extend(PyNMF.fit_batch(fits))
+            for perturbation in range(p0, min(self.perturbations, p0 + nb)):
+                self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+            del fits, stack
         self.params.flag = 1
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
         # stack: W m_loc x k x P (column-major over (k, P) as the reference's order='F' reshape, :234-235), H k x n_loc x P
@@ -207,6 +233,22 @@ class PyNMFk:
         writer.save_cluster_results(cluster_stats)
         self.params.flag = 3
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+
+    def _batch_size(self):
+        """How many perturbation fits run together (PyNMF.fit_batch): all of them on one rank with the product's own
+        operators -- as many as fit next to each other in the GPU's free memory (each holds its perturbed copy of the data) --
+        else 1.  `params.nmfk_batch` = False / 0 / 1 keeps the one-by-one fits, an integer caps the batch."""
+        want = getattr(self.params, "nmfk_batch", True)
+        if want is False or self.p != 1 or self.ops is not None or not torch.cuda.is_available():
+            return 1
+        cap = self.perturbations if want is True else max(1, int(want))
+        try:
+            free = torch.cuda.mem_get_info()[0]
+        except Exception:  # noqa: BLE001
+            return 1
+        m, n = self.A_ij.shape
+        per = m * n * 4 * 1.25 + (m + n) * max(int(self.end_k), 1) * 4 * 8 + (64 << 20)
+        return int(max(1, min(cap, self.perturbations, (0.6 * free) // per)))
 
     def pvalueAnalysis(self):
         """pyDNMFk.py:261-299: walk k upwards; whenever the PREVIOUS k clustered well (min silhouette > sill_thr) and

@@ -1,0 +1,161 @@
+"""Whole fits and batched fits (csrc/dnmf_fit.hip, include/dnmf.h "Whole fits on one rank").
+
+  * one library call (`dnmf_*_fit`) against the per-step Python loop it replaces (`params.fit_loop = 'python'`): the same
+    kernels in the same order on the same operands -- BIT-identical factors; the two squared norms come from fp64 atomic
+    sums whose order is free, so the error is compared to 1e-12 relative;
+  * a batch of B problems in one call (blockIdx.z = problem) against B calls of their own: bit-identical factors, problem
+    by problem -- the property the NMFk sweep relies on when it fits its perturbations together;
+  * the NMFk driver with and without batching: identical statistics and the same estimate.
+The parity of the fits themselves against the reference goldens is tests/test_gpu_parity.py (which now runs through the
+whole-fit entry points).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+CASES = [  # m, n, k, method, norm, precision, itr
+    (1024, 256, 16, "mu", "kl", "float32", 25),       # the reference's swim example shape, 16-wide kernels
+    (1024, 256, 17, "mu", "kl", "float32", 21),       # k = 17: 32-wide kernels on zero-padded factor images
+    (1024, 256, 4, "mu", "fro", "float32", 25),
+    (300, 200, 7, "mu", "fro", "float32", 12),        # nothing aligned
+    (300, 200, 7, "mu", "kl", "float32", 12),
+    (2048, 512, 6, "hals", "fro", "bfloat16", 15),    # BASELINE config 5's method and storage
+    (2048, 512, 40, "hals", "fro", "float32", 11),
+    (640, 384, 64, "mu", "fro", "bfloat16", 11),
+    (1536, 640, 128, "mu", "kl", "float32", 6),
+    (333, 129, 3, "hals", "fro", "float32", 11),
+]
+
+
+def _args(k, itr, norm, method, precision, **kw):
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.utils import parse
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, 1, 1, k
+    args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+    args.norm, args.method, args.W_update, args.precision = norm, method, True, precision
+    for key, v in kw.items():
+        setattr(args, key, v)
+    return args
+
+
+def _problem(m, n, k, seed, precision):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A = torch.rand(m, n, device="cuda", generator=g) + 0.01
+    if seed % 2:
+        A[:, ::7] = 0.0                                # zeros in the data (the KL quotient's edge case)
+    if precision == "bfloat16":
+        A = A.to(torch.bfloat16)
+    return A, torch.rand(m, k, device="cuda", generator=g), torch.rand(k, n, device="cuda", generator=g)
+
+
+@pytest.mark.parametrize("m,n,k,method,norm,precision,itr", CASES)
+def test_whole_fit_equals_step_loop(m, n, k, method, norm, precision, itr):
+    from pydnmfk_amd.pyDNMF import PyNMF
+    A, W0, H0 = _problem(m, n, k, 3, precision)
+    for w_update in (True, False):
+        f1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update))
+        assert f1._whole_fit_ok(f1._ops())
+        W1, H1, e1 = f1.fit()
+        f2 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update, fit_loop="python"))
+        assert not f2._whole_fit_ok(f2._ops())
+        W2, H2, e2 = f2.fit()
+        assert torch.equal(W1, W2) and torch.equal(H1, H2), (w_update, float((W1 - W2).abs().max()), float((H1 - H2).abs().max()))
+        assert abs(e1 - e2) <= 1e-12 * max(1.0, abs(e2))
+        assert np.isfinite(e1)
+
+
+@pytest.mark.parametrize("m,n,k,method,norm,precision,itr", CASES)
+def test_batched_fit_is_bit_identical_to_single_fits(m, n, k, method, norm, precision, itr):
+    from pydnmfk_amd.pyDNMF import PyNMF
+    B = 5
+    probs = [_problem(m, n, k, 10 + b, precision) for b in range(B)]
+    single = [PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision)).fit() for A, W0, H0 in probs]
+    fits = [PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision)) for A, W0, H0 in probs]
+    batched = PyNMF.fit_batch(fits)
+    assert getattr(fits[0], "_stack", None) is not None and fits[0]._stack.shape[0] == B      # it did run as ONE batch
+    for b in range(B):
+        assert torch.equal(batched[b][0], single[b][0]) and torch.equal(batched[b][1], single[b][1]), b
+        assert abs(batched[b][2] - single[b][2]) <= 1e-12 * max(1.0, abs(single[b][2])), b
+    # the problems are different problems (a batch that mapped every z to problem 0 would pass the loop above only for b = 0)
+    assert not torch.equal(batched[0][0], batched[1][0])
+
+
+def test_batch_falls_back_to_single_fits_on_mixed_shapes():
+    from pydnmfk_amd.pyDNMF import PyNMF
+    a = _problem(512, 256, 8, 1, "float32")
+    b = _problem(512, 128, 8, 2, "float32")
+    fits = [PyNMF(A, factors=[W0, H0], params=_args(8, 7, "fro", "mu", "float32")) for A, W0, H0 in (a, b)]
+    out = PyNMF.fit_batch(fits)
+    ref = [PyNMF(A, factors=[W0, H0], params=_args(8, 7, "fro", "mu", "float32")).fit() for A, W0, H0 in (a, b)]
+    for o, r in zip(out, ref):
+        assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1])
+
+
+def test_fit_c_api_argument_errors():
+    """strides that do not span a problem / are not 16-byte multiples, overlapping operands, a workspace too small"""
+    from pydnmfk_amd._lib import lib
+    m, n, k, B = 256, 128, 8, 2
+    A = torch.rand(B, m, n, device="cuda")
+    W = torch.rand(B, m, k, device="cuda")
+    H = torch.rand(B, k, n, device="cuda")
+    sq = torch.zeros(B, 2, dtype=torch.float64, device="cuda")
+    nb = lib.dnmf_ws_bytes_fit(m, n, k, B)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(a_stride=m * n, w_stride=m * k, h_stride=k * n, wsb=nb, Wp=None):
+        return lib.dnmf_mu_fro_fit(A.data_ptr(), m, n, n, (Wp if Wp is not None else W).data_ptr(), k, H.data_ptr(), n, k, 1.2e-7, 1, 3,
+                                   B, a_stride, w_stride, h_stride, sq.data_ptr(), ws.data_ptr(), wsb, st)
+    assert call() == 0
+    assert call(a_stride=m * n - 4) == -1            # does not span a problem
+    assert call(w_stride=m * k + 1) == -1            # not a multiple of 16 bytes
+    assert call(wsb=nb - 1) == -2
+    assert call(Wp=A) == -1                          # W inside A: operands overlap
+    assert b"overlap" in lib.dnmf_last_error()
+    torch.cuda.synchronize()
+
+
+def _nmfk(A, tmp, tag, batch, method="mu", norm="kl", **kw):
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from pydnmfk_amd.utils import parse
+    comms = MPI_comm(None, 1, 1)
+    args = parse()
+    args.comm1, args.comm, args.p_r, args.p_c = comms.comm, comms, 1, 1
+    args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    args.fpath, args.fname, args.ftype = str(tmp) + "/", "b", "npy"
+    args.start_k, args.end_k, args.step_k, args.sill_thr, args.itr, args.init = 2, 5, 1, 0.8, 80, "rand"
+    args.noise_var, args.verbose, args.norm, args.method, args.checkpoint = 0.03, False, norm, method, False
+    args.prune, args.perturbations = True, 6
+    args.results_path = str(tmp) + "/results_%s/" % tag
+    args.nmfk_batch = batch
+    for key, v in kw.items():
+        setattr(args, key, v)
+    nm = PyNMFk(A, factors=None, params=args)
+    return nm, nm.fit()
+
+
+@pytest.mark.parametrize("method,norm,precision,io", [("mu", "kl", "float32", "numpy"), ("hals", "fro", "bfloat16", "torch"),
+                                                     ("mu", "fro", "float32", "torch")])
+def test_nmfk_batched_equals_one_by_one(tmp_path, method, norm, precision, io):
+    """the driver fits its perturbations together (nmfk_batch, default) or one after another: same numbers, same estimate"""
+    rs = np.random.RandomState(5)
+    A = (rs.rand(384, 3) @ rs.rand(3, 192) + 0.01 * rs.rand(384, 192)).astype(np.float32)
+    A[5, :] = 0                                        # one all-zero row: prune=True drops it in every perturbation
+    X = A if io == "numpy" else torch.from_numpy(A).cuda()
+    kw = dict(precision=precision) if precision != "float32" else {}
+    a, nopt_a = _nmfk(X, tmp_path, "batched", True, method, norm, **kw)
+    b, nopt_b = _nmfk(X, tmp_path, "single", False, method, norm, **kw)
+    c, nopt_c = _nmfk(X, tmp_path, "four", 4, method, norm, **kw)      # 6 perturbations as a batch of 4 and a batch of 2
+    assert a._batch_size() == 6 and b._batch_size() == 1 and c._batch_size() == 4
+    assert nopt_a == nopt_b == nopt_c
+    for k in a.stats:
+        for key in ("recon_err", "avgErr", "clusterSilhouetteCoefficients", "avgSilhouetteCoefficients", "L_err", "L_errDist"):
+            for other in (b, c):
+                np.testing.assert_allclose(np.asarray(a.stats[k][key], dtype=np.float64), np.asarray(other.stats[k][key], dtype=np.float64),
+                                           rtol=1e-12, atol=0, err_msg="%s k=%d" % (key, k))
