@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--grid", default=None, help="config 4 / 5: process grid 'RxC' (default: 8 ranks 4x2, 4: 2x2, 2: 2x1 for config 4; 1xN for config 5)")
     ap.add_argument("--perturbations", type=int, default=20, help="config 5")
     ap.add_argument("--itr", type=int, default=100, help="config 5: HALS iterations per fit")
+    ap.add_argument("--nmfk-batch", default="auto", help="config 5: perturbation fits per batched whole-fit call (auto = all that fit in memory; "
+                    "1 = one by one, each still ONE library call; with --fit-loop python = the round-4 path: a Python step loop per fit)")
+    ap.add_argument("--fit-loop", default="native", choices=["native", "python"], help="config 5: whole fits in the library (default) or the per-step Python loop")
     ap.add_argument("--start-k", type=int, default=2, help="config 5")
     ap.add_argument("--end-k", type=int, default=16, help="config 5")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for debugging)")
@@ -755,6 +758,9 @@ def run_config5(a, job):
         q.start_k, q.end_k, q.step_k, q.fname, q.checkpoint = start_k, end_k, 1, "c5", False
         q.perturbations, q.noise_var, q.sampling, q.sill_thr = pert, 0.03, "uniform", 0.8
         q.precision, q.results_path, q.timing_stats, q.rng = "bfloat16", tmp + "/", False, "device"
+        q.nmfk_batch = True if a.nmfk_batch == "auto" else int(a.nmfk_batch)
+        if a.fit_loop == "python":
+            q.fit_loop = "python"
         return q
 
     nopt = [None]
@@ -784,6 +790,7 @@ def run_config5(a, job):
                        "block_per_gpu": [e[0] - s[0] + 1, e[1] - s[1] + 1],
                        "parallelism": "single GPU" if world == 1 else "%d x %d blocks of X over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend)},
             "fits_per_step": fits, "estimated_k": int(nopt[0]), "seconds_per_sweep": elapsed / a.steps,
+            "nmfk_batch": a.nmfk_batch, "fit_loop": a.fit_loop,
             "hals_iterations_per_sec": (fits + nk) * a.itr * a.steps / elapsed,
         }
     if not a.no_kernel_timing:
