@@ -1013,7 +1013,8 @@ def main():
                 if world > 1 and a.exchange == "auto" and not os.environ.get("DNMF_BENCH_NO_DIRECT"):
                     try:
                         kp_ = 32 if k <= 32 else (64 if k <= 64 else 128)
-                        nmsg = max(k * n, m_l * k) + 8 * 64 + kp_ * kp_ + 1024
+                        # sized from GLOBAL quantities: every rank must ask for the same capacity (the asymmetric m_l differs between ranks)
+                        nmsg = max(k * n, -(-m // world) * k) + 8 * 64 + kp_ * kp_ + 1024
                         good = p._native_comm.enable_direct(comms.comm, nmsg)
                         if good:
                             xt = torch.rand(k * n + kp_ * kp_, device=dev) - 0.25
@@ -1073,6 +1074,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(W).all() and torch.isfinite(H).all()
+    if multi and mg.get("exchange_used") == "native-direct":
+        # a direct allreduce that gave up on a peer inside the timed loop would have timed garbage: fatal on every rank together
+        if max_over_ranks(1.0 if p._native_comm.direct_timed_out() else 0.0) > 0:
+            sys.exit("bench.py: a direct allreduce timed out during the timed steps -- the measurement is void")
 
     # N > 1: where the step's time goes.  (a) the same step with the exchange stubbed out (NullExchange: every allreduce
     # returns at once, so H diverges between ranks -- timing only; H is re-broadcast afterwards): per-rank compute-only

@@ -307,11 +307,20 @@ int dnmf_comm_rccl_version(int* version, char* origin, size_t origin_bytes);
  * DNMF_DIRECT_MAX_RANKS ranks, messages of an even number of floats.  Rank-ordered sums with one owner per element: every rank
  * ends with identical bits.  Works on RCCL and on hosted communicators alike (it needs neither). ---- */
 #define DNMF_DIRECT_MAX_RANKS 16
-#define DNMF_DIRECT_HANDLE_BYTES 64
-/* allocate this rank's region for messages of up to max_floats floats; handle_out receives DNMF_DIRECT_HANDLE_BYTES bytes */
+#define DNMF_DIRECT_HANDLE_BYTES 80
+/* allocate this rank's region (uncached device memory; DNMF_EHIP when the device has none to give -- there is no cached
+ * fall-back) for messages of up to max_floats floats; handle_out receives DNMF_DIRECT_HANDLE_BYTES bytes (the IPC handle and the
+ * region's capacity).  EVERY rank must pass the same max_floats: peers address each other's regions with one capacity. */
 int dnmf_comm_direct_init(dnmf_comm_t* comm, size_t max_floats, void* handle_out);
-/* handles = nranks x DNMF_DIRECT_HANDLE_BYTES bytes in rank order (this rank's own entry is ignored) */
+/* handles = nranks x DNMF_DIRECT_HANDLE_BYTES bytes in rank order; DNMF_EINVAL when any rank's capacity differs from this rank's
+ * (every rank sees every entry, so a mismatch fails the call on all of them) */
 int dnmf_comm_direct_connect(dnmf_comm_t* comm, const void* handles);
+/* undo init / connect (a set-up that failed on some rank): device synchronise, unmap the peers, free the own region.  The host
+ * makes sure no peer is still reading this rank's region (a barrier); dnmf_comm_destroy does the same unmapping */
+int dnmf_comm_direct_teardown(dnmf_comm_t* comm);
+/* how long a wait of a direct allreduce may see no progress before it gives up (default 30 s; rank skew of seconds is ordinary:
+ * result I/O on rank 0, first-call module loads) */
+int dnmf_comm_set_direct_timeout(dnmf_comm_t* comm, double seconds);
 /* on != 0: allreduces over ALL ranks that fit the regions (the packed exchange of the 1D steps, dnmf_comm_allreduce with
  * group 0) take the direct path; everything else stays on RCCL / the hosted function */
 int dnmf_comm_set_direct(dnmf_comm_t* comm, int on);
@@ -321,7 +330,9 @@ int dnmf_comm_allreduce_direct(dnmf_comm_t* comm, float* buf, size_t count, void
  * p_r > 1, pure latency): every rank pushes its values into its peers' regions, sums in rank order.  With dnmf_comm_set_direct
  * the HALS step entry points use it for their norm exchanges. */
 int dnmf_comm_allreduce_direct_f64(dnmf_comm_t* comm, double* buf, size_t count, void* stream);
-/* *timed_out != 0: a wait of a direct allreduce saw no progress for ~2 s and gave up (a peer is gone): results are invalid */
+/* *timed_out != 0: a wait of a direct allreduce saw no progress for the time-out and gave up (a peer is gone): every result since
+ * is INVALID.  Sticky.  Callers check it where they synchronise anyway -- PyNMF.fit at the end of a fit, all ranks agreeing on the
+ * outcome before they raise -- and treat it as fatal. */
 int dnmf_comm_direct_status(dnmf_comm_t* comm, int* timed_out);
 int dnmf_comm_destroy(dnmf_comm_t* comm);
 int dnmf_comm_info(const dnmf_comm_t* comm, int* nranks, int* rank, int* p_r, int* p_c);

@@ -92,6 +92,9 @@ SIGNATURES["dnmf_comm_rccl_version"] = [ctypes.POINTER(c_int), c_void_p, c_size_
 SIGNATURES["dnmf_comm_direct_init"] = [c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_direct_connect"] = [c_void_p, c_void_p]
 SIGNATURES["dnmf_comm_set_direct"] = [c_void_p, c_int]
+SIGNATURES["dnmf_comm_direct_teardown"] = [c_void_p]
+SIGNATURES["dnmf_comm_set_direct_timeout"] = [c_void_p, ctypes.c_double]
+DIRECT_HANDLE_BYTES = 80           # DNMF_DIRECT_HANDLE_BYTES
 SIGNATURES["dnmf_comm_allreduce_direct"] = [c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_allreduce_direct_f64"] = [c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_direct_status"] = [c_void_p, ctypes.POINTER(c_int)]

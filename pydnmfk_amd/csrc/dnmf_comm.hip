@@ -78,6 +78,7 @@ struct dnmf_comm {
     size_t direct_cap = 0;                                       // floats per message
     char* direct_peer[DNMF_DIRECT_MAX_RANKS] = {};               // [rank] = the own region
     unsigned long long direct_seq = 0, direct_small_seq = 0;
+    unsigned long long direct_patience = 30ull * 100000000ull;   // 30 s of the 100 MHz wall clock (dnmf_comm_set_direct_timeout)
 };
 
 namespace {
@@ -130,6 +131,7 @@ int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
 // call).  A wait that sees no progress for about two seconds sets the region's status word (dnmf_comm_direct_status) and gives up.
 // NOT measured on more than one GPU (this pool has none): bench.py treats it as a third arm of its warm-up A/B and only after
 // its result has matched RCCL's on the warm-up step.
+constexpr unsigned long long DIRECT_MAGIC = 0x444e4d4644495231ull;      // "DNMFDIR1"
 constexpr size_t DIRECT_HDR = 8192;       // flag1 @0, flag2 @1024, status @2048, small-message flags @3072, small-message slots @4096
 struct DirectArgs {
     char* peer[DNMF_DIRECT_MAX_RANKS];
@@ -137,6 +139,7 @@ struct DirectArgs {
     size_t cap;                      // floats per send / reduced buffer
     size_t count, chunk;             // message length, floats per owner
     unsigned long long seq;
+    unsigned long long patience;     // ticks of the 100 MHz wall clock a wait may see no progress (dnmf_comm_set_direct_timeout)
 };
 __device__ __forceinline__ unsigned long long* d_flags(char* region, int which) { return reinterpret_cast<unsigned long long*>(region + 1024 * which); }
 __device__ __forceinline__ float* d_send(char* region, size_t cap, int par) { return reinterpret_cast<float*>(region + DIRECT_HDR) + (size_t)par * cap; }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(64) void direct_signal_wait_kernel(DirectArgs a, in
         const unsigned long long t0 = wall_clock64();             // (100 MHz, independent of the shader clock)
         while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 200000000ull) {              // 2 s: a peer is gone -- say so instead of hanging the GPU
+            if (wall_clock64() - t0 > a.patience) {                // a peer is gone -- say so instead of hanging the GPU
                 __hip_atomic_store(d_flags(a.peer[a.rank], 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -196,6 +199,7 @@ int direct_allreduce(dnmf_comm* cm, float* buf, size_t count, hipStream_t st) {
     a.chunk = (cdiv((long)count, cm->nranks) + 1) / 2 * 2;
     a.seq = ++cm->direct_seq;
     a.par = (int)(a.seq & 1);
+    a.patience = cm->direct_patience;
     float* send = reinterpret_cast<float*>(cm->direct_peer[cm->rank] + DIRECT_HDR) + (size_t)a.par * a.cap;
     HIP_OK(hipMemcpyAsync(send, buf, count * sizeof(float), hipMemcpyDeviceToDevice, st), "allreduce(direct): copy");
     const unsigned g1 = (unsigned)std::max<long>(1, std::min<long>(64, cdiv((long)a.chunk, 512)));
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64) void direct_small_f64_kernel(DirectArgs a, doub
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 200000000ull) {
+            if (wall_clock64() - t0 > a.patience) {
                 __hip_atomic_store(d_flags(a.peer[a.rank], 2), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -251,6 +255,7 @@ int direct_allreduce_small_f64(dnmf_comm* cm, double* buf, size_t count, hipStre
     a.P = cm->nranks; a.rank = cm->rank; a.cap = cm->direct_cap; a.count = count;
     a.seq = ++cm->direct_small_seq;
     a.par = (int)(a.seq & 1);
+    a.patience = cm->direct_patience;
     hipLaunchKernelGGL(direct_small_f64_kernel, dim3(1), dim3(64), 0, st, a, buf, (int)count);
     return check_launch("allreduce(direct, small)");
 }
@@ -598,21 +603,25 @@ int dnmf_comm_direct_init(dnmf_comm_t* c, size_t max_floats, void* handle_out) {
     REQUIRE(c && handle_out && max_floats >= 2 && c->nranks <= DNMF_DIRECT_MAX_RANKS, "comm_direct_init: bad arguments (%d ranks, at most %d)",
             c ? c->nranks : 0, DNMF_DIRECT_MAX_RANKS);
     REQUIRE(!c->direct_peer[c->rank], "comm_direct_init: already set up");
-    static_assert(sizeof(hipIpcMemHandle_t) <= DNMF_DIRECT_HANDLE_BYTES, "IPC handle size");
+    static_assert(sizeof(hipIpcMemHandle_t) + 2 * sizeof(unsigned long long) <= DNMF_DIRECT_HANDLE_BYTES, "IPC handle size");
     const size_t cap = (max_floats + 63) / 64 * 64;
     const size_t bytes = DIRECT_HDR + 4 * cap * sizeof(float);
     void* region = nullptr;
-    // uncached device memory: flags and data are read by peers while kernels of this GPU run
-    if (hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_OK(hipMalloc(&region, bytes), "comm_direct_init: allocation");
-    }
-    HIP_OK(hipMemset(region, 0, bytes), "comm_direct_init: memset");
+    // UNCACHED (fine-grained) device memory: flags and data are read by peers while kernels of this GPU run.  No fallback to an
+    // ordinary allocation: its coherence across agents is not what the protocol was validated on -- the rank fails here, the
+    // host's agreement round (NativeComm.enable_direct) keeps every rank on the communicator's own allreduce.
+    hipError_t e = hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DNMF_EHIP, "comm_direct_init: uncached allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); }
+    if ((e = hipMemset(region, 0, bytes)) != hipSuccess) { (void)hipFree(region); return fail(DNMF_EHIP, "comm_direct_init: memset: %s", hipGetErrorString(e)); }
     hipIpcMemHandle_t h;
-    hipError_t e = hipIpcGetMemHandle(&h, region);
+    e = hipIpcGetMemHandle(&h, region);
     if (e != hipSuccess) { (void)hipFree(region); return fail(DNMF_EHIP, "comm_direct_init: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
+    // the exchanged blob: [IPC handle | capacity in floats | magic] -- peers compute offsets into EVERY region from one capacity,
+    // so dnmf_comm_direct_connect requires all of them equal
     memset(handle_out, 0, DNMF_DIRECT_HANDLE_BYTES);
     memcpy(handle_out, &h, sizeof(h));
+    const unsigned long long tail[2] = {(unsigned long long)cap, DIRECT_MAGIC};
+    memcpy((char*)handle_out + sizeof(h), tail, sizeof(tail));
     c->direct_peer[c->rank] = (char*)region;
     c->direct_cap = cap;
     return DNMF_OK;
@@ -620,6 +629,13 @@ int dnmf_comm_direct_init(dnmf_comm_t* c, size_t max_floats, void* handle_out) {
 
 int dnmf_comm_direct_connect(dnmf_comm_t* c, const void* handles) {
     REQUIRE(c && handles && c->direct_peer[c->rank], "comm_direct_connect: call dnmf_comm_direct_init first");
+    for (int q = 0; q < c->nranks; ++q) {       // every rank sees every blob: a mismatch anywhere fails the connect everywhere
+        unsigned long long tail[2];
+        memcpy(tail, (const char*)handles + (size_t)q * DNMF_DIRECT_HANDLE_BYTES + sizeof(hipIpcMemHandle_t), sizeof(tail));
+        REQUIRE(tail[1] == DIRECT_MAGIC, "comm_direct_connect: rank %d did not initialise its region", q);
+        REQUIRE(tail[0] == (unsigned long long)c->direct_cap, "comm_direct_connect: rank %d sized its region for %llu floats, this rank for %zu "
+                "(every rank must pass the same max_floats to dnmf_comm_direct_init)", q, tail[0], c->direct_cap);
+    }
     for (int q = 0; q < c->nranks; ++q) {
         if (q == c->rank || c->direct_peer[q]) continue;
         hipIpcMemHandle_t h;
@@ -629,6 +645,32 @@ int dnmf_comm_direct_connect(dnmf_comm_t* c, const void* handles) {
         if (e != hipSuccess) return fail(DNMF_EHIP, "comm_direct_connect: hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e));
         c->direct_peer[q] = (char*)p;
     }
+    return DNMF_OK;
+}
+
+// undo dnmf_comm_direct_init / _connect (a set-up that failed on some rank, or the end of the communicator): unmap the peers,
+// free the own region.  The caller makes sure no peer still reads it (NativeComm.close runs a host barrier first).
+static void direct_teardown(dnmf_comm* c) {
+    c->direct_on = 0;
+    for (int q = 0; q < c->nranks && q < DNMF_DIRECT_MAX_RANKS; ++q) {
+        if (!c->direct_peer[q]) continue;
+        if (q == c->rank) (void)hipFree(c->direct_peer[q]);
+        else (void)hipIpcCloseMemHandle(c->direct_peer[q]);
+        c->direct_peer[q] = nullptr;
+    }
+    c->direct_cap = 0;
+}
+
+int dnmf_comm_direct_teardown(dnmf_comm_t* c) {
+    REQUIRE(c, "comm_direct_teardown: null communicator");
+    (void)hipDeviceSynchronize();
+    direct_teardown(c);
+    return DNMF_OK;
+}
+
+int dnmf_comm_set_direct_timeout(dnmf_comm_t* c, double seconds) {
+    REQUIRE(c && seconds >= 0.001 && seconds <= 86400.0, "comm_set_direct_timeout: 0.001 .. 86400 seconds");
+    c->direct_patience = (unsigned long long)(seconds * 1e8);
     return DNMF_OK;
 }
 
@@ -663,11 +705,7 @@ int dnmf_comm_allreduce_direct_f64(dnmf_comm_t* c, double* buf, size_t count, vo
 
 int dnmf_comm_destroy(dnmf_comm_t* c) {
     if (!c) return DNMF_OK;
-    for (int q = 0; q < c->nranks && q < DNMF_DIRECT_MAX_RANKS; ++q) {
-        if (!c->direct_peer[q]) continue;
-        if (q == c->rank) (void)hipFree(c->direct_peer[q]);
-        else (void)hipIpcCloseMemHandle(c->direct_peer[q]);
-    }
+    direct_teardown(c);
     Rccl* r = rccl();
     for (int q = 0; q < MAX_CHUNKS; ++q) {
         if (c->ready[q]) (void)hipEventDestroy(c->ready[q]);

@@ -606,6 +606,15 @@ class NativeComm:
 
     def close(self):
         if getattr(self, "handle", None):
+            host = getattr(self, "_direct_host", None)
+            if host is not None and host.size > 1:
+                # peers may still be reading this rank's exported region (their last gather): drain the device and meet
+                # the others before the region is freed.  Best effort -- a rank that is already gone cannot be waited for.
+                try:
+                    torch.cuda.synchronize()
+                    host.barrier()
+                except Exception:  # noqa: BLE001
+                    pass
             lib.dnmf_comm_destroy(self.handle)
             self.handle = None
 
@@ -621,24 +630,69 @@ class NativeComm:
         64-byte handles.  Collective; returns True when EVERY rank is connected (the ranks agree before anybody uses it), else
         False on every rank.  `set_direct(True)` then routes the world allreduces that fit through it."""
         import ctypes
-        hbuf = ctypes.create_string_buffer(64)
+        from ._lib import DIRECT_HANDLE_BYTES
+        hbuf = ctypes.create_string_buffer(DIRECT_HANDLE_BYTES)
         ok = 1
+        self.direct_error = None
         try:
             check(lib.dnmf_comm_direct_init(self.handle, int(max_floats), hbuf))
-        except Exception:  # noqa: BLE001
-            ok = 0
+        except Exception as ex:  # noqa: BLE001
+            ok, self.direct_error = 0, ex
         handles = host_comm.allgather(bytes(hbuf.raw))
         if ok:
-            try:
+            try:   # (a rank that sized its region differently, or failed its init, fails the connect on EVERY rank)
                 check(lib.dnmf_comm_direct_connect(self.handle, b"".join(handles)))
-            except Exception:  # noqa: BLE001
-                ok = 0
+            except Exception as ex:  # noqa: BLE001
+                ok, self.direct_error = 0, ex
         nbad = int(host_comm.allreduce(0 if ok else 1)) if host_comm.size > 1 else (0 if ok else 1)
         self.direct_ready = nbad == 0
+        if not self.direct_ready:
+            # nobody uses the regions: unmap and free them now (a later enable_direct starts from scratch); the barrier keeps a
+            # region alive until every peer has unmapped it
+            if host_comm.size > 1:
+                host_comm.barrier()
+            lib.dnmf_comm_direct_teardown(self.handle)
+        else:
+            self._direct_host = host_comm
         return self.direct_ready
+
+    def set_direct_timeout(self, seconds):
+        check(lib.dnmf_comm_set_direct_timeout(self.handle, float(seconds)))
+
+    def direct_self_check(self, host_comm, count=4096):
+        """First contact: the same random vector summed by the direct allreduce and by the communicator's own allreduce (RCCL or
+        the hosted function) -- both sum in a fixed order per element, but not the SAME order, so the comparison allows fp32
+        rounding of the sum -- and the status word; the ranks agree on the outcome.  The stacked-rank tests of this
+        repository run all ranks on one GPU (one L2): what can go wrong across xGMI -- a peer's freshly copied send buffer not
+        yet visible to a system-scope load -- shows here, on the machine at hand, before any factor depends on it."""
+        g = torch.Generator(device="cuda")
+        g.manual_seed(977 + self.rank)
+        x = torch.rand(int(count), device="cuda", generator=g)
+        ok = 1
+        try:
+            for _ in range(3):                                  # both parities of the buffers, twice
+                a, b = x.clone(), x.clone()
+                check(lib.dnmf_comm_allreduce_direct(self.handle, a.data_ptr(), a.numel(), _stream()))
+                was = self._get_direct_on()
+                self.set_direct(False)
+                try:
+                    self.allreduce_(b)
+                finally:
+                    self.set_direct(was)
+                if not bool(((a - b).abs() <= 1e-5 * self.size).all()) or self.direct_timed_out():
+                    ok = 0
+                x = x * 0.5 + 0.25
+        except Exception as ex:  # noqa: BLE001
+            ok, self.direct_error = 0, ex
+        nbad = int(host_comm.allreduce(0 if ok else 1)) if host_comm.size > 1 else (0 if ok else 1)
+        return nbad == 0
+
+    def _get_direct_on(self):
+        return bool(getattr(self, "_direct_on", False))
 
     def set_direct(self, on=True):
         check(lib.dnmf_comm_set_direct(self.handle, int(bool(on))))
+        self._direct_on = bool(on)
 
     def allreduce_direct_(self, t):
         _req(t, "t", t.dim())
@@ -809,12 +863,19 @@ def native_comm_for(params):
             # every rank falls back together when any rank cannot connect)
             kk = int(getattr(params, "end_k", None) or getattr(params, "k", None) or 128)
             kp = 32 if kk <= 32 else (64 if kk <= 64 else 128)
-            nmax = kk * max(int(params.m), int(params.n)) + 8 * 64 + kp * kp + 2048
-            if nc.enable_direct(params.comm1, nmax):
-                nc.set_direct(True)
+            nmax = kk * max(int(params.m), int(params.n)) + 8 * 64 + kp * kp + 2048      # (global sizes: the same on every rank)
+            import warnings
+            if not nc.enable_direct(params.comm1, nmax):
+                warnings.warn("params.direct_allreduce: the peer regions could not be connected on every rank (%s) -- staying on the "
+                              "communicator's own allreduce" % (nc.direct_error,))
             else:
-                import warnings
-                warnings.warn("params.direct_allreduce: the peer regions could not be connected on every rank -- staying on the communicator's own allreduce")
+                if getattr(params, "direct_timeout", None):
+                    nc.set_direct_timeout(params.direct_timeout)
+                if nc.direct_self_check(params.comm1):           # first contact on THIS machine, agreed over the ranks
+                    nc.set_direct(True)
+                else:
+                    warnings.warn("params.direct_allreduce: the direct allreduce did not reproduce the communicator's own sum on this "
+                                  "machine (%s) -- staying on the communicator's own allreduce" % (nc.direct_error,))
         params._native_comm = nc
     return nc
 

@@ -240,6 +240,13 @@ class PyNMF:
             if nbad:
                 raise bad if bad is not None else RuntimeError(
                     "HALS W sweep timed out on %d other rank(s) (params.hals_sweep = 'columns' selects the per-column sweep)" % nbad)
+        nc = getattr(self.params, "_native_comm", None)
+        if nc is not None and getattr(nc, "direct_ready", False) and nc._get_direct_on():
+            # a direct allreduce that gave up waiting for a peer has produced garbage since: fatal, on every rank together
+            nbad = int(self.params.comm1.allreduce(1 if nc.direct_timed_out() else 0))
+            if nbad:
+                raise RuntimeError("direct allreduce: a wait timed out on %d rank(s) (a peer stalled longer than params.direct_timeout, "
+                                   "default 30 s): the factors of this fit are invalid" % nbad)
         self.relative_err(sq)
         if self.verbose is True and self.rank == 0:
             print('relative error is:', self.recon_err)

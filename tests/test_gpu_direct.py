@@ -28,7 +28,12 @@ def _rank(rank, world, port, q):
         groups = {0: comms.comm, 1: comms.cart_1d_row(), 2: comms.cart_1d_column()}
         nc = NativeComm.hosted(world, rank, world, 1, _torch_hosted_collective(groups))
         n_max = 64 * 8192 + 64 * 64
+        # every rank must size its region alike (peers compute offsets into each other's regions from ONE capacity): a mismatch
+        # fails the set-up on EVERY rank, the regions are released, and a second set-up starts from scratch
+        assert not nc.enable_direct(comms.comm, n_max + 64 * rank)
+        assert "sized its region" in str(nc.direct_error)
         assert nc.enable_direct(comms.comm, n_max)
+        assert nc.direct_self_check(comms.comm)            # first contact: direct sum == the communicator's own sum, agreed over ranks
         dev = torch.device("cuda", 0)
         out = {}
         for n in (2, 130, 4096, 100002, n_max):
@@ -91,6 +96,16 @@ def _rank(rank, world, port, q):
         #  bits of every norm -- its per-step parity budget is 5e-5, tests/_mp.py)
         tol = dict(rtol=5e-6, atol=1e-7) if world == 2 else dict(rtol=2e-4, atol=2e-5)
         out["hals_step"] = bool(torch.allclose(res[0][0], res[1][0], **tol) and torch.allclose(res[0][1], res[1][1], **tol))
+        # a peer that never arrives: the wait gives up after the configured time and says so (sticky status word) instead of
+        # hanging the GPU.  Last use of the regions in this test: the sequence numbers of the ranks differ afterwards.
+        dist.barrier()
+        nc.set_direct_timeout(0.2)
+        if rank == 0:
+            nc.allreduce_direct_(torch.ones(64, device=dev))
+            torch.cuda.synchronize()
+            out["timeout_reported"] = nc.direct_timed_out()
+        else:
+            out["timeout_reported"] = not nc.direct_timed_out()
         q.put((rank, out, None))
         dist.barrier()
         nc.close()
