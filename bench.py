@@ -727,10 +727,21 @@ def run_config5(a, job):
     from pydnmfk_amd.utils import determine_block_params, parse
 
     world, rank, dev = job.world, job.rank, job.dev
-    p_r, p_c = parse_grid(a.grid, world, (1, world))
+    # N GPUs share the sweep the MI355X way unless a grid is asked for: every GPU holds the WHOLE X (0.5 GB of bf16 here, 288 GB of
+    # HBM) and fits its share of the perturbations as one-rank problems -- no exchange inside a fit (params.nmfk_split =
+    # 'perturbations', pydnmfk_amd/pyDNMFk.py); --grid RxC cuts X into the reference's blocks instead (every fit on all ranks)
+    shared = world > 1 and not a.grid
     m, n = a.m, a.n
-    comms = MPI_comm(None, p_r, p_c)
-    s, e = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_index_range_asymm()
+    if shared:
+        from pydnmfk_amd.dist_comm import COMM_WORLD, SoloGrid
+        p_r = p_c = 1
+        comms, whole = SoloGrid(rank), COMM_WORLD()
+        s, e = determine_block_params(0, (1, 1), (m, n)).determine_block_index_range_asymm()
+    else:
+        p_r, p_c = parse_grid(a.grid, world, (1, world))
+        comms = MPI_comm(None, p_r, p_c)
+        whole = comms.comm
+        s, e = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_index_range_asymm()
     # planted rank 6, identifiable (the recipe of tests/test_gpu_nmfk_sweep.py at this size): six Gaussian bumps along the rows,
     # sparse uniform mixing, 0.5 % noise -- the sweep must come back with estimated_k = 6
     g = torch.Generator(device=dev)
@@ -739,7 +750,7 @@ def run_config5(a, job):
     cen = torch.linspace(0.075 * m, m - 0.075 * m, 6, device=dev)[None, :]
     Wt = torch.exp(-(x - cen) ** 2 / (2 * (0.044 * m) ** 2))
     Ht = torch.rand(6, n, device=dev, generator=g) * (torch.rand(6, n, device=dev, generator=g) < 0.7)
-    g.manual_seed(1234 + rank)
+    g.manual_seed(1234 + (0 if shared else rank))                      # (shared sweep: the same X on every rank)
     X = (Wt[s[0]:e[0] + 1] @ Ht[:, s[1]:e[1] + 1])
     X += 0.005 * torch.rand(X.shape, device=dev, generator=g)
     del x, cen
@@ -747,13 +758,15 @@ def run_config5(a, job):
     del X, Wt, Ht
     import tempfile
     tmp = tempfile.mkdtemp(prefix="dnmf_c5_") if rank == 0 else None
-    tmp = comms.comm.bcast(tmp, root=0) if world > 1 else tmp
+    tmp = whole.bcast(tmp, root=0) if world > 1 else tmp
 
     def params(start_k, end_k, pert, itr):
         q = parse()
-        q.comm1, q.comm, q.p_r, q.p_c = comms.comm, comms, p_r, p_c
+        q.comm1, q.comm, q.p_r, q.p_c = (whole if shared else comms.comm), comms, p_r, p_c
         q.row_comm, q.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
         q.size, q.rank = world, rank
+        if shared:
+            q.nmfk_split = "perturbations"
         q.norm, q.method, q.init, q.itr, q.verbose, q.prune = "fro", "hals", "rand", itr, False, False
         q.start_k, q.end_k, q.step_k, q.fname, q.checkpoint = start_k, end_k, 1, "c5", False
         q.perturbations, q.noise_var, q.sampling, q.sill_thr = pert, 0.03, "uniform", 0.8
@@ -788,7 +801,10 @@ def run_config5(a, job):
                                        a.start_k, a.end_k, a.perturbations, a.itr, m, n, p_r, p_c, CONFIGS[5]["label"]),
                        "m": m, "n": n, "k_range": [a.start_k, a.end_k], "perturbations": a.perturbations, "itr": a.itr,
                        "block_per_gpu": [e[0] - s[0] + 1, e[1] - s[1] + 1],
-                       "parallelism": "single GPU" if world == 1 else "%d x %d blocks of X over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend)},
+                       "parallelism": "single GPU" if world == 1 else (
+                           "perturbations over %d ranks, the whole X on every GPU (no exchange inside a fit; factors gathered per k over %s)" % (
+                               world, "RCCL" if a.backend == "nccl" else a.backend) if shared else
+                           "%d x %d blocks of X over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend))},
             "fits_per_step": fits, "estimated_k": int(nopt[0]), "seconds_per_sweep": elapsed / a.steps,
             "nmfk_batch": a.nmfk_batch, "fit_loop": a.fit_loop,
             "hals_iterations_per_sec": (fits + nk) * a.itr * a.steps / elapsed,

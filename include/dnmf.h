@@ -171,7 +171,8 @@ int dnmf_column_err(const float* A, long m, long n, long lda, const float* W, lo
 
 /* NMFk perturbation (pyDNMFk.py:42-44, sample.randM): X_per = X * (1 + noise_var + 2 noise_var U), U ~ U[0,1) per element from a
  * counter-based generator keyed by `seed` and the element's position (stateless: the same (seed, position) gives the same value).
- * One pass; bf16 != 0: X and X_per are bfloat16 (scaled in fp32, rounded once).  cols % 8 == 0, 16-byte aligned rows. */
+ * One pass; bf16 != 0: X and X_per are bfloat16 (scaled in fp32, rounded once).  Any shape and alignment (16-byte aligned rows of
+ * whole 8-element vectors take a vector kernel, everything else one element per thread -- the values are the same either way). */
 int dnmf_perturb_uniform(const void* X, void* X_per, long rows, long cols, long ldx, long ldo, float noise_var,
                          unsigned long long seed, int bf16, void* stream);
 

@@ -60,6 +60,10 @@ FLAGS = [
     ('step_k', int, 1, False, 'rank increment'),
     ('sill_thr', float, 0.6, False, 'silhouette threshold of the rank estimate'),
     ('sampling', str, 'uniform', False, 'perturbation law: uniform / poisson'),
+    ('nmfk_split', str, 'data', False, 'how the ranks of a pyDNMFk job share the sweep: data (the reference: blocks of X on a p_r x p_c grid) or '
+                                       'perturbations (every rank holds the whole X and fits its share of the perturbations as one-rank problems: '
+                                       '--p_r=1 --p_c=1 with any number of ranks; no exchange inside a fit)'),
+    ('nmfk_batch', int, 0, False, 'perturbation fits of one rank that run together in one batched library call (0 = as many as fit in memory; 1 = one by one)'),
 ]
 
 
@@ -83,12 +87,27 @@ def main():
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.pyDNMF import PyNMF
     from pydnmfk_amd.pyDNMFk import PyNMFk
-    comms = MPI_comm(None, args.p_r, args.p_c)
-    args.size, args.rank, args.comm1, args.comm = comms.size, comms.rank, comms.comm, comms
+    args.nmfk_batch = True if args.nmfk_batch == 0 else args.nmfk_batch
+    if args.nmfk_split not in ('data', 'perturbations'):
+        raise SystemExit("--nmfk_split must be data or perturbations")
+    shared = args.process == 'pyDNMFk' and args.nmfk_split == 'perturbations' and world > 1
+    if shared:
+        # every rank reads the WHOLE matrix (a 1 x 1 grid of its own); the job's ranks share the perturbations (PyNMFk)
+        if args.p_r * args.p_c != 1:
+            raise SystemExit("--nmfk_split=perturbations fits one-rank problems: --p_r=1 --p_c=1 (the %d ranks share the perturbations)" % world)
+        from pydnmfk_amd.dist_comm import COMM_WORLD, SoloGrid
+        whole = COMM_WORLD()
+        comms = SoloGrid(whole.world_rank)
+        args.size, args.rank, args.comm1, args.comm = 1, 0, comms.comm, comms
+    else:
+        comms = MPI_comm(None, args.p_r, args.p_c)
+        args.size, args.rank, args.comm1, args.comm = comms.size, comms.rank, comms.comm, comms
     args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+    A_ij = data_read(args).read()
+    if shared:
+        args.size, args.rank, args.comm1 = whole.size, whole.rank, whole      # PyNMFk builds the fits' one-rank bag from here
     if args.rank == 0:
         print('Starting ', args.process, '...')
-    A_ij = data_read(args).read()
     if args.rng == 'device':
         # the rank's block goes to the GPU ONCE (bf16 storage is rounded here); PyNMF / PyNMFk then work on device tensors:
         # perturbations and the rand init are drawn on the GPU, factors stay there between the fits of an NMFk sweep
@@ -124,7 +143,7 @@ def main():
     else:
         raise SystemExit("--process must be pyDNMF or pyDNMFk")
     if world > 1:
-        comms.comm.barrier()
+        args.comm1.barrier()
         dist.destroy_process_group()
 
 

@@ -666,13 +666,19 @@ int dnmf_sqnorm_bf16a(const void* A, long m, long n, long lda, double* out, void
 // X_per = X * (1 + nv + 2 nv U[0,1)) in one pass (pyDNMFk.py:42-44); `bf16` != 0: X and X_per are bfloat16 (config 5's storage)
 int dnmf_perturb_uniform(const void* X, void* X_per, long rows, long cols, long ldx, long ldo, float noise_var,
                          unsigned long long seed, int bf16, void* stream) {
-    REQUIRE(X && X_per && rows >= 1 && cols >= 8 && cols % 8 == 0 && ldx >= cols && ldo >= cols && ldx % 8 == 0 && ldo % 8 == 0 &&
-            aligned16(X) && aligned16(X_per), "perturb_uniform: rows of 16-byte aligned vectors of 8 elements (cols %ld, ld %ld / %ld)", cols, ldx, ldo);
-    const long total = rows * (cols / 8);
-    const unsigned grid = (unsigned)std::min<long>(cdiv(total, 256), 256L * 32);
+    REQUIRE(X && X_per && rows >= 1 && cols >= 1 && ldx >= cols && ldo >= cols, "perturb_uniform: bad arguments (cols %ld, ld %ld / %ld)", cols, ldx, ldo);
     hipStream_t st = S(stream);
-    if (bf16) hipLaunchKernelGGL(perturb_uniform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)X, (bf16_t*)X_per, rows, cols, ldx, ldo, noise_var, seed);
-    else hipLaunchKernelGGL(perturb_uniform_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, (float*)X_per, rows, cols, ldx, ldo, noise_var, seed);
+    // rows of 16-byte aligned vectors of 8 elements: the vector kernel; anything else: one element per thread, SAME values
+    const bool vec = cols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && aligned16(X) && aligned16(X_per);
+    const long total = vec ? rows * (cols / 8) : rows * cols;
+    const unsigned grid = (unsigned)std::min<long>(cdiv(total, 256), 256L * 32);
+    if (vec) {
+        if (bf16) hipLaunchKernelGGL(perturb_uniform_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)X, (bf16_t*)X_per, rows, cols, ldx, ldo, noise_var, seed);
+        else hipLaunchKernelGGL(perturb_uniform_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, (float*)X_per, rows, cols, ldx, ldo, noise_var, seed);
+    } else {
+        if (bf16) hipLaunchKernelGGL(perturb_uniform_any_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)X, (bf16_t*)X_per, rows, cols, ldx, ldo, noise_var, seed);
+        else hipLaunchKernelGGL(perturb_uniform_any_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)X, (float*)X_per, rows, cols, ldx, ldo, noise_var, seed);
+    }
     return check_launch("perturb_uniform");
 }
 

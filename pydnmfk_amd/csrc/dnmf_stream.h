@@ -57,6 +57,29 @@ __global__ __launch_bounds__(256) void perturb_uniform_kernel(const TA* __restri
     }
 }
 
+// The same perturbation for ANY shape and alignment, one element per thread: element (r, c) has linear index L = r cols + c and
+// takes the high (L even) or low (L odd) 24 bits of the hash of pair L >> 1 -- exactly the value the vector kernel above gives
+// it, so which kernel runs never changes a result (one random stream per seed whatever the block's shape: ADVICE r04).
+template <typename TA>
+__global__ __launch_bounds__(256) void perturb_uniform_any_kernel(const TA* __restrict__ X, TA* __restrict__ out, long rows, long cols,
+                                                                  long ldx, long ldo, float nv, unsigned long long seed) {
+    const long total = rows * cols;
+    const unsigned long long key = mix64(seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / cols, c = idx % cols;
+        const unsigned long long h = mix64(key + ((unsigned long long)idx >> 1) * 0x9E3779B97F4A7C15ull);
+        const float u = (idx & 1) ? (float)((unsigned)(h >> 8) & 0xffffffu) * (1.0f / 16777216.0f)
+                                  : (float)((unsigned)(h >> 40)) * (1.0f / 16777216.0f);
+        if constexpr (std::is_same<TA, float>::value) {
+            out[r * ldo + c] = X[r * ldx + c] * fmaf(2.0f * nv, u, 1.0f + nv);
+        } else {
+            const float v = bf16_lo((unsigned int)X[r * ldx + c]) * fmaf(2.0f * nv, u, 1.0f + nv);
+            const unsigned int w = __float_as_uint(v);
+            out[r * ldo + c] = (bf16_t)((w + 0x7fffu + ((w >> 16) & 1u)) >> 16);
+        }
+    }
+}
+
 // =============================================================================================== element-wise passes
 // clamp / column- and row-scaling / the KL multiply-divide: one read-modify-write pass over a rows x cols matrix, at most
 // one streamed operand S beside it and a k-vector x indexed by row or by column.  HBM-bound, so what matters is 16-byte

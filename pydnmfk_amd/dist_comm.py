@@ -367,3 +367,21 @@ class _SelfComm(TorchComm):
 
     def _solo(self):
         return True
+
+
+class SoloGrid:
+    """A 1 x 1 grid of this process alone inside a larger torch.distributed job: what the fits of a perturbation-shared NMFk
+    sweep run on (pyDNMFk.PyNMFk, `params.nmfk_split = 'perturbations'`) -- every collective returns at once."""
+
+    def __init__(self, world_rank=0):
+        self.comm = _SelfComm(world_rank)
+        self.rank, self.size, self.p_r, self.p_c, self.coord2d = 0, 1, 1, 1, [0, 0]
+
+    def cart_1d_row(self):
+        return self.comm
+
+    def cart_1d_column(self):
+        return self.comm
+
+    def Free(self):
+        pass

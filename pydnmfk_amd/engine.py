@@ -358,15 +358,14 @@ class HipOps:
 
     def perturb_uniform(self, X, noise_var, seed, out=None):
         """X * (1 + nv + 2 nv U[0,1)) element-wise in ONE pass (NMFk's `sample.randM`, pyDNMFk.py:42-44), in X's storage type
-        (float32 or bfloat16).  None when the shape does not fit the kernel (the caller keeps its torch expression).  `out`:
+        (float32 or bfloat16), any shape: the value of an element depends on (seed, position) only.  None for tensors the
+        kernel does not take (not 2-D / strided columns: the caller keeps its torch expression).  `out`:
         a contiguous destination of X's shape and type (else a new tensor)."""
         if not (X.is_cuda and X.dim() == 2 and X.dtype in (torch.float32, torch.bfloat16) and X.stride(1) == 1):
             return None
         rows, cols = X.shape
         ld = _ld(X)
-        if cols % 8 or ld % 8 or X.data_ptr() % 16:
-            return None
-        if out is None or out.shape != X.shape or out.dtype != X.dtype or not out.is_contiguous() or out.data_ptr() % 16:
+        if out is None or out.shape != X.shape or out.dtype != X.dtype or not out.is_contiguous():
             out = torch.empty(rows, cols, dtype=X.dtype, device=X.device)
         check(lib.dnmf_perturb_uniform(X.data_ptr(), out.data_ptr(), rows, cols, ld, cols, float(noise_var), int(seed) & (2**64 - 1),
                                        int(X.dtype == torch.bfloat16), _stream()))

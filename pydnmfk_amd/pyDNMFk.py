@@ -85,9 +85,31 @@ class PyNMFk:
         self.A_ij = A_ij
         self.ops = ops
         self.local_m, self.local_n = self.A_ij.shape
+        # `params.nmfk_split`: how a job of N ranks shares an NMFk sweep.  'data' (default) = the reference: X is cut into the
+        # blocks of a p_r x p_c grid and every fit runs on all ranks (pyDNMFk.py:218-258).  'perturbations' = every rank
+        # holds the WHOLE X (288 GB of HBM per MI355X) and fits the perturbations p = rank, rank + N, ... as one-rank problems
+        # -- no exchange inside a fit; the factors then meet on every rank for the clustering (dist_clustering.py:84-160), the
+        # regression fit and the statistics, which every rank evaluates on the full stacks: the numbers are those of the
+        # 1 x 1 run, N times sooner through the fits.
+        self.split = var_init(params, 'nmfk_split', default='data')
+        if self.split not in ('data', 'perturbations'):
+            raise ValueError("params.nmfk_split = %r: 'data' or 'perturbations'" % (self.split,))
+        self.world = params.comm1
+        if self.split == 'perturbations' and self.world.size > 1:
+            import copy
+            from .dist_comm import SoloGrid
+            solo = SoloGrid(self.world.world_rank)
+            params = copy.copy(params)          # the fits' own bag: one-rank communicators, a 1 x 1 grid
+            params.comm1, params.comm, params.row_comm, params.col_comm = solo.comm, solo, solo.cart_1d_row(), solo.cart_1d_column()
+            params.p_r = params.p_c = 1
+            if "grid" in vars(params) and params.grid:
+                params.grid = [1, 1]
+            for stale in ("_native_comm", "exchange"):
+                if hasattr(params, stale):
+                    delattr(params, stale)
         self.params = params
         self.comm1 = self.params.comm1
-        self.rank = self.comm1.rank
+        self.rank = self.world.rank
         if "grid" in vars(self.params) and self.params.grid:
             self.p_r, self.p_c = self.params.grid[0], self.params.grid[1]
         else:
@@ -134,8 +156,8 @@ class PyNMFk:
             print('Rank estimated by NMFk = ', nopt)
         else:
             nopt = None
-        nopt = self.comm1.bcast(nopt, root=0)
-        self.comm1.barrier()
+        nopt = self.world.bcast(nopt, root=0)
+        self.world.barrier()
         from .dist_nmf import release_buffers
         release_buffers()                       # the sweep's scratch (sized for the largest k) is not kept alive
         return nopt
@@ -155,14 +177,16 @@ class PyNMFk:
         # covers all of them (PyNMF.fit_batch; bit-identical to the one-by-one fits, which nb = 1 still runs).
         from .engine import stack_alloc
         nb = self._batch_size()
-        for p0 in range(0, self.perturbations, nb):
+        shared = self.split == 'perturbations' and self.world.size > 1
+        mine = list(range(self.world.rank, self.perturbations, self.world.size)) if shared else list(range(self.perturbations))
+        for p0 in range(0, len(mine), nb):
             fits, stack = [], None
-            for perturbation in range(p0, min(self.perturbations, p0 + nb)):
+            chunk = mine[p0:p0 + nb]
+            for b, perturbation in enumerate(chunk):
                 if self.rank == 0 and self.verbose:
                     print('Current perturbation =', perturbation)
-                b = perturbation - p0
                 if nb > 1 and stack is None and isinstance(self.A_ij, torch.Tensor) and self.A_ij.is_cuda and self.A_ij.dim() == 2:
-                    stack = stack_alloc(min(nb, self.perturbations - p0), self.A_ij.shape[0], self.A_ij.shape[1], self.A_ij.dtype,
+                    stack = stack_alloc(len(chunk), self.A_ij.shape[0], self.A_ij.shape[1], self.A_ij.dtype,
                                         self.A_ij.device)            # the perturbed copies are written straight into it
                 data = sample(data=self.A_ij, noise_var=self.noise_var, method=self.sampling, seed=perturbation * 1000,
                               out=None if stack is None else stack[b]).fit()
@@ -173,16 +197,18 @@ class PyNMFk:
                 if nb > 1:
                     if stack is None or tuple(stack.shape[1:]) != tuple(f.A_ij.shape) or stack.dtype != f.A_ij.dtype:
                         if b == 0:           # (host data, bf16 storage of fp32 input, pruned shapes: the stack takes the fit's block)
-                            stack = stack_alloc(min(nb, self.perturbations - p0), f.A_ij.shape[0], f.A_ij.shape[1], f.A_ij.dtype,
-                                                f.A_ij.device)
+                            stack = stack_alloc(len(chunk), f.A_ij.shape[0], f.A_ij.shape[1], f.A_ij.dtype, f.A_ij.device)
                     if stack is not None and tuple(stack.shape[1:]) == tuple(f.A_ij.shape) and stack.dtype == f.A_ij.dtype:
                         f.adopt_stack(stack, b)
                 fits.append(f)
                 del data
             results.extend(PyNMF.fit_batch(fits))
-            for perturbation in range(p0, min(self.perturbations, p0 + nb)):
+            for perturbation in chunk:
                 self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
             del fits, stack
+        if shared:
+            results = self._gather_fits(results, mine)
+            perturbation = self.perturbations - 1
         self.params.flag = 1
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
         # stack: W m_loc x k x P (column-major over (k, P) as the reference's order='F' reshape, :234-235), H k x n_loc x P
@@ -228,18 +254,51 @@ class PyNMFk:
         self.stats[self.k] = cluster_stats
         if getattr(self.params, "ftype", None) is None:
             self.params.ftype = None
-        writer = data_write(self.params)
-        writer.save_factors([_np(self.AvgW), _np(self.AvgH)], reg=True)                                 # :254-256
-        writer.save_cluster_results(cluster_stats)
+        if not shared or self.rank == 0:        # (every rank of a perturbation-shared sweep holds the same results: rank 0 writes)
+            writer = data_write(self.params)
+            writer.save_factors([_np(self.AvgW), _np(self.AvgH)], reg=True)                             # :254-256
+            writer.save_cluster_results(cluster_stats)
         self.params.flag = 3
         self.cp._save_checkpoint(self.params.flag, perturbation, self.k)
+
+    def _gather_fits(self, results, mine):
+        """Perturbation-shared sweep: every rank has fitted its own perturbations; all ranks end with all (W, H, err) in
+        perturbation order.  One allgather of the stacked factors per k (ranks with one perturbation fewer pad their stack)."""
+        world, P = self.world, self.perturbations
+        numpy_io = bool(results) and not isinstance(results[0][0], torch.Tensor)
+        dev = torch.device("cuda", torch.cuda.current_device()) if (self.ops is None and torch.cuda.is_available()) else torch.device("cpu")
+
+        def _t(x):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            return t.to(dev)
+        per = -(-P // world.size)                          # perturbations of the busiest rank
+        if results:
+            W0, H0 = _t(results[0][0]), _t(results[0][1])
+            shp = (tuple(W0.shape), tuple(H0.shape), W0.dtype)
+        else:
+            shp = None
+        shp = [s_ for s_ in world.allgather(shp) if s_ is not None][0]
+        Ws = torch.zeros((per,) + shp[0], dtype=shp[2], device=dev)
+        Hs = torch.zeros((per,) + shp[1], dtype=shp[2], device=dev)
+        errs = torch.zeros(per, dtype=torch.float64, device=dev)
+        for i, r in enumerate(results):
+            Ws[i], Hs[i], errs[i] = _t(r[0]), _t(r[1]), float(r[2])
+        allW = world.allgather_blocks(Ws, [tuple(Ws.shape)] * world.size)
+        allH = world.allgather_blocks(Hs, [tuple(Hs.shape)] * world.size)
+        allE = world.allgather_blocks(errs, [tuple(errs.shape)] * world.size)
+        out = []
+        for p in range(P):
+            r, i = p % world.size, p // world.size
+            W, H, e = allW[r][i], allH[r][i], float(allE[r][i])
+            out.append((W.cpu().numpy(), H.cpu().numpy(), e) if numpy_io else (W, H, e))
+        return out
 
     def _batch_size(self):
         """How many perturbation fits run together (PyNMF.fit_batch): all of them on one rank with the product's own
         operators -- as many as fit next to each other in the GPU's free memory (each holds its perturbed copy of the data) --
         else 1.  `params.nmfk_batch` = False / 0 / 1 keeps the one-by-one fits, an integer caps the batch."""
         want = getattr(self.params, "nmfk_batch", True)
-        if want is False or self.p != 1 or self.ops is not None or not torch.cuda.is_available():
+        if want is False or self.params.p_r * self.params.p_c != 1 or self.ops is not None or not torch.cuda.is_available():
             return 1
         cap = self.perturbations if want is True else max(1, int(want))
         try:

@@ -291,9 +291,17 @@ def run_nmfk_golden_rank(rank, world, port, fixture, q, use_hip, extra):
         meta = json.loads(str(z["meta"]))
         A = z["A"]
         p_r, p_c = meta["grid"]
-        comms = MPI_comm(None, p_r, p_c)
         args = parse()
-        args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = world, rank, comms.comm, comms, p_r, p_c
+        if (extra or {}).get("nmfk_split") == "perturbations":
+            # a 1 x 1 fixture on `world` ranks that SHARE its perturbations: every rank holds the whole matrix
+            # (pydnmfk_amd/pyDNMFk.py, params.nmfk_split), the job's communicator is the world
+            from pydnmfk_amd.dist_comm import COMM_WORLD, SoloGrid
+            assert (p_r, p_c) == (1, 1)
+            comms = SoloGrid(rank)
+            args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = world, rank, COMM_WORLD(), comms, 1, 1
+        else:
+            comms = MPI_comm(None, p_r, p_c)
+            args.size, args.rank, args.comm1, args.comm, args.p_r, args.p_c = world, rank, comms.comm, comms, p_r, p_c
         args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
         tmp = [tempfile.mkdtemp() if rank == 0 else None]
         if world > 1:
@@ -321,13 +329,14 @@ def run_nmfk_golden_rank(rank, world, port, fixture, q, use_hip, extra):
         q.put((rank, None, traceback.format_exc()))
 
 
-def run_nmfk_golden(fixture, use_hip=False, timeout=600, extra=None):
-    """-> [(nopt, {k: statistics}) per rank]"""
+def run_nmfk_golden(fixture, use_hip=False, timeout=600, extra=None, world=None):
+    """-> [(nopt, {k: statistics}) per rank].  `world`: ranks of the job when they SHARE the perturbations of a 1 x 1 fixture
+    (extra = {"nmfk_split": "perturbations"}); default: the fixture's grid."""
     import json
     import numpy as np
     from tests._golden import GOLDEN
     grid = json.loads(str(np.load(os.path.join(GOLDEN, fixture))["meta"]))["grid"]
-    world = grid[0] * grid[1]
+    world = world or grid[0] * grid[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()

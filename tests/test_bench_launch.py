@@ -145,6 +145,21 @@ def test_config5_sweep_line_small():
 
 
 @pytest.mark.gpu
+def test_config5_two_ranks_share_the_perturbations():
+    """`--config 5 --gpus 2` (gloo, both ranks on the one GPU): the ranks hold the whole X and share the perturbation fits
+    (params.nmfk_split = 'perturbations'); the planted rank must come back, and the single-rank sweep must agree on it."""
+    common = ["--config", "5", "--rows", "4096", "--cols", "512", "--end-k", "8", "--perturbations", "4", "--itr", "60",
+              "--no-cpu-baseline", "--no-kernel-timing"]
+    r = _run(common + ["--gpus", "2", "--backend", "gloo"], env_extra={"DNMF_BENCH_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["fits_per_step"] == 28 and out["value"] > 0
+    assert out["config"]["parallelism"].startswith("perturbations over 2 ranks") and out["config"]["block_per_gpu"] == [4096, 512]
+    one = _json_line(_run(common).stdout)
+    assert out["estimated_k"] == one["estimated_k"] == 6
+
+
+@pytest.mark.gpu
 def test_config2_line_small_steps():
     r = _run(["--config", "2", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-sustained"])
     assert r.returncode == 0, r.stderr[-4000:]

@@ -466,5 +466,16 @@ def test_perturb_uniform_is_the_reference_distribution(ops):
     Yb = ops.perturb_uniform(Xb, nv, 1000)
     assert Yb.dtype == torch.bfloat16
     assert torch.equal(Yb, ops.perturb_uniform(Xb.float(), nv, 1000).to(torch.bfloat16))
-    # shapes the kernel does not take are left to the caller
-    assert ops.perturb_uniform(X[:, :1001], nv, 1) is None
+    # ANY shape: a block whose rows are not whole aligned 8-element vectors takes the element-per-thread kernel, which gives every
+    # element the value the vector kernel gives it -- one random stream per seed whatever the block's shape.  A view
+    # with an odd pitch / an unaligned base of the SAME logical matrix must therefore reproduce Y exactly
+    odd = torch.zeros(m, n + 3, device=dev)
+    odd[:, 1:n + 1] = X
+    assert torch.equal(ops.perturb_uniform(odd[:, 1:n + 1], nv, 1000), Y)
+    Z = ops.perturb_uniform(X[:, :1001].contiguous(), nv, 1)         # cols % 8 != 0
+    rz = (Z.double() / X[:, :1001].double() - 1 - nv) / (2 * nv)
+    assert Z.shape == (m, 1001) and float(rz.min()) > -1e-5 and float(rz.max()) < 1 + 1e-5 and abs(float(rz.mean()) - 0.5) < 2e-3
+    oddb = odd.to(torch.bfloat16)
+    assert torch.equal(ops.perturb_uniform(oddb[:, 1:n + 1], nv, 1000), Yb)
+    # strided columns are left to the caller
+    assert ops.perturb_uniform(X[:, ::2], nv, 1) is None

@@ -45,6 +45,30 @@ def test_nmfk_hals_and_two_rank_fixtures_on_gpu(fixture, exchange, golden_dir):
     check_nmfk_fixture(outs, np.load(golden_dir + "/" + fixture), tight=False)
 
 
+@pytest.mark.parametrize("fixture,world", [("nmfk_hals_1x1.npz", 2), ("nmfk_1x1.npz", 4)])
+def test_nmfk_perturbations_over_ranks_on_gpu(fixture, world, golden_dir):
+    """`params.nmfk_split = 'perturbations'` with the HIP kernels: `world` processes on the one GPU hold the whole matrix and
+    share the perturbation fits (each rank's share runs as ONE batched whole-fit call), every rank clusters the gathered factors.
+    The statistics equal the one-rank run's exactly -- a problem's result does not depend on which batch it was fitted in -- and
+    meet the reference's 1 x 1 fixture.  (hals_sweep = 'columns': two processes share the GPU here, which the persistent W sweep
+    must not be asked to do.)"""
+    from tests._mp import run_nmfk_golden
+    from tests.test_nmfk_cpu import check_nmfk_fixture
+    z = np.load(golden_dir + "/" + fixture)
+    extra = {"hals_sweep": "columns"}
+    one = run_nmfk_golden(fixture, use_hip=True, timeout=600, extra=dict(extra))
+    many = run_nmfk_golden(fixture, use_hip=True, timeout=600, extra=dict(extra, nmfk_split="perturbations"), world=world)
+    assert len(many) == world
+    for o in many:
+        assert o[0] == one[0][0]
+        for k in one[0][1]:
+            for key, val in one[0][1][k].items():
+                np.testing.assert_allclose(np.asarray(o[1][k][key], dtype=np.float64), np.asarray(val, dtype=np.float64), rtol=1e-12, atol=0,
+                                           err_msg="k=%d %s" % (k, key))
+    if "meta" in z.files:
+        check_nmfk_fixture(many, z, tight=False)
+
+
 def test_nmfk_device_resident_input(tmp_path, golden_dir):
     """CUDA-tensor input: perturbations are drawn on the device (different stream, same distribution) -> the estimate
     and the error levels still match, silhouettes are compared loosely."""

@@ -153,6 +153,25 @@ def test_nmfk_hals_and_two_rank_fixtures(fixture, golden_dir):
     check_nmfk_fixture(run_nmfk_golden(fixture, use_hip=False, timeout=600), np.load(golden_dir + "/" + fixture), tight=True)
 
 
+@pytest.mark.parametrize("fixture,world", [("nmfk_hals_1x1.npz", 2), ("nmfk_hals_1x1.npz", 4)])
+def test_nmfk_perturbations_over_ranks_equal_the_one_rank_run(fixture, world, golden_dir):
+    """`params.nmfk_split = 'perturbations'`: the ranks of the job hold the whole matrix and share the perturbation fits
+    (rank r fits p = r, r + N, ...), then every rank clusters the gathered factors.  Same seeds per perturbation => the statistics
+    of the one-rank run, EXACTLY (same arithmetic on the same operands; nothing is summed across ranks), on every rank -- and
+    therefore the reference's own 1 x 1 statistics (the fixture) at the one-rank tolerance."""
+    from tests._mp import run_nmfk_golden
+    z = np.load(golden_dir + "/" + fixture)
+    one = run_nmfk_golden(fixture, use_hip=False, timeout=600)
+    many = run_nmfk_golden(fixture, use_hip=False, timeout=600, extra={"nmfk_split": "perturbations"}, world=world)
+    assert len(many) == world
+    for o in many:
+        assert o[0] == one[0][0]
+        for k in one[0][1]:
+            for key, val in one[0][1][k].items():
+                assert np.array_equal(np.asarray(o[1][k][key]), np.asarray(val)), (k, key)
+    check_nmfk_fixture(many, z, tight=True)
+
+
 def test_sample_follows_reference_stream():
     """pyDNMFk.py:26-49: X * (1 + nv + 2 nv U) with the global numpy RNG seeded per perturbation."""
     from pydnmfk_amd.pyDNMFk import sample
