@@ -267,6 +267,53 @@ int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, l
                             int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride,
                             double* sq_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- The update path in float64.  The reference computes in the dtype of A_ij (pyDNMF.py:68; its own tests feed float64,
+ * tests/test_dist_nmf_1d.py:14-20): these are the float64 twins of the primitives above, on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64), one plain tile shape each -- correctness first, the fp32 path is the tuned one.  Everything is `double`
+ * in device memory, row-major, leading dimensions in elements; eps = 2.220446049250313e-16; k <= DNMF_MAX_K; Gram matrices are
+ * plain k x k blocks with their own leading dimension `ldg` (no padding contract).  `ws` >= dnmf_f64_ws_bytes(m, n, k) where an
+ * entry point takes one.  The KL products go through the materialised quotient U = A / (W H + eps) (dnmf_f64_kl_quot, an m x n
+ * buffer of the caller -- the reference materialises it too, dist_nmf.py:806) followed by dnmf_f64_aht / dnmf_f64_wta on U; the
+ * error evaluation through the materialised squared residual (dnmf_f64_sqdiff) and the ordered sums.  Host sequencing of these
+ * primitives (1D and 2D grids, exchanges over torch.distributed): pydnmfk_amd/dist_nmf.py with engine.HipOpsF64. ---- */
+size_t dnmf_f64_ws_bytes(long m, long n, int k);
+/* C[m x kc] = X[m x n] Y[kc x n]^T   (A H^T: dist_nmf.py:730; H H^T = global_gram(H.T), :729, with X = Y = H) */
+int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int kc, long ldy, double* C, long ldc, void* ws,
+                 size_t ws_bytes, void* stream);
+/* C[kc x n] = W[m x kc]^T A[m x n]   (W^T A: dist_nmf.py:749; W^T W = global_gram(W), :748, with A = W) */
+int dnmf_f64_wta(const double* A, long m, long n, long lda, const double* W, int kc, long ldw, double* C, long ldc, void* ws,
+                 size_t ws_bytes, void* stream);
+/* W *= AH / (W G + eps)   (dist_nmf.py:731-732, :244-245) */
+int dnmf_f64_mu_update_w(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, double eps,
+                         void* stream);
+/* H *= AtW / (G H + eps); clamp != 0: H = max(H, eps) afterwards   (dist_nmf.py:750-751, :224-225; pyDNMF.py:156) */
+int dnmf_f64_mu_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps,
+                         int clamp, void* stream);
+/* U[m x n] = A / (W H + eps)   (dist_nmf.py:806) */
+int dnmf_f64_kl_quot(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                     double* U, long ldu, void* stream);
+/* R[m x n] = (A - W H)^2 element-wise   (pyDNMF.py:207, :229) */
+int dnmf_f64_sqdiff(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double* R,
+                    long ldr, void* stream);
+/* *out = sum X (sq == 0) or sum X^2 (sq != 0), fixed summation order   (np.linalg.norm(.)**2, pyDNMF.py:208,215) */
+int dnmf_f64_sum(const double* X, long rows, long cols, long ldx, int sq, double* out, void* ws, size_t ws_bytes, void* stream);
+/* x[c] = sum_r X[r][c] (or of squares)   (sum_along_axis(W, axis=0), dist_nmf.py:793; the column sums of column_err, pyDNMF.py:229) */
+int dnmf_f64_colsum(const double* X, long m, long n, long ldx, int sq, double* x, void* ws, size_t ws_bytes, void* stream);
+/* x[r] = sum_c H[r][c]   (sum_along_axis(H, axis=1), dist_nmf.py:793-795) */
+int dnmf_f64_rowsum(const double* H, int k, long n, long ldh, double* x, void* stream);
+/* element-wise passes.  op 0: X = max(X, eps) (pyDNMF.py:156); 1: X[r][c] /= x[c] + eps (:192); 2: X[r][c] *= x[r] (:193);
+ * 3: X[r][c] *= S[r][c] / (x[r] + eps) (dist_nmf.py:847-849); 4: X[r][c] *= S[r][c] / (x[c] + eps) (:828-830); clamp != 0 (ops 3, 4):
+ * max(., eps) afterwards */
+int dnmf_f64_ew(int op, double* X, long rows, long cols, long ldx, const double* S, long lds_, const double* x, double eps, int clamp,
+                void* stream);
+/* HALS (dist_nmf.py:873-934): one column of the W sweep (as dnmf_hals_w_col; *ss2_out = this rank's sum of squares of the new
+ * column, WRITTEN, not accumulated), the final scale, the H sweep */
+int dnmf_f64_hals_w_col(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, int kk,
+                        const double* prev_ss2, double eps, double* ss2_out, void* ws, size_t ws_bytes, void* stream);
+int dnmf_f64_hals_w_scale(double* W, long m, long ldw, int col, const double* ss2, void* stream);
+int dnmf_f64_hals_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps,
+                           void* stream);
+
 /* ---- Grid exchanges inside the library (RCCL over xGMI; replaces MPI_comm, dist_comm.py:16-56, and the mpi4py calls of
  * global_gram / global_mm, dist_nmf.py:681,707).  RCCL is bound at run time (dlopen; an RCCL already in the process -- the
  * PyTorch host's -- is preferred), so the library loads without it; these entry points then return DNMF_ECOMM.

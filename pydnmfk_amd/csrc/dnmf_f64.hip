@@ -1,0 +1,523 @@
+// dnmf_f64.hip -- the update path in float64 (the reference computes in the dtype of A_ij, pyDNMF.py:68, and its own tests feed
+// np.random.rand float64 arrays, tests/test_dist_nmf_1d.py:14-20).  Correctness first: ONE plain tile shape per kernel family on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64), no LDS, no tuning -- the fp32 path (csrc/dnmf_nt.h ...) is the tuned one.
+//
+// v_mfma_f64_16x16x4_f64 operand maps (lane l, i = l & 15, q = l >> 4):
+//   A-operand: A[row i][kk = q]   B-operand: B[kk = q][col i]   C/D: col = i, row = q + 4 * reg (reg in [0, 4))
+// Three GEMM forms (cf. csrc/dnmf.hip):
+//   NT  C[r][j] = sum_c X[r][c] Y[j][c]      A H^T, H H^T      (contraction index contiguous in both operands)
+//   TN  C[j][c] = sum_r X[r][j] Y[r][c]      W^T A, W^T W      (contraction over the rows; partial slabs + ordered reduction)
+//   NN  S[r][c] = sum_j X[r][j] Y[j][c]      W H, W G, G H     (fused epilogues: quotient, squared residual, the MU updates)
+// The contraction order inside a tile is permuted freely (sums are order-agnostic up to rounding).
+#include "dnmf_common.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+#define REQ(cond, ...) do { if (!(cond)) return fail(DNMF_EINVAL, __VA_ARGS__); } while (0)
+inline hipStream_t ST(void* s) { clear_hip_error(); return reinterpret_cast<hipStream_t>(s); }
+inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+inline int tiles16(int k) { return (k + 15) / 16; }
+
+// four consecutive doubles row[c .. c + 3]; zero outside [.., cend) or when !ok.  vec: the row pointer is 16-byte aligned and c is even
+__device__ __forceinline__ void ld4(double (&d)[4], const double* __restrict__ row, long c, long cend, bool ok, bool vec) {
+    if (ok && vec && c + 4 <= cend) {
+        const f64x2 a = *reinterpret_cast<const f64x2*>(row + c), b = *reinterpret_cast<const f64x2*>(row + c + 2);
+        d[0] = a[0]; d[1] = a[1]; d[2] = b[0]; d[3] = b[1];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = (ok && c + e < cend) ? row[c + e] : 0.0;
+    }
+}
+
+// ================================================================================================ NT form
+// out[split][r][j] = sum_{c in split} X[r][c] Y[j][c];  one wave = 16 rows x NT 16-column tiles of the output
+template <int NT>
+__global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ X, long ldx, long m, long n, const double* __restrict__ Y,
+                                                     long ldy, int kc, double* __restrict__ out, long ldo, long split_stride,
+                                                     long cols_per_split, int vec) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (r0 >= m) return;
+    const long cb = (long)blockIdx.y * cols_per_split;
+    const long ce = cb + cols_per_split < n ? cb + cols_per_split : n;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const bool rok = r0 + i < m;
+    const double* xrow = X + (r0 + i) * ldx;
+    for (long c = cb; c < ce; c += 16) {
+        double a[4];
+        ld4(a, xrow, c + 4 * q, ce, rok, vec != 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double b[4];
+            ld4(b, Y + (long)(16 * t + i) * ldy, c + 4 * q, ce, 16 * t + i < kc, vec != 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t] = MFMA64(a[e], b[e], acc[t]);
+        }
+    }
+    double* o = out + (long)blockIdx.y * split_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + q + 4 * r;
+            const int col = 16 * t + i;
+            if (row < m && col < kc) o[row * ldo + col] = acc[t][r];
+        }
+}
+
+// ================================================================================================ TN form
+// P[chunk][j][c] = sum_{r in chunk} X[r][j] Y[r][c];  one wave = one 16-column block of Y x NT 16-row tiles of the output
+template <int NT>
+__global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ X, long ldx, int kc, const double* __restrict__ Y, long ldy,
+                                                     long n, long m, long rows_per_chunk, int ncolblk, long nwaves,
+                                                     double* __restrict__ P, long chunk_stride, long ldp) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= nwaves) return;
+    const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * 16;
+    const long rb = chunk * rows_per_chunk;
+    const long re = rb + rows_per_chunk < m ? rb + rows_per_chunk : m;
+    f64x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const bool cok = c0 + i < n;
+    for (long r = rb; r < re; r += 16) {
+        double b[4], a[NT][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // four steps of 4 rows: 16 rows of loads in flight
+            const long row = r + 4 * u + q;
+            const bool ok = row < re;
+            b[u] = (ok && cok) ? Y[row * ldy + c0 + i] : 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t][u] = (ok && 16 * t + i < kc) ? X[row * ldx + 16 * t + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA64(a[t][u], b[u], acc[t]);
+    }
+    double* o = P + chunk * chunk_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + q + 4 * r;
+            if (j < kc && cok) o[(long)j * ldp + c0 + i] = acc[t][r];
+        }
+}
+
+// out[r][c] = sum_s P[s][r][c] in slab order (bitwise deterministic)
+__global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ P, long stride, long ldp, int nsplit,
+                                                         double* __restrict__ out, long ldo, long rows, long cols) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const long r = idx / cols, c = idx % cols;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += P[(long)k * stride + r * ldp + c];
+    out[r * ldo + c] = s;
+}
+
+// ================================================================================================ NN form, row strips
+// S[r][c] = sum_j X[r][j] Y[j][c] for the wave's 16 rows (its X fragment stays in registers) and a range of 16-column tiles:
+//   NN_QUOT    O[r][c] = A[r][c] / (S + eps)              (the KL quotient U, dist_nmf.py:806)
+//   NN_SQDIFF  O[r][c] = (A[r][c] - S)^2                  (relative_err / column_err, pyDNMF.py:207, :229)
+//   NN_UPD_W   X[r][c] *= A[r][c] / (S + eps), X = W, Y = G, A = A H^T   (dist_nmf.py:731-732; the wave owns its rows of W and has
+//              read them into registers before it writes)
+enum { NN_QUOT = 0, NN_SQDIFF = 1, NN_UPD_W = 2 };
+template <int KS, int MODE>       // KS = contraction steps of 4 (kc <= 4 KS)
+__global__ __launch_bounds__(256) void f64_nn_rows_kernel(const double* X, long ldx, long m, int kc, const double* __restrict__ Y,
+                                                          long ldy, long n, const double* __restrict__ A, long lda, double* O,
+                                                          long ldo, double eps, long cols_per_wave) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (r0 >= m) return;
+    double xa[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xa[s] = (r0 + i < m && 4 * s + q < kc) ? X[(r0 + i) * ldx + 4 * s + q] : 0.0;
+    const long cb = (long)blockIdx.y * cols_per_wave;
+    const long ce = cb + cols_per_wave < n ? cb + cols_per_wave : n;
+    for (long c0 = cb; c0 < ce; c0 += 16) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool cok = c0 + i < n;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double b = (cok && 4 * s + q < kc) ? Y[(long)(4 * s + q) * ldy + c0 + i] : 0.0;
+            acc = MFMA64(xa[s], b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + q + 4 * r;
+            if (row < m && cok) {
+                const double a = A[row * lda + c0 + i];
+                if constexpr (MODE == NN_QUOT) O[row * ldo + c0 + i] = a / (acc[r] + eps);
+                else if constexpr (MODE == NN_SQDIFF) { const double d = a - acc[r]; O[row * ldo + c0 + i] = d * d; }
+                else O[row * ldo + c0 + i] = O[row * ldo + c0 + i] * (a / (acc[r] + eps));
+            }
+        }
+    }
+}
+
+// NN form, column strips: H[j][c] *= S[j][c] / ((G H)[j][c] + eps) for the wave's 16 columns and ALL rows j (dist_nmf.py:750-751);
+// the wave reads its columns of H into registers before it writes them.  clamp: H = max(H, eps) afterwards (pyDNMF.py:156)
+template <int KS>
+__global__ __launch_bounds__(256) void f64_upd_h_kernel(double* __restrict__ H, int k, long n, long ldh, const double* __restrict__ Sm, long lds_,
+                                                        const double* __restrict__ G, long ldg, double eps, int clamp) {
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long c0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (c0 >= n) return;
+    const bool cok = c0 + i < n;
+    double hb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) hb[s] = (cok && 4 * s + q < k) ? H[(long)(4 * s + q) * ldh + c0 + i] : 0.0;
+    for (int jt = 0; 16 * jt < k; ++jt) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const double a = (16 * jt + i < k && 4 * s + q < k) ? G[(long)(16 * jt + i) * ldg + 4 * s + q] : 0.0;
+            acc = MFMA64(a, hb[s], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + q + 4 * r;
+            if (j < k && cok) {
+                double v = H[(long)j * ldh + c0 + i] * (Sm[(long)j * lds_ + c0 + i] / (acc[r] + eps));
+                if (clamp) v = v > eps ? v : eps;
+                H[(long)j * ldh + c0 + i] = v;
+            }
+        }
+    }
+}
+
+// ================================================================================================ streaming kernels
+enum { E_CLAMP = 0, E_COLS_DIV = 1, E_ROWS_MUL = 2, E_KL_BYROW = 3, E_KL_BYCOL = 4 };
+__global__ __launch_bounds__(256) void f64_ew_kernel(int op, double* __restrict__ X, long rows, long cols, long ldx, const double* __restrict__ Sm,
+                                                     long lds_, const double* __restrict__ x, double eps, int clamp) {
+    const long total = rows * cols;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / cols, c = idx % cols;
+        double v = X[r * ldx + c];
+        if (op == E_CLAMP) v = v > eps ? v : eps;                                  // np.maximum(X, eps), pyDNMF.py:156
+        else if (op == E_COLS_DIV) v = v / (x[c] + eps);                          // pyDNMF.py:192
+        else if (op == E_ROWS_MUL) v = v * x[r];                                  // pyDNMF.py:193
+        else if (op == E_KL_BYROW) v = v * (Sm[r * lds_ + c] / (x[r] + eps));      // dist_nmf.py:847-849
+        else v = v * (Sm[r * lds_ + c] / (x[c] + eps));                            // dist_nmf.py:828-830
+        if (clamp && op != E_CLAMP) v = v > eps ? v : eps;
+        X[r * ldx + c] = v;
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {       // fixed-order tree: deterministic
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double out = red[0];
+    __syncthreads();
+    return out;
+}
+
+// part[blockIdx.x] = sum over the block's grid-stride share of f(X); SQ: squares
+template <bool SQ>
+__global__ __launch_bounds__(256) void f64_sum_partial_kernel(const double* __restrict__ X, long rows, long cols, long ldx, double* __restrict__ part) {
+    __shared__ double red[256];
+    const long total = rows * cols;
+    double acc = 0.0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const double v = X[(idx / cols) * ldx + idx % cols];
+        acc += SQ ? v * v : v;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void f64_sum_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) acc += part[p];
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// x[r] = sum_c H[r][c]: one workgroup per row
+__global__ __launch_bounds__(256) void f64_rowsum_kernel(const double* __restrict__ H, long n, long ldh, double* __restrict__ x) {
+    __shared__ double red[256];
+    const double* row = H + (long)blockIdx.x * ldh;
+    double acc = 0.0;
+    for (long c = threadIdx.x; c < n; c += 256) acc += row[c];
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) x[blockIdx.x] = s;
+}
+
+// P[chunk][c] = sum_{r in chunk} f(X[r][c]) (SQ: squares): a thread per column, coalesced across the row
+template <bool SQ>
+__global__ __launch_bounds__(256) void f64_colsum_partial_kernel(const double* __restrict__ X, long m, long n, long ldx, long rows_per_chunk,
+                                                                 double* __restrict__ P) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const long rb = (long)blockIdx.y * rows_per_chunk;
+    const long re = rb + rows_per_chunk < m ? rb + rows_per_chunk : m;
+    double acc = 0.0;
+    for (long r = rb; r < re; ++r) { const double v = X[r * ldx + c]; acc += SQ ? v * v : v; }
+    P[(long)blockIdx.y * n + c] = acc;
+}
+
+// ================================================================================================ HALS (dist_nmf.py:873-934)
+// one column of the W sweep: pending normalisation of column kk - 1, then W[:, kk] = max(W[:, kk] G[kk][kk] + AH[:, kk] - W G[:, kk],
+// eps) and the partial sums of its squares (utils.py:367-391)
+__global__ __launch_bounds__(256) void f64_hals_w_col_kernel(double* __restrict__ W, long m, int k, long ldw, const double* __restrict__ AH,
+                                                             long ldah, const double* __restrict__ G, long ldg, int kk,
+                                                             const double* __restrict__ prev_ss2, double eps, double* __restrict__ part) {
+    __shared__ double red[256];
+    const double pn = (prev_ss2 && kk > 0) ? sqrt(*prev_ss2) : 0.0;
+    double acc = 0.0;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < m; r += (long)gridDim.x * 256) {
+        double* w = W + r * ldw;
+        if (pn > 0.0) w[kk - 1] = w[kk - 1] / pn;
+        double dot = 0.0;
+        for (int l = 0; l < k; ++l) dot += w[l] * G[(long)l * ldg + kk];
+        double v = w[kk] * G[(long)kk * ldg + kk] + AH[r * ldah + kk] - dot;
+        v = v > eps ? v : eps;
+        w[kk] = v;
+        acc += v * v;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void f64_scale_col_kernel(double* __restrict__ W, long m, long ldw, int col, const double* __restrict__ ss2) {
+    const double nrm = sqrt(*ss2);
+    if (!(nrm > 0.0)) return;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < m; r += (long)gridDim.x * 256) W[r * ldw + col] = W[r * ldw + col] / nrm;
+}
+// H sweep: rows in sequence, a thread per column (dist_nmf.py:905-909)
+__global__ __launch_bounds__(256) void f64_hals_h_kernel(double* __restrict__ H, int k, long n, long ldh, const double* __restrict__ AtW,
+                                                         long ldatw, const double* __restrict__ G, long ldg, double eps) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    for (int kk = 0; kk < k; ++kk) {
+        double dot = 0.0;
+        for (int l = 0; l < k; ++l) dot += G[(long)kk * ldg + l] * H[(long)l * ldh + c];
+        const double v = H[(long)kk * ldh + c] + AtW[(long)kk * ldatw + c] - dot;
+        H[(long)kk * ldh + c] = v > eps ? v : eps;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool vec_ok(const double* p, long ld) { return ((uintptr_t)p & 15) == 0 && ld % 2 == 0; }
+
+struct TnPlan64 { int ncolblk; long nchunks, rows_per_chunk; };
+TnPlan64 plan_tn64(long m, long n) {
+    TnPlan64 p;
+    p.ncolblk = (int)cdiv(n, 16);
+    long nch = std::max<long>(1, 4096 / p.ncolblk);
+    nch = std::min<long>(nch, std::max<long>(1, cdiv(m, 64)));
+    p.rows_per_chunk = round_up(cdiv(m, nch), 16);
+    p.nchunks = cdiv(m, p.rows_per_chunk);
+    return p;
+}
+long nt_splits(long m, long n) { return m <= 1024 ? std::max<long>(1, std::min<long>(256, n / 512)) : 1; }
+
+int sum_all(bool sq, const double* X, long rows, long cols, long ldx, double* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int nparts = (int)std::min<long>(1024, cdiv(rows * cols, 256 * 8));
+    if (ws_bytes < (size_t)nparts * sizeof(double)) return fail(DNMF_EWS, "f64 sum: workspace too small");
+    if (sq) hipLaunchKernelGGL(f64_sum_partial_kernel<true>, dim3(nparts), dim3(256), 0, st, X, rows, cols, ldx, (double*)ws);
+    else hipLaunchKernelGGL(f64_sum_partial_kernel<false>, dim3(nparts), dim3(256), 0, st, X, rows, cols, ldx, (double*)ws);
+    hipLaunchKernelGGL(f64_sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nparts, out);
+    return check_launch("f64 sum");
+}
+
+int colsum_any(bool sq, const double* X, long m, long n, long ldx, double* x, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long nch = std::max<long>(1, std::min<long>(cdiv(m, 64), 2048 / std::max<long>(1, cdiv(n, 256))));
+    const long rpc = cdiv(m, nch);
+    const long chunks = cdiv(m, rpc);
+    if (ws_bytes < (size_t)chunks * n * sizeof(double)) return fail(DNMF_EWS, "f64 colsum: workspace too small");
+    const dim3 grid((unsigned)cdiv(n, 256), (unsigned)chunks);
+    if (sq) hipLaunchKernelGGL(f64_colsum_partial_kernel<true>, grid, dim3(256), 0, st, X, m, n, ldx, rpc, (double*)ws);
+    else hipLaunchKernelGGL(f64_colsum_partial_kernel<false>, grid, dim3(256), 0, st, X, m, n, ldx, rpc, (double*)ws);
+    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const double*)ws, n, n, (int)chunks, x, n, 1L, n);
+    return check_launch("f64 colsum");
+}
+
+template <int MODE>
+int launch_nn_rows(const double* X, long ldx, long m, int kc, const double* Y, long ldy, long n, const double* A, long lda, double* O, long ldo,
+                   double eps, hipStream_t st) {
+    // column range per wave: the whole width for the in-place W update (the wave owns its rows), else about 8192 waves in all
+    long cpw = n;
+    if (MODE != NN_UPD_W) {
+        const long rowtiles = cdiv(m, 16);
+        const long want = std::max<long>(1, 8192 / rowtiles);
+        cpw = std::max<long>(64, round_up(cdiv(n, want), 16));
+    }
+    const dim3 grid((unsigned)cdiv(cdiv(m, 16), 4), (unsigned)cdiv(n, cpw));
+#define NN_CASE(KS_) hipLaunchKernelGGL((f64_nn_rows_kernel<KS_, MODE>), grid, dim3(256), 0, st, X, ldx, m, kc, Y, ldy, n, A, lda, O, ldo, eps, cpw)
+    if (kc <= 16) NN_CASE(4); else if (kc <= 32) NN_CASE(8); else if (kc <= 64) NN_CASE(16); else NN_CASE(32);
+#undef NN_CASE
+    return check_launch("f64 nn");
+}
+
+}  // namespace
+
+extern "C" {
+
+// scratch for any f64 entry point on an m x n block: the partial slabs of the TN / NT forms and of the reductions; the m x n
+// quotient / residual image the KL products and the error evaluation go through is a separate buffer of the caller (U)
+size_t dnmf_f64_ws_bytes(long m, long n, int k) {
+    if (k < 1 || k > DNMF_MAX_K || m < 1 || n < 1) return 0;
+    const size_t kp = 16 * tiles16(k), D = sizeof(double);
+    auto colsum_slabs = [](long rows, long cols) {
+        return (size_t)std::max<long>(1, std::min<long>(cdiv(rows, 64), 2048 / std::max<long>(1, cdiv(cols, 256)))) * cols;
+    };
+    size_t b = 2048 * D;                                                               // block partials of the sums
+    b = std::max(b, (size_t)plan_tn64(m, n).nchunks * kp * round_up(n, 16) * D);       // W^T A
+    b = std::max(b, (size_t)plan_tn64(m, k).nchunks * kp * round_up(k, 16) * D);       // W^T W
+    b = std::max(b, (size_t)nt_splits(k, n) * k * kp * D);                             // H H^T (column splits)
+    if (nt_splits(m, n) > 1) b = std::max(b, (size_t)nt_splits(m, n) * m * kp * D);    // A H^T of a short A
+    b = std::max(b, colsum_slabs(m, n) * D);                                           // column sums of an m x n image
+    b = std::max(b, colsum_slabs(m, k) * D);                                           // column sums of W
+    return al256(b) + 256;
+}
+
+// C[m x kc] = X[m x n] Y[kc x n]^T  (A H^T: global_mm(A, H.T), dist_nmf.py:730; H H^T: global_gram(H.T), :729 -- X = Y = H)
+int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int kc, long ldy, double* C, long ldc, void* ws, size_t ws_bytes,
+                 void* stream) {
+    REQ(X && Y && C && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_MAX_K && ldx >= n && ldy >= n && ldc >= kc, "f64 aht: bad arguments");
+    hipStream_t st = ST(stream);
+    const long ns = nt_splits(m, n);
+    const long cps = ns > 1 ? round_up(cdiv(n, ns), 16) : round_up(n, 16);
+    const long nsplit = cdiv(n, cps);
+    const int kp = 16 * tiles16(kc);
+    double* out = C; long ldo = ldc, sstride = 0;
+    if (nsplit > 1) {
+        if (!ws || ws_bytes < (size_t)nsplit * m * kp * sizeof(double)) return fail(DNMF_EWS, "f64 aht: workspace too small");
+        out = (double*)ws; ldo = kp; sstride = m * kp;
+    }
+    const int vec = vec_ok(X, ldx) && vec_ok(Y, ldy) && cps % 2 == 0;
+    const dim3 grid((unsigned)cdiv(cdiv(m, 16), 4), (unsigned)nsplit);
+#define NT_CASE(NT_) hipLaunchKernelGGL((f64_nt_kernel<NT_>), grid, dim3(256), 0, st, X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps, vec)
+    const int nt = tiles16(kc);
+    if (nt <= 1) NT_CASE(1); else if (nt <= 2) NT_CASE(2); else if (nt <= 4) NT_CASE(4); else NT_CASE(8);
+#undef NT_CASE
+    int rc = check_launch("f64 aht");
+    if (rc || nsplit == 1) return rc;
+    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv(m * kc, 256)), dim3(256), 0, st, (const double*)ws, sstride, ldo, (int)nsplit, C, ldc,
+                       m, (long)kc);
+    return check_launch("f64 aht(reduce)");
+}
+
+// C[kc x n] = X[m x kc]^T Y[m x n]  (W^T A: global_mm(W.T, A), dist_nmf.py:749; W^T W: global_gram(W), :748 -- Y = X = W)
+int dnmf_f64_wta(const double* Y, long m, long n, long ldy, const double* X, int kc, long ldx, double* C, long ldc, void* ws, size_t ws_bytes,
+                 void* stream) {
+    REQ(X && Y && C && ws && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_MAX_K && ldy >= n && ldx >= kc && ldc >= n, "f64 wta: bad arguments");
+    hipStream_t st = ST(stream);
+    const TnPlan64 p = plan_tn64(m, n);
+    const int kp = 16 * tiles16(kc);
+    const long ldp = round_up(n, 16);
+    if (ws_bytes < (size_t)p.nchunks * kp * ldp * sizeof(double)) return fail(DNMF_EWS, "f64 wta: workspace too small");
+    const long nwaves = p.nchunks * p.ncolblk;
+    const dim3 grid((unsigned)cdiv(nwaves, 4));
+#define TN_CASE(NT_) hipLaunchKernelGGL((f64_tn_kernel<NT_>), grid, dim3(256), 0, st, X, ldx, kc, Y, ldy, n, m, p.rows_per_chunk, p.ncolblk, nwaves, \
+                                        (double*)ws, (long)kp * ldp, ldp)
+    const int nt = tiles16(kc);
+    if (nt <= 1) TN_CASE(1); else if (nt <= 2) TN_CASE(2); else if (nt <= 4) TN_CASE(4); else TN_CASE(8);
+#undef TN_CASE
+    int rc = check_launch("f64 wta");
+    if (rc) return rc;
+    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv((long)kc * n, 256)), dim3(256), 0, st, (const double*)ws, (long)kp * ldp, ldp,
+                       (int)p.nchunks, C, ldc, (long)kc, n);
+    return check_launch("f64 wta(reduce)");
+}
+
+// W *= AH / (W G + eps)  (dist_nmf.py:731-732, :244-245)
+int dnmf_f64_mu_update_w(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, double eps, void* stream) {
+    REQ(W && AH && G && m >= 1 && k >= 1 && k <= DNMF_MAX_K && ldw >= k && ldah >= k && ldg >= k, "f64 mu_update_w: bad arguments");
+    return launch_nn_rows<NN_UPD_W>(W, ldw, m, k, G, ldg, k, AH, ldah, W, ldw, eps, ST(stream));
+}
+
+// H *= AtW / (G H + eps), clamp: H = max(H, eps) afterwards  (dist_nmf.py:750-751, :224-225; pyDNMF.py:156)
+int dnmf_f64_mu_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps, int clamp,
+                         void* stream) {
+    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 mu_update_h: bad arguments");
+    hipStream_t st = ST(stream);
+    const dim3 grid((unsigned)cdiv(cdiv(n, 16), 4));
+#define UH_CASE(KS_) hipLaunchKernelGGL((f64_upd_h_kernel<KS_>), grid, dim3(256), 0, st, H, k, n, ldh, AtW, ldatw, G, ldg, eps, clamp)
+    if (k <= 16) UH_CASE(4); else if (k <= 32) UH_CASE(8); else if (k <= 64) UH_CASE(16); else UH_CASE(32);
+#undef UH_CASE
+    return check_launch("f64 mu_update_h");
+}
+
+// U[m x n] = A / (W H + eps)  (the KL quotient, dist_nmf.py:806; the reference materialises it too)
+int dnmf_f64_kl_quot(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                     double* U, long ldu, void* stream) {
+    REQ(A && W && H && U && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_MAX_K && lda >= n && ldw >= k && ldh >= n && ldu >= n, "f64 kl_quot: bad arguments");
+    return launch_nn_rows<NN_QUOT>(W, ldw, m, k, H, ldh, n, A, lda, U, ldu, eps, ST(stream));
+}
+
+// R[m x n] = (A - W H)^2 element-wise  (pyDNMF.py:207, :229: the caller sums it -- dnmf_f64_sum / dnmf_f64_colsum)
+int dnmf_f64_sqdiff(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double* R, long ldr,
+                    void* stream) {
+    REQ(A && W && H && R && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_MAX_K && lda >= n && ldw >= k && ldh >= n && ldr >= n, "f64 sqdiff: bad arguments");
+    return launch_nn_rows<NN_SQDIFF>(W, ldw, m, k, H, ldh, n, A, lda, R, ldr, 0.0, ST(stream));
+}
+
+// *out = sum X (sq == 0) or sum X^2 (sq != 0) over a rows x cols matrix, fixed summation order
+int dnmf_f64_sum(const double* X, long rows, long cols, long ldx, int sq, double* out, void* ws, size_t ws_bytes, void* stream) {
+    REQ(X && out && ws && rows >= 1 && cols >= 1 && ldx >= cols, "f64 sum: bad arguments");
+    return sum_all(sq != 0, X, rows, cols, ldx, out, ws, ws_bytes, ST(stream));
+}
+
+// x[c] = sum_r X[r][c] (or of squares): sum_along_axis(W, axis=0), dist_nmf.py:793; the per-column sums of column_err, pyDNMF.py:229
+int dnmf_f64_colsum(const double* X, long m, long n, long ldx, int sq, double* x, void* ws, size_t ws_bytes, void* stream) {
+    REQ(X && x && ws && m >= 1 && n >= 1 && ldx >= n, "f64 colsum: bad arguments");
+    return colsum_any(sq != 0, X, m, n, ldx, x, ws, ws_bytes, ST(stream));
+}
+
+// x[r] = sum_c H[r][c]  (sum_along_axis(H, axis=1), dist_nmf.py:793-795)
+int dnmf_f64_rowsum(const double* H, int k, long n, long ldh, double* x, void* stream) {
+    REQ(H && x && k >= 1 && n >= 1 && ldh >= n, "f64 rowsum: bad arguments");
+    hipLaunchKernelGGL(f64_rowsum_kernel, dim3(k), dim3(256), 0, ST(stream), H, n, ldh, x);
+    return check_launch("f64 rowsum");
+}
+
+// op 0: X = max(X, eps); 1: X[r][c] /= x[c] + eps; 2: X[r][c] *= x[r]; 3: X[r][c] *= S[r][c] / (x[r] + eps); 4: ... / (x[c] + eps);
+// clamp (ops 3, 4): max(., eps) afterwards
+int dnmf_f64_ew(int op, double* X, long rows, long cols, long ldx, const double* Sm, long lds_, const double* x, double eps, int clamp,
+                void* stream) {
+    REQ(X && rows >= 1 && cols >= 1 && ldx >= cols && op >= 0 && op <= 4 && (op == E_CLAMP || x) && (op < E_KL_BYROW || (Sm && lds_ >= cols)),
+        "f64 ew: bad arguments");
+    const unsigned grid = (unsigned)std::min<long>(cdiv(rows * cols, 256), 8192);
+    hipLaunchKernelGGL(f64_ew_kernel, dim3(grid), dim3(256), 0, ST(stream), op, X, rows, cols, ldx, Sm, lds_, x, eps, clamp);
+    return check_launch("f64 ew");
+}
+
+// one column of the HALS W sweep (dist_nmf.py:886-887): see dnmf_hals_w_col; *ss2_out = sum of squares of the new column
+int dnmf_f64_hals_w_col(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, int kk,
+                        const double* prev_ss2, double eps, double* ss2_out, void* ws, size_t ws_bytes, void* stream) {
+    REQ(W && AH && G && ss2_out && ws && m >= 1 && k >= 1 && k <= DNMF_MAX_K && kk >= 0 && kk < k && ldw >= k && ldah >= k && ldg >= k,
+        "f64 hals_w_col: bad arguments");
+    hipStream_t st = ST(stream);
+    const int nb = (int)std::min<long>(cdiv(m, 256), 1024);
+    if (ws_bytes < (size_t)nb * sizeof(double)) return fail(DNMF_EWS, "f64 hals_w_col: workspace too small");
+    hipLaunchKernelGGL(f64_hals_w_col_kernel, dim3(nb), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, ldg, kk, prev_ss2, eps, (double*)ws);
+    hipLaunchKernelGGL(f64_sum_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, ss2_out);
+    return check_launch("f64 hals_w_col");
+}
+// W[:, col] /= sqrt(*ss2) if > 0 (dist_nmf.py:890-891)
+int dnmf_f64_hals_w_scale(double* W, long m, long ldw, int col, const double* ss2, void* stream) {
+    REQ(W && ss2 && m >= 1 && col >= 0 && ldw > col, "f64 hals_w_scale: bad arguments");
+    hipLaunchKernelGGL(f64_scale_col_kernel, dim3((unsigned)std::min<long>(cdiv(m, 256), 2048)), dim3(256), 0, ST(stream), W, m, ldw, col, ss2);
+    return check_launch("f64 hals_w_scale");
+}
+// H sweep (dist_nmf.py:905-909)
+int dnmf_f64_hals_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps, void* stream) {
+    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 hals_update_h: bad arguments");
+    hipLaunchKernelGGL(f64_hals_h_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ST(stream), H, k, n, ldh, AtW, ldatw, G, ldg, eps);
+    return check_launch("f64 hals_update_h");
+}
+
+}  // extern "C"

@@ -22,10 +22,11 @@ def _buf(key, numel, like):
     """Persistent scratch tensors: a fresh nmf_algorithms_* object is built every iteration (pyDNMF.py:154,169), so
     buffers live in a module cache -- ONE buffer per role and device, grown on demand (an NMFk sweep over k reuses it;
     every use is stream-ordered).  `release_buffers()` drops them."""
-    key = (like.device, key[0])
+    dtype = torch.float64 if like.dtype == torch.float64 else torch.float32     # (bf16-stored data: float32 factors and products)
+    key = (like.device, key[0], dtype)
     t = _cache.get(key)
     if t is None or t.numel() < numel:
-        t = torch.zeros(numel, dtype=torch.float32, device=like.device)
+        t = torch.zeros(numel, dtype=dtype, device=like.device)
         _cache[key] = t
     return t
 
@@ -37,9 +38,9 @@ def release_buffers():
     engine._ws_cache.clear()
 
 
-def _default_ops(params=None):
+def _default_ops(params=None, like=None):
     from .engine import ops_for
-    return ops_for(params)
+    return ops_for(params, like.dtype if like is not None else None)
 
 
 def _kp(k):
@@ -110,7 +111,7 @@ class nmf_algorithms_1D(_Base):
         self.rank = self.comm1.rank
         self.local_W_m = self.W_i.shape[0]
         self.local_H_n = self.H_j.shape[1]
-        self.ops = ops if ops is not None else _default_ops(params)
+        self.ops = ops if ops is not None else _default_ops(params, A_ij)
 
     def update(self, clamp=False):
         """One step; `clamp=True` additionally applies H = max(H, eps), W = max(W, eps) after it
@@ -299,7 +300,7 @@ class nmf_algorithms_2D(_Base):
         self.rank = self.comm1.rank
         self.local_W_m = self.W_ij.shape[0]
         self.local_H_n = self.H_ij.shape[1]
-        self.ops = ops if ops is not None else _default_ops(params)
+        self.ops = ops if ops is not None else _default_ops(params, A_ij)
         # per-member slice sizes inside the sub-communicators: the partition rule (utils.py:99-103), unless pruning
         # changed them (then PyNMF has exchanged the actual sizes once and left them on params)
         from .utils import determine_block_params

@@ -531,6 +531,230 @@ HIP_OPS_BF16X6 = HipOpsBf16x6()
 
 
 
+class HipOpsF64:
+    """The operator set in float64 (csrc/dnmf_f64.hip: the fp64 matrix cores, one plain tile shape per kernel family).  The
+    reference computes in the dtype of A_ij (pyDNMF.py:68): float64 data are factorised in float64, eps = 2.22e-16.  The same
+    method surface as HipOps for the primitives the choreography (dist_nmf.py) sequences; no whole-step / whole-fit entry points
+    (the choreography's generic path runs), no bf16 storage, no block-column products."""
+
+    name = "hip-f64"
+    aht_hblocks = None
+    kl_uht_hblocks = None
+    dtype = torch.float64
+
+    @staticmethod
+    def _r(t, name, ndim=2):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise TypeError("%s: expected a CUDA tensor (no CPU fallback)" % name)
+        _same_device(t, name)
+        if t.dtype != torch.float64:
+            raise TypeError("%s: dtype %s in the float64 operator set" % (name, t.dtype))
+        if t.dim() != ndim or (t.numel() and t.stride(-1) != 1):
+            raise ValueError("%s: must be %d-D row-major with unit inner stride" % (name, ndim))
+        return t
+
+    @staticmethod
+    def _ws(m, n, k, device):
+        nbytes = lib.dnmf_f64_ws_bytes(int(m), int(n), int(k))
+        if nbytes == 0:
+            raise ValueError("bad problem shape m=%d n=%d k=%d" % (m, n, k))
+        return _scratch(nbytes, device)
+
+    _img = {}
+
+    @classmethod
+    def _image(cls, m, n, device):
+        """the m x n float64 image the KL quotient / the squared residual are materialised in (one per device, grown on demand)"""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        t = cls._img.get(key)
+        if t is None or t.numel() < m * n:
+            cls._img.pop(key, None)
+            t = torch.empty(m * n, dtype=torch.float64, device=device)
+            cls._img[key] = t
+        return t[: m * n].view(m, n)
+
+    # ---- grams and the two big contractions
+    def gram_hht(self, H, out):
+        r = self._r; r(H, "H"); r(out, "G")
+        k, n = H.shape
+        ws = self._ws(k, n, k, H.device)
+        check(lib.dnmf_f64_aht(H.data_ptr(), k, n, _ld(H), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def gram_wtw(self, W, out):
+        r = self._r; r(W, "W"); r(out, "G")
+        m, k = W.shape
+        ws = self._ws(m, k, k, W.device)
+        check(lib.dnmf_f64_wta(W.data_ptr(), m, k, _ld(W), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def aht(self, A, H, out):
+        r = self._r; r(A, "A"); r(H, "H"); r(out, "AH")
+        m, n = A.shape
+        k = H.shape[0]
+        ws = self._ws(m, n, k, A.device)
+        check(lib.dnmf_f64_aht(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def wta(self, A, W, out):
+        r = self._r; r(A, "A"); r(W, "W"); r(out, "AtW")
+        m, n = A.shape
+        k = W.shape[1]
+        ws = self._ws(m, n, k, A.device)
+        check(lib.dnmf_f64_wta(A.data_ptr(), m, n, _ld(A), W.data_ptr(), k, _ld(W), out.data_ptr(), _ld(out), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def wta_gram(self, A, W, out, G):
+        self.gram_wtw(W, G)
+        return self.wta(A, W, out)
+
+    # ---- updates
+    def mu_update_w(self, W, AH, G, eps):
+        r = self._r; r(W, "W"); r(AH, "AH"); r(G, "G")
+        m, k = W.shape
+        check(lib.dnmf_f64_mu_update_w(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), _ld(G), float(eps), _stream()))
+
+    def mu_update_h(self, H, AtW, G, eps, clamp=False):
+        r = self._r; r(H, "H"); r(AtW, "AtW"); r(G, "G")
+        k, n = H.shape
+        check(lib.dnmf_f64_mu_update_h(H.data_ptr(), k, n, _ld(H), AtW.data_ptr(), _ld(AtW), G.data_ptr(), _ld(G), float(eps),
+                                       int(bool(clamp)), _stream()))
+
+    def aht_update_w(self, A, H, G, W, eps):
+        """W *= (A H^T) / (W G + eps) (dist_nmf.py:716-732): the product, then the update"""
+        m, k = W.shape
+        AH = torch.empty(m, k, dtype=torch.float64, device=W.device)
+        self.aht(A, H, AH)
+        self.mu_update_w(W, AH, G, eps)
+
+    # ---- HALS
+    def hals_ss2(self, k, like):
+        return torch.zeros(k, dtype=torch.float64, device=like.device)
+
+    def hals_w_col(self, W, AH, G, kk, ss2, eps):
+        r = self._r; r(W, "W"); r(AH, "AH"); r(G, "G")
+        m, k = W.shape
+        ws = self._ws(m, k, k, W.device)
+        prev = ss2[kk - 1:].data_ptr() if kk > 0 else None
+        check(lib.dnmf_f64_hals_w_col(W.data_ptr(), m, k, _ld(W), AH.data_ptr(), _ld(AH), G.data_ptr(), _ld(G), int(kk), prev, float(eps),
+                                      ss2[kk:].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+
+    def hals_w_scale(self, W, col, ss2):
+        self._r(W, "W")
+        check(lib.dnmf_f64_hals_w_scale(W.data_ptr(), W.shape[0], _ld(W), int(col), ss2[col:].data_ptr(), _stream()))
+
+    def hals_update_w(self, W, AH, G, eps):
+        k = W.shape[1]
+        ss2 = self.hals_ss2(k, W)
+        for kk in range(k):
+            self.hals_w_col(W, AH, G, kk, ss2, eps)
+        self.hals_w_scale(W, k - 1, ss2)
+
+    hals_update_w_columns = hals_update_w
+
+    def hals_check(self):
+        pass                                           # (no persistent sweep in this operator set)
+
+    def hals_update_h(self, H, AtW, G, eps):
+        r = self._r; r(H, "H"); r(AtW, "AtW"); r(G, "G")
+        k, n = H.shape
+        check(lib.dnmf_f64_hals_update_h(H.data_ptr(), k, n, _ld(H), AtW.data_ptr(), _ld(AtW), G.data_ptr(), _ld(G), float(eps), _stream()))
+
+    # ---- KL
+    def _quot(self, A, W, H, eps):
+        r = self._r; r(A, "A"); r(W, "W"); r(H, "H")
+        m, n = A.shape
+        U = self._image(m, n, A.device)
+        check(lib.dnmf_f64_kl_quot(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), W.shape[1], float(eps),
+                                   U.data_ptr(), n, _stream()))
+        return U
+
+    def kl_uht(self, A, W, H, eps, out):
+        return self.aht(self._quot(A, W, H, eps), H, out)          # (A / (W H + eps)) H^T, dist_nmf.py:806,810
+
+    def kl_wtu(self, A, W, H, eps, out):
+        return self.wta(self._quot(A, W, H, eps), W, out)          # W^T (A / (W H + eps)), dist_nmf.py:806,808
+
+    def rowsum(self, H, out):
+        self._r(H, "H"); self._r(out, "x", 1)
+        check(lib.dnmf_f64_rowsum(H.data_ptr(), H.shape[0], H.shape[1], _ld(H), out.data_ptr(), _stream()))
+        return out
+
+    def colsum(self, W, out):
+        self._r(W, "W"); self._r(out, "x", 1)
+        m, k = W.shape
+        ws = self._ws(m, k, k, W.device)
+        check(lib.dnmf_f64_colsum(W.data_ptr(), m, k, _ld(W), 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def _ew(self, op, X, S, x, eps, clamp=False):
+        self._r(X, "X")
+        check(lib.dnmf_f64_ew(op, X.data_ptr(), X.shape[0], X.shape[1], _ld(X), S.data_ptr() if S is not None else None,
+                              _ld(S) if S is not None else 0, x.data_ptr() if x is not None else None, float(eps), int(bool(clamp)), _stream()))
+
+    def kl_update_w(self, W, S, x, eps):
+        self._r(S, "S"); self._r(x, "x", 1)
+        self._ew(4, W, S, x, eps)
+
+    def kl_update_h(self, H, S, x, eps, clamp=False):
+        self._r(S, "S"); self._r(x, "x", 1)
+        self._ew(3, H, S, x, eps, clamp)
+
+    # ---- fit helpers
+    def clamp_min(self, X, eps):
+        self._ew(0, X, None, None, eps)
+
+    def scale_cols_div(self, W, s, eps):
+        self._r(s, "s", 1)
+        self._ew(1, W, None, s, eps)
+
+    def scale_rows_mul(self, H, s):
+        self._r(s, "s", 1)
+        self._ew(2, H, None, s, 0.0)
+
+    def perturb_uniform(self, X, noise_var, seed, out=None):
+        return None                                    # (the caller's torch expression, in float64)
+
+    def sqnorm(self, A):
+        self._r(A, "A")
+        out = torch.empty(1, dtype=torch.float64, device=A.device)
+        ws = self._ws(A.shape[0], A.shape[1], 1, A.device)
+        check(lib.dnmf_f64_sum(A.data_ptr(), A.shape[0], A.shape[1], _ld(A), 1, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def _sqdiff(self, A, W, H):
+        r = self._r; r(A, "A"); r(W, "W"); r(H, "H")
+        m, n = A.shape
+        R = self._image(m, n, A.device)
+        check(lib.dnmf_f64_sqdiff(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), W.shape[1], R.data_ptr(), n, _stream()))
+        return R
+
+    def resid_sqnorm(self, A, W, H):
+        R = self._sqdiff(A, W, H)
+        out = torch.empty(1, dtype=torch.float64, device=A.device)
+        ws = self._ws(A.shape[0], A.shape[1], W.shape[1], A.device)
+        check(lib.dnmf_f64_sum(R.data_ptr(), R.shape[0], R.shape[1], R.shape[1], 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def column_err_sums(self, A, W, H):
+        m, n = A.shape
+        out = torch.zeros(2, n, dtype=torch.float64, device=A.device)
+        ws = self._ws(m, n, W.shape[1], A.device)
+        R = self._sqdiff(A, W, H)
+        check(lib.dnmf_f64_colsum(R.data_ptr(), m, n, n, 0, out[0].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        check(lib.dnmf_f64_colsum(A.data_ptr(), m, n, _ld(A), 1, out[1].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out[0], out[1]
+
+    def empty(self, shape, like):
+        return torch.empty(shape, dtype=torch.float64, device=like.device)
+
+    def zeros(self, shape, like):
+        return torch.zeros(shape, dtype=torch.float64, device=like.device)
+
+
+HIP_OPS_F64 = HipOpsF64()
+
+
 class NativeComm:
     """The grid's RCCL communicators INSIDE libdnmf_hip.so (csrc/dnmf_comm.hip) and the whole-step entry points on top of
     them: one library call enqueues kernels -> allreduce -> kernels, no Python between the launches.  Built from the host's
@@ -879,9 +1103,11 @@ def native_comm_for(params):
     return nc
 
 
-def ops_for(params=None):
+def ops_for(params=None, dtype=None):
     """The operator set `params` asks for: `params.gemm` = 'fp32' (default: the fp32-MFMA contractions, the parity
-    reference) or 'bf16x6' (HipOpsBf16x6)."""
+    reference) or 'bf16x6' (HipOpsBf16x6); float64 data (`dtype`) take the float64 set whatever `gemm` says."""
+    if dtype is torch.float64:
+        return HIP_OPS_F64
     mode = getattr(params, "gemm", None) or "fp32"
     if mode == "fp32":
         return HIP_OPS

@@ -9,7 +9,8 @@ eps when i % 10 == 0 (after that step's update), and on the last step column-nor
 Everything numeric runs in libdnmf_hip.so; there is no CPU path.
 
 Differences from the reference, all deliberate and documented in DESIGN.md:
-  * compute dtype is float32 (the engine's only dtype); float64 input raises; `params.precision = 'bfloat16'` (or a
+  * compute dtype follows the data, as in the reference (pyDNMF.py:68): float32 (the tuned path) or float64 (the fp64 matrix
+    cores, engine.HipOpsF64: correctness first, one plain tile shape); `params.precision = 'bfloat16'` (or a
     bfloat16 tensor) keeps the data block in HBM as bf16 -- storage only, Frobenius mu / hals -- with W, H and every
     product in float32: the fit equals the float32 fit of the bf16-rounded data (BASELINE config 5);
   * method is 'mu' (fro / kl) or 'hals' (fro); 'bcd' is not provided; init is 'rand' or 'nnsvd' (1D grids);
@@ -29,8 +30,6 @@ def _to_device(x, device, dtype=torch.float32, what="A_ij"):
         t = x
     else:
         t = torch.from_numpy(np.ascontiguousarray(x))
-    if t.dtype == torch.float64 and what == "A_ij":
-        raise TypeError("PyNMF: float64 input; the MI355X engine computes in float32 -- cast with .astype('float32')")
     # factors take the data's compute dtype on entry, as in the reference (`factors[i].astype(self.A_ij.dtype)`,
     # pyDNMF.py:92-96): NMFk hands the float64 medians / centroids of its clustering to the regression fit
     return t.to(device=device, dtype=dtype).contiguous()
@@ -44,6 +43,11 @@ def storage_dtype(A_ij, params):
         return torch.bfloat16
     if isinstance(A_ij, torch.Tensor) and A_ij.dtype == torch.bfloat16:
         return torch.bfloat16
+    # float64 data are factorised in float64 (the reference computes in A_ij's dtype, pyDNMF.py:68; `precision` only casts
+    # the file in data_read, main.py:29) on the fp64 matrix cores (engine.HipOpsF64)
+    dt = A_ij.dtype if isinstance(A_ij, torch.Tensor) else getattr(A_ij, "dtype", None)
+    if dt in (torch.float64, np.dtype("float64")):
+        return torch.float64
     return torch.float32
 
 
@@ -67,6 +71,7 @@ class PyNMF:
             device = A_ij.device if isinstance(A_ij, torch.Tensor) else torch.device("cpu")
         self.device = device
         self.a_dtype = storage_dtype(A_ij, params)
+        self.c_dtype = torch.float64 if self.a_dtype == torch.float64 else torch.float32      # factors, products, eps
         self.A_ij = _to_device(A_ij, device, self.a_dtype)
         self.params = params
         self.m_loc, self.n_loc = self.A_ij.shape
@@ -80,7 +85,7 @@ class PyNMF:
         self.cart_1d_row, self.cart_1d_column, self.comm = self.params.row_comm, self.params.col_comm, self.params.comm
         self.verbose = self.params.verbose if getattr(self.params, "verbose", False) else False
         self.rank = self.comm1.rank
-        self.eps = float(np.finfo(np.float32).eps)                  # pyDNMF.py:68 for float32 data
+        self.eps = float(np.finfo(np.float64 if self.c_dtype == torch.float64 else np.float32).eps)   # pyDNMF.py:68
         self.params.eps = self.eps
         self.norm = var_init(self.params, 'norm', default='kl')     # :70
         self.method = var_init(self.params, 'method', default='mu')
@@ -101,8 +106,8 @@ class PyNMF:
         self.data_op = data_operations(self.A_ij, self.params)      # :88 -> params.m, n, m_loc, n_loc, ...
         self.params = self.data_op.params
         if factors is not None:                                     # :90-96 (copied on entry)
-            W0 = _to_device(factors[0], device, what="factors").clone()
-            H0 = _to_device(factors[1], device, what="factors").clone()
+            W0 = _to_device(factors[0], device, self.c_dtype, what="factors").clone()
+            H0 = _to_device(factors[1], device, self.c_dtype, what="factors").clone()
         else:
             W0, H0 = self.init_factors()
         if self.topo == '1d':
@@ -137,7 +142,7 @@ class PyNMF:
             raise NotImplementedError("init='%s': 'rand', 'nnsvd' or factors=... are provided" % self.init)
         if getattr(self.params, "rng", None) == "device" and self.device.type == "cuda":
             return self._init_factors_device()
-        f32 = np.float32
+        f32 = np.float64 if self.c_dtype == torch.float64 else np.float32        # (`.astype(self.A_ij.dtype)`, pyDNMF.py:113)
         if self.topo == '2d':
             W = np.random.rand(self.params.m_loc, self.k).astype(f32)
             H = np.random.rand(self.k, self.params.n_loc).astype(f32)
@@ -149,7 +154,7 @@ class PyNMF:
             H = np.random.rand(self.k, self.n_loc).astype(f32)
             W = np.random.rand(self.m_loc, self.k).astype(f32) if self.rank == 0 else None
             W = self.comm1.bcast(W, root=0)
-        return _to_device(W, self.device), _to_device(H, self.device)
+        return _to_device(W, self.device, self.c_dtype), _to_device(H, self.device, self.c_dtype)
 
     def _init_factors_device(self):
         """`params.rng = 'device'` (what main.py / pyDNMFk_Runner select): the same uniform [0,1) init (pyDNMF.py:110-129),
@@ -162,24 +167,24 @@ class PyNMF:
 
         def draw(shape, salt):
             if seed is None:
-                return torch.rand(shape, dtype=torch.float32, device=dev)
+                return torch.rand(shape, dtype=self.c_dtype, device=dev)
             g = torch.Generator(device=dev)
             g.manual_seed(int(seed) * 1000003 + salt)
-            return torch.rand(shape, dtype=torch.float32, device=dev, generator=g)
+            return torch.rand(shape, dtype=self.c_dtype, device=dev, generator=g)
         if self.topo == '2d':
             return draw((self.params.m_loc, self.k), 2 * self.rank + 1), draw((self.k, self.params.n_loc), 2 * self.rank + 2)
         if self.p_c == 1:
             W = draw((self.m_loc, self.k), 2 * self.rank + 1)
-            H = self.comm1.bcast(draw((self.k, self.n_loc), 0) if self.rank == 0 else torch.empty(self.k, self.n_loc, device=dev), root=0)
+            H = self.comm1.bcast(draw((self.k, self.n_loc), 0) if self.rank == 0 else torch.empty(self.k, self.n_loc, dtype=self.c_dtype, device=dev), root=0)
         else:
             H = draw((self.k, self.n_loc), 2 * self.rank + 2)
-            W = self.comm1.bcast(draw((self.m_loc, self.k), 0) if self.rank == 0 else torch.empty(self.m_loc, self.k, device=dev), root=0)
+            W = self.comm1.bcast(draw((self.m_loc, self.k), 0) if self.rank == 0 else torch.empty(self.m_loc, self.k, dtype=self.c_dtype, device=dev), root=0)
         return W.contiguous(), H.contiguous()
 
     def _ops(self):
         if self.ops is None:
             from .engine import ops_for
-            self.ops = ops_for(self.params)
+            self.ops = ops_for(self.params, self.c_dtype)
         return self.ops
 
     def _out(self, t):

@@ -216,9 +216,13 @@ class PyNMFk:
         # run on the update engine's kernels); with an injected checker back end they stay where they are
         dev = torch.device("cuda", torch.cuda.current_device()) if (self.ops is None and torch.cuda.is_available()) else None
 
+        f64 = (self.A_ij.dtype == torch.float64) if isinstance(self.A_ij, torch.Tensor) else (self.A_ij.dtype == np.float64)
+
         def _t(x):
             t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
-            t = t.to(torch.float32) if t.dtype == torch.float64 else t      # (prune=True hands float64 back, as the reference)
+            # (float32 data with prune=True hand float64 factors back, as the reference does: the stacks stay float32 then;
+            #  float64 data are clustered in float64)
+            t = t.to(torch.float32) if (t.dtype == torch.float64 and not f64) else t
             return t.to(dev) if (dev is not None and not t.is_cuda) else t
         Ws = [_t(r[0]) for r in results]
         Hs = [_t(r[1]) for r in results]

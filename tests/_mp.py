@@ -91,7 +91,8 @@ def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
         q.put((rank, None, traceback.format_exc()))
 
 
-def run_case(name, use_hip=False, timeout=240, extra=None):
+def run_case(name, use_hip=False, timeout=240, extra=None, tols=None):
+    """`tols` = (per step, per fit, error) overrides the float32 budgets (the float64 goldens: 1e-10 / 1e-8 / 1e-9)"""
     meta = load_case(name)[0]
     world = meta["grid"][0] * meta["grid"][1]
     ctx = mp.get_context("spawn")
@@ -111,7 +112,10 @@ def run_case(name, use_hip=False, timeout=240, extra=None):
                 tol = 5e-5 if hals else 1e-5
             else:
                 tol = 2e-3 if hals else 1e-4      # HALS cancels: see tests/test_oracle_golden.py::test_fit
-            assert dw <= tol and dh <= tol and de <= 1e-5, (name, rank, itr, dw, dh, de)
+            tol_e = 1e-5
+            if tols is not None:
+                tol, tol_e = (tols[0] if itr == "step1" else tols[1]), tols[2]
+            assert dw <= tol and dh <= tol and de <= tol_e, (name, rank, itr, dw, dh, de)
 
 
 def run_bf16_rank(rank, world, port, grid, method, q, use_hip, cfg=None):
