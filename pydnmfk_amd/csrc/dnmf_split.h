@@ -66,12 +66,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& s1, u32x4& s2
 // the six piece products of one 32 x 32 x 16 tile step, small terms first
 __device__ __forceinline__ void mfma_x6(f32x16& acc, const u32x4& a1, const u32x4& a2, const u32x4& a3, const u32x4& b1,
                                         const u32x4& b2, const u32x4& b3) {
-#ifdef DNMF_TUNING_3PROD      // timing experiment only (wrong results): how much of the pass is the matrix pipe?
-    acc = mfma_bf16(a2, b1, acc);
-    acc = mfma_bf16(a1, b2, acc);
-    acc = mfma_bf16(a1, b1, acc);
-    return;
-#endif
     acc = mfma_bf16(a3, b1, acc);
     acc = mfma_bf16(a2, b2, acc);
     acc = mfma_bf16(a1, b3, acc);
@@ -299,22 +293,16 @@ __device__ __forceinline__ void ntx_mainloop(f32x16 (&acc)[1][KT], const TX* __r
     }
 }
 
-}  // namespace
-#ifdef DNMF_NTX2      // tools/ntxproto.hip only: the second A H^T main loop (tools/dnmf_split_nt2.h), an experiment that measured no gain
-#include "dnmf_split_nt2.h"
-#endif
-namespace {
 
 // tiles in flight: 4 register sets at KP = 64 with fp32 A (28 registers a set), 2 where a set is 40-64 registers (KP = 128, or
 // bf16 A with its 64-index H tiles); bf16 A at KP = 128 stages 128 KiB, i.e. one workgroup per CU, and may use its registers
 // NW = waves (32-row groups) per workgroup: 4 in the shipped library.  NW = 6 (192 rows, 166 registers with two register sets
 // in flight, three waves per SIMD) exists for A/B runs: it is slower (2.16 vs 1.91 ms at the headline shape).
-// ML = 1 (tools/ntxproto.hip only, -DDNMF_NTX2; fp32 A at KP = 64, whole 128-row workgroups): the main loop of
-// tools/dnmf_split_nt2.h -- A cut before LDS into wave-private piece tiles, two tiles in flight (182 registers).  Same bits; 3 % faster
-// timed alone, 1 % slower inside the iteration: the pass is bound by the power limit, not by its schedule.
-// Round 4: out of the library (tuning build included); the prototype bench keeps it compilable as the record of that measurement.
+// (A second main loop -- A cut before LDS into wave-private piece tiles, two tiles in flight, 182 registers -- gave the same bits, 3 %
+// faster timed alone and 1 % slower inside the iteration: the pass is bound by the power limit, not by its schedule.  Measured in
+// rounds 3 / 4 (profiles/r03d_ntxproto.txt) and removed.)
 template <int KT, int MODE, int AUX, typename TX = float, int NW = 4,
-          int NSET = ((KT == 2 && std::is_same<TX, float>::value && NW == 4) ? 4 : 2), int ML = 0>
+          int NSET = ((KT == 2 && std::is_same<TX, float>::value && NW == 4) ? 4 : 2)>
 __global__ __launch_bounds__(64 * NW, (KT == 4 && std::is_same<TX, bf16_t>::value) ? 1 : 2) void ntx_kernel(NtArgs p, SplitOperand ys) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = 32 * NW;
@@ -333,10 +321,6 @@ __global__ __launch_bounds__(64 * NW, (KT == 4 && std::is_same<TX, bf16_t>::valu
 
     const TX* X = static_cast<const TX*>(p.X);
     if (row0 + BM <= p.nrows) {
-#ifdef DNMF_NTX2
-        if constexpr (ML == 1) ntx2_mainloop<KT, 2, AUX != 0>(acc, X, p.ldx, row0, ys, cbeg, cend, smem);
-        else
-#endif
         ntx_mainloop<KT, true, AUX != 0, NSET, TX, NW>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
     } else ntx_mainloop<KT, false, false, 2, TX, NW>(acc, X, p.ldx, p.nrows, row0, ys, cbeg, cend, smem);
 
