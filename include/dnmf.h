@@ -13,7 +13,7 @@
  *   - every leading dimension must be >= the logical row length (lda >= n, ...);
  *   - `ws` is caller-provided device scratch of at least dnmf_ws_bytes(m, n, k) bytes;
  *   - return value: 0 on success, negative DNMF_E* on error (dnmf_last_error() has text);
- *   - k <= DNMF_MAX_K.  Internally k is padded to KP = 32/64/128; "gram" buffers G are
+ *   - k <= DNMF_MAX_K.  Internally k is padded to KP = 32/64/128/256; "gram" buffers G are
  *     always KP x KP, ld = KP, zero padded (dnmf_kp(k) returns KP).
  * Collectives: the kernels above the "Grid exchanges" section never communicate -- a host may issue the p_r x p_c grid
  * exchanges itself between these calls, exactly where the reference calls mpi4py (dist_nmf.py:681,707,114,163,169,195,
@@ -29,7 +29,11 @@
 extern "C" {
 #endif
 
-#define DNMF_MAX_K 128
+#define DNMF_MAX_K 256        /* the primitives, the local whole steps and the whole fits */
+#define DNMF_TUNED_MAX_K 128  /* the tuned kernels' own limit: beyond it the contractions run as two passes over A and the k x k products
+                               * on plain MFMA kernels (csrc/dnmf_wide.hip).  Also the limit of the float64 path, the bf16x6 arithmetic,
+                               * bf16 storage of A in the error evaluation, the fused dnmf_aht_update_w, the block-column (hblocks)
+                               * products and the library-sequenced grid steps (dnmf_*_step_1d / _2d: the host keeps its choreography) */
 #define DNMF_OK 0
 #define DNMF_EINVAL (-1)   /* bad shape / null pointer / k too large */
 #define DNMF_EWS (-2)      /* workspace too small */
@@ -38,7 +42,7 @@ extern "C" {
 
 const char* dnmf_last_error(void);
 int dnmf_version(void);
-/* padded rank used for internal k x k buffers (32, 64 or 128); <0 if k unsupported */
+/* padded rank used for internal k x k buffers (32, 64, 128 or 256); <0 if k unsupported */
 int dnmf_kp(int k);
 /* scratch bytes sufficient for ANY entry point below on an m x n block with rank k */
 size_t dnmf_ws_bytes(long m, long n, int k);
@@ -270,7 +274,7 @@ int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, l
 /* ---- The update path in float64.  The reference computes in the dtype of A_ij (pyDNMF.py:68; its own tests feed float64,
  * tests/test_dist_nmf_1d.py:14-20): these are the float64 twins of the primitives above, on the fp64 matrix cores
  * (v_mfma_f64_16x16x4_f64), one plain tile shape each -- correctness first, the fp32 path is the tuned one.  Everything is `double`
- * in device memory, row-major, leading dimensions in elements; eps = 2.220446049250313e-16; k <= DNMF_MAX_K; Gram matrices are
+ * in device memory, row-major, leading dimensions in elements; eps = 2.220446049250313e-16; k <= DNMF_TUNED_MAX_K; Gram matrices are
  * plain k x k blocks with their own leading dimension `ldg` (no padding contract).  `ws` >= dnmf_f64_ws_bytes(m, n, k) where an
  * entry point takes one.  The KL products go through the materialised quotient U = A / (W H + eps) (dnmf_f64_kl_quot, an m x n
  * buffer of the caller -- the reference materialises it too, dist_nmf.py:806) followed by dnmf_f64_aht / dnmf_f64_wta on U; the

@@ -25,6 +25,13 @@
 #include "dnmf_nn.h"
 #include "dnmf_k16.h"
 
+// csrc/dnmf_wide.hip: the k x k products of ranks 128 < k <= 256
+#define HID __attribute__((visibility("hidden")))
+HID int dnmf_wide_mu_update_w_(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, long ldg, float eps, void* stream);
+HID int dnmf_wide_mu_update_h_(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, long ldg, float eps, int clamp,
+                               void* stream);
+#undef HID
+
 char* dnmf_errbuf_() {
     static thread_local char buf[DNMF_ERRBUF] = "";
     return buf;
@@ -200,6 +207,10 @@ struct WsLayout {
 };
 
 size_t partial_bytes(long m, long n, int k) {
+    if (wide_k(k))      // the panel calls of the contractions and of the Gram blocks + the m x n quotient image of the KL products
+        return align256(std::max(std::max(partial_bytes(m, n, WIDE_PANEL), (size_t)256 * HALS_MAX_WG * sizeof(unsigned long long) + 256 * sizeof(double)),
+                                 std::max(partial_bytes(m, WIDE_PANEL, WIDE_PANEL), partial_bytes(WIDE_PANEL, n, WIDE_PANEL)))) +
+               align256((size_t)m * round_up(n, 4) * sizeof(float));
     const int kt = kt_of(k), kp = 32 * kt;
     size_t b = 0;
     if (k <= 16 && n % 64 == 0) {   // tn16 partial slabs (fp32: V = 4; bf16: V = 8 has fewer column blocks, more chunks)
@@ -244,7 +255,7 @@ size_t partial_bytes(long m, long n, int k) {
 }
 
 WsLayout ws_layout(long m, long n, int k) {
-    const int kp = 32 * kt_of(k);
+    const int kp = kp_of(k);
     WsLayout w;
     w.g_off = 0;
     w.s_off = align256((size_t)kp * kp * sizeof(float));
@@ -269,15 +280,44 @@ extern "C" {
 
 const char* dnmf_last_error(void) { return dnmf_errbuf_(); }
 int dnmf_version(void) { return 100; }
-int dnmf_kp(int k) { const int kt = kt_of(k); return kt < 0 ? -1 : 32 * kt; }
+int dnmf_kp(int k) { return kp_of(k); }
 
 size_t dnmf_ws_bytes(long m, long n, int k) {
-    if (kt_of(k) < 0 || m < 1 || n < 1) return 0;
+    if (kp_of(k) < 0 || m < 1 || n < 1) return 0;
     return ws_layout(m, n, k).total;
 }
 
 
+}  // extern "C"
+namespace {
+template <typename TA>
+int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah, void* stream, long hblk = 0);
+template <typename TA>
+int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw, void* ws, size_t ws_bytes, void* stream,
+             float* G = nullptr);
+// Gram matrices of a wide rank: the zero-padded 256 x 256 buffer, filled block by block with the tuned contractions
+// (H_p H_q^T = "A H^T" with A = H_p; W_p^T W_q = "W^T A" with A = W_q)
+int wide_gram(bool hht, const float* F, long len, int k, long ld, float* G, void* ws, size_t ws_bytes, void* stream) {
+    if (batch_memset(G, 0, (size_t)256 * 256 * sizeof(float), S(stream)) != hipSuccess) return fail(DNMF_EHIP, "gram: memset failed");
+    for (int p = 0; p < 2; ++p)
+        for (int q = 0; q < 2; ++q) {
+            const int kx = p ? k - WIDE_PANEL : WIDE_PANEL, ky = q ? k - WIDE_PANEL : WIDE_PANEL;
+            float* blk = G + (long)p * WIDE_PANEL * 256 + q * WIDE_PANEL;
+            int rc;
+            if (hht) rc = aht_impl<float>(F + (long)p * WIDE_PANEL * ld, kx, len, ld, F + (long)q * WIDE_PANEL * ld, ky, ld, blk, 256, stream);
+            else rc = wta_impl<float>(F + q * WIDE_PANEL, len, ky, ld, F + p * WIDE_PANEL, kx, ld, blk, 256, ws, ws_bytes, stream);
+            if (rc) return rc;
+        }
+    return DNMF_OK;
+}
+}  // namespace
+extern "C" {
+
 int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, size_t ws_bytes, void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(H && G && n >= 1 && ldh >= n, "gram_hht: bad arguments (k=%d n=%ld)", k, n);
+        return wide_gram(true, H, n, k, ldh, G, ws, ws_bytes, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && G && ws && n >= 1 && ldh >= n, "gram_hht: bad arguments (k=%d n=%ld)", k, n);
     const int kp = 32 * kt;
@@ -299,6 +339,10 @@ int dnmf_gram_hht(const float* H, int k, long n, long ldh, float* G, void* ws, s
 }
 
 int dnmf_gram_wtw(const float* W, long m, int k, long ldw, float* G, void* ws, size_t ws_bytes, void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(W && G && ws && m >= 1 && ldw >= k, "gram_wtw: bad arguments (k=%d m=%ld)", k, m);
+        return wide_gram(false, W, m, k, ldw, G, ws, ws_bytes, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && G && ws && m >= 1 && ldw >= k, "gram_wtw: bad arguments (k=%d m=%ld)", k, m);
     const int kp = 32 * kt;
@@ -346,7 +390,12 @@ int try_nt16(const NtArgs& a, bool fast, long n, int k, hipStream_t st) {
 // hblk = 0: H is one k x n matrix (ldh).  hblk > 0 (fp32 A): H is the stack of n / hblk column blocks [q][k][hblk], ldh = hblk.
 template <typename TA>
 int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, float* AH, long ldah,
-             void* stream, long hblk = 0) {
+             void* stream, long hblk) {
+    if (wide_k(k)) {                                               // A H^T splits exactly along the rows of H: two passes over A
+        REQUIRE(!hblk && H && AH && ldah >= k && ldh >= n, "aht: bad arguments (k = %d; H as column blocks: k <= %d)", k, DNMF_TUNED_MAX_K);
+        if (int rc = aht_impl<TA>(A, m, n, lda, H, WIDE_PANEL, ldh, AH, ldah, stream, 0)) return rc;
+        return aht_impl<TA>(A, m, n, lda, H + (long)WIDE_PANEL * ldh, k - WIDE_PANEL, ldh, AH + WIDE_PANEL, ldah, stream, 0);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && H && AH && m >= 1 && n >= 1 && lda >= n && ldah >= k, "aht: bad arguments");
     REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0 && (n / 16) * (hblk / 16) < (1L << 32)) : ldh >= n,
@@ -368,6 +417,7 @@ int aht_impl(const TA* A, long m, long n, long lda, const float* H, int k, long 
 template <typename TA>
 int aht_update_w_impl(const TA* A, long m, long n, long lda, const float* H, int k, long ldh, const float* G,
                       float* W, long ldw, float eps, void* stream) {
+    REQUIRE(!wide_k(k), "aht_update_w: the fused form takes k <= %d (dnmf_aht followed by dnmf_mu_update_w beyond it)", DNMF_TUNED_MAX_K);
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && H && G && W && m >= 1 && n >= 1 && (lda >= n || alias_ok(lda)) && ldh >= n && ldw >= k, "aht_update_w: bad arguments");
     NtArgs a{};
@@ -427,6 +477,10 @@ extern "C" {
 
 int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
                      void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(W && AH && G && m >= 1 && ldw >= k && ldah >= k, "mu_update_w: bad arguments");
+        return dnmf_wide_mu_update_w_(W, m, k, ldw, AH, ldah, G, 256, eps, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && W && AH && G && m >= 1 && ldw >= k && ldah >= k, "mu_update_w: bad arguments");
     REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "mu_update_w: leading dimension beyond the 32-bit tile offsets");
@@ -461,7 +515,13 @@ namespace {
 // column block 0 of every row chunk accumulates it, the reduction launch sums the partial tiles), otherwise dnmf_gram_wtw first.
 template <typename TA>
 int wta_impl(const TA* A, long m, long n, long lda, const float* W, int k, long ldw, float* AtW, long ldatw,
-             void* ws, size_t ws_bytes, void* stream, float* G = nullptr) {
+             void* ws, size_t ws_bytes, void* stream, float* G) {
+    if (wide_k(k)) {                                               // W^T A splits exactly along the columns of W: two passes over A
+        REQUIRE(W && AtW && ws && ldw >= k && ldatw >= n, "wta: bad arguments (k = %d)", k);
+        if (G) if (int rc = dnmf_gram_wtw(W, m, k, ldw, G, ws, ws_bytes, stream)) return rc;
+        if (int rc = wta_impl<TA>(A, m, n, lda, W, WIDE_PANEL, ldw, AtW, ldatw, ws, ws_bytes, stream, nullptr)) return rc;
+        return wta_impl<TA>(A, m, n, lda, W + WIDE_PANEL, k - WIDE_PANEL, ldw, AtW + (long)WIDE_PANEL * ldatw, ldatw, ws, ws_bytes, stream, nullptr);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && AtW && ws && m >= 1 && n >= 1 && (lda >= n || alias_ok(lda)) && ldw >= k && ldatw >= n, "wta: bad arguments");
     const int kp = 32 * kt;
@@ -571,6 +631,10 @@ extern "C" {
 
 int dnmf_mu_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
                      int clamp, void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
+        return dnmf_wide_mu_update_h_(H, k, n, ldh, AtW, ldatw, G, 256, eps, clamp, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "mu_update_h: bad arguments");
     // 32-bit tile offsets of the buffer accesses: (27 + 4) rows of a 32-row block plus the column part stay below 2 GiB
@@ -695,9 +759,8 @@ int dnmf_rowsum(const float* H, int k, long n, long ldh, float* x, void* stream)
 }
 
 int dnmf_colsum(const float* W, long m, int k, long ldw, float* x, void* ws, size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && W && x && ws && m >= 1 && ldw >= k, "colsum: bad arguments");
-    const int kp = 32 * kt;
+    const int kp = kp_of(k);
+    REQUIRE(kp > 0 && W && x && ws && m >= 1 && ldw >= k, "colsum: bad arguments");
     // slabs of 128 rows (a 32768-row shard gives 256 workgroups; 1024-row slabs left it on 32 CUs: 116 us for 16 MiB),
     // at most 1024 slabs; the partials are summed in slab order by one small launch
     const long rows_per_blk = std::max<long>(128, round_up(cdiv(m, 1024), 8));
@@ -725,8 +788,7 @@ namespace {
 template <typename TA>
 int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k,
                      float eps, int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_fro_step: bad arguments");
+    REQUIRE(kp_of(k) > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_fro_step: bad arguments");
     const WsLayout L = ws_layout(m, n, k);
     if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_fro_step: workspace %zu < %zu", ws_bytes, L.total);
     char* base = (char*)ws;
@@ -737,7 +799,11 @@ int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, 
     int rc;
     if (w_update) {                                                                   // dist_nmf.py:716-732
         if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
-        if ((rc = aht_update_w_impl<TA>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
+        if (wide_k(k)) {                                             // beyond the fused kernel's rank: the product, then the update
+            const long ldah = round_up(k, 4);
+            if ((rc = aht_impl<TA>(A, m, n, lda, H, k, ldh, Sb, ldah, stream, 0))) return rc;
+            if ((rc = dnmf_mu_update_w(W, m, k, ldw, Sb, ldah, G, eps, stream))) return rc;
+        } else if ((rc = aht_update_w_impl<TA>(A, m, n, lda, H, k, ldh, G, W, ldw, eps, stream))) return rc;
     }
     const long ldatw = round_up(n, 4);                                                // dist_nmf.py:736-751
     if ((rc = wta_impl<TA>(A, m, n, lda, W, k, ldw, Sb, ldatw, part, part_bytes, stream, G))) return rc;   // + W^T W (:705)
@@ -759,8 +825,7 @@ int dnmf_mu_fro_step_bf16a(const void* A, long m, long n, long lda, float* W, lo
 
 int dnmf_mu_kl_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
                     int w_update, int clamp, void* ws, size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_kl_step: bad arguments");
+    REQUIRE(kp_of(k) > 0 && A && W && H && ws && m >= 1 && n >= 1, "mu_kl_step: bad arguments");
     const WsLayout L = ws_layout(m, n, k);
     if (ws_bytes < L.total) return fail(DNMF_EWS, "mu_kl_step: workspace %zu < %zu", ws_bytes, L.total);
     char* base = (char*)ws;

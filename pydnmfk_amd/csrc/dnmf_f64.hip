@@ -368,7 +368,7 @@ extern "C" {
 // scratch for any f64 entry point on an m x n block: the partial slabs of the TN / NT forms and of the reductions; the m x n
 // quotient / residual image the KL products and the error evaluation go through is a separate buffer of the caller (U)
 size_t dnmf_f64_ws_bytes(long m, long n, int k) {
-    if (k < 1 || k > DNMF_MAX_K || m < 1 || n < 1) return 0;
+    if (k < 1 || k > DNMF_TUNED_MAX_K || m < 1 || n < 1) return 0;
     const size_t kp = 16 * tiles16(k), D = sizeof(double);
     auto colsum_slabs = [](long rows, long cols) {
         return (size_t)std::max<long>(1, std::min<long>(cdiv(rows, 64), 2048 / std::max<long>(1, cdiv(cols, 256)))) * cols;
@@ -386,7 +386,7 @@ size_t dnmf_f64_ws_bytes(long m, long n, int k) {
 // C[m x kc] = X[m x n] Y[kc x n]^T  (A H^T: global_mm(A, H.T), dist_nmf.py:730; H H^T: global_gram(H.T), :729 -- X = Y = H)
 int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int kc, long ldy, double* C, long ldc, void* ws, size_t ws_bytes,
                  void* stream) {
-    REQ(X && Y && C && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_MAX_K && ldx >= n && ldy >= n && ldc >= kc, "f64 aht: bad arguments");
+    REQ(X && Y && C && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_TUNED_MAX_K && ldx >= n && ldy >= n && ldc >= kc, "f64 aht: bad arguments");
     hipStream_t st = ST(stream);
     const long ns = nt_splits(m, n);
     const long cps = ns > 1 ? round_up(cdiv(n, ns), 16) : round_up(n, 16);
@@ -413,7 +413,7 @@ int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int
 // C[kc x n] = X[m x kc]^T Y[m x n]  (W^T A: global_mm(W.T, A), dist_nmf.py:749; W^T W: global_gram(W), :748 -- Y = X = W)
 int dnmf_f64_wta(const double* Y, long m, long n, long ldy, const double* X, int kc, long ldx, double* C, long ldc, void* ws, size_t ws_bytes,
                  void* stream) {
-    REQ(X && Y && C && ws && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_MAX_K && ldy >= n && ldx >= kc && ldc >= n, "f64 wta: bad arguments");
+    REQ(X && Y && C && ws && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_TUNED_MAX_K && ldy >= n && ldx >= kc && ldc >= n, "f64 wta: bad arguments");
     hipStream_t st = ST(stream);
     const TnPlan64 p = plan_tn64(m, n);
     const int kp = 16 * tiles16(kc);
@@ -435,14 +435,14 @@ int dnmf_f64_wta(const double* Y, long m, long n, long ldy, const double* X, int
 
 // W *= AH / (W G + eps)  (dist_nmf.py:731-732, :244-245)
 int dnmf_f64_mu_update_w(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, double eps, void* stream) {
-    REQ(W && AH && G && m >= 1 && k >= 1 && k <= DNMF_MAX_K && ldw >= k && ldah >= k && ldg >= k, "f64 mu_update_w: bad arguments");
+    REQ(W && AH && G && m >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && ldw >= k && ldah >= k && ldg >= k, "f64 mu_update_w: bad arguments");
     return launch_nn_rows<NN_UPD_W>(W, ldw, m, k, G, ldg, k, AH, ldah, W, ldw, eps, ST(stream));
 }
 
 // H *= AtW / (G H + eps), clamp: H = max(H, eps) afterwards  (dist_nmf.py:750-751, :224-225; pyDNMF.py:156)
 int dnmf_f64_mu_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps, int clamp,
                          void* stream) {
-    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 mu_update_h: bad arguments");
+    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 mu_update_h: bad arguments");
     hipStream_t st = ST(stream);
     const dim3 grid((unsigned)cdiv(cdiv(n, 16), 4));
 #define UH_CASE(KS_) hipLaunchKernelGGL((f64_upd_h_kernel<KS_>), grid, dim3(256), 0, st, H, k, n, ldh, AtW, ldatw, G, ldg, eps, clamp)
@@ -454,14 +454,14 @@ int dnmf_f64_mu_update_h(double* H, int k, long n, long ldh, const double* AtW, 
 // U[m x n] = A / (W H + eps)  (the KL quotient, dist_nmf.py:806; the reference materialises it too)
 int dnmf_f64_kl_quot(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
                      double* U, long ldu, void* stream) {
-    REQ(A && W && H && U && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_MAX_K && lda >= n && ldw >= k && ldh >= n && ldu >= n, "f64 kl_quot: bad arguments");
+    REQ(A && W && H && U && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && lda >= n && ldw >= k && ldh >= n && ldu >= n, "f64 kl_quot: bad arguments");
     return launch_nn_rows<NN_QUOT>(W, ldw, m, k, H, ldh, n, A, lda, U, ldu, eps, ST(stream));
 }
 
 // R[m x n] = (A - W H)^2 element-wise  (pyDNMF.py:207, :229: the caller sums it -- dnmf_f64_sum / dnmf_f64_colsum)
 int dnmf_f64_sqdiff(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double* R, long ldr,
                     void* stream) {
-    REQ(A && W && H && R && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_MAX_K && lda >= n && ldw >= k && ldh >= n && ldr >= n, "f64 sqdiff: bad arguments");
+    REQ(A && W && H && R && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && lda >= n && ldw >= k && ldh >= n && ldr >= n, "f64 sqdiff: bad arguments");
     return launch_nn_rows<NN_SQDIFF>(W, ldw, m, k, H, ldh, n, A, lda, R, ldr, 0.0, ST(stream));
 }
 
@@ -498,7 +498,7 @@ int dnmf_f64_ew(int op, double* X, long rows, long cols, long ldx, const double*
 // one column of the HALS W sweep (dist_nmf.py:886-887): see dnmf_hals_w_col; *ss2_out = sum of squares of the new column
 int dnmf_f64_hals_w_col(double* W, long m, int k, long ldw, const double* AH, long ldah, const double* G, long ldg, int kk,
                         const double* prev_ss2, double eps, double* ss2_out, void* ws, size_t ws_bytes, void* stream) {
-    REQ(W && AH && G && ss2_out && ws && m >= 1 && k >= 1 && k <= DNMF_MAX_K && kk >= 0 && kk < k && ldw >= k && ldah >= k && ldg >= k,
+    REQ(W && AH && G && ss2_out && ws && m >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && kk >= 0 && kk < k && ldw >= k && ldah >= k && ldg >= k,
         "f64 hals_w_col: bad arguments");
     hipStream_t st = ST(stream);
     const int nb = (int)std::min<long>(cdiv(m, 256), 1024);
@@ -515,7 +515,7 @@ int dnmf_f64_hals_w_scale(double* W, long m, long ldw, int col, const double* ss
 }
 // H sweep (dist_nmf.py:905-909)
 int dnmf_f64_hals_update_h(double* H, int k, long n, long ldh, const double* AtW, long ldatw, const double* G, long ldg, double eps, void* stream) {
-    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 hals_update_h: bad arguments");
+    REQ(H && AtW && G && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && ldh >= n && ldatw >= n && ldg >= k, "f64 hals_update_h: bad arguments");
     hipLaunchKernelGGL(f64_hals_h_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ST(stream), H, k, n, ldh, AtW, ldatw, G, ldg, eps);
     return check_launch("f64 hals_update_h");
 }

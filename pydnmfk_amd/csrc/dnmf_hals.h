@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void hals_w_col_kernel(float* __restrict__ W, 
                                                         const double* __restrict__ prev_ss2, float eps,
                                                         double* __restrict__ ss2_out, BatchTab bt) {
     REBASE(W); REBASE(AH); REBASE(G); REBASE(prev_ss2); REBASE(ss2_out);
-    __shared__ float gcol[DNMF_MAX_K];
+    __shared__ float gcol[DNMF_MAX_K];      // (any rank up to DNMF_MAX_K = 256)
     for (int j = threadIdx.x; j < k; j += blockDim.x) gcol[j] = G[(long)j * kp + kk];
     __syncthreads();
     float inv_den = 0.f;   // ss of the previous column (0 = no pending normalisation)

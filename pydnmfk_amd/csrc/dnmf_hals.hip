@@ -7,16 +7,20 @@
 #include "dnmf_update.h"
 #include "dnmf_hals.h"
 
+// csrc/dnmf_wide.hip
+__attribute__((visibility("hidden"))) int dnmf_wide_hals_update_h_(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G,
+                                                                   long ldg, float eps, void* stream);
+
 extern "C" {
 
 static int hals_w_col_launch(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, int kk,
                              const double* prev_ss2, float eps, double* ss2_out, bool zero, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
+    const int kpg = kp_of(k);                                       // (the column kernel takes any rank: G's pitch is all it needs)
+    REQUIRE(kpg > 0 && W && AH && G && ss2_out && m >= 1 && ldw >= k && ldah >= k && kk >= 0 && kk < k, "hals_w_col: bad arguments");
     hipStream_t st = S(stream);
     if (zero && batch_memset(ss2_out, 0, sizeof(double), st) != hipSuccess) return fail(DNMF_EHIP, "hals_w_col: memset failed");
     const unsigned grid = (unsigned)std::min<long>(cdiv(m, 256), 2048);
-    DNMF_LAUNCH(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, 32 * kt, kk, prev_ss2,
+    DNMF_LAUNCH(hals_w_col_kernel, dim3(grid), dim3(256), 0, st, W, m, k, ldw, AH, ldah, G, kpg, kk, prev_ss2,
                        eps, ss2_out);
     return check_launch("hals_w_col");
 }
@@ -120,9 +124,9 @@ extern "C" {
 
 int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
                       size_t ws_bytes, void* stream) {
-    const int kt = kt_of(k);
-    REQUIRE(kt > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
-    const int kp = 32 * kt;
+    const int kt = kt_of(k);                                        // (-1 for a wide rank: the column launches below)
+    const int kp = kp_of(k);
+    REQUIRE(kp > 0 && W && AH && G && ws && m >= 1 && ldw >= k && ldah >= k, "hals_sweep_w: bad arguments");
     const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
     const size_t t_off = align256(slab_bytes + (size_t)kp * sizeof(double));
     if (ws_bytes < slab_bytes + (size_t)kp * sizeof(double)) return fail(DNMF_EWS, "hals_sweep_w: workspace too small");
@@ -131,7 +135,7 @@ int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long l
     float* T = (float*)((char*)ws + t_off);
     static const int mode = (int)tune("DNMF_HALS_SWEEP", 1);     // 0: always the column-per-launch path (A/B runs)
     int rc = 1;
-    if (mode && ws_bytes >= t_off + (size_t)m * kp * sizeof(float)) {
+    if (mode && kt > 0 && ws_bytes >= t_off + (size_t)m * kp * sizeof(float)) {
         hipStream_t st = S(stream);
         if (kt == 1) rc = launch_hals_sweep<1>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
         else if (kt == 2) rc = launch_hals_sweep<2>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st);
@@ -157,6 +161,10 @@ int dnmf_hals_sweep_status(int* timed_out, void* stream) {
 
 int dnmf_hals_update_h(float* H, int k, long n, long ldh, const float* AtW, long ldatw, const float* G, float eps,
                        void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "hals_update_h: bad arguments");
+        return dnmf_wide_hals_update_h_(H, k, n, ldh, AtW, ldatw, G, 256, eps, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && H && AtW && G && n >= 1 && ldh >= n && ldatw >= n, "hals_update_h: bad arguments");
     const dim3 grid((unsigned)cdiv(n, 256)), block(256);

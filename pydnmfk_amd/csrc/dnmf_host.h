@@ -7,10 +7,14 @@
 namespace {
 
 // =============================================================================================== host side
-int kt_of(int k) {
-    if (k < 1 || k > DNMF_MAX_K) return -1;
+int kt_of(int k) {      // 32-wide tiles of the TUNED kernels' padded rank; -1 beyond their limit (wide ranks: wide_k)
+    if (k < 1 || k > DNMF_TUNED_MAX_K) return -1;
     return k <= 32 ? 1 : (k <= 64 ? 2 : 4);
 }
+// 128 < k <= 256: served by composition of the tuned kernels and the plain kernels of csrc/dnmf_wide.hip
+inline bool wide_k(int k) { return k > DNMF_TUNED_MAX_K && k <= DNMF_MAX_K; }
+inline int kp_of(int k) { return wide_k(k) ? 256 : (kt_of(k) < 0 ? -1 : 32 * kt_of(k)); }
+constexpr int WIDE_PANEL = 128;          // the panels a wide rank is cut into
 
 // lda == 0 (every row of A aliases one row: A becomes cache resident) is an experiment of the tuning build only
 // (tools/kbench.py ALIAS=1); the shipped library requires lda >= n everywhere, as include/dnmf.h says

@@ -20,6 +20,31 @@ __attribute__((visibility("hidden"))) int dnmf_kl_uht_pipe_(const float* A, long
                                                             float* out, long ldo, long split_stride, long cols_per_split,
                                                             int nsplit, void* stream);
 
+// csrc/dnmf_wide.hip: ranks 128 < k <= 256
+#define HID __attribute__((visibility("hidden")))
+HID int dnmf_wide_quot_(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k, float eps, float* U,
+                        long ldu, void* stream);
+HID int dnmf_wide_resid_(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k, double* out,
+                         void* stream);
+HID int dnmf_wide_column_err_(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k, double* num,
+                              double* den, void* stream);
+#undef HID
+
+namespace {
+// The KL products of a wide rank: U = A / (W H + eps) materialised at the END of the caller's workspace (dnmf_ws_bytes reserves the
+// image for k > 128), then the tuned contraction on U.  uht: U H^T; else W^T U.
+int wide_kl_product(bool uht, const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k, float eps,
+                    float* out, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    const long ldu = round_up(n, 4);
+    const size_t ub = align256((size_t)m * ldu * sizeof(float));
+    if (!ws || ws_bytes < ub) return fail(DNMF_EWS, "kl product (k = %d): workspace %zu < %zu (the quotient image)", k, ws_bytes, ub);
+    const size_t inner = (ws_bytes - ub) & ~size_t(255);
+    float* U = (float*)((char*)ws + inner);
+    if (int rc = dnmf_wide_quot_(A, m, n, lda, W, ldw, H, ldh, k, eps, U, ldu, stream)) return rc;
+    return uht ? dnmf_aht(U, m, n, ldu, H, k, ldh, out, ldo, stream) : dnmf_wta(U, m, n, ldu, W, k, ldw, out, ldo, ws, inner, stream);
+}
+}  // namespace
+
 extern "C" {
 
 static NnArgs nn_args(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
@@ -47,6 +72,11 @@ namespace {
 template <typename TA>
 int resid_sqnorm_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh,
                       int k, double* out, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
+    if (wide_k(k)) {
+        REQUIRE((std::is_same<TA, float>::value) && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n,
+                "resid_sqnorm: bad arguments (k = %d: float32 data)", k);
+        return dnmf_wide_resid_(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, out, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && out && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "resid_sqnorm: bad arguments");
     hipStream_t st = S(stream);
@@ -117,6 +147,11 @@ namespace {
 template <typename TA>
 int column_err_impl(const TA* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
                     double* num, double* den, void* stream) {
+    if (wide_k(k)) {
+        REQUIRE((std::is_same<TA, float>::value) && A && W && H && num && den && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n,
+                "column_err: bad arguments (k = %d: float32 data)", k);
+        return dnmf_wide_column_err_(reinterpret_cast<const float*>(A), m, n, lda, W, ldw, H, ldh, k, num, den, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && num && den && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n, "column_err: bad arguments");
     hipStream_t st = S(stream);
@@ -174,6 +209,11 @@ bool pad_factors_hblocks(const float*& W, long& ldw, const float*& H, long& ldh,
 // hblk = 0: H is one k x n matrix (ldh).  hblk > 0: H is the stack of n / hblk column blocks [q][k][hblk] (ldh = hblk).
 int kl_uht_impl(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, long hblk, int k,
                 float eps, float* UHT, long ldo, void* ws, size_t ws_bytes, void* stream) {   // (W, ldw, H, ldh, k may be re-pointed at padded copies)
+    if (wide_k(k)) {
+        REQUIRE(!hblk && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= k,
+                "kl_uht: bad arguments (k = %d; H as column blocks: k <= %d)", k, DNMF_TUNED_MAX_K);
+        return wide_kl_product(true, A, m, n, lda, W, ldw, H, ldh, k, eps, UHT, ldo, ws, ws_bytes, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && UHT && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldo >= k, "kl_uht: bad arguments");
     REQUIRE(hblk ? (ldh == hblk && n % hblk == 0 && hblk % BK == 0) : ldh >= n, "kl_uht: bad H layout (ldh %ld, block %ld, n %ld)", ldh, hblk, n);
@@ -267,6 +307,10 @@ int dnmf_kl_uht_hblocks(const float* A, long m, long n, long lda, const float* W
 
 int dnmf_kl_wtu(const float* A, long m, long n, long lda, const float* W, long ldw, const float* H, long ldh, int k,
                 float eps, float* WTU, long ldo, void* ws, size_t ws_bytes, void* stream) {
+    if (wide_k(k)) {
+        REQUIRE(A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
+        return wide_kl_product(false, A, m, n, lda, W, ldw, H, ldh, k, eps, WTU, ldo, ws, ws_bytes, stream);
+    }
     const int kt = kt_of(k);
     REQUIRE(kt > 0 && A && W && H && WTU && ws && m >= 1 && n >= 1 && lda >= n && ldw >= k && ldh >= n && ldo >= n, "kl_wtu: bad arguments");
     const int kp = 32 * kt;

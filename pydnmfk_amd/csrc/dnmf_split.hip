@@ -20,7 +20,7 @@ bool split_shape(const TA* A, long m, long n, long lda, int k) {
     // k = 17 on (the 32-wide kernels; iteration at 262144 x 8192, k = 32: 2.39 ms, three-product kernels 1.48 ms); at k <= 16 the
     // 16-wide fp32 kernels are as fast (1.39-1.43 ms vs 1.43-1.46 ms) and stay.
     const int kmin = std::is_same<TA, bf16_t>::value ? 17 : 33;
-    return k >= kmin && k <= DNMF_MAX_K && n % 128 == 0 && lda % V == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+    return k >= kmin && k <= DNMF_TUNED_MAX_K && n % 128 == 0 && lda % V == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT", 1) != 0;
 }
 
@@ -191,7 +191,7 @@ int wta_x6(const TA* A, long m, long n, long lda, const float* W, int k, long ld
 // ---------------------------------------------------------------------------------------------- KL products
 // whole 128-column blocks, 16-byte aligned rows of A; other shapes run the fp32 kernels.
 bool klx_shape(const float* A, long m, long n, long lda, int k) {
-    return k >= 1 && k <= DNMF_MAX_K && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
+    return k >= 1 && k <= DNMF_TUNED_MAX_K && n % 128 == 0 && lda % 4 == 0 && aligned16(A) && lda >= n && lda <= 4 * n && m >= 1 &&
            n < (1L << 19) && tune("DNMF_SPLIT_KL", 1) != 0;
 }
 
@@ -261,6 +261,7 @@ extern "C" {
 size_t dnmf_ws_bytes_bf16x6(long m, long n, int k) {
     const size_t base = dnmf_ws_bytes(m, n, k);
     if (!base) return 0;
+    if (k > DNMF_TUNED_MAX_K) return align256(base);              // (wide ranks: every entry point forwards to the fp32 path)
     size_t extra = 0;
     if (n % 128 == 0) extra = h_image_bytes(n, 32 * kt_of(k)) + wta_need(m, n, k);      // (k <= 32: bf16-stored A only)
     if (n % 128 == 0) extra = std::max(extra, klx_need(m, n, k));

@@ -44,9 +44,10 @@ def _default_ops(params=None, like=None):
 
 
 def _kp(k):
-    if k < 1 or k > 128:
-        raise ValueError("rank k=%d unsupported (1 <= k <= 128)" % k)
-    return 32 if k <= 32 else (64 if k <= 64 else 128)
+    """the padded rank of the k x k buffers (dnmf_kp): 32 / 64 / 128, and 256 for the wide ranks 128 < k <= 256 (csrc/dnmf_wide.hip)"""
+    if k < 1 or k > 256:
+        raise ValueError("rank k=%d unsupported (1 <= k <= 256)" % k)
+    return 32 if k <= 32 else (64 if k <= 64 else (128 if k <= 128 else 256))
 
 
 def _pad64(x):
@@ -126,9 +127,9 @@ class nmf_algorithms_1D(_Base):
         the RCCL communicator inside libdnmf_hip.so) -- same kernels in the same order as the choreography below, no Python
         between the launches.  float32 data, the product's own operator set, more than one rank."""
         hals = self.method.upper() == 'HALS' and self.norm.upper() == 'FRO'
-        if (self.p == 1 and not getattr(self.params, "native_always", False)) or \
+        if (self.p == 1 and not getattr(self.params, "native_always", False)) or self.k > 128 or \
                 not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))):
-            return False
+            return False            # (k > 128: the library-sequenced steps stop at the tuned kernels' rank; the choreography below does not)
         if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
             return False
         fro = self.norm.upper() == 'FRO'
@@ -264,7 +265,7 @@ class nmf_algorithms_1D(_Base):
         m_l, n_l = A.shape
         if W_update:                                               # KL_MU_update_W :813-830
             off = _pad64(m_l * k)
-            buf = _buf(("uhx", m_l, k), off + 128, A)
+            buf = _buf(("uhx", m_l, k), off + 256, A)
             UHT, x2 = buf[: m_l * k].view(m_l, k), buf[off: off + k]
             ops.rowsum(H, x2)                                      # :827
             ops.kl_uht(A, W, H, eps, UHT)                          # :806,:810
@@ -272,7 +273,7 @@ class nmf_algorithms_1D(_Base):
                 self.comm1.allreduce_(buf[: off + k])              # :797,:707
             ops.kl_update_w(W, UHT, x2, eps)
         off = _pad64(k * n_l)                                      # KL_MU_update_H :832-849
-        buf = _buf(("wux", k, n_l), off + 128, A)
+        buf = _buf(("wux", k, n_l), off + 256, A)
         WTU, x1 = buf[: k * n_l].view(k, n_l), buf[off: off + k]
         ops.colsum(W, x1)                                          # :846
         ops.kl_wtu(A, W, H, eps, WTU)                              # :806,:808
@@ -324,7 +325,7 @@ class nmf_algorithms_2D(_Base):
         communicators inside libdnmf_hip.so, kernels -- is ONE library call (dnmf_mu_*_step_2d): same kernels in the same
         order as the choreography below, even and ragged grids.  Pruned factors, bf16-stored A and the other operator sets
         keep the choreography."""
-        if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip":
+        if getattr(self.params, "exchange", None) not in ("native", "native-hosted") or getattr(self.ops, "name", "") != "hip" or self.k > 128:
             return False
         hals = self.method.upper() == 'HALS' and self.norm.upper() == 'FRO'
         if not (hals or (self.method.upper() == 'MU' and self.norm.upper() in ('FRO', 'KL'))):
@@ -466,7 +467,7 @@ class nmf_algorithms_2D(_Base):
     def KL_MU_update(self, W_update=True, clamp=False):
         ops, A, W, H, eps, k = self.ops, self.A_ij, self.W_ij, self.H_ij, self.eps, self.k
         m_l, n_l = A.shape
-        x = _buf(("x", 128), 128, A)[:k]
+        x = _buf(("x", 256), 256, A)[:k]
         if W_update:                                               # KL_MU_update_W :351-369
             ops.rowsum(H, x)
             self.comm1.allreduce_(x)                               # sum_axis :346-349

@@ -61,7 +61,7 @@ def _stream():
 def kp(k):
     v = lib.dnmf_kp(int(k))
     if v < 0:
-        raise ValueError("rank k=%d unsupported (1 <= k <= 128)" % k)
+        raise ValueError("rank k=%d unsupported (1 <= k <= 256)" % k)
     return v
 
 
@@ -211,6 +211,10 @@ class HipOps:
         sfx = _req_a(A); _req(H, "H"); _req(G, "G"); _req(W, "W")
         m, n = A.shape
         k = H.shape[0]
+        if k > 128:      # beyond the fused kernel's rank: the product (two passes over A), then the update
+            AH = torch.empty(m, k, dtype=torch.float32, device=W.device)
+            self.aht(A, H, AH)
+            return self.mu_update_w(W, AH, G, eps)
         check(_fn("aht_update_w", sfx)(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
                                     _ld(W), float(eps), _stream()))
 
@@ -485,6 +489,8 @@ class HipOpsBf16x6(HipOps):
         sfx = _req_a(A); _req(H, "H"); _req(G, "G"); _req(W, "W")
         m, n = A.shape
         k = H.shape[0]
+        if k > 128:
+            return HipOps.aht_update_w(self, A, H, G, W, eps)
         ws = self._ws6(m, n, k, A.device)
         check(_fn("aht_update_w", sfx + "_bf16x6")(A.data_ptr(), m, n, _ld(A), H.data_ptr(), k, _ld(H), G.data_ptr(), W.data_ptr(),
                                            _ld(W), float(eps), ws.data_ptr(), ws.numel(), _stream()))

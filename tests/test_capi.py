@@ -27,14 +27,19 @@ def test_header_symbols_exported_and_bound():
 def test_argument_validation_without_gpu():
     from pydnmfk_amd._lib import lib
     assert lib.dnmf_version() >= 100
-    assert [lib.dnmf_kp(k) for k in (1, 4, 32, 33, 64, 65, 128)] == [32, 32, 32, 64, 64, 128, 128]
-    assert lib.dnmf_kp(0) < 0 and lib.dnmf_kp(129) < 0
+    assert [lib.dnmf_kp(k) for k in (1, 4, 32, 33, 64, 65, 128, 129, 256)] == [32, 32, 32, 64, 64, 128, 128, 256, 256]
+    assert lib.dnmf_kp(0) < 0 and lib.dnmf_kp(257) < 0
+    # wide ranks (128 < k <= 256): the workspace carries the m x n quotient image of the KL products; the library-sequenced grid
+    # steps and the float64 path stop at the tuned kernels' rank
+    assert lib.dnmf_ws_bytes(4096, 1024, 200) >= lib.dnmf_ws_bytes(4096, 1024, 128) + 4 * 4096 * 1024
+    assert lib.dnmf_ws_bytes_1d(4096, 1024, 200) == 0 and lib.dnmf_f64_ws_bytes(4096, 1024, 200) == 0
+    assert lib.dnmf_aht_update_w(None, 8, 8, 8, None, 200, 8, None, None, 200, 1e-7, None) == -1 and b"fused form" in lib.dnmf_last_error()
     assert lib.dnmf_ws_bytes(0, 10, 4) == 0
     assert lib.dnmf_ws_bytes(262144, 8192, 64) > 64 * 8192 * 4
     # null pointers / bad rank are rejected before any HIP call
     assert lib.dnmf_aht(None, 8, 8, 8, None, 4, 8, None, 4, None) == -1
     assert b"aht" in lib.dnmf_last_error()
-    assert lib.dnmf_mu_fro_step(None, 8, 8, 8, None, 4, None, 8, 200, 1e-7, 1, 0, None, 0, None) == -1
+    assert lib.dnmf_mu_fro_step(None, 8, 8, 8, None, 4, None, 8, 300, 1e-7, 1, 0, None, 0, None) == -1
     # the exchange entry points (csrc/dnmf_comm.hip): argument checks come before any RCCL / HIP call
     assert lib.dnmf_ws_bytes_1d(0, 10, 4) == 0
     assert lib.dnmf_ws_bytes_1d(32768, 8192, 64) >= lib.dnmf_ws_bytes(32768, 8192, 64) + 4 * (64 * 8192 + 64 * 64)
