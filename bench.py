@@ -557,8 +557,24 @@ def run_config4(a, job):
               "rccl": rccl_record() if a.backend == "nccl" else None}
         if emu:
             mg["emulated"] = ("rank 0 of a %d x %d grid on a single GPU: its own %d x %d block, real kernels and launches, the collectives of the "
-                              "step issued on one-rank groups (EmulatedGroup: no wire time; the library-sequenced step needs the real grid)" % (p_r, p_c, m_l, n_l))
+                              "step issued on one-rank groups -- no wire time -- by torch.distributed between the launches (EmulatedGroup) or inside "
+                              "the library (dnmf_comm_create_emulated: one call per step)" % (p_r, p_c, m_l, n_l))
         modes = ["torch"] if a.exchange in ("auto", "torch") else []
+        if emu and a.backend == "nccl" and a.exchange in ("auto", "native"):
+            # the library-sequenced step of the emulated member: the same kernels, every collective issued inside libdnmf_hip.so on a
+            # one-rank RCCL communicator -- what `params.exchange = 'native'` runs on the real grid, minus the wire
+            try:
+                from pydnmfk_amd.engine import NativeComm
+                p._native_comm = NativeComm.emulated(p_r, p_c, 0)
+                p.exchange = "native"
+                step(1)
+                torch.cuda.synchronize()
+                if p._native_comm.steps < 1:
+                    raise RuntimeError("the step did not run inside the library")
+                modes.append("native")
+            except Exception as exc:  # noqa: BLE001
+                mg["native_exchange_unavailable"] = repr(exc)
+            p.exchange = "torch"
         if world > 1 and a.backend == "nccl" and a.exchange in ("auto", "native"):
             p.exchange = "native"
             from pydnmfk_amd.engine import native_comm_for

@@ -350,6 +350,10 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
 /* send / recv are untyped: the element type is the op's (float32 for ops 0-2, float64 for DNMF_ALLREDUCE_F64) */
 typedef int (*dnmf_collective_fn)(void* user, int op, int group, const void* send, void* recv, size_t count, void* stream);
 int dnmf_comm_create_hosted(int nranks, int rank, int p_r, int p_c, dnmf_collective_fn fn, void* user, dnmf_comm_t** comm);
+/* MEASUREMENT aid (bench.py --emulate-ranks, a one-GPU box): member `rank` of a p_r x p_c grid whose collectives are all issued
+ * for real on a ONE-rank RCCL communicator -- launch and stream-ordering costs without a wire, buffers of the real grid's sizes.
+ * The step entry points run as on the grid; the numbers they produce are not a factorisation of anything. */
+int dnmf_comm_create_emulated(int p_r, int p_c, int rank, dnmf_comm_t** comm);
 /* the RCCL this library bound at run time: *version = ncclGetVersion's code (e.g. 22604; 0 if the symbol is absent), `origin` =
  * how it was found ("already in the process" = the host framework's copy, or the library name that was loaded).  For run records. */
 int dnmf_comm_rccl_version(int* version, char* origin, size_t origin_bytes);

@@ -87,6 +87,7 @@ SIGNATURES["dnmf_comm_unique_id"] = [c_void_p]
 SIGNATURES["dnmf_comm_create"] = [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
 COLLECTIVE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p)   # dnmf_collective_fn
 SIGNATURES["dnmf_comm_create_hosted"] = [c_int, c_int, c_int, c_int, COLLECTIVE_FN, c_void_p, ctypes.POINTER(c_void_p)]
+SIGNATURES["dnmf_comm_create_emulated"] = [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]
 SIGNATURES["dnmf_comm_destroy"] = [c_void_p]
 SIGNATURES["dnmf_comm_rccl_version"] = [ctypes.POINTER(c_int), c_void_p, c_size_t]
 SIGNATURES["dnmf_comm_direct_init"] = [c_void_p, c_size_t, c_void_p]

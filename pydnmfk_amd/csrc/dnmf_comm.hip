@@ -79,6 +79,7 @@ struct dnmf_comm {
     char* direct_peer[DNMF_DIRECT_MAX_RANKS] = {};               // [rank] = the own region
     unsigned long long direct_seq = 0, direct_small_seq = 0;
     unsigned long long direct_patience = 30ull * 100000000ull;   // 30 s of the 100 MHz wall clock (dnmf_comm_set_direct_timeout)
+    int emulated = 0;                                            // measurement: ONE member of a p_r x p_c grid, every collective on a one-rank RCCL communicator
 };
 
 namespace {
@@ -109,6 +110,7 @@ int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
     if (cm->null_exchange) return 1;
     if (group_size(cm, g) == 1 && (!cm->always || cm->hook)) return 1;   // (a hosted communicator never sees a group of one)
     if (cm->hook) { *out = nullptr; return 0; }
+    if (cm->emulated) { *out = cm->world; return 0; }            // every group's call is issued for real, on the one-rank communicator
     ncclComm_t c = group_comm(cm, g);
     if (!c && group_size(cm, g) == 1) c = cm->world;              // `always` on a one-rank communicator
     if (!c) return fail(DNMF_EINVAL, "%s: sub-communicator %d missing", what, g);
@@ -321,6 +323,9 @@ int allgather_f32(dnmf_comm* cm, int g, const float* send, float* recv, size_t c
     }
     if (cm->hook) return cm->hook(cm->hook_user, OP_ALLGATHER, g, send, recv, count, st) ? fail(DNMF_ECOMM, "allgather: the host collective failed") : DNMF_OK;
     NCCL_OK(rccl()->AllGather(send, recv, count, ncclFloat32, c, st), "allgather");
+    if (cm->emulated)      // (the other members' blocks: copies of this one, so that the step runs on finite numbers)
+        for (int q = 1; q < group_size(cm, g); ++q)
+            HIP_OK(hipMemcpyAsync(recv + (size_t)q * count, recv, count * sizeof(float), hipMemcpyDeviceToDevice, st), "allgather: copy");
     return DNMF_OK;
 }
 
@@ -335,7 +340,7 @@ int reduce_scatter_f32(dnmf_comm* cm, int g, const float* send, float* recv, siz
         return DNMF_OK;
     }
     if (cm->hook) return cm->hook(cm->hook_user, OP_REDUCE_SCATTER, g, send, recv, count, st) ? fail(DNMF_ECOMM, "reduce_scatter: the host collective failed") : DNMF_OK;
-    NCCL_OK(rccl()->ReduceScatter(send, recv, count, ncclFloat32, ncclSum, c, st), "reduce_scatter");
+    NCCL_OK(rccl()->ReduceScatter(cm->emulated ? send + (size_t)member * count : send, recv, count, ncclFloat32, ncclSum, c, st), "reduce_scatter");
     return DNMF_OK;
 }
 
@@ -571,6 +576,28 @@ int dnmf_comm_create(const void* unique_id, int nranks, int rank, int p_r, int p
     for (int q = 0; q < MAX_CHUNKS; ++q)
         if (hipEventCreateWithFlags(&c->ready[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->done[q], hipEventDisableTiming) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create: events"); }
+    *out = c;
+    return DNMF_OK;
+}
+
+// MEASUREMENT ONLY (bench.py --emulate-ranks on a one-GPU box): member `rank` of a p_r x p_c grid whose collectives -- world, row
+// and column groups alike -- are issued for real on a ONE-rank RCCL communicator: launch and stream-ordering costs are real, there
+// is no wire, and the buffers have the sizes of the real grid (the other members' allgather blocks are copies of this member's).
+// The step entry points then run exactly as on the grid; their results are not a factorisation of anything.
+int dnmf_comm_create_emulated(int p_r, int p_c, int rank, dnmf_comm_t** out) {
+    REQUIRE(out && p_r >= 1 && p_c >= 1 && rank >= 0 && rank < p_r * p_c, "comm_create_emulated: bad arguments (grid %d x %d, member %d)", p_r, p_c, rank);
+    Rccl* r = rccl();
+    if (!r) return fail(DNMF_ECOMM, "comm_create_emulated: no RCCL library found (librccl.so.1)");
+    dnmf_comm* c = new dnmf_comm();
+    c->nranks = p_r * p_c; c->rank = rank; c->p_r = p_r; c->p_c = p_c; c->emulated = 1;
+    ncclUniqueId id;
+    ncclResult_t e = r->GetUniqueId(&id);
+    if (e == ncclSuccess) e = r->CommInitRank(&c->world, 1, id, 0);
+    if (e != ncclSuccess) { delete c; return nccl_fail("comm_create_emulated", e); }
+    if (hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create_emulated: stream"); }
+    for (int q = 0; q < MAX_CHUNKS; ++q)
+        if (hipEventCreateWithFlags(&c->ready[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->done[q], hipEventDisableTiming) != hipSuccess) { dnmf_comm_destroy(c); return fail(DNMF_EHIP, "comm_create_emulated: events"); }
     *out = c;
     return DNMF_OK;
 }

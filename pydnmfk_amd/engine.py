@@ -833,6 +833,22 @@ class NativeComm:
         self.steps = 0                 # whole steps the choreography handed to the library (tests read it)
         return self
 
+    @classmethod
+    def emulated(cls, p_r, p_c, rank=0):
+        """MEASUREMENT ONLY (bench.py --emulate-ranks): member `rank` of a p_r x p_c grid on a one-GPU box; every collective of
+        the step entry points is issued for real on a one-rank RCCL communicator (dnmf_comm_create_emulated)."""
+        import ctypes
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        check(lib.dnmf_comm_create_emulated(int(p_r), int(p_c), int(rank), ctypes.byref(h)))
+        self.handle, self.size, self.rank, self.p_r, self.p_c = h, int(p_r) * int(p_c), int(rank), int(p_r), int(p_c)
+        self.device = torch.cuda.current_device()
+        self._ws = None
+        self.overlap_chunks = 1
+        self.steps = 0
+        self.is_emulated = True
+        return self
+
     def close(self):
         if getattr(self, "handle", None):
             host = getattr(self, "_direct_host", None)
@@ -1065,7 +1081,7 @@ def native_comm_for(params):
     if mode not in ("native", "native-hosted"):
         return None
     nc = getattr(params, "_native_comm", None)
-    stale = nc is not None and (nc.size != int(params.comm1.size) or (
+    stale = nc is not None and not getattr(nc, "is_emulated", False) and (nc.size != int(params.comm1.size) or (
         int(params.p_r) * int(params.p_c) == nc.size and (nc.p_r, nc.p_c) != (int(params.p_r), int(params.p_c))))
     if stale:      # (a grid that does not multiply to the communicator's size is an emulated share -- bench.py, tests -- and is left alone)
         # the bag was reused with another grid (pyDNMFk_Runner.run(grid=...) twice): every rank sees the same mismatch, so
