@@ -58,6 +58,16 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _req_g(G, k, name="G"):
+    """a Gram buffer the library WRITES: the zero-padded KP x KP block with ld = KP (include/dnmf.h) -- its size is part of the
+    contract (KP = 256 for 128 < k <= 256), so a smaller tensor is refused here rather than overrun there"""
+    _req(G, name)
+    n = kp(k)
+    if G.shape[0] < n or G.shape[1] != n or G.stride(0) != n:
+        raise ValueError("%s: rank %d needs the contiguous %d x %d Gram buffer (dnmf_kp), got %s with pitch %d" % (name, k, n, n, tuple(G.shape), G.stride(0)))
+    return G
+
+
 def kp(k):
     v = lib.dnmf_kp(int(k))
     if v < 0:
@@ -139,14 +149,14 @@ class HipOps:
 
     # ---- grams
     def gram_hht(self, H, out):
-        _req(H, "H"); _req(out, "G")
+        _req(H, "H"); _req_g(out, H.shape[0])
         k, n = H.shape
         ws = workspace(k, n, k, H.device)
         check(lib.dnmf_gram_hht(H.data_ptr(), k, n, _ld(H), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return out
 
     def gram_wtw(self, W, out):
-        _req(W, "W"); _req(out, "G")
+        _req(W, "W"); _req_g(out, W.shape[1])
         m, k = W.shape
         ws = workspace(m, k, k, W.device)
         check(lib.dnmf_gram_wtw(W.data_ptr(), m, k, _ld(W), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
@@ -186,7 +196,7 @@ class HipOps:
         if type(self).wta is not HipOps.wta:
             self.gram_wtw(W, G)
             return self.wta(A, W, out)
-        sfx = _req_a(A); _req(W, "W"); _req(out, "AtW"); _req(G, "G")
+        sfx = _req_a(A); _req(W, "W"); _req(out, "AtW"); _req_g(G, W.shape[1])
         m, n = A.shape
         k = W.shape[1]
         ws = workspace(m, n, k, A.device)

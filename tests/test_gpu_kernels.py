@@ -382,7 +382,11 @@ def test_errors_are_loud(ops):
     with pytest.raises(TypeError):
         ops.sqnorm(torch.rand(4, 4, device="cuda", dtype=torch.float64))        # float64
     with pytest.raises((ValueError, DnmfError)):
-        ops.gram_wtw(torch.rand(300, 200, device="cuda"), torch.empty(128, 128, device="cuda"))  # k > 128
+        ops.gram_wtw(torch.rand(300, 300, device="cuda"), torch.empty(256, 256, device="cuda"))  # k > 256
+    with pytest.raises(ValueError):     # a Gram buffer smaller than the KP x KP block the library writes (k = 200 -> KP = 256)
+        ops.gram_wtw(torch.rand(300, 200, device="cuda"), torch.empty(128, 128, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.gram_hht(torch.rand(40, 300, device="cuda"), torch.empty(32, 32, device="cuda"))
 
 
 def test_clock_probe_reads_a_plausible_clock():

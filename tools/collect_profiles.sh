@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes, condensed into profiles/<tag>_<workload>_*.
-# Usage: tools/collect_profiles.sh <tag> [workload ...]      workloads: bench kl kl16 kl32 kl64 c4 c5 elt128 hals16 hals64 k16 bf16 elt c2 split klsplit klsplit128  (default: the first eight)
+# Usage: tools/collect_profiles.sh <tag> [workload ...]      workloads: bench kl kl16 kl32 kl64 c4 c5 c5s c5s1 f64 wide elt128 hals16 hals64 k16 bf16 elt c2 split klsplit klsplit128  (default: the first eight)
 # The profiled program always stands directly after `--` (no env / bash -c / wrapper: the profiler's preloaded library has
 # already initialised the GPU, a re-exec from there takes the box down).  PMC counters are collected in their own runs.
 set -u
@@ -23,6 +23,10 @@ prog() {   # the command line of a workload: "full" (stats pass) or "short" (PMC
     elt128) echo "$R/tools/eltbench.py 128" ;;
     c4)     echo "$R/bench.py --config 4 --emulate-ranks 8 --steps 10 --warmup 2 --no-cpu-baseline" ;;
     c5)     echo "$R/bench.py --config 5 --no-cpu-baseline" ;;
+    c5s)    echo "$R/bench.py --config 5 --rows 1024 --cols 256 --no-cpu-baseline --no-kernel-timing" ;;
+    c5s1)   echo "$R/bench.py --config 5 --rows 1024 --cols 256 --no-cpu-baseline --no-kernel-timing --nmfk-batch 1" ;;
+    f64)    echo "$R/tools/f64bench.py 65536 4096 64" ;;
+    wide)   echo "$R/tools/kbench.py 65536 4096 192" ;;
     c2)     echo "$R/tools/config_bench.py c2" ;;
     split)  echo "$R/tools/splitbench.py 262144 8192 64 --nocheck" ;;
     klsplit) echo "$R/tools/klsplitbench.py 32768 16384 16 --nocheck" ;;
