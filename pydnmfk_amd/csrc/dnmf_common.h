@@ -124,6 +124,12 @@ inline void* batch_ptr(const void* p, int z) {
 }
 inline hipError_t batch_memset(void* p, int value, size_t bytes, hipStream_t st) {
     const int B = dnmf_batch_()->B;
+    if (B == 1) return hipMemsetAsync(p, value, bytes, st);
+    // the problems' copies are `stride` apart: ONE two-dimensional fill (B rows of `bytes`) instead of B fills -- the slot slab of
+    // the persistent HALS sweep is reset before every sweep, and at the NMFk sweep shape 20 fills per sweep were a third of the
+    // GPU time of a batched fit (profiles/r05_c5s_*)
+    const long stride = (char*)batch_ptr(p, 1) - (char*)p;
+    if (stride >= (long)bytes) return hipMemset2DAsync(p, (size_t)stride, value, bytes, (size_t)B, st);
     for (int z = 0; z < B; ++z) {
         const hipError_t e = hipMemsetAsync(batch_ptr(p, z), value, bytes, st);
         if (e != hipSuccess) return e;

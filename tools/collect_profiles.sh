@@ -43,4 +43,10 @@ for w in $WL; do
     timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $(prog $w short) > /dev/null 2> $OUT/pmc_write.log ;;
   esac
   (cd $R && python3 tools/summarize_profiles.py $OUT ${TAG}_$w "$(prog $w full | sed "s#$R/##")")
+  # only gpurun_out/ travels back (64 MiB at most): the condensed artefacts and the program's own output go to
+  # gpurun_out/profiles_out/ (copy them into profiles/), the raw traces are dropped on the box
+  mkdir -p $R/gpurun_out/profiles_out
+  cp $R/profiles/${TAG}_${w}_* $R/gpurun_out/profiles_out/ 2>/dev/null
+  cp $OUT/stdout.json $R/gpurun_out/profiles_out/${TAG}_${w}_output.json 2>/dev/null
+  rm -rf $OUT/stats $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
 done
