@@ -75,6 +75,24 @@ class custom_clustering:
         return pairs
 
     @staticmethod
+    def greedy_orders(dist):
+        """`change_order(greedy_lsa(dist[:, :, p]))` for every group p at once: the k strike-out rounds run on a [P][k k] array
+        (np.argmax takes the FIRST maximum in the row-major order of dist[:, :, p], as the per-group loop does), so the cost is
+        k vectorised rounds instead of k P small ones -- at the NMFk sweep shape the per-group Python loop was a third of the
+        clustering's wall time.  Returns a list of P orders (order[centroid] = feature)."""
+        k, _, P = dist.shape
+        X = np.array(np.transpose(dist, (2, 0, 1)), dtype=np.float64, copy=True)          # [P][centroid][feature]
+        orders = np.tile(np.arange(k), (P, 1))
+        rows = np.arange(P)
+        for _ in range(k):
+            flat = X.reshape(P, k * k).argmax(axis=1)
+            c, f = flat // k, flat % k
+            orders[rows, c] = f
+            X[rows, :, f] = -np.inf
+            X[rows, c, :] = -np.inf
+        return [list(map(int, o)) for o in orders]
+
+    @staticmethod
     def change_order(pairs):
         """:51-57  order[centroid] = feature."""
         ans = list(range(len(pairs)))
@@ -95,7 +113,7 @@ class custom_clustering:
         for rnd in range(rounds):
             # similarities of every group's vectors to the centroids: k x k x P, one allreduce per round
             dist = self._allreduce(self._centroid_similarities(centroids)).cpu().numpy()
-            orders = [self.change_order(self.greedy_lsa(dist[:, :, p])) for p in range(P)]
+            orders = self.greedy_orders(dist)           # = [change_order(greedy_lsa(dist[:, :, p])) for p in range(P)]
             permute_order.extend(orders)
             if any(j != identity for j in orders):
                 # all P groups reordered with one gather each (feature index = dim 1 of W_all, dim 0 of H_all)
@@ -145,14 +163,19 @@ class custom_clustering:
         distances = torch.arccos(torch.clamp(gram, -1.0, 1.0)).cpu().numpy().astype(np.float64)
         if k == 1:
             return np.ones((k, n_pert))
-        a = np.zeros((k, n_pert))
-        b = np.zeros((k, n_pert))
-        for kk in range(k):
-            for n in range(n_pert):
-                a[kk, n] = 1 / (n_pert - 1) * np.sum(distances[kk, n, kk, :])
-                tmp = np.sum(distances[kk, n, :, :], axis=1)
-                tmp[kk] = np.inf
-                b[kk, n] = 1 / n_pert * np.min(tmp)
+        return self._silhouettes_from_distances(distances)
+
+    @staticmethod
+    def _silhouettes_from_distances(distances):
+        """:147-160  a = mean distance to the own cluster's other members, b = mean distance to the nearest other cluster, per
+        (cluster, perturbation); the reference's double loop as array operations (same sums over the same contiguous axis)."""
+        k, n_pert = distances.shape[0], distances.shape[1]
+        S = np.sum(distances, axis=3)                                   # [k][P][k]: sum over the members of every cluster
+        idx = np.arange(k)
+        a = 1 / (n_pert - 1) * S[idx, :, idx]                           # own cluster
+        S = S.copy()
+        S[idx, :, idx] = np.inf
+        b = 1 / n_pert * np.min(S, axis=2)
         return (b - a) / np.maximum(a, b)
 
     def fit(self):
