@@ -380,6 +380,13 @@ int dnmf_comm_set_direct_timeout(dnmf_comm_t* comm, double seconds);
 /* on != 0: allreduces over ALL ranks that fit the regions (the packed exchange of the 1D steps, dnmf_comm_allreduce with
  * group 0) take the direct path; everything else stays on RCCL / the hosted function */
 int dnmf_comm_set_direct(dnmf_comm_t* comm, int on);
+/* With the direct path on, the W sweep of the HALS steps on grids whose W rows are spread over ranks (p_r > 1; every 2D grid) is ONE
+ * persistent launch instead of k column launches + k allreduces: every workgroup publishes its column partial into its slot of every
+ * rank's slab (two 1 MiB slabs by sweep parity live in the exported regions), polls its own rank's slab and sums all ranks' slots in
+ * slot order -- identical bits on every rank (csrc/dnmf_hals.h, HalsPeers).  Taken when EVERY rank can keep its rows resident (the
+ * ranks agree once per shape through a 16-float allreduce; otherwise all of them keep the column launches).  A peer that stalls
+ * longer than the direct time-out sets the sticky word dnmf_hals_sweep_status reports.  *count = such sweeps issued so far. */
+int dnmf_comm_hals_xsweeps(dnmf_comm_t* comm, unsigned long long* count);
 /* in-place SUM allreduce of `count` floats over all ranks through the peer regions, on `stream` */
 int dnmf_comm_allreduce_direct(dnmf_comm_t* comm, float* buf, size_t count, void* stream);
 /* the ONE-launch form for 1..8 doubles (the column norms of the HALS W sweep: k dependent 8-byte allreduces per iteration on

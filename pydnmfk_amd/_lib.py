@@ -94,6 +94,7 @@ SIGNATURES["dnmf_comm_direct_init"] = [c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_direct_connect"] = [c_void_p, c_void_p]
 SIGNATURES["dnmf_comm_set_direct"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_direct_teardown"] = [c_void_p]
+SIGNATURES["dnmf_comm_hals_xsweeps"] = [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
 SIGNATURES["dnmf_comm_set_direct_timeout"] = [c_void_p, ctypes.c_double]
 DIRECT_HANDLE_BYTES = 80           # DNMF_DIRECT_HANDLE_BYTES
 SIGNATURES["dnmf_comm_allreduce_direct"] = [c_void_p, c_void_p, c_size_t, c_void_p]

@@ -13,6 +13,11 @@
 #include "dnmf_common.h"
 #include "dnmf_host.h"
 
+// csrc/dnmf_hals.hip: the persistent W sweep with the column norms summed over the ranks of `pe` (nullptr: applicability check only)
+__attribute__((visibility("hidden"))) int dnmf_hals_sweep_w_peers_(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G,
+                                                                   float eps, void* ws, size_t ws_bytes, const HalsPeers* pe, int* nwg,
+                                                                   void* stream);
+
 namespace {
 
 struct Rccl {
@@ -80,6 +85,9 @@ struct dnmf_comm {
     unsigned long long direct_seq = 0, direct_small_seq = 0;
     unsigned long long direct_patience = 30ull * 100000000ull;   // 30 s of the 100 MHz wall clock (dnmf_comm_set_direct_timeout)
     int emulated = 0;                                            // measurement: ONE member of a p_r x p_c grid, every collective on a one-rank RCCL communicator
+    // cross-rank persistent HALS W sweep over the peer regions (hals_sweep_exchanged): the ranks' agreement for the last shape seen
+    unsigned long long hals_seq = 0;                             // sweeps issued: its parity selects the slot slab
+    long xs_m = -1; int xs_k = -1, xs_ok = 0, xs_first = 0, xs_total = 0;
 };
 
 namespace {
@@ -122,7 +130,7 @@ int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
 // SURVEY section 5 / VERDICT r03: the packed [W^T A | W^T W] message of config 3 is 2 MiB -- latency-bound for a ring over
 // point-to-point xGMI links.  The direct form reads PEER memory instead: every rank owns a region of uncached device memory
 // exported with hipIpcGetMemHandle and mapped by all the others;
-//   region = [flag1[P] | flag2[P] | status]  [send, parity 0 | send, parity 1]  [reduced, parity 0 | reduced, parity 1]
+//   region = [flag1[P] | flag2[P] | status]  [send, parity 0 | send, parity 1]  [reduced, parity 0 | reduced, parity 1]  [HALS slot slab x 2]
 // and one allreduce is, on the caller's stream:  copy the message into send[parity]  ->  signal + wait (everybody has written)  ->
 // REDUCE: rank r sums chunk r of all P send buffers in rank order (one owner per element: every rank ends with the same bits,
 // whatever the timing) into reduced[parity]  ->  signal + wait  ->  GATHER every chunk from its owner.  Four small launches; the
@@ -130,11 +138,14 @@ int resolve(dnmf_comm* cm, int g, ncclComm_t* out, const char* what) {
 // spinning on flags the peers store with system scope.  Alternating parity makes a trailing barrier unnecessary: a rank reaches
 // call s + 2 only after every peer has signalled in call s + 1, i.e. has finished reading the buffers of call s.
 // Remote data are read with system-scope loads (no stale lines from the previous step: the same addresses carry new data every
-// call).  A wait that sees no progress for about two seconds sets the region's status word (dnmf_comm_direct_status) and gives up.
+// call).  A wait that sees no progress for the configured time (30 s by default) sets the region's status word (dnmf_comm_direct_status) and gives up.
 // NOT measured on more than one GPU (this pool has none): bench.py treats it as a third arm of its warm-up A/B and only after
 // its result has matched RCCL's on the warm-up step.
 constexpr unsigned long long DIRECT_MAGIC = 0x444e4d4644495231ull;      // "DNMFDIR1"
 constexpr size_t DIRECT_HDR = 8192;       // flag1 @0, flag2 @1024, status @2048, small-message flags @3072, small-message slots @4096
+// behind the four message buffers: the two slot slabs (by sweep parity) of the cross-rank persistent HALS W sweep, 1 MiB each
+constexpr size_t HALS_SLAB_BYTES = (size_t)DNMF_TUNED_MAX_K * HALS_MAX_WG * sizeof(unsigned long long);
+inline size_t direct_hals_off(size_t cap) { return (DIRECT_HDR + 4 * cap * sizeof(float) + 255) & ~size_t(255); }
 struct DirectArgs {
     char* peer[DNMF_DIRECT_MAX_RANKS];
     int P, rank, par;
@@ -291,9 +302,55 @@ int allreduce_f64(dnmf_comm* cm, int g, double* buf, size_t count, hipStream_t s
 
 // The W sweep of HALS with cross-rank column norms (dist_nmf.py:884-891 with utils.norm :388-391): column kernel, 8-byte
 // allreduce, next column (which first applies the pending normalisation), final scale.  ss2 = k device doubles.
+// Do ALL ranks take the one-launch cross-rank sweep for this shape?  Decided once per (rows, rank k) by the ranks together: every rank
+// contributes its workgroup count (0: the persistent sweep does not apply here -- too many rows to keep resident, workspace too
+// small) through a world allreduce; the sweep is on when every rank can and the slots fit a column of the slab.  The counts also
+// give each rank its first slot.  (Host-synchronous, once per shape.)
+int hals_xsweep_agree(dnmf_comm* cm, float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    cm->xs_m = m; cm->xs_k = k; cm->xs_ok = 0;
+    int nwg = 0;
+    const bool mine = ws && ws_bytes >= 64 * sizeof(float) &&
+                      dnmf_hals_sweep_w_peers_(W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, nullptr, &nwg, (void*)st) == 0;
+    float host[DNMF_DIRECT_MAX_RANKS] = {};
+    host[cm->rank] = mine ? (float)nwg : -1.0e6f;                  // (a rank that cannot poisons the sum of its own slot)
+    float* dev = (float*)ws;
+    HIP_OK(hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, st), "hals sweep: agreement");
+    HIP_OK(hipStreamSynchronize(st), "hals sweep: agreement");
+    if (int rc = allreduce_f32(cm, G_WORLD, dev, DNMF_DIRECT_MAX_RANKS, st)) return rc;
+    HIP_OK(hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st), "hals sweep: agreement");
+    HIP_OK(hipStreamSynchronize(st), "hals sweep: agreement");
+    int total = 0, first = 0;
+    bool all = true;
+    for (int q = 0; q < cm->nranks; ++q) {
+        if (!(host[q] >= 1.0f)) all = false;
+        if (q < cm->rank) first += (int)host[q];
+        total += (int)host[q];
+    }
+    cm->xs_ok = all && total <= HALS_MAX_WG;
+    cm->xs_first = first; cm->xs_total = total;
+    return DNMF_OK;
+}
+
 int hals_sweep_exchanged(dnmf_comm* cm, float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                         double* ss2, void* stream) {
+                         double* ss2, void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = S(stream);
+    // ONE persistent launch when the direct peer regions are up (dnmf_comm_set_direct) and every rank can keep its rows resident:
+    // the column partials cross the ranks through the slot slabs in the exported regions (csrc/dnmf_hals.h, HalsPeers)
+    if (cm->direct_on && !cm->null_exchange && k <= DNMF_TUNED_MAX_K && cm->nranks <= DNMF_DIRECT_MAX_RANKS) {
+        if (cm->xs_m != m || cm->xs_k != k)
+            if (int rc = hals_xsweep_agree(cm, W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, st)) return rc;
+        if (cm->xs_ok) {
+            HalsPeers pe{};
+            pe.P = cm->nranks; pe.rank = cm->rank; pe.first = cm->xs_first; pe.total = cm->xs_total; pe.patience = cm->direct_patience;
+            const size_t off = direct_hals_off(cm->direct_cap) + (size_t)(cm->hals_seq & 1) * HALS_SLAB_BYTES;
+            for (int q = 0; q < cm->nranks; ++q) pe.slab[q] = reinterpret_cast<unsigned long long*>(cm->direct_peer[q] + off);
+            ++cm->hals_seq;
+            const int rc = dnmf_hals_sweep_w_peers_(W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, &pe, nullptr, stream);
+            if (rc != 1) return rc;
+            return fail(DNMF_EINVAL, "hals sweep: the persistent sweep the ranks agreed on does not apply on rank %d", cm->rank);
+        }
+    }
     HIP_OK(hipMemsetAsync(ss2, 0, (size_t)k * sizeof(double), st), "hals sweep: memset");
     int rc;
     for (int kk = 0; kk < k; ++kk) {
@@ -632,14 +689,18 @@ int dnmf_comm_direct_init(dnmf_comm_t* c, size_t max_floats, void* handle_out) {
     REQUIRE(!c->direct_peer[c->rank], "comm_direct_init: already set up");
     static_assert(sizeof(hipIpcMemHandle_t) + 2 * sizeof(unsigned long long) <= DNMF_DIRECT_HANDLE_BYTES, "IPC handle size");
     const size_t cap = (max_floats + 63) / 64 * 64;
-    const size_t bytes = DIRECT_HDR + 4 * cap * sizeof(float);
+    const size_t bytes = direct_hals_off(cap) + 2 * HALS_SLAB_BYTES;
     void* region = nullptr;
     // UNCACHED (fine-grained) device memory: flags and data are read by peers while kernels of this GPU run.  No fallback to an
     // ordinary allocation: its coherence across agents is not what the protocol was validated on -- the rank fails here, the
     // host's agreement round (NativeComm.enable_direct) keeps every rank on the communicator's own allreduce.
     hipError_t e = hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(DNMF_EHIP, "comm_direct_init: uncached allocation of %zu bytes: %s", bytes, hipGetErrorString(e)); }
-    if ((e = hipMemset(region, 0, bytes)) != hipSuccess) { (void)hipFree(region); return fail(DNMF_EHIP, "comm_direct_init: memset: %s", hipGetErrorString(e)); }
+    if ((e = hipMemset(region, 0, bytes)) != hipSuccess ||                                         // flags, buffers; the HALS slot slabs: "empty"
+        (e = hipMemset((char*)region + direct_hals_off(cap), 0xff, 2 * HALS_SLAB_BYTES)) != hipSuccess) {
+        (void)hipFree(region);
+        return fail(DNMF_EHIP, "comm_direct_init: memset: %s", hipGetErrorString(e));
+    }
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, region);
     if (e != hipSuccess) { (void)hipFree(region); return fail(DNMF_EHIP, "comm_direct_init: hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
@@ -698,6 +759,12 @@ int dnmf_comm_direct_teardown(dnmf_comm_t* c) {
 int dnmf_comm_set_direct_timeout(dnmf_comm_t* c, double seconds) {
     REQUIRE(c && seconds >= 0.001 && seconds <= 86400.0, "comm_set_direct_timeout: 0.001 .. 86400 seconds");
     c->direct_patience = (unsigned long long)(seconds * 1e8);
+    return DNMF_OK;
+}
+
+int dnmf_comm_hals_xsweeps(dnmf_comm_t* c, unsigned long long* count) {
+    REQUIRE(c && count, "comm_hals_xsweeps: null pointer");
+    *count = c->hals_seq;
     return DNMF_OK;
 }
 
@@ -1035,7 +1102,7 @@ int hals_fro_step_1d_impl(const TA* A, long m_l, long n_l, long lda, float* W, l
         if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;                 // :882
         if ((rc = AOps<TA>::aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
         if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
-        if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, stream);   // :884-891
+        if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, ws, kws, stream);   // :884-891
         else rc = hals_sweep_local(W, m_l, k, ldw, AH, k, Gx, eps, column_sweep, ss2, ws, kws, stream);
         if (rc) return rc;
     }
@@ -1090,7 +1157,7 @@ int hals_fro_step_2d_impl(const TA* A, long m_l, long n_l, long lda, float* W, l
         if (rc) return rc;
         const float* AH;
         if ((rc = g.scatter_to_w(V, &AH))) return rc;
-        if (c->nranks > 1) rc = hals_sweep_exchanged(c, W, m_w, k, ldw, AH, k, G, eps, ss2, stream);      // :428-434
+        if (c->nranks > 1) rc = hals_sweep_exchanged(c, W, m_w, k, ldw, AH, k, G, eps, ss2, ws, kws, stream);      // :428-434
         else rc = hals_sweep_local(W, m_w, k, ldw, AH, k, G, eps, 0, ss2, ws, kws, stream);
         if (rc) return rc;
     }

@@ -85,6 +85,16 @@ __device__ __forceinline__ void rebase(T*& p, const BatchTab& bt) { p = (T*)((ch
 // persistent HALS W sweep (csrc/dnmf_hals.h); the workspace query (csrc/dnmf.hip) sizes its slot slab from these
 constexpr int HALS_WG = 512;                 // threads per workgroup = rows per workgroup
 constexpr int HALS_MAX_WG = 1024;            // slots per column (2 per polling thread at most)
+// The same sweep ACROSS ranks (W's rows spread over the ranks of a row grid: the column norms are global, utils.py:388-391): every
+// workgroup publishes its column partial into its slot of EVERY rank's slab (slabs live in the IPC-exported regions of
+// csrc/dnmf_comm.hip), polls its own rank's slab and sums all ranks' slots in slot order.  P = 0: the local sweep.
+struct HalsPeers {
+    int P, rank;
+    int first;                               // this rank's first slot = workgroups of the ranks before it
+    int total;                               // slots per column = workgroups of all ranks (<= HALS_MAX_WG)
+    unsigned long long patience;             // ticks of the 100 MHz wall clock a poll may see no progress
+    unsigned long long* slab[DNMF_DIRECT_MAX_RANKS];   // every rank's slab of this sweep's parity, as mapped into this process
+};
 
 namespace {
 

@@ -197,8 +197,9 @@ __device__ __forceinline__ double block_sum_fixed(double v, double* red) {
 __device__ unsigned int g_hals_timeout = 0;
 
 template <int NQ>
-__device__ __forceinline__ double hals_poll(const unsigned long long* col, int nwg) {
+__device__ __forceinline__ double hals_poll(const unsigned long long* col, int nwg, unsigned long long patience = 0) {
     const int lane = threadIdx.x & 63;
+    const bool sys = patience != 0;          // cross-rank sweep: the slots are written by peers (system scope), waits are bounded in time
     unsigned long long bits[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bits[q] = (lane + 64 * q < nwg) ? HALS_EMPTY : 0ull;   // beyond the grid: +0.0, never awaited
@@ -207,13 +208,16 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
     // the sticky word g_hals_timeout (dnmf_hals_sweep_status reports it to the host) and lets the missing slots keep their
     // "empty" pattern, which is a NaN: the column norm -- and with it W -- turns NaN instead of the GPU hanging.
     bool complete = false;
-    for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+    const unsigned long long t0 = sys ? wall_clock64() : 0ull;
+    for (unsigned spins = 0; sys || spins < (1u << 21); ++spins) {
         unsigned long long v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int s = lane + 64 * q;
-            v[q] = __hip_atomic_load(col + (s < nwg ? s : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[q] = sys ? __hip_atomic_load(col + (s < nwg ? s : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                       : __hip_atomic_load(col + (s < nwg ? s : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (sys && (spins & 1023) == 1023 && wall_clock64() - t0 > patience) break;     // a peer is gone: say so (g_hals_timeout)
         bool missing = false;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -236,17 +240,23 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
 template <int KP, int KK>
 __device__ __forceinline__ void hals_col_step(float (&t)[KP], float& u, int k, bool live, float eps, const float* gs,
                                               unsigned long long* __restrict__ slab, double* __restrict__ ss2_out,
-                                              double* red, int nwg, int dbg) {
+                                              double* red, int nwg, int dbg, const HalsPeers& pe) {
     asm volatile("" ::: "memory");
     if (KK >= k) return;                                  // uniform
     const double sq = live ? (double)u * (double)u : 0.0;
     const double part = block_sum_fixed(sq, red);
-    unsigned long long* col = slab + (long)KK * HALS_MAX_WG;
-    if (threadIdx.x == 0) {
+    unsigned long long* col = (pe.P ? pe.slab[pe.rank] : slab) + (long)KK * HALS_MAX_WG;
+    {
         unsigned long long bits = (unsigned long long)__double_as_longlong(part);
         if (bits == HALS_EMPTY) bits = 0x7ff8000000000000ull;            // (a NaN with that payload cannot occur)
-        __hip_atomic_store(col + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pe.P == 0) {
+            if (threadIdx.x == 0) __hip_atomic_store(col + blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if ((int)threadIdx.x < pe.P) {             // thread q: this workgroup's slot in rank q's slab (the value is its own flag)
+            __hip_atomic_store(pe.slab[threadIdx.x] + (long)KK * HALS_MAX_WG + pe.first + blockIdx.x, bits, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+    if (pe.P) nwg = pe.total;                             // all ranks' workgroups, in rank order: the same sum on every rank
     // the one entry of G on the next column's critical path is read before the wait
     float g_next = 0.f;
     if constexpr (KK + 1 < KP) g_next = gs[KK * KP + KK + 1];
@@ -269,9 +279,10 @@ __device__ __forceinline__ void hals_col_step(float (&t)[KP], float& u, int k, b
     } else if (threadIdx.x < 256) {
         const int base = (threadIdx.x >> 6) * 256, cnt = nwg - base;
         if (cnt > 0) {
-            if (cnt <= 64) mine = hals_poll<1>(col + base, cnt);
-            else if (cnt <= 128) mine = hals_poll<2>(col + base, cnt);
-            else mine = hals_poll<4>(col + base, cnt);
+            const unsigned long long pat = pe.P ? pe.patience : 0ull;
+            if (cnt <= 64) mine = hals_poll<1>(col + base, cnt, pat);
+            else if (cnt <= 128) mine = hals_poll<2>(col + base, cnt, pat);
+            else mine = hals_poll<4>(col + base, cnt, pat);
         }
     }
     const double ss2 = block_sum_fixed(mine, red);
@@ -288,8 +299,8 @@ __device__ __forceinline__ void hals_col_step(float (&t)[KP], float& u, int k, b
 template <int KP, int... Ks>
 __device__ __forceinline__ void hals_sweep_all(float (&t)[KP], float& u, int k, bool live, float eps, const float* gs,
                                                unsigned long long* __restrict__ slab, double* __restrict__ ss2_out,
-                                               double* red, int nwg, int dbg, std::integer_sequence<int, Ks...>) {
-    (hals_col_step<KP, Ks>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg), ...);
+                                               double* red, int nwg, int dbg, const HalsPeers& pe, std::integer_sequence<int, Ks...>) {
+    (hals_col_step<KP, Ks>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg, pe), ...);
 }
 
 // waves per SIMD: what the row (KP registers) + the fp64 reductions + the slot polling hold; 8-wave workgroups, so the device keeps 4 / 4 / 2 x 256 CUs x 4 SIMDs x 64 rows = 262144 / 262144 / 131072 rows
@@ -297,7 +308,7 @@ __device__ __forceinline__ void hals_sweep_all(float (&t)[KP], float& u, int k, 
 template <int KP, bool VEC>
 __global__ __launch_bounds__(HALS_WG, KP <= 64 ? 4 : 2) void hals_w_sweep_kernel(
     float* __restrict__ W, long m, int k, long ldw, const float* __restrict__ T, long ldt, const float* __restrict__ G,
-    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out, int dbg, BatchTab bt) {
+    float eps, unsigned long long* __restrict__ slab, double* __restrict__ ss2_out, int dbg, HalsPeers pe, BatchTab bt) {
     REBASE(W); REBASE(T); REBASE(G); REBASE(slab); REBASE(ss2_out);
     __shared__ double red[HALS_WG / 64];
     // G (KP x KP, zero padded, symmetric) staged once per workgroup: every use is a row segment G[r][c0 .. c0+3] at a
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(HALS_WG, KP <= 64 ? 4 : 2) void hals_w_sweep_kernel
     }
     // 2. the column sweep
     float u = fmaxf(t[0], eps);
-    hals_sweep_all<KP>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg, std::make_integer_sequence<int, KP>{});
+    hals_sweep_all<KP>(t, u, k, live, eps, gs, slab, ss2_out, red, nwg, dbg, pe, std::make_integer_sequence<int, KP>{});
     // 3. store the row
     if (live) {
         float* orow = W + i * ldw;

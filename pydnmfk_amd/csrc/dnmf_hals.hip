@@ -61,9 +61,12 @@ long resident_workgroups(K kernel, int threads, size_t lds) {
     return (long)cus * per_cu;
 }
 
+// pe != nullptr: the cross-rank sweep (HalsPeers, dnmf_common.h) -- the slot slabs are the peers' exported ones (pe->slab), this
+// rank's slab of the sweep's parity is reset AFTER the kernel (see dnmf_comm.hip).  check_only: no launch, 0 = the sweep applies
 template <int KT>
 int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                      unsigned long long* slab, double* ss2, float* T, hipStream_t st) {
+                      unsigned long long* slab, double* ss2, float* T, hipStream_t st, const HalsPeers* pe = nullptr,
+                      bool check_only = false) {
     constexpr int KP = 32 * KT;
     const long ldt = KP;
     const bool vecw = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;   // pass 1 reads W, AH
@@ -92,8 +95,11 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
     }
     if (grid > HALS_MAX_WG || grid * dnmf_batch_()->B > (vec ? cap_v[dev] : cap_s[dev])) return 1;   // not applicable: the caller takes the column path
     if (ldw >= (1L << 23) || ldah >= (1L << 23)) return 1;                        // beyond the 32-bit tile offsets of pass 1: column path
-    if (batch_memset(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
+    if (check_only) return 0;
+    if (!pe && batch_memset(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
         return fail(DNMF_EHIP, "hals_sweep_w: memset failed");
+    HalsPeers peers{};                       // P = 0: the local sweep
+    if (pe) peers = *pe;
     {   // pass 1: T = AH - W G' (G' = G masked to l > j), the W-update kernel in its HALS mode
         constexpr size_t lds1 = (size_t)KP * (KP + 4) * sizeof(float);
         constexpr int OCC = KT == 4 ? 4 : 5;
@@ -115,9 +121,14 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
         if (rc) return rc;
     }
     static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
-    if (vec) DNMF_LAUNCH((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
-    else DNMF_LAUNCH((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg);
-    return check_launch("hals_sweep_w");
+    if (vec) DNMF_LAUNCH((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
+    else DNMF_LAUNCH((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
+    if (int rc = check_launch("hals_sweep_w")) return rc;
+    // cross-rank: this rank's slab of this parity goes back to "empty" behind the sweep that used it -- a peer writes the sweep
+    // after next into it only after finishing the next one, which needs this rank's next sweep, which is enqueued behind this fill
+    if (pe && hipMemsetAsync(pe->slab[pe->rank], 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
+        return fail(DNMF_EHIP, "hals_sweep_w: reset of the peer slab failed");
+    return DNMF_OK;
 }
 }  // namespace
 extern "C" {
@@ -144,6 +155,34 @@ int dnmf_hals_sweep_w(float* W, long m, int k, long ldw, const float* AH, long l
     if (rc != 1) return rc;
     return dnmf_hals_update_w(W, m, k, ldw, AH, ldah, G, eps, ss2, stream);   // too many rows to keep resident: one launch per column
 }
+
+}  // extern "C"
+
+// library-internal (csrc/dnmf_comm.hip): the persistent sweep with the column norms summed over the ranks of `pe`.
+// pe == nullptr: only tell whether the sweep applies to this shape on this device (0) or not (1); returns the workgroup count in *nwg
+__attribute__((visibility("hidden"))) int dnmf_hals_sweep_w_peers_(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G,
+                                                                   float eps, void* ws, size_t ws_bytes, const HalsPeers* pe, int* nwg,
+                                                                   void* stream);
+int dnmf_hals_sweep_w_peers_(float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws, size_t ws_bytes,
+                             const HalsPeers* pe, int* nwg, void* stream) {
+    const int kt = kt_of(k);
+    if (kt < 0 || !ws) return 1;
+    const int kp = 32 * kt;
+    const size_t slab_bytes = (size_t)kp * HALS_MAX_WG * sizeof(unsigned long long);
+    const size_t t_off = align256(slab_bytes + (size_t)kp * sizeof(double));
+    if (ws_bytes < t_off + (size_t)m * kp * sizeof(float)) return 1;
+    if (nwg) *nwg = (int)cdiv(m, HALS_WG);
+    unsigned long long* slab = (unsigned long long*)ws;                 // (unused by the cross-rank sweep: the peers' slabs serve)
+    double* ss2 = (double*)((char*)ws + slab_bytes);
+    float* T = (float*)((char*)ws + t_off);
+    hipStream_t st = S(stream);
+    const bool chk = pe == nullptr;
+    if (kt == 1) return launch_hals_sweep<1>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st, pe, chk);
+    if (kt == 2) return launch_hals_sweep<2>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st, pe, chk);
+    return launch_hals_sweep<4>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st, pe, chk);
+}
+
+extern "C" {
 
 int dnmf_hals_sweep_status(int* timed_out, void* stream) {
     REQUIRE(timed_out, "hals_sweep_status: null pointer");

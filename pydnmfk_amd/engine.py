@@ -901,6 +901,7 @@ class NativeComm:
                 ok, self.direct_error = 0, ex
         nbad = int(host_comm.allreduce(0 if ok else 1)) if host_comm.size > 1 else (0 if ok else 1)
         self.direct_ready = nbad == 0
+        self.direct_max_floats = int(max_floats)
         if not self.direct_ready:
             # nobody uses the regions: unmap and free them now (a later enable_direct starts from scratch); the barrier keeps a
             # region alive until every peer has unmapped it
@@ -910,6 +911,13 @@ class NativeComm:
         else:
             self._direct_host = host_comm
         return self.direct_ready
+
+    def hals_xsweeps(self):
+        """cross-rank persistent HALS W sweeps issued through the peer regions so far (dnmf_comm_hals_xsweeps)"""
+        import ctypes
+        n = ctypes.c_ulonglong(0)
+        check(lib.dnmf_comm_hals_xsweeps(self.handle, ctypes.byref(n)))
+        return int(n.value)
 
     def set_direct_timeout(self, seconds):
         check(lib.dnmf_comm_set_direct_timeout(self.handle, float(seconds)))
@@ -922,7 +930,8 @@ class NativeComm:
         yet visible to a system-scope load -- shows here, on the machine at hand, before any factor depends on it."""
         g = torch.Generator(device="cuda")
         g.manual_seed(977 + self.rank)
-        x = torch.rand(int(count), device="cuda", generator=g)
+        count = max(2, min(int(count), int(getattr(self, "direct_max_floats", count))) // 2 * 2)      # (an even count within the regions)
+        x = torch.rand(count, device="cuda", generator=g)
         ok = 1
         try:
             for _ in range(3):                                  # both parities of the buffers, twice

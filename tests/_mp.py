@@ -83,6 +83,9 @@ def run_case_rank(rank, world, port, name, q, use_hip, extra=None):
                     (itr, getattr(getattr(args, "_native_comm", None), "steps", None))
                 if (extra or {}).get("direct_allreduce"):                         # ... with its world allreduce over the peer regions
                     assert getattr(args._native_comm, "direct_ready", False) and not args._native_comm.direct_timed_out()
+                    if meta.get("method") == "hals" and p_r > 1 and meta["W_update"]:
+                        # ... and every W sweep as ONE persistent launch across the ranks (csrc/dnmf_hals.h, HalsPeers)
+                        assert args._native_comm.hals_xsweeps() == itr, (itr, args._native_comm.hals_xsweeps())
         q.put((rank, out, None))
         if world > 1:
             dist.barrier()

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
                     help="torch: dist.all_reduce between the launches; native: the library's own RCCL communicator, one C call per step")
     ap.add_argument("--chunks", type=int, default=None, help="overlap chunks of the H phase (default: the path's own default)")
+    ap.add_argument("--direct", action="store_true", help="with --exchange native: the peer regions of the direct allreduce are set up (this one "
+                    "rank is its own peer) -- the HALS W sweep then runs as ONE persistent launch whose column norms cross the ranks through "
+                    "the slot slabs in those regions (no wire here: the kernel's own cost)")
     a = ap.parse_args()
     from pydnmfk_amd.dist_comm import MPI_comm, TorchComm
     from pydnmfk_amd.dist_nmf import nmf_algorithms_1D
@@ -59,6 +62,10 @@ def main():
         p.exchange, p.native_always = "native", True
         p._native_comm = NativeComm(comms.comm, 1, 1)
         p._native_comm.set_always_exchange(True)
+        if a.direct:
+            kp = 32 if k <= 32 else (64 if k <= 64 else 128)
+            assert p._native_comm.enable_direct(comms.comm, k * max(m_l, n) + kp * kp + 4096)
+            p._native_comm.set_direct(True)
     g = torch.Generator(device=dev).manual_seed(1)
     A = torch.rand(m_l, n, device=dev, generator=g)
     W = torch.rand(m_l, k, device=dev, generator=g)
@@ -77,7 +84,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = {"ranks_emulated": a.ranks, "rows_per_rank": m_l, "n": n, "k": k, "collectives": not a.no_collectives,
-           "exchange": a.exchange, "chunks": a.chunks, "method": a.method,
+           "exchange": a.exchange, "chunks": a.chunks, "method": a.method, "direct": bool(a.direct),
            "ms_per_step": round(el / a.steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / a.steps * 1e3, 4)}
     print(json.dumps(out))
     if not a.no_collectives:
