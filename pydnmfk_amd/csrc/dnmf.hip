@@ -486,6 +486,30 @@ int dnmf_mu_update_w(float* W, long m, int k, long ldw, const float* AH, long ld
     REQUIRE(ldw < (1L << 23) && ldah < (1L << 23), "mu_update_w: leading dimension beyond the 32-bit tile offsets");
     const bool fast = aligned16(W) && aligned16(AH) && ldw % 4 == 0 && ldah % 4 == 0 && k % 4 == 0;
     hipStream_t st = S(stream);
+    {   // 16-row wave tiles (update_w16_kernel; round 5): full ranks, whole tiles, aligned rows, 2 GiB descriptor windows.  Measured on
+        // the isolation pass (k x 2^22, tools/dbg/w16_ab.sh): k = 32: 0.346 -> 0.310 ms (0.58 -> 0.65 of HBM), k = 64: 0.759 -> 0.632
+        // (0.53 -> 0.64), k = 128: 1.49 -> 1.40 (0.54 -> 0.58: the matrix work of 2 n k^2 flops bounds that one).  Workgroups walk
+        // their tiles grid-stride; capped at 1024 workgroups from k = 64 on (G staged once per several tiles: 0.648 -> 0.632 at
+        // k = 64), one tile per wave at k = 32.  DNMF_UPD_W16 = 0 (tuning build): the 32-row kernel; > 1: that cap.
+        static const long w16 = tune("DNMF_UPD_W16", 1);
+        if (w16 && fast && k == 32 * kt && m % 16 == 0 && 16 * ldw * 4 + k * 4 < 0x7fffffffL && 16 * ldah * 4 + k * 4 < 0x7fffffffL) {
+            const long tiles = m / 16;
+            auto run = [&](auto kt_c, auto nwv_c, auto occ_c) {
+                constexpr int KT_ = decltype(kt_c)::value, NWV_ = decltype(nwv_c)::value, OCC_ = decltype(occ_c)::value;
+                constexpr size_t lds = (size_t)(32 * KT_) * (32 * KT_ + 4) * sizeof(float);
+                static bool once = false;
+                if (!once) { allow_lds(update_w16_kernel<KT_, NWV_, OCC_>, lds); once = true; }
+                const long cap = w16 > 1 ? w16 : (KT_ == 1 ? (1L << 30) : 1024L);
+                const unsigned grid = (unsigned)std::min<long>(cdiv(tiles, NWV_), cap);
+                DNMF_LAUNCH((update_w16_kernel<KT_, NWV_, OCC_>), dim3(grid), dim3(64 * NWV_), lds, st, W, m, ldw, AH, ldah, G, eps);
+                return check_launch("mu_update_w(16)");
+            };
+            using std::integral_constant;
+            if (kt == 1) return run(integral_constant<int, 1>{}, integral_constant<int, 4>{}, integral_constant<int, 8>{});
+            if (kt == 2) return run(integral_constant<int, 2>{}, integral_constant<int, 4>{}, integral_constant<int, 8>{});
+            return run(integral_constant<int, 4>{}, integral_constant<int, 8>{}, integral_constant<int, 4>{});
+        }
+    }
     // waves per SIMD requested from the compiler (3.2 GB pass, k = 64: 3 / 4 / 5 / 6 -> 4.68 / 4.72 / 4.76 / 4.67 TB/s;
     // k = 128 holds 120 registers: 4)
     static const int var0 = (int)tune("DNMF_UPD_W", 0);

@@ -265,4 +265,61 @@ __global__ __launch_bounds__(64 * NWV, (EDGE || V == 1) ? edge_occ(KT, OCC) : OC
     }
 }
 
+// =============================================================================================== W update, 16-row wave tiles
+// Round 5.  update_w_seq_kernel puts 32 rows of W across the 32 lanes of a half-wave, so one 16-byte load
+// instruction touches 32 rows x 32 bytes: every 128-byte line of W and S is completed by FOUR instructions, and with 20 waves'
+// tiles in flight per CU the line is gone from the 32 KiB L1 before the fourth arrives (L2 hit rate 0.68 in profiles/r04c_elt_*:
+// two of three re-touches are L2 requests).  The kernel is bound by that request stream + its MFMAs back to back: 520 us of
+// traffic (what the MFMA-free ew_kernel<4> needs for the same bytes) + 221 us of matrix work = the 755 us measured.
+// Here a wave tile is 16 rows on v_mfma_f32_16x16x4_f32: lane (i, q) owns row i and the 16-byte pieces at columns 16 c + 4 q, so an
+// instruction touches 16 rows x 64 bytes -- a line is completed by TWO instructions, issued back to back.  Same arithmetic
+// order per element? No: the contraction order inside a row differs from the 32-row kernel (sums agree to fp32 rounding; both are
+// pinned against float64 in tests/test_gpu_kernels.py::test_mu_updates).
+//   D[j][i] = sum_l G[j][l] W[i][l]:  A operand lane (j = l & 15, q) = G[16 jt + j][16 c + 4 q + e], B operand lane (i, q) =
+//   W[i][16 c + 4 q + e] (e = 0..3: four steps per 16-byte piece), C/D lane (i, q) register r = (W G)[i][16 jt + 4 q + r] -- the
+//   piece (jt, q) of row i: the register that fed the product is the value the epilogue scales, as in the 32-row kernel.
+#define MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+template <int KT, int NWV, int OCC>
+__global__ __launch_bounds__(64 * NWV, OCC) void update_w16_kernel(float* __restrict__ W, long m, long ldw, const float* __restrict__ Sm,
+                                                                   long lds_, const float* __restrict__ G, float eps, BatchTab bt) {
+    REBASE(W); REBASE(Sm); REBASE(G);
+    constexpr int KP = 32 * KT, GP = KP + 4, NC = KP / 16;
+    extern __shared__ __attribute__((aligned(16))) float gs[];
+    for (int idx = threadIdx.x; idx < KP * KP / 4; idx += 64 * NWV) {
+        const int gr = idx / (KP / 4), gc = (idx % (KP / 4)) * 4;
+        *reinterpret_cast<f32x4*>(&gs[gr * GP + gc]) = *reinterpret_cast<const f32x4*>(G + gr * KP + gc);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long ntiles = m / 16;                                    // (m % 16 == 0: the host checks)
+    for (long t = (long)blockIdx.x * NWV + wid; t < ntiles; t += (long)gridDim.x * NWV) {
+        const long row0 = t * 16;
+        const i32x4 wrs = buf_rsrc(W + row0 * ldw), srs = buf_rsrc(Sm + row0 * lds_);
+        int woff = (int)(((long)i * ldw + 4 * q) * 4), soff = (int)(((long)i * lds_ + 4 * q) * 4);
+        asm volatile("" : "+v"(woff));                             // (keeps the piece offsets in the instructions' immediates)
+        asm volatile("" : "+v"(soff));
+        float w[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) buf_load<4>(w[c], wrs, woff + 64 * c, 0);
+#pragma unroll
+        for (int jt = 0; jt < NC; ++jt) {
+            float sv[4];
+            buf_load<4>(sv, srs, soff + 64 * jt, 0);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float a[4];
+                load_vec_raw<4>(a, &gs[(16 * jt + i) * GP + 16 * c + 4 * q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = MFMA16F(a[e], w[c][e], acc);
+            }
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = w[jt][r] * mu_quot(sv[r], acc[r] + eps);
+            buf_store<4>(o, wrs, woff + 64 * jt, 0);
+        }
+    }
+}
+
 }  // namespace
