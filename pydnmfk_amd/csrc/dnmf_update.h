@@ -322,4 +322,9 @@ __global__ __launch_bounds__(64 * NWV, OCC) void update_w16_kernel(float* __rest
     }
 }
 
+// (The H-side mirror of this kernel -- KP rows x 32 columns per wave, lane (i, q) owning two columns and the rows 16 t + 4 q + e, 8-wave
+// workgroups sharing the 66 KiB of G at k = 128 -- was built and measured in round 5: correct, and SLOWER than update_h_seq_kernel<4, 2,
+// 2> on the 6.4 GB pass (1.445-1.467 ms against 1.406: the H kernel's loads were whole lines already, and its 32x32x2 tiles read G
+// from LDS half as often per flop).  Not kept.)
+
 }  // namespace
