@@ -47,7 +47,7 @@ FLAGS = [
     ('checkpoint', _flag, False, False, 'keep a coarse NMFk checkpoint'),
     ('timing_stats', _flag, False, False, 'accepted for compatibility; ignored'),
     ('prune', _flag, False, False, 'drop all-zero rows / columns before factorising'),
-    ('precision', str, 'float32', False, 'storage of the data on the GPU: float32 or bfloat16 (Frobenius mu / hals; fp32 arithmetic)'),
+    ('precision', str, 'float32', False, 'dtype the input file is cast to (reference main.py:29): float32 (the tuned path), float64 (factorised in float64 on the fp64 matrix cores), float16 (read as such, computed in float32) or bfloat16 (storage of the data on the GPU, Frobenius mu / hals; fp32 arithmetic)'),
     ('gemm', str, 'fp32', False, 'arithmetic of the two big Frobenius contractions: fp32 (fp32 MFMA) or bf16x6 (six bf16 piece products, fp32-grade)'),
     ('rng', str, 'device', False, 'where random numbers are drawn: device (the data block goes to the GPU once, perturbations and the rand init are drawn there) or numpy (the reference\'s host stream: every fit draws and uploads host arrays)'),
     ('exchange', str, 'auto', False, 'who sequences the exchanges of a multi-rank step: torch (torch.distributed between the kernel launches), native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step) or auto (native for hals on grids with p_r > 1, where the per-column norm exchanges make the Python-sequenced step host-bound; torch otherwise)'),

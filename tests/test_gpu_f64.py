@@ -204,3 +204,28 @@ def test_reference_own_test_recipe_in_float64(grid):
         assert err is None, "rank %d failed:\n%s" % (rank, err)
         for key, (e, dt, name) in out.items():
             assert e < 1e-3 and dt == "float64" and name == "hip-f64", (grid, rank, key, e, dt, name)
+
+
+@pytest.mark.parametrize("rng", ["device", "numpy"])
+def test_cli_precision_float64(tmp_path, golden_dir, rng):
+    """main.py --precision float64 (reference main.py:29: the file is cast to that dtype and factorised in it): the factors come
+    back float64 and reproduce the matrix as well as the reported error says -- and the run agrees with the float32 run to float32"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A = np.load(golden_dir + "/data_swim.npz")["A"].astype(np.float64)
+    np.save(tmp_path / "swimcopy.npy", A)
+    errs = {}
+    for prec in ("float64", "float32"):
+        cmd = [sys.executable, os.path.join(root, "main.py"), "--process=pyDNMF", "--p_r=1", "--p_c=1", "--fpath=%s/" % tmp_path,
+               "--fname=swimcopy", "--ftype=npy", "--k=4", "--itr=60", "--norm=fro", "--method=mu", "--precision=%s" % prec,
+               "--rng=%s" % rng, "--results_path=%s/res_%s/" % (tmp_path, prec)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[prec] = float(out.stdout.strip().split("relative error =")[-1])
+        W = np.load(tmp_path / ("res_%s" % prec) / "W_factors" / "W_0.npy")
+        H = np.load(tmp_path / ("res_%s" % prec) / "H_factors" / "H_0.npy")
+        assert W.shape == (1024, 4) and H.shape == (4, 256) and W.dtype == np.dtype(prec) and H.dtype == np.dtype(prec)
+        assert abs(np.linalg.norm(A - W @ H) / np.linalg.norm(A) - errs[prec]) < (1e-10 if prec == "float64" else 1e-5)
+    assert 0.3 < errs["float64"] < 0.9
