@@ -229,3 +229,22 @@ def test_cli_precision_float64(tmp_path, golden_dir, rng):
         assert W.shape == (1024, 4) and H.shape == (4, 256) and W.dtype == np.dtype(prec) and H.dtype == np.dtype(prec)
         assert abs(np.linalg.norm(A - W @ H) / np.linalg.norm(A) - errs[prec]) < (1e-10 if prec == "float64" else 1e-5)
     assert 0.3 < errs["float64"] < 0.9
+
+
+def test_nmfk_sweep_in_float64(tmp_path, golden_dir):
+    """the NMFk driver on float64 data (perturbations, fits, clustering, regression fit and column errors all in float64): the
+    three-feature problem of the reference's NMFk fixture comes back with the same estimate and stable-cluster silhouettes"""
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from tests.test_nmfk_cpu import _args
+    z = np.load(golden_dir + "/nmfk_1x1.npz")
+    A = z["A"].astype(np.float64)
+    comms = MPI_comm(None, 1, 1)
+    nmfk = PyNMFk(A, factors=None, params=_args(tmp_path, comms))
+    nopt = nmfk.fit()
+    assert nopt == int(z["nopt"]) == 3
+    for k in (1, 2, 3):
+        st = nmfk.stats[k]
+        assert np.asarray(st["L_err"]).dtype == np.float64
+        assert np.allclose(st["clusterSilhouetteCoefficients"], z["k%d_clusterSilhouetteCoefficients" % k], atol=0.08), k
+        assert abs(st["avgErr"] / float(z["k%d_avgErr" % k]) - 1) < 2e-2, k      # (a float64 trajectory against the fixture's float32 one)
