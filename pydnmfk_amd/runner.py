@@ -16,7 +16,8 @@ from .pyDNMFk import PyNMFk
 class pyDNMFk_Runner:
     def __init__(self, init="rand", itr=5000, norm="kl", method="mu", verbose=False, checkpoint=False,
                  timing_stats=False, prune=False, precision="float32", perturbations=20, noise_var=0.015,
-                 sill_thr=0.6, sampling="uniform", process="pyDNMF", rng="device", exchange="auto"):
+                 sill_thr=0.6, sampling="uniform", process="pyDNMF", rng="device", exchange="auto", nmfk_split="data",
+                 nmfk_batch=True, direct_allreduce=False):
         self.init, self.itr, self.norm, self.method = init, itr, norm, method
         self.verbose, self.checkpoint, self.timing_stats, self.prune = verbose, checkpoint, timing_stats, prune
         self.precision = precision
@@ -28,6 +29,11 @@ class pyDNMFk_Runner:
         if exchange not in ("auto", "torch", "native"):
             raise ValueError("exchange should be auto, torch or native")
         self._exchange_request = exchange
+        # pyDNMFk over several GPUs: 'data' = the reference's block grid (X cut over the ranks), 'perturbations' = every rank holds the
+        # whole X and fits its share of the perturbations (run(grid=[1, 1]) on any number of ranks; pydnmfk_amd/pyDNMFk.py)
+        if nmfk_split not in ("data", "perturbations"):
+            raise ValueError("nmfk_split should be data or perturbations")
+        self.nmfk_split, self.nmfk_batch, self.direct_allreduce = nmfk_split, nmfk_batch, direct_allreduce
         self.fpath = self.ftype = self.fname = self.results_path = None
         self.k_range = self.step_k = None
         if self.process not in ["pyDNMFk", "pyDNMF"]:
@@ -57,13 +63,22 @@ class pyDNMFk_Runner:
         self.fpath, self.ftype, self.fname, self.results_path = fpath, ftype, fname, results_path
         self.results_paths = results_path
         self.k_range, self.step_k, self.grid, self.k = k_range, step_k, grid, k
-        self.comm = MPI_comm(self.main_comm, self.grid[0], self.grid[1])
+        shared = self.process == "pyDNMFk" and self.nmfk_split == "perturbations" and self.main_comm.size > 1
+        if shared:       # every rank reads the WHOLE matrix on a 1 x 1 grid of its own; PyNMFk shares the perturbations over main_comm
+            if self.grid[0] * self.grid[1] != 1:
+                raise ValueError("nmfk_split='perturbations' fits one-rank problems: grid=[1, 1] (the ranks share the perturbations)")
+            from .dist_comm import SoloGrid
+            self.comm = SoloGrid(self.main_comm.world_rank)
+        else:
+            self.comm = MPI_comm(self.main_comm, self.grid[0], self.grid[1])
         self.comm1 = self.comm.comm
         self.col_comm = self.comm.cart_1d_column()
         self.row_comm = self.comm.cart_1d_row()
         if self.verbose and self.rank == 0:
             print("Reading data now")
         A_ij = data_read(self).read()
+        if shared:
+            self.comm1 = self.main_comm
         numpy_out = True
         if self.rng == "device" and torch.cuda.is_available():
             import numpy as np
