@@ -48,14 +48,19 @@ template <int KT> struct KlUhtOcc { static constexpr int value = KT == 4 ? 2 : (
 // otherwise they refill the one set right after the quotient consumed it (second product + next first product of latency).
 // ABL (tuning build only, tools/kluht_ab.py): ablations that give wrong results but tell where the time goes -- 1: no
 // barrier, 2: no quotient, 4: A pieces loaded once, 8: H tile loaded / staged once, 16: no second product, 32: no first product, 64: line-coalesced A requests, 128: one LDS read per product and tile
-template <int KT, bool A2, int OCC = KlUhtOcc<KT>::value, int ABL = 0, int AUXA = 0>
+// MR (round 5): 32-row groups per wave.  MR = 2: a wave owns 64 rows -- two S^T tiles, two out strips, two sets of A
+// pieces -- and every H fragment read from LDS (both products) feeds TWO MFMAs: half the LDS reads per matrix instruction, the
+// one term of the k <= 64 kernels' instruction mix that a wider tile can shrink.  Same arithmetic per element in the same order:
+// bit identical to MR = 1.  The workgroup then covers 256 rows.
+template <int KT, bool A2, int OCC = KlUhtOcc<KT>::value, int ABL = 0, int AUXA = 0, int MR = 1>
 __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, BatchTab bt) {
+    static_assert(MR == 1 || ABL == 0, "the ablations exist for the one-group kernel");
     rebase_args(p, bt);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KP = 32 * KT, STAGE = KP * BK, NY = KP / 32, NG = 4 * KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-    const long arow0 = (long)blockIdx.x * 128;
-    const long arow = arow0 + wave * 32 + li;
+    const long arow0 = (long)blockIdx.x * 128 * MR;
+    const long arow = arow0 + wave * 32 * MR + li;                 // the lane's row of group 0; group r: + 32 r
     const long cbeg = (long)blockIdx.y * p.cols_per_split;
     long cend = cbeg + p.cols_per_split;
     if (cend > p.n) cend = p.n;
@@ -63,7 +68,10 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, Batc
     const float* Hb = p.H + (p.hblk ? (cbeg / p.hblk) * p.hextra : 0);    // this split's column block of H (block uniform)
     const i32x4 rsa = buf_rsrc(p.A + arow0 * p.lda + cbeg), rsh = buf_rsrc(Hb + cbeg);
     const int va = (ABL & 64) ? (int)((wave * 32 + (lane >> 3)) * p.lda * 4) + 16 * (lane & 7)    // (ablation: line-coalesced requests, wrong data)
-                              : (int)((wave * 32 + li) * p.lda * 4) + 16 * h;     // A[arow][c0 + 8 g + 4 h ..+3] at va + 32 g (+ tile offset)
+                              : (int)((wave * 32 * MR + li) * p.lda * 4) + 16 * h;     // A[arow][c0 + 8 g + 4 h ..+3] at va + 32 g (+ tile offset)
+    int vam[MR];                                                    // group r: 32 r rows further down
+#pragma unroll
+    for (int r = 0; r < MR; ++r) vam[r] = va + (int)(32 * r * p.lda * 4);
     const int lda32 = (int)(p.lda * 32);
     int vh[NY];
     stage_offsets<KP, 256>(vh, p.ldh, tid);
@@ -80,25 +88,31 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, Batc
     // staging: thread t owns chunk t & 7 of rows (t >> 3) + 32 it
     const int aw = (tid >> 3) * BK + (((tid & 7) ^ ((tid >> 4) & 7)) << 2);
 
-    f32x16 out[KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
+    f32x16 out[MR][KT];  // (U H^T)^T tile: rows j (KT tiles of 32), lanes i
 #pragma unroll
-    for (int jt = 0; jt < KT; ++jt)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[jt][r] = 0.f;
-    float wreg[NG][4];   // W[arow][8 s + 4 h + e]: the lane's own row, B operand of the first product for the whole kernel
+        for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
-    for (int s = 0; s < NG; ++s) load_vec_raw<4>(wreg[s], p.W + arow * p.ldw + 8 * s + 4 * h);
+            for (int r = 0; r < 16; ++r) out[m][jt][r] = 0.f;
+    float wreg[MR][NG][4];   // W[arow + 32 m][8 s + 4 h + e]: the lane's own rows, B operand of the first product for the whole kernel
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int s = 0; s < NG; ++s) load_vec_raw<4>(wreg[m][s], p.W + (arow + 32 * m) * p.ldw + 8 * s + 4 * h);
 
     f32x4 hst[NY];
-    float a0[4][4], a1[A2 ? 4 : 1][4];
+    float a0[MR][4][4], a1[A2 ? MR : 1][A2 ? 4 : 1][4];
     float hv[2][4];
     f32x4 hh[2];
 
-    auto load_a = [&](float (&a)[4][4], int so) {
+    auto load_a = [&](auto& a, int so) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if constexpr ((ABL & 64) != 0) buf_load<4, AUXA>(a[g], rsa, va, so + g * lda32);
-            else buf_load<4, AUXA>(a[g], rsa, va + 32 * g, so);
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if constexpr ((ABL & 64) != 0) buf_load<4, AUXA>(a[m][g], rsa, va, so + g * lda32);
+                else buf_load<4, AUXA>(a[m][g], rsa, vam[m] + 32 * g, so);
     };
     auto store_h = [&](float* stage) {
 #pragma unroll
@@ -118,36 +132,42 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, Batc
 
     // one 32-column tile: H tile in stage CUR (visible), hv[0] = its first-step values (already read), ac = its A pieces;
     // tn = the tile to request (clamped to the last one: the loop is branch free, a request past the end re-reads it unused)
-    auto tile = [&](auto CUR, float (&ac)[4][4], float (&an)[A2 ? 4 : 1][4], int tn) {
+    auto tile = [&](auto CUR, auto& ac, auto& an, int tn) {
         constexpr int cur = decltype(CUR)::value;
         const float* Hs = smem + cur * STAGE;
         float* Hn = smem + (cur ^ 1) * STAGE;
         const int so = tn * (BK * 4);                       // wave uniform
         if constexpr (!(ABL & 8)) stage_load_buf<NY, false>(hst, rsh, vh, so);
         if constexpr (A2 && !(ABL & 4)) load_a(an, so);
-        f32x16 st;   // S^T tile (rows c, lanes i), eps = initial value: S + eps costs nothing
+        f32x16 st[MR];   // S^T tiles (rows c, lanes i), eps = initial value: S + eps costs nothing
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = p.eps;
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] = p.eps;
         static_for<0, NG>([&](auto S) {
             constexpr int s = decltype(S)::value;
             if constexpr (s + 1 < NG) read_hv(hv[(s + 1) & 1], Hs, std::integral_constant<int, s + 1>{});
             else read_hh(hh[0], Hs, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if constexpr (!(ABL & 32)) st = MFMA32(hv[s & 1][e], wreg[s][e], st);
-                else st[e] += hv[s & 1][e] * wreg[s][e];
+            for (int m = 0; m < MR; ++m)                    // (group by group: four MFMAs on one chain behind its eps block, HAZARD 2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if constexpr (!(ABL & 32)) st[m] = MFMA32(hv[s & 1][e], wreg[m][s][e], st[m]);
+                    else st[m][e] += hv[s & 1][e] * wreg[m][s][e];
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int e = 0; e < 4; e += 2)
-                if constexpr (!(ABL & 2)) {                                   // U^T (dist_nmf.py:806): two reciprocals, ONE packed multiply
-                    const f32x2 r = {__builtin_amdgcn_rcpf(st[4 * g + e]), __builtin_amdgcn_rcpf(st[4 * g + e + 1])};
-                    const f32x2 q = f32x2{ac[g][e], ac[g][e + 1]} * r;
-                    st[4 * g + e] = q[0]; st[4 * g + e + 1] = q[1];
-                } else if (g == 0 && e == 0) st[0] += ac[0][0] + ac[1][1] + ac[2][2] + ac[3][3];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2)
+                    if constexpr (!(ABL & 2)) {                                   // U^T (dist_nmf.py:806): two reciprocals, ONE packed multiply
+                        const f32x2 r = {__builtin_amdgcn_rcpf(st[m][4 * g + e]), __builtin_amdgcn_rcpf(st[m][4 * g + e + 1])};
+                        const f32x2 q = f32x2{ac[m][g][e], ac[m][g][e + 1]} * r;
+                        st[m][4 * g + e] = q[0]; st[m][4 * g + e + 1] = q[1];
+                    } else if (g == 0 && e == 0) st[m][0] += ac[m][0][0] + ac[m][1][1] + ac[m][2][2] + ac[m][3][3];
         if constexpr (!A2 && !(ABL & 4)) load_a(ac, so);
         static_for<0, NG>([&](auto Q) {
             constexpr int q = decltype(Q)::value, g = q / KT, jt = q % KT;
@@ -159,9 +179,11 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, Batc
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if constexpr (!(ABL & 16)) out[jt] = MFMA32(hh[q & 1][e], st[4 * g + e], out[jt]);
-                else out[jt][e] += hh[q & 1][e] * st[4 * g + e];
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if constexpr (!(ABL & 16)) out[m][jt] = MFMA32(hh[q & 1][e], st[m][4 * g + e], out[m][jt]);
+                    else out[m][jt][e] += hh[q & 1][e] * st[m][4 * g + e];
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -189,13 +211,16 @@ __global__ __launch_bounds__(256, OCC) void kl_uht_pipe_kernel(KlUhtArgs p, Batc
     }
 
     // out[jt] (reg, lane): j = jt*32 + crow(reg, h), i = arow; registers 4g..4g+3 are 4 consecutive j
-    float* dst = p.out + (long)blockIdx.y * p.split_stride + arow * p.ldo;
 #pragma unroll
-    for (int jt = 0; jt < KT; ++jt)
+    for (int m = 0; m < MR; ++m) {
+        float* dst = p.out + (long)blockIdx.y * p.split_stride + (arow + 32 * m) * p.ldo;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(dst + jt * 32 + 8 * g + 4 * h) =
-                f32x4{out[jt][4 * g], out[jt][4 * g + 1], out[jt][4 * g + 2], out[jt][4 * g + 3]};
+        for (int jt = 0; jt < KT; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(dst + jt * 32 + 8 * g + 4 * h) =
+                    f32x4{out[m][jt][4 * g], out[m][jt][4 * g + 1], out[m][jt][4 * g + 2], out[m][jt][4 * g + 3]};
+    }
 }
 
 }  // namespace

@@ -37,6 +37,30 @@ int dnmf_kl_uht_pipe_(const float* A, long rowtiles, long n, long lda, const flo
 #undef KV
     }
 #endif
+#ifdef DNMF_TUNING
+    {   // MR = 2: 64-row wave tiles (256-row workgroups) for k <= 64 -- DNMF_KLUHT_MR: 0 off, 2 = with the second A register set, 3 = without.
+        // Round 5, measured and NOT shipped: bit identical, LDS instructions per MFMA 0.41 -> 0.20, LDS wait cycles
+        // -70 %, and the same time at k = 32 (0.655 -> 0.645 ms, MFMA busy 82 -> 80 % at 2.05 -> 2.02 GHz) and +25..50 % at k = 64 (250
+        // registers: two waves per SIMD) -- profiles/r05_kluht_mr_pmc.txt.  The LDS reads were not what holds these products back.
+        static const long mr = tune("DNMF_KLUHT_MR", 0);
+        if (mr >= 2 && kt <= 2 && rowtiles >= 2) {
+            const long pairs = rowtiles / 2;
+            const dim3 grid2((unsigned)pairs, (unsigned)nsplit);
+            if (kt == 1 && mr == 2) DNMF_LAUNCH((kl_uht_pipe_kernel<1, true, 2, 0, 0, 2>), grid2, block, lds, st, a);
+            else if (kt == 1) DNMF_LAUNCH((kl_uht_pipe_kernel<1, false, 2, 0, 0, 2>), grid2, block, lds, st, a);
+            else if (mr == 2) DNMF_LAUNCH((kl_uht_pipe_kernel<2, true, 2, 0, 0, 2>), grid2, block, lds, st, a);
+            else DNMF_LAUNCH((kl_uht_pipe_kernel<2, false, 2, 0, 0, 2>), grid2, block, lds, st, a);
+            if (int rc = check_launch("kl_uht(pipe, 64-row)")) return rc;
+            if (!(rowtiles & 1)) return DNMF_OK;
+            const long r0 = pairs * 256;                                  // one 128-row tile left: the one-group kernel on it
+            a.A += r0 * lda; a.W += r0 * ldw; a.out += r0 * ldo;
+            const dim3 grid1(1u, (unsigned)nsplit);
+            if (kt == 1) DNMF_LAUNCH((kl_uht_pipe_kernel<1, true>), grid1, block, lds, st, a);
+            else DNMF_LAUNCH((kl_uht_pipe_kernel<2, true>), grid1, block, lds, st, a);
+            return check_launch("kl_uht(pipe)");
+        }
+    }
+#endif
     if (kt == 1) DNMF_LAUNCH((kl_uht_pipe_kernel<1, true>), grid, block, lds, st, a);
     else if (kt == 2) DNMF_LAUNCH((kl_uht_pipe_kernel<2, true>), grid, block, lds, st, a);
     else DNMF_LAUNCH((kl_uht_pipe_kernel<4, false>), grid, block, lds, st, a);
