@@ -88,6 +88,8 @@ def parse_args():
                     help="N > 1: who issues the allreduce -- torch.distributed between the kernel launches, or the library's own "
                          "RCCL communicator inside a one-call step (csrc/dnmf_comm.hip); 'auto' (default) times both in the "
                          "warm-up and uses the faster")
+    ap.add_argument("--overlap-2d", action="store_true", help="config 4 on a 2D grid (torch-sequenced exchange): start the allgather of the updated "
+                    "H slices behind each step's H update (params.overlap_2d), so that it runs under the next step's first kernels")
     ap.add_argument("--overlap-chunks", default="auto",
                     help="N > 1: column chunks of the H phase's overlapped exchange; 'auto' (default) times 1 / 2 / 4 in "
                          "the warm-up and uses the fastest")
@@ -547,8 +549,14 @@ def run_config4(a, job):
         W = p.comm1.bcast(W, root=0) if p_r == 1 else W
     cls = nmf_algorithms_2D if two_d else nmf_algorithms_1D
 
+    if getattr(a, "overlap_2d", False) and two_d:
+        p.overlap_2d = True
+
     def step(it, params=p):
-        cls(A, W, H, params=params).update(clamp=(it % 10 == 0))
+        if two_d:
+            cls(A, W, H, params=params).update(clamp=(it % 10 == 0), more=True)
+        else:
+            cls(A, W, H, params=params).update(clamp=(it % 10 == 0))
 
     multi = world > 1 or emu > 1
     mg = None
@@ -603,6 +611,7 @@ def run_config4(a, job):
         else:
             p.exchange = modes[0]
         mg["exchange_used"] = p.exchange
+        mg["overlap_2d"] = bool(getattr(p, "overlap_2d", False)) and p.exchange == "torch"
 
     for it in range(a.warmup):
         step(it)

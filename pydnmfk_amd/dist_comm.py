@@ -160,6 +160,22 @@ class TorchComm:
         recv = rc.to(send.device)
         return [recv[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)]
 
+    def allgather_blocks_begin(self, x, shapes):
+        """Start `allgather_blocks(x, shapes)` and return a handle whose wait() gives the list of blocks.  Over RCCL (and gloo on
+        host tensors) the collective runs asynchronously: it starts when the kernels enqueued so far have produced `x`, and
+        whatever the caller launches before wait() overlaps it.  `x` must not change until wait()."""
+        if self._solo() or self._staged(x.reshape(-1)):
+            return _Ready(self.allgather_blocks(x, shapes))
+        numels = [int(np.prod(s)) for s in shapes]
+        mx = max(numels)
+        send = x.reshape(-1)
+        if send.numel() < mx:
+            send = torch.cat([send, send.new_zeros(mx - send.numel())])
+        send = send.contiguous()
+        rc = send.new_empty(self.size * mx)
+        work = dist.all_gather_into_tensor(rc, send, group=self.group, async_op=True)
+        return _Pending(work, lambda: [rc[q * mx: q * mx + numels[q]].view(*shapes[q]) for q in range(self.size)], keep=(send, rc))
+
     def reduce_scatter_rows(self, full, counts):
         """SUM reduce-scatter of a (sum(counts) x c) row-major buffer by row blocks (MPI Reduce_scatter, dist_nmf.py:169,202).
         Over RCCL the wire carries what the reference's does -- one block per member: equal blocks go straight into
@@ -205,6 +221,27 @@ class _Done:
         return True
 
 
+class _Ready:
+    """Handle of a gather that has already happened: wait() hands its result over."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def wait(self):
+        return self.value
+
+
+class _Pending:
+    """Handle of an asynchronous gather: wait() orders it before what the caller enqueues next and builds the result."""
+
+    def __init__(self, work, result, keep=()):
+        self.work, self.result, self.keep = work, result, keep
+
+    def wait(self):
+        self.work.wait()
+        return self.result()
+
+
 class NullExchange:
     """A communicator whose exchanges return at once (rank / size of the wrapped one).  MEASUREMENT ONLY: bench.py times
     the step with it to separate a rank's compute from the exchange; on more than one rank the results are wrong by
@@ -228,6 +265,9 @@ class NullExchange:
 
     def allreduce(self, x, op=None):
         return x
+
+    def allgather_blocks_begin(self, x, shapes):
+        return _Ready(self.allgather_blocks(x, shapes))
 
     def allgather_blocks(self, x, shapes):
         """every member's block = a copy of this rank's (right sizes for the kernels that follow, no exchange)"""
@@ -295,6 +335,22 @@ class EmulatedGroup:
         for q in range(1, self.size):
             rc[q * mx: (q + 1) * mx].copy_(rc[:mx])
         return [rc[q * mx: q * mx + int(np.prod(shapes[q]))].view(*shapes[q]) for q in range(self.size)]
+
+    def allgather_blocks_begin(self, x, shapes):
+        """the asynchronous form (params.overlap_2d): the real call is issued with async_op, the copies follow in wait()"""
+        mx = max(int(np.prod(sh)) for sh in shapes)
+        send = x.reshape(-1)
+        if send.numel() < mx:
+            send = torch.cat([send, send.new_zeros(mx - send.numel())])
+        send = send.contiguous()
+        rc = send.new_empty(self.size * mx)
+        work = dist.all_gather_into_tensor(rc[:mx], send, group=self.inner.group, async_op=True)
+
+        def result():
+            for q in range(1, self.size):
+                rc[q * mx: (q + 1) * mx].copy_(rc[:mx])
+            return [rc[q * mx: q * mx + int(np.prod(shapes[q]))].view(*shapes[q]) for q in range(self.size)]
+        return _Pending(work, result, keep=(send, rc))
 
     def reduce_scatter_rows(self, full, counts):
         c = full.shape[1]

@@ -315,10 +315,33 @@ class nmf_algorithms_2D(_Base):
             self.h_counts = [determine_block_params(q, (1, self.p_r), (self.k, n_l)).determine_block_shape_asymm()[1]
                              for q in range(self.p_r)]
 
-    def update(self, clamp=False):
+    def update(self, clamp=False, more=False):
+        """One step.  `more` (PyNMF.fit passes it for every step but the last): another step on the SAME factor tensors follows --
+        with `params.overlap_2d` the allgather of the updated H slices that the next step's W phase begins with (dist_nmf.py:
+        195-197, :283-287) is started now, behind this step's H update, and runs while this step's last kernels, the host's way
+        to the next step and that step's first kernels and allreduce are issued."""
         if not self._native_step(clamp):
             self._dispatch(clamp)
+            if more and getattr(self.params, "overlap_2d", False) and self.W_update and hasattr(self.cartesian1d_row, "allgather_blocks_begin"):
+                self._prefetch_h()
         return self.W_ij, self.H_ij
+
+    def _prefetch_h(self):
+        import weakref
+        h = self.cartesian1d_row.allgather_blocks_begin(self.H_ij, [(self.k, c) for c in self.h_counts])
+        # valid for this very tensor object in this very state: the next step's gather_H takes it, anything else discards it
+        self.params._h_prefetch = (weakref.ref(self.H_ij), self.H_ij._version, self.H_ij.data_ptr(), tuple(self.H_ij.shape), h)
+
+    def _take_prefetched_h(self):
+        pf = self.params.__dict__.pop("_h_prefetch", None)
+        if pf is None:
+            return None
+        ref, ver, ptr, shape, h = pf
+        blocks = h.wait()                      # (always completed: an abandoned collective must not outlive the step)
+        if ref() is self.H_ij and ver == self.H_ij._version and ptr == self.H_ij.data_ptr() and shape == tuple(self.H_ij.shape):
+            self.params._h_prefetch_hits = getattr(self.params, "_h_prefetch_hits", 0) + 1      # (tests read it)
+            return blocks
+        return None
 
     def _native_step(self, clamp):
         """`params.exchange = 'native'`: the whole MU step -- kernels, allreduce / allgather / reduce-scatter over the RCCL
@@ -372,7 +395,9 @@ class nmf_algorithms_2D(_Base):
         allgather's receive buffer itself is returned, viewed [p_r][k][n_h] -- the kernels read H as column blocks and nothing
         is re-assembled.  Otherwise (ragged slices, bf16-stored A, the bf16x6 operator set) the blocks are concatenated:
         one copy of k x n_l floats."""
-        blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
+        blocks = self._take_prefetched_h()     # (params.overlap_2d: started behind the previous step's H update)
+        if blocks is None:
+            blocks = self.cartesian1d_row.allgather_blocks(self.H_ij, [(self.k, c) for c in self.h_counts])
         if len(blocks) == 1:
             return blocks[0]
         if stacked and self._h_blockable(stacked):

@@ -208,7 +208,7 @@ class PyNMF:
             clamp = (i % 10 == 0)                                   # :155 / :170, fused into the step
             if self.topo == '2d':
                 self.W_ij, self.H_ij = nmf_algorithms_2D(self.A_ij, self.W_ij, self.H_ij, params=self.params,
-                                                         ops=ops).update(clamp=clamp)
+                                                         ops=ops).update(clamp=clamp, more=(i < self.itr - 1))
             else:
                 self.W_i, self.H_j = nmf_algorithms_1D(self.A_ij, self.W_i, self.H_j, params=self.params,
                                                        ops=ops).update(clamp=clamp)

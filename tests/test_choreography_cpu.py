@@ -204,3 +204,67 @@ def test_scratch_buffers_survive_a_shrinking_rank():
         p.comm1, p.eps, p.W_update, p.norm, p.method = _StackComm(), 1.1920929e-07, True, "fro", "mu"
         dist_nmf.nmf_algorithms_1D(A, torch.from_numpy(rs.rand(m_l, k).astype(np.float32)), torch.from_numpy(rs.rand(k, n_l).astype(np.float32)), params=p, ops=OracleOps()).update()
     dist_nmf.release_buffers()
+
+
+def _overlap2d_rank(rank, world, port, name, q):
+    """PyNMF.fit on one rank of a 2D golden case twice -- with and without params.overlap_2d -- through the checker back end"""
+    import os
+    import traceback
+    try:
+        import torch
+        import torch.distributed as dist
+        from oracle import nmf_oracle as orc
+        from pydnmfk_amd.dist_comm import MPI_comm
+        from pydnmfk_amd.pyDNMF import PyNMF
+        from pydnmfk_amd.utils import determine_block_params, parse
+        from tests._golden import load_case
+        from tests._ops_double import OracleOps
+        torch.set_num_threads(1)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        meta, A, W0, H0, z = load_case(name)
+        p_r, p_c = meta["grid"]
+        comms = MPI_comm(None, p_r, p_c)
+        itr = max(meta["itrs"])
+        res = []
+        for overlap in (False, True):
+            args = parse()
+            args.comm1, args.comm, args.p_r, args.p_c, args.k = comms.comm, comms, p_r, p_c, meta["k"]
+            args.row_comm, args.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
+            args.itr, args.init, args.verbose, args.prune = itr, "rand", False, False
+            args.norm, args.method, args.W_update, args.overlap_2d = meta["norm"], meta.get("method", "mu"), meta["W_update"], overlap
+            s, e = determine_block_params(rank, (p_r, p_c), A.shape).determine_block_index_range_asymm()
+            (w0, w1), (h0, h1) = orc.factor_ranges(rank, p_r, p_c, meta["m"], meta["n"])
+            W, H, err = PyNMF(A[s[0]:e[0] + 1, s[1]:e[1] + 1], factors=[W0[w0:w1], H0[:, h0:h1]], params=args, ops=OracleOps()).fit()
+            res.append((W, H, err, getattr(args, "_h_prefetch_hits", 0)))
+        same = bool(np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2])
+        q.put((rank, (same, res[0][3], res[1][3], itr), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("name", ["t24x12_2x2_fro_float32", "r50x39_4x2_kl_float32", "r50x39_3x2_fro_float32", "r50x39_2x3_hals_float32"])
+def test_2d_prefetch_of_the_next_h_gather_is_bit_equal(name):
+    """`params.overlap_2d`: the allgather of the updated H slices that the next step's W phase begins with is started behind this
+    step's H update (asynchronously) and taken over by the next step -- the same blocks, hence bit-identical factors and error, on
+    even and ragged 2D grids; every step but the first consumes a prefetched gather."""
+    import torch.multiprocessing as mp
+    from tests._golden import load_case
+    from tests._mp import free_port
+    meta = load_case(name)[0]
+    world = meta["grid"][0] * meta["grid"][1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_overlap2d_rank, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, err in res:
+        assert err is None, "rank %d failed:\n%s" % (rank, err)
+        same, hits_off, hits_on, itr = out
+        assert same and hits_off == 0 and hits_on == itr - 1, (rank, out)
