@@ -1057,12 +1057,21 @@ int dnmf_mu_kl_step_2d(const float* A, long m_l, long n_l, long lda, float* W, l
     if ((rc = dnmf_colsum(W, m_w, k, ldw, x, ws, kws, stream))) return rc;                                // KL_MU_update_H :371-389
     if ((rc = allreduce_f32(c, G_WORLD, x, (size_t)k, st))) return rc;
     if ((rc = g.gather_w(W, &Wi))) return rc;                                                             // :387
-    if (g.sliced) {                                                // WTU_glob :311-312 slice by slice
-        for (int q = 0; q < c->p_r; ++q) {
-            const float* Hq = g.blocked ? Hop + (size_t)q * k * n_h : Hop + q * n_h;                      // block q of the stack / those columns of H_j
-            if ((rc = dnmf_kl_wtu(A + q * n_h, m_l, n_h, lda, Wi, k, Hq, g.blocked ? n_h : hb, k, eps, Yb + (size_t)q * k * n_h, n_h,
-                                  ws, kws, stream))) return rc;
+    if (g.sliced && c->p_r > 1) {
+        // WTU_glob :311-312.  Round 5: ONE full-width product, then the k x n_l result is cut into the reduce-scatter's member blocks
+        // (scatter_to_h) -- p_r sliced launches that wrote the blocks directly cost 4.19 ms against 3.97 + 0.04 ms on the config-4
+        // block (each slice pays its own partial slabs and tail; tools/dbg/kl_slices.py).  The product wants H_j as one matrix:
+        // assembled from the gathered blocks (k x n_l floats, one copy per member).
+        if (g.blocked) {
+            float* Hj = g.at(g.L.hj_off);
+            for (int q = 0; q < c->p_r; ++q)
+                COPY2D(Hj + (size_t)q * n_h, n_l, Hop + (size_t)q * k * n_h, n_h, n_h, k, "mu_kl_step_2d: assemble H_j");
+            Hop = Hj; hb = n_l;
         }
+        if ((rc = dnmf_kl_wtu(A, m_l, n_l, lda, Wi, k, Hop, hb, k, eps, Y, n_l, ws, kws, stream))) return rc;
+        g.sliced = false;                                          // (scatter_to_h cuts Y into the member blocks)
+    } else if (g.sliced) {                                         // one member: its "slice" is the whole width, written where the update reads it
+        if ((rc = dnmf_kl_wtu(A, m_l, n_h, lda, Wi, k, Hop, g.blocked ? n_h : hb, k, eps, Yb, n_h, ws, kws, stream))) return rc;
     } else if ((rc = dnmf_kl_wtu(A, m_l, n_l, lda, Wi, k, Hop, hb, k, eps, Y, n_l, ws, kws, stream))) return rc;
     const float* WTU;
     if ((rc = g.scatter_to_h(Y, &WTU))) return rc;                                                        // :314-316

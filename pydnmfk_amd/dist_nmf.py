@@ -510,9 +510,17 @@ class nmf_algorithms_2D(_Base):
         if not W_update:                                           #  gathered is still current -- one exchange less)
             H_j = self.gather_H(stacked="kl_uht_hblocks")
         if H_j.dim() == 3:                                         # member q's columns are block q of the stack
-            nh = self.h_counts[0]
-            ks = self._product_scattered_to_H(                     # :311-312, :314-316
-                lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[c0 // nh], eps, out))
+            # :311-312, :314-316.  Round 5: ONE full-width product on H_j assembled from the gathered blocks, then the k x n_l result
+            # is cut into the reduce-scatter's member blocks -- p_r sliced launches that wrote the blocks directly cost 4.19 ms
+            # against 3.97 + 0.04 ms on the config-4 block (each slice pays its own partial slabs and tail; tools/dbg/kl_slices.py)
+            nh, p = self.h_counts[0], len(self.h_counts)
+            Hf = _buf(("Hjf", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l)
+            Hf.view(k, p, nh).copy_(H_j.permute(1, 0, 2))
+            Y = _buf(("Y", k, n_l), k * n_l, A)[: k * n_l].view(k, n_l)
+            ops.kl_wtu(A, W_i, Hf, eps, Y)
+            buf = _buf(("Yb", k, n_l), p * k * nh, A)[: p * k * nh]
+            buf.view(p, k, nh).copy_(Y.view(k, p, nh).permute(1, 0, 2))
+            ks = self.cartesian1d_row.reduce_scatter_rows(buf.view(p * k, nh), [k] * p)
         else:
             ks = self._product_scattered_to_H(
                 lambda c0, c1, out: ops.kl_wtu(A[:, c0:c1], W_i, H_j[:, c0:c1], eps, out))

@@ -133,8 +133,9 @@ class _StackComm:
 @pytest.mark.parametrize("norm,expected_cats", [("kl", 0), ("fro", 0)])
 def test_2d_step_reassembles_nothing_for_kl(norm, expected_cats, monkeypatch):
     """VERDICT r02 #3b: with equal, 32-column-aligned slices the 2D steps hand the allgather's receive buffer to the kernels
-    as it is (H as column blocks: `ops.kl_uht_hblocks` / `ops.aht_hblocks`; the H phase's slices are the blocks) -- no
-    torch.cat / copy between the collectives and the products.  Counted on the choreography itself with a two-member
+    as it is (H as column blocks: `ops.kl_uht_hblocks` / `ops.aht_hblocks`; the Frobenius H phase's slices are the blocks) --
+    no torch.cat between the collectives and the products.  (Round 5: the KL H phase re-packs H_j and its k x n_l result around
+    ONE full-width `kl_wtu` -- two strided copy_ calls, measured faster than p_r sliced launches; still no cat.)  Counted on the choreography itself with a two-member
     stand-in communicator."""
     import numpy as np
     import torch
