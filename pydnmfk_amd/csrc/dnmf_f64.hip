@@ -33,94 +33,198 @@ __device__ __forceinline__ void ld4(double (&d)[4], const double* __restrict__ r
     }
 }
 
+// N consecutive doubles (N = 1, 2, 4) as ld4 above
+template <int N>
+__device__ __forceinline__ void ldn(double (&d)[N], const double* __restrict__ row, long c, long cend, bool ok, bool vec) {
+    if constexpr (N == 4) ld4(d, row, c, cend, ok, vec);
+    else if constexpr (N == 2) {
+        if (ok && vec && c + 2 <= cend) { const f64x2 a = *reinterpret_cast<const f64x2*>(row + c); d[0] = a[0]; d[1] = a[1]; }
+        else { d[0] = (ok && c < cend) ? row[c] : 0.0; d[1] = (ok && c + 1 < cend) ? row[c + 1] : 0.0; }
+    } else d[0] = (ok && c < cend) ? row[c] : 0.0;
+}
+
 // ================================================================================================ NT form
-// out[split][r][j] = sum_{c in split} X[r][c] Y[j][c];  one wave = 16 rows x NT 16-column tiles of the output
-template <int NT>
+// out[split][r][j] = sum_{c in split} X[r][c] Y[j][c];  one wave = RT 16-row tiles x NT 16-column tiles of the output.
+// Round 5 (second pass): the first version gave a wave ONE row tile, so every wave read all of Y for 16 rows of X -- four times the
+// bytes of X through the L2 at k = 64 -- and nothing was in flight while its 16 MFMAs ran.  Now a Y fragment feeds RT row tiles
+// (RT NT = 16 accumulators of 16 x 16), the loads of chunk c + 16 are issued before the MFMAs of chunk c (two register sets), and
+// consecutive MFMAs are independent (e outermost).
+// CH = 16-column chunks per step: lane group q owns the 4 CH CONSECUTIVE columns c + 4 CH q .. of a step in both operands (the order of
+// the contraction is free), so a row moves in pieces of 128 CH bytes.
+constexpr int nt_ch(int rt, int nt) { return rt * nt <= 8 ? 2 : 1; }      // (two register sets of loads must fit 256 VGPRs)
+template <int RT, int NT>
 __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ X, long ldx, long m, long n, const double* __restrict__ Y,
                                                      long ldy, int kc, double* __restrict__ out, long ldo, long split_stride,
-                                                     long cols_per_split, int vec) {
+                                                     long cols_per_split, int vx, int vy) {
+    constexpr int CH = nt_ch(RT, NT);
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * RT);
     if (r0 >= m) return;
     const long cb = (long)blockIdx.y * cols_per_split;
     const long ce = cb + cols_per_split < n ? cb + cols_per_split : n;
-    f64x4 acc[NT];
+    f64x4 acc[RT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const bool rok = r0 + i < m;
-    const double* xrow = X + (r0 + i) * ldx;
-    for (long c = cb; c < ce; c += 16) {
-        double a[4];
-        ld4(a, xrow, c + 4 * q, ce, rok, vec != 0);
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double b[4];
-            ld4(b, Y + (long)(16 * t + i) * ldy, c + 4 * q, ce, 16 * t + i < kc, vec != 0);
+        for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const double* xrow[RT]; bool rok[RT];
+    const double* yrow[NT]; bool jok[NT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t] = MFMA64(a[e], b[e], acc[t]);
+    for (int rt = 0; rt < RT; ++rt) { const long r = r0 + 16 * rt + i; rok[rt] = r < m; xrow[rt] = X + (rok[rt] ? r : m - 1) * ldx; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const int j = 16 * t + i; jok[t] = j < kc; yrow[t] = Y + (long)(jok[t] ? j : kc - 1) * ldy; }
+    auto load = [&](double (&a)[RT][CH][4], double (&b)[NT][CH][4], long c) {
+#pragma unroll
+        for (int v = 0; v < CH; ++v) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ld4(a[rt][v], xrow[rt], c + 4 * CH * q + 4 * v, ce, rok[rt], vx != 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ld4(b[t][v], yrow[t], c + 4 * CH * q + 4 * v, ce, jok[t], vy != 0);
         }
+    };
+    auto mma = [&](const double (&a)[RT][CH][4], const double (&b)[NT][CH][4]) {
+#pragma unroll
+        for (int v = 0; v < CH; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[rt][t] = MFMA64(a[rt][v][e], b[t][v][e], acc[rt][t]);
+    };
+    constexpr long STEP = 16 * CH;
+    double a0[RT][CH][4], b0[NT][CH][4], a1[RT][CH][4], b1[NT][CH][4];
+    load(a0, b0, cb);
+    for (long c = cb; c < ce; c += 2 * STEP) {
+        const bool second = c + STEP < ce;
+        if (second) load(a1, b1, c + STEP);
+        mma(a0, b0);
+        if (!second) break;
+        if (c + 2 * STEP < ce) load(a0, b0, c + 2 * STEP);
+        mma(a1, b1);
     }
     double* o = out + (long)blockIdx.y * split_stride;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + 16 * rt + q + 4 * r;
+                const int col = 16 * t + i;
+                if (row < m && col < kc) o[row * ldo + col] = acc[rt][t][r];
+            }
+}
+
+// ================================================================================================ TN form
+// P[chunk][j][c] = sum_{r in chunk} X[r][j] Y[r][c];  one wave = 16 CT columns of Y x NT 16-row tiles of the output (CT NT = 16
+// accumulators: CT = 4 up to k = 64, 2 beyond).
+// The MFMA's 16 columns / 16 rows are a free permutation of the output's: column tile cb holds the columns c0 + CT i + cb, so lane i
+// reads CT consecutive doubles of a row of Y with one access (and writes its results the same way); row tile t holds the factor
+// columns (t / VJ) 16 VJ + VJ i + t % VJ (VJ = min(NT, 4) consecutive doubles of a row of X per lane).
+constexpr int tn_ct(int nt) { return nt <= 4 ? 4 : 2; }
+template <int NT>
+__global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ X, long ldx, int kc, const double* __restrict__ Y, long ldy,
+                                                     long n, long m, long rows_per_chunk, int ncolblk, long nwaves,
+                                                     double* __restrict__ P, long chunk_stride, long ldp, int vx, int vy) {
+    constexpr int VJ = NT < 4 ? NT : 4, NV = NT / VJ, CT = tn_ct(NT);
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= nwaves) return;
+    const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * (16 * CT);
+    const long rb = chunk * rows_per_chunk;
+    const long re = rb + rows_per_chunk < m ? rb + rows_per_chunk : m;
+    f64x4 acc[NT][CT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CT; ++cb) acc[t][cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    auto load = [&](double (&a)[4][NV][VJ], double (&b)[4][CT], long r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                              // four steps of 4 rows
+            const long row = r + 4 * u + q;
+            const bool ok = row < re;
+            const long rr = ok ? row : re - 1;
+            ldn<CT>(b[u], Y + rr * ldy, c0 + CT * i, n, ok, vy != 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ldn<VJ>(a[u][v], X + rr * ldx, 16 * VJ * v + VJ * i, kc, ok, vx != 0);
+        }
+    };
+    auto mma = [&](const double (&a)[4][NV][VJ], const double (&b)[4][CT]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb) acc[t][cb] = MFMA64(a[u][t / VJ][t % VJ], b[u][cb], acc[t][cb]);
+    };
+    double a0[4][NV][VJ], b0[4][CT], a1[4][NV][VJ], b1[4][CT];
+    load(a0, b0, rb);
+    for (long r = rb; r < re; r += 32) {
+        const bool second = r + 16 < re;
+        if (second) load(a1, b1, r + 16);
+        mma(a0, b0);
+        if (!second) break;
+        if (r + 32 < re) load(a0, b0, r + 32);
+        mma(a1, b1);
+    }
+    double* o = P + chunk * chunk_stride;
+    const bool vst = (ldp % 2 == 0) && (((uintptr_t)P & 15) == 0) && (chunk_stride % 2 == 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long row = r0 + q + 4 * r;
-            const int col = 16 * t + i;
-            if (row < m && col < kc) o[row * ldo + col] = acc[t][r];
+            const int ip = q + 4 * r;
+            const int j = (t / VJ) * 16 * VJ + VJ * ip + t % VJ;
+            if (j >= kc) continue;
+            double* dst = o + (long)j * ldp + c0 + CT * i;
+            if (vst && c0 + CT * i + CT <= n) {
+#pragma unroll
+                for (int cb = 0; cb < CT; cb += 2) *reinterpret_cast<f64x2*>(dst + cb) = f64x2{acc[t][cb][r], acc[t][cb + 1][r]};
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb)
+                    if (c0 + CT * i + cb < n) dst[cb] = acc[t][cb][r];
+            }
         }
 }
 
-// ================================================================================================ TN form
-// P[chunk][j][c] = sum_{r in chunk} X[r][j] Y[r][c];  one wave = one 16-column block of Y x NT 16-row tiles of the output
-template <int NT>
-__global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ X, long ldx, int kc, const double* __restrict__ Y, long ldy,
-                                                     long n, long m, long rows_per_chunk, int ncolblk, long nwaves,
-                                                     double* __restrict__ P, long chunk_stride, long ldp) {
-    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gw >= nwaves) return;
-    const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * 16;
-    const long rb = chunk * rows_per_chunk;
-    const long re = rb + rows_per_chunk < m ? rb + rows_per_chunk : m;
-    f64x4 acc[NT];
+// out[r][c] = sum_s P[s][r][c] in slab order (bitwise deterministic); a thread owns two consecutive columns (cols even, 16-byte rows:
+// the host checks) or one
+template <int V>
+__global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ P, long stride, long ldp, int nsplit,
+                                                         double* __restrict__ out, long ldo, long rows, long cols) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long cv = cols / V;
+    if (idx >= rows * cv) return;
+    const long r = idx / cv, c = (idx % cv) * V;
+    const double* p = P + r * ldp + c;
+    double s[V];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const bool cok = c0 + i < n;
-    for (long r = rb; r < re; r += 16) {
-        double b[4], a[NT][4];
+    for (int e = 0; e < V; ++e) s[e] = 0.0;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {                              // four slabs in flight, added in slab order
+        double v[4][V];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                              // four steps of 4 rows: 16 rows of loads in flight
-            const long row = r + 4 * u + q;
-            const bool ok = row < re;
-            b[u] = (ok && cok) ? Y[row * ldy + c0 + i] : 0.0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a[t][u] = (ok && 16 * t + i < kc) ? X[row * ldx + 16 * t + i] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (V == 2) { const f64x2 t = *reinterpret_cast<const f64x2*>(p + (long)(k + u) * stride); v[u][0] = t[0]; v[u][1] = t[1]; }
+            else v[u][0] = p[(long)(k + u) * stride];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA64(a[t][u], b[u], acc[t]);
+            for (int e = 0; e < V; ++e) s[e] += v[u][e];
     }
-    double* o = P + chunk * chunk_stride;
+    for (; k < nsplit; ++k)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int e = 0; e < V; ++e) s[e] += p[(long)k * stride + e];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 16 * t + q + 4 * r;
-            if (j < kc && cok) o[(long)j * ldp + c0 + i] = acc[t][r];
-        }
+    for (int e = 0; e < V; ++e) out[r * ldo + c + e] = s[e];
 }
-
-// out[r][c] = sum_s P[s][r][c] in slab order (bitwise deterministic)
-__global__ __launch_bounds__(256) void f64_reduce_kernel(const double* __restrict__ P, long stride, long ldp, int nsplit,
-                                                         double* __restrict__ out, long ldo, long rows, long cols) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const long r = idx / cols, c = idx % cols;
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += P[(long)k * stride + r * ldp + c];
-    out[r * ldo + c] = s;
+inline void launch_reduce64(const double* P, long stride, long ldp, int nsplit, double* out, long ldo, long rows, long cols, hipStream_t st) {
+    const bool v2 = cols % 2 == 0 && ldp % 2 == 0 && stride % 2 == 0 && ((uintptr_t)P & 15) == 0;
+    if (v2) hipLaunchKernelGGL(f64_reduce_kernel<2>, dim3((unsigned)cdiv(rows * (cols / 2), 256)), dim3(256), 0, st, P, stride, ldp, nsplit, out, ldo, rows, cols);
+    else hipLaunchKernelGGL(f64_reduce_kernel<1>, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, st, P, stride, ldp, nsplit, out, ldo, rows, cols);
 }
 
 // ================================================================================================ NN form, row strips
@@ -160,6 +264,89 @@ __global__ __launch_bounds__(256) void f64_nn_rows_kernel(const double* X, long 
                 else O[row * ldo + c0 + i] = O[row * ldo + c0 + i] * (a / (acc[r] + eps));
             }
         }
+    }
+}
+
+// The two m x n images (quotient, squared residual), column-resident: one wave owns 16 CT columns -- its k x 16 CT fragment of H stays
+// in registers -- and walks down a range of rows 16 at a time, the loads of the next row tile (its rows of W and its 16 x 16 CT piece of
+// A) issued before the MFMAs of this one.  The 16 CT columns are permuted as in the TN form (tile cb = columns c0 + CT i + cb: rows of
+// H, A and O move as CT consecutive doubles per lane); the contraction index of step s in lane group q is q KS + s, so a lane reads KS
+// CONSECUTIVE doubles of its row of W.  (The first version kept 16 rows of W resident and re-read all of H per row tile -- four
+// times A's bytes through the L2 at k = 64 -- with nothing in flight under its MFMAs: 2.67 ms at 65536 x 4096, k = 64.)
+constexpr int nn_ct(int ks) { return ks <= 16 ? 4 : 2; }
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) void f64_nn_cols_kernel(const double* __restrict__ X, long ldx, long m, int kc, const double* __restrict__ Y,
+                                                          long ldy, long n, const double* __restrict__ A, long lda, double* __restrict__ O,
+                                                          long ldo, double eps, long rows_per_wave, int ncolblk, long nwaves, int vx, int vy,
+                                                          int va, int vo) {
+    constexpr int CT = nn_ct(KS);
+    const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= nwaves) return;
+    const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * (16 * CT);
+    const long rb = chunk * rows_per_wave;
+    const long re = rb + rows_per_wave < m ? rb + rows_per_wave : m;
+    double hb[KS][CT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = q * KS + s;
+        ldn<CT>(hb[s], Y + (long)(j < kc ? j : kc - 1) * ldy, c0 + CT * i, n, j < kc, vy != 0);
+    }
+    auto load = [&](double (&xa)[KS], double (&av)[4][CT], long r0) {
+        const long row = r0 + i;
+        const double* xr = X + (row < re ? row : re - 1) * ldx;
+#pragma unroll
+        for (int v = 0; v < KS / 4; ++v) {
+            double t4[4];
+            ld4(t4, xr, q * KS + 4 * v, kc, row < re, vx != 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[4 * v + e] = t4[e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row2 = r0 + q + 4 * r;
+            ldn<CT>(av[r], A + (row2 < re ? row2 : re - 1) * lda, c0 + CT * i, n, row2 < re, va != 0);
+        }
+    };
+    auto tile = [&](const double (&xa)[KS], const double (&av)[4][CT], long r0) {
+        f64x4 acc[CT];
+#pragma unroll
+        for (int cb = 0; cb < CT; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb) acc[cb] = MFMA64(xa[s], hb[s][cb], acc[cb]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = r0 + q + 4 * r;
+            if (row >= re) continue;
+            double o[CT];
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb) {
+                const double a = av[r][cb], sum = acc[cb][r];
+                if constexpr (MODE == NN_QUOT) o[cb] = a / (sum + eps);
+                else { const double d = a - sum; o[cb] = d * d; }
+            }
+            double* dst = O + row * ldo + c0 + CT * i;
+            if (vo && c0 + CT * i + CT <= n) {
+#pragma unroll
+                for (int cb = 0; cb < CT; cb += 2) *reinterpret_cast<f64x2*>(dst + cb) = f64x2{o[cb], o[cb + 1]};
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < CT; ++cb)
+                    if (c0 + CT * i + cb < n) dst[cb] = o[cb];
+            }
+        }
+    };
+    double xa0[KS], av0[4][CT], xa1[KS], av1[4][CT];
+    load(xa0, av0, rb);
+    for (long r = rb; r < re; r += 32) {
+        const bool second = r + 16 < re;
+        if (second) load(xa1, av1, r + 16);
+        tile(xa0, av0, r);
+        if (!second) break;
+        if (r + 32 < re) load(xa0, av0, r + 32);
+        tile(xa1, av1, r + 16);
     }
 }
 
@@ -312,16 +499,20 @@ __global__ __launch_bounds__(256) void f64_hals_h_kernel(double* __restrict__ H,
 bool vec_ok(const double* p, long ld) { return ((uintptr_t)p & 15) == 0 && ld % 2 == 0; }
 
 struct TnPlan64 { int ncolblk; long nchunks, rows_per_chunk; };
-TnPlan64 plan_tn64(long m, long n) {
+TnPlan64 plan_tn64(long m, long n, int k) {
     TnPlan64 p;
-    p.ncolblk = (int)cdiv(n, 16);
-    long nch = std::max<long>(1, 4096 / p.ncolblk);
+    p.ncolblk = (int)cdiv(n, 16 * tn_ct(tiles16(k)));
+    long nch = std::max<long>(1, 2048 / p.ncolblk);
     nch = std::min<long>(nch, std::max<long>(1, cdiv(m, 64)));
     p.rows_per_chunk = round_up(cdiv(m, nch), 16);
     p.nchunks = cdiv(m, p.rows_per_chunk);
     return p;
 }
-long nt_splits(long m, long n) { return m <= 1024 ? std::max<long>(1, std::min<long>(256, n / 512)) : 1; }
+long nt_splits(long m, long n) {
+    if (m <= 1024) return std::max<long>(1, std::min<long>(256, n / 512));
+    const long forced = tune("DNMF_F64_NT_SPLIT", 0);
+    return forced > 0 ? std::min<long>(forced, std::max<long>(1, n / 512)) : 1;
+}
 
 int sum_all(bool sq, const double* X, long rows, long cols, long ldx, double* out, void* ws, size_t ws_bytes, hipStream_t st) {
     const int nparts = (int)std::min<long>(1024, cdiv(rows * cols, 256 * 8));
@@ -340,13 +531,27 @@ int colsum_any(bool sq, const double* X, long m, long n, long ldx, double* x, vo
     const dim3 grid((unsigned)cdiv(n, 256), (unsigned)chunks);
     if (sq) hipLaunchKernelGGL(f64_colsum_partial_kernel<true>, grid, dim3(256), 0, st, X, m, n, ldx, rpc, (double*)ws);
     else hipLaunchKernelGGL(f64_colsum_partial_kernel<false>, grid, dim3(256), 0, st, X, m, n, ldx, rpc, (double*)ws);
-    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const double*)ws, n, n, (int)chunks, x, n, 1L, n);
+    launch_reduce64((const double*)ws, n, n, (int)chunks, x, n, 1L, n, st);
     return check_launch("f64 colsum");
 }
 
 template <int MODE>
 int launch_nn_rows(const double* X, long ldx, long m, int kc, const double* Y, long ldy, long n, const double* A, long lda, double* O, long ldo,
                    double eps, hipStream_t st) {
+    if constexpr (MODE != NN_UPD_W) {
+        const int ks = kc <= 16 ? 4 : kc <= 32 ? 8 : kc <= 64 ? 16 : 32;
+        const int ncolblk = (int)cdiv(n, 16 * nn_ct(ks));
+        long nch = std::max<long>(1, 2048 / ncolblk);
+        nch = std::min<long>(nch, std::max<long>(1, cdiv(m, 64)));
+        const long rpw = round_up(cdiv(m, nch), 16);
+        const long nwaves = cdiv(m, rpw) * ncolblk;
+        const int vx = vec_ok(X, ldx), vy = vec_ok(Y, ldy), va = vec_ok(A, lda), vo = vec_ok(O, ldo);
+#define NNC_CASE(KS_) hipLaunchKernelGGL((f64_nn_cols_kernel<KS_, MODE>), dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, st, X, ldx, m, kc, Y, ldy, n, \
+                                         A, lda, O, ldo, eps, rpw, ncolblk, nwaves, vx, vy, va, vo)
+        if (ks == 4) NNC_CASE(4); else if (ks == 8) NNC_CASE(8); else if (ks == 16) NNC_CASE(16); else NNC_CASE(32);
+#undef NNC_CASE
+        return check_launch("f64 nn(cols)");
+    }
     // column range per wave: the whole width for the in-place W update (the wave owns its rows), else about 8192 waves in all
     long cpw = n;
     if (MODE != NN_UPD_W) {
@@ -374,8 +579,8 @@ size_t dnmf_f64_ws_bytes(long m, long n, int k) {
         return (size_t)std::max<long>(1, std::min<long>(cdiv(rows, 64), 2048 / std::max<long>(1, cdiv(cols, 256)))) * cols;
     };
     size_t b = 2048 * D;                                                               // block partials of the sums
-    b = std::max(b, (size_t)plan_tn64(m, n).nchunks * kp * round_up(n, 16) * D);       // W^T A
-    b = std::max(b, (size_t)plan_tn64(m, k).nchunks * kp * round_up(k, 16) * D);       // W^T W
+    b = std::max(b, (size_t)plan_tn64(m, n, k).nchunks * kp * round_up(n, 16) * D);       // W^T A
+    b = std::max(b, (size_t)plan_tn64(m, k, k).nchunks * kp * round_up(k, 16) * D);       // W^T W
     b = std::max(b, (size_t)nt_splits(k, n) * k * kp * D);                             // H H^T (column splits)
     if (nt_splits(m, n) > 1) b = std::max(b, (size_t)nt_splits(m, n) * m * kp * D);    // A H^T of a short A
     b = std::max(b, colsum_slabs(m, n) * D);                                           // column sums of an m x n image
@@ -397,16 +602,19 @@ int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int
         if (!ws || ws_bytes < (size_t)nsplit * m * kp * sizeof(double)) return fail(DNMF_EWS, "f64 aht: workspace too small");
         out = (double*)ws; ldo = kp; sstride = m * kp;
     }
-    const int vec = vec_ok(X, ldx) && vec_ok(Y, ldy) && cps % 2 == 0;
-    const dim3 grid((unsigned)cdiv(cdiv(m, 16), 4), (unsigned)nsplit);
-#define NT_CASE(NT_) hipLaunchKernelGGL((f64_nt_kernel<NT_>), grid, dim3(256), 0, st, X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps, vec)
+    const int vx = vec_ok(X, ldx) && cps % 2 == 0, vy = vec_ok(Y, ldy) && cps % 2 == 0;
     const int nt = tiles16(kc);
-    if (nt <= 1) NT_CASE(1); else if (nt <= 2) NT_CASE(2); else if (nt <= 4) NT_CASE(4); else NT_CASE(8);
+    int rt = (m >= 16 * 4 * 256 && nt <= 4) ? 4 : (m >= 16 * 2 * 256 ? 2 : 1);     // row tiles per wave: 16 accumulators at most
+    if (tune("DNMF_F64_NT_RT", 0)) rt = (int)tune("DNMF_F64_NT_RT", 0);
+#define NT_CASE(RT_, NT_) hipLaunchKernelGGL((f64_nt_kernel<RT_, NT_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)nsplit), dim3(256), 0, st, \
+                                             X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps, vx, vy)
+#define NT_ROWS(NT_) do { if (rt == 4) NT_CASE(4, NT_); else if (rt == 2) NT_CASE(2, NT_); else NT_CASE(1, NT_); } while (0)
+    if (nt <= 1) NT_ROWS(1); else if (nt <= 2) NT_ROWS(2); else if (nt <= 4) NT_ROWS(4); else if (rt >= 2) NT_CASE(2, 8); else NT_CASE(1, 8);
+#undef NT_ROWS
 #undef NT_CASE
     int rc = check_launch("f64 aht");
     if (rc || nsplit == 1) return rc;
-    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv(m * kc, 256)), dim3(256), 0, st, (const double*)ws, sstride, ldo, (int)nsplit, C, ldc,
-                       m, (long)kc);
+    launch_reduce64((const double*)ws, sstride, ldo, (int)nsplit, C, ldc, m, (long)kc, st);
     return check_launch("f64 aht(reduce)");
 }
 
@@ -415,21 +623,21 @@ int dnmf_f64_wta(const double* Y, long m, long n, long ldy, const double* X, int
                  void* stream) {
     REQ(X && Y && C && ws && m >= 1 && n >= 1 && kc >= 1 && kc <= DNMF_TUNED_MAX_K && ldy >= n && ldx >= kc && ldc >= n, "f64 wta: bad arguments");
     hipStream_t st = ST(stream);
-    const TnPlan64 p = plan_tn64(m, n);
+    const TnPlan64 p = plan_tn64(m, n, kc);
     const int kp = 16 * tiles16(kc);
     const long ldp = round_up(n, 16);
     if (ws_bytes < (size_t)p.nchunks * kp * ldp * sizeof(double)) return fail(DNMF_EWS, "f64 wta: workspace too small");
     const long nwaves = p.nchunks * p.ncolblk;
     const dim3 grid((unsigned)cdiv(nwaves, 4));
+    const int vx = vec_ok(X, ldx), vy = vec_ok(Y, ldy);
 #define TN_CASE(NT_) hipLaunchKernelGGL((f64_tn_kernel<NT_>), grid, dim3(256), 0, st, X, ldx, kc, Y, ldy, n, m, p.rows_per_chunk, p.ncolblk, nwaves, \
-                                        (double*)ws, (long)kp * ldp, ldp)
+                                        (double*)ws, (long)kp * ldp, ldp, vx, vy)
     const int nt = tiles16(kc);
     if (nt <= 1) TN_CASE(1); else if (nt <= 2) TN_CASE(2); else if (nt <= 4) TN_CASE(4); else TN_CASE(8);
 #undef TN_CASE
     int rc = check_launch("f64 wta");
     if (rc) return rc;
-    hipLaunchKernelGGL(f64_reduce_kernel, dim3((unsigned)cdiv((long)kc * n, 256)), dim3(256), 0, st, (const double*)ws, (long)kp * ldp, ldp,
-                       (int)p.nchunks, C, ldc, (long)kc, n);
+    launch_reduce64((const double*)ws, (long)kp * ldp, ldp, (int)p.nchunks, C, ldc, (long)kc, n, st);
     return check_launch("f64 wta(reduce)");
 }
 

@@ -106,6 +106,25 @@ def test_f64_primitives_match_torch(ops, m, n, k):
     assert rel(Hh, Hr) < 1e-11
 
 
+@pytest.mark.parametrize("m,n,k", [(200, 150, 6), (2100, 333, 20), (4200, 131, 64), (9000, 70, 100)])
+def test_f64_products_on_unaligned_views(ops, m, n, k):
+    """The big products on operands that rule out the 16-byte accesses: odd pitches, bases 8 bytes off (views of larger tensors) --
+    the kernels fall back to 8-byte accesses lane by lane, same sums."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(7 * m + n + k)
+    A = torch.rand(m + 1, n + 3, dtype=torch.float64, device=dev, generator=g)[1:, 1:n + 1]
+    W = torch.rand(m, k + 1, dtype=torch.float64, device=dev, generator=g)[:, 1:]
+    H = torch.rand(k, n + 1, dtype=torch.float64, device=dev, generator=g)[:, 1:]
+    tol = 1e-13
+    assert rel(ops.aht(A, H, torch.empty(m, k, dtype=torch.float64, device=dev)), A @ H.t()) < tol
+    assert rel(ops.wta(A, W, torch.empty(k, n, dtype=torch.float64, device=dev)), W.t() @ A) < tol
+    U = A / (W @ H + EPS)
+    assert rel(ops.kl_uht(A, W, H, EPS, torch.empty(m, k, dtype=torch.float64, device=dev)), U @ H.t()) < tol
+    assert rel(ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, dtype=torch.float64, device=dev)), W.t() @ U) < tol
+    R = A - W @ H
+    assert abs(float(ops.resid_sqnorm(A, W, H)) / float((R * R).sum()) - 1) < tol
+
+
 def _args(k, itr, norm, W_update=True, method="mu", prune=False):
     from pydnmfk_amd.dist_comm import MPI_comm
     from pydnmfk_amd.utils import parse
