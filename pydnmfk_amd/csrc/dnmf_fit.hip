@@ -5,6 +5,7 @@
 // of the per-step entry points, in the order the per-step callers issue them -- problem z of a batch runs the instructions
 // a single fit runs, on the same operands (csrc/dnmf_common.h "batched launches").
 #include "dnmf_common.h"
+#include "dnmf_small.h"
 
 // csrc/dnmf.hip: offsets of the step workspace {G, S, x, partials, total}
 __attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]);
@@ -15,8 +16,29 @@ enum { FIT_MU_FRO = 0, FIT_MU_KL = 1, FIT_HALS_FRO = 2 };
 
 inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
-// per-problem workspace: [ step workspace | s: KP floats (column sums of W) | ss2: KP doubles | sq: 2 doubles ]
-struct FitWs { size_t g_off, s_off, part_off, step_total, cs_off, ss2_off, sq_off, total; };
+// The persistent small-problem MU/KL fit (csrc/dnmf_small.h): which shapes take it and with what geometry.  fp32 A, k <= 32, the slab of A +
+// all of H + the slab's W in the 160 KiB of LDS of a CU (8-wave workgroups = 128-row slabs when that fits, else 4-wave = 64-row), at
+// most 64 slabs per problem -- in practice n up to ~500 columns and m up to 8192 rows: the reference's example sizes.
+struct SmallPlan { int kp, nw, P; long ns; size_t lds, part_floats, bytes; bool ok; };
+SmallPlan small_kl_plan(long m, long n, int k) {
+    SmallPlan s{};
+    if (k < 1 || k > 32 || n > 4096 || tune("DNMF_SMALL_FIT", 1) == 0) return s;
+    s.kp = k <= 16 ? 16 : 32;
+    s.ns = round_up(n, 16);
+    for (int nw : {8, 4}) {
+        const size_t lds = small_kl_lds(s.kp, nw, n);
+        const long P = cdiv(m, 16L * nw);
+        if (lds <= 160 * 1024 && P <= 64 && (nw == 4 || P >= 2)) { s.nw = nw; s.P = (int)P; s.lds = lds; break; }
+    }
+    if (!s.nw) return s;
+    s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp;
+    s.bytes = ((s.part_floats * sizeof(float) + 255) & ~size_t(255)) + 256;          // ... + the arrival counter
+    s.ok = true;
+    return s;
+}
+
+// per-problem workspace: [ step workspace | s: KP floats (column sums of W) | ss2: KP doubles | sq: 2 doubles | small-fit partials ]
+struct FitWs { size_t g_off, s_off, part_off, step_total, cs_off, ss2_off, sq_off, small_off, total; };
 
 FitWs fit_layout(long m, long n, int k) {
     size_t o[5];
@@ -30,7 +52,8 @@ FitWs fit_layout(long m, long n, int k) {
     f.cs_off = al256(f.step_total);
     f.ss2_off = f.cs_off + al256((size_t)kp * sizeof(float));
     f.sq_off = f.ss2_off + al256((size_t)kp * sizeof(double));
-    f.total = f.sq_off + 256;
+    f.small_off = f.sq_off + 256;
+    f.total = f.small_off + small_kl_plan(m, n, k).bytes;
     return f;
 }
 
@@ -68,6 +91,58 @@ int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float
     return DNMF_OK;
 }
 
+// all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
+template <int KP, int NW>
+int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    static int cus = 0;
+    if (!cus) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kl_fit_kernel<KP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(DNMF_EHIP, "small fit: device query failed");
+        cus = prop.multiProcessorCount;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, small_kl_fit_kernel<KP, NW>, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
+        clear_hip_error();
+        return DNMF_OK;                                             // (not taken: the step loop runs)
+    }
+    const long cap = (long)nb * cus;
+    if (cap < sp.P) return DNMF_OK;
+    const int per_launch = (int)std::min<long>(batch, cap / sp.P);
+    const int launches = (int)cdiv(batch, per_launch);
+    const int each = (int)cdiv(batch, launches);                       // balanced: 20 problems, room for 16 -> 10 + 10
+    for (int z0 = 0; z0 < batch; z0 += each) {
+        a.z0 = z0;
+        const int nz = std::min(each, batch - z0);
+        hipLaunchKernelGGL((small_kl_fit_kernel<KP, NW>), dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
+        int rc = check_launch("small_kl_fit_kernel");
+        if (rc) return rc;
+    }
+    *taken = true;
+    return DNMF_OK;
+}
+
+int small_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update, int itr,
+                 int batch, long a_stride, long w_stride, long h_stride, char* ws, const FitWs& f, void* stream, bool* taken) {
+    *taken = false;
+    const SmallPlan sp = small_kl_plan(m, n, k);
+    if (!sp.ok || itr < 1) return DNMF_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SmallKlArgs a{};
+    a.A = A; a.lda = lda; a.a_stride = a_stride; a.W = W; a.ldw = ldw; a.w_stride = w_stride; a.H = H; a.ldh = ldh; a.h_stride = h_stride;
+    a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = w_update;
+    a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
+    a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.dbg = (int)tune("DNMF_SMALL_DBG", 0);
+    a.patience = 200000000ull;                                         // 2 s of the 100 MHz wall clock
+    if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
+    if (hipMemset2DAsync(a.bar, f.total, 0, sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
+    if (sp.kp == 16) return sp.nw == 8 ? small_kl_launch<16, 8>(sp, a, batch, st, taken) : small_kl_launch<16, 4>(sp, a, batch, st, taken);
+    return sp.nw == 8 ? small_kl_launch<32, 8>(sp, a, batch, st, taken) : small_kl_launch<32, 4>(sp, a, batch, st, taken);
+}
+
 int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
              int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
              void* ws, size_t ws_bytes, void* stream) {
@@ -99,7 +174,16 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
     }
     char* base = (char*)ws;
     int rc = DNMF_OK;
-    for (int i = 0; i < itr && !rc; ++i) {                                            // pyDNMF.py:151-172
+    bool small = false;
+    if (method == FIT_MU_KL && !bf) {
+        // small problems: the whole loop as one persistent kernel per batch (csrc/dnmf_small.h); launched unbatched -- it indexes the problems itself
+        const int B = ctx->B;
+        ctx->B = 1;
+        rc = small_kl_fit((const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
+        ctx->B = B;
+        if (rc) return rc;
+    }
+    for (int i = 0; i < itr && !rc && !small; ++i) {                                  // pyDNMF.py:151-172
         const int clamp = (i % 10 == 0);
         if (method == FIT_MU_FRO)
             rc = bf ? dnmf_mu_fro_step_bf16a(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream)
@@ -131,7 +215,21 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
 
 }  // namespace
 
+// read-and-clear of the persistent small fit's sticky time-out word (csrc/dnmf_hals.hip: dnmf_hals_sweep_status reports it with the sweep's)
+__attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out) {
+    unsigned v = 0;
+    const unsigned zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_small_timeout), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return DNMF_EHIP;
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_small_timeout), &zero, sizeof(zero), 0, hipMemcpyHostToDevice) != hipSuccess) return DNMF_EHIP;
+    *out = v;
+    return DNMF_OK;
+}
+
 extern "C" {
+
+int dnmf_mu_kl_fit_persistent(long m, long n, int k) {
+    return (m >= 1 && n >= 1 && small_kl_plan(m, n, k).ok) ? 1 : 0;
+}
 
 size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch) {
     if (dnmf_kp(k) < 0 || m < 1 || n < 1 || batch < 1) return 0;

@@ -182,6 +182,8 @@ int dnmf_hals_sweep_w_peers_(float* W, long m, int k, long ldw, const float* AH,
     return launch_hals_sweep<4>(W, m, k, ldw, AH, ldah, G, eps, slab, ss2, T, st, pe, chk);
 }
 
+__attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out);      // csrc/dnmf_fit.hip
+
 extern "C" {
 
 int dnmf_hals_sweep_status(int* timed_out, void* stream) {
@@ -194,7 +196,9 @@ int dnmf_hals_sweep_status(int* timed_out, void* stream) {
         return fail(DNMF_EHIP, "hals_sweep_status: read failed");
     if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_hals_timeout), &zero, sizeof(zero), 0, hipMemcpyHostToDevice) != hipSuccess)
         return fail(DNMF_EHIP, "hals_sweep_status: clear failed");
-    *timed_out = v != 0;
+    unsigned int v2 = 0;                                   // the persistent small-problem fit (csrc/dnmf_small.h) reports through the same call
+    if (dnmf_small_timeout_take_(&v2) != DNMF_OK) return fail(DNMF_EHIP, "hals_sweep_status: read of the small-fit word failed");
+    *timed_out = (v != 0) || (v2 != 0);
     return DNMF_OK;
 }
 

@@ -1,0 +1,298 @@
+// dnmf_small.h -- a whole MU/KL fit of a SMALL problem as ONE persistent kernel (round 5).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf_fit.hip launches this one).
+//
+// Why: the reference's own examples factorise 1024 x 256 matrices (examples/dist_pynmfk_2d_Swim.py: k = 14..18, 5000 KL steps per
+// fit, 20 perturbations per k).  At that size a step is ~11 dependent launches of 4-12 us each, whatever the batch: 90 us per
+// batched step, host-bound and latency-bound at once (profiles/r05_fitgap_*).  Here a problem's rows are cut into slabs of R = 16 NW
+// rows, one workgroup per slab, all workgroups of all problems of a batch resident at once; a workgroup keeps its slab of A, its
+// rows of W and the whole of H in LDS for the entire fit and runs the iterations itself:
+//
+//   W phase (dist_nmf.py:806,810,828-830), local to the slab: wave w owns 16 rows.  Per 16-column tile: S^T = H^T W^T on
+//     v_mfma_f32_16x16x4_f32 -- its C registers are U = A / (S + eps) for (row = lane, four consecutive columns), which is exactly the
+//     A operand of the next product U H^T (the contraction runs over those columns) -- accumulated over the tiles, then
+//     W *= U H^T / (rowsum(H) + eps).
+//   H phase (:806,808,847-849): wave w owns the column tiles w, w + NW, ...; per 16-row tile S = W H with the operands swapped, so that
+//     U lands as (column = lane, four consecutive rows) = the B operand of W^T U.  The slab's k x n partial goes to global memory.
+//   grid barrier over the problem's workgroups; every workgroup sums the partials (fixed order: the same sum for any grid) for its share of
+//     H's elements, updates them (clamped every tenth step, pyDNMF.py:155-156), writes them; second barrier; everybody re-reads H.
+//
+// Two barriers per step among the <= 64 workgroups of ONE problem (an arrival counter per problem + release / acquire fences at
+// device scope); waits are bounded by the wall clock and report through a sticky word, as the persistent HALS sweep does.
+// The sums are fp32 MFMA accumulations in a different association than the big kernels' (dnmf_kl16.h): results agree with the step
+// path to fp32 rounding, not bit for bit (tests/test_gpu_fit.py pins both against float64).
+#pragma once
+#include "dnmf_common.h"
+
+namespace {
+
+#define SM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct SmallKlArgs {
+    const float* A; long lda, a_stride;          // strides between the problems of a batch, in elements
+    float* W; long ldw, w_stride;
+    float* H; long ldh, h_stride;
+    int m, n, k;
+    float eps;
+    int itr, w_update;
+    float* part; long part_stride;               // per problem: [P][KP][NS] partial W^T U, then [P][KP] column sums of the slabs' W
+    unsigned* bar; long bar_stride;              // per problem: arrival counter (zeroed before the launch)
+    unsigned long long patience;                 // ticks of the 100 MHz wall clock a barrier may wait
+    int z0;                                      // first problem of this launch
+    int dbg;                                     // tuning build: 1 = no barriers, 2 = no W phase, 4 = no H phase (timing only)
+};
+
+__device__ unsigned int g_small_timeout = 0;     // sticky: a barrier of a persistent fit gave up (dnmf_hals_sweep_status reports it)
+
+// sum over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15), the same value in all of them, fixed association
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        const int b = __builtin_bit_cast(int, x);
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+}
+
+// The data that cross workgroups inside the kernel (the partials, the updated H) move as relaxed DEVICE-scope atomic stores / loads:
+// coherent at the device level by themselves (write-through, no stale lines), so the barrier needs no cache write-back / invalidate
+// -- the first version bracketed the barriers with __threadfence() (an L2 write-back + invalidate each) and a step took 107 us.
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// arrive at / wait for the `gen`-th barrier of the problem's nwg workgroups (counter monotonic: gen nwg arrivals in all)
+__device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, unsigned long long patience, int dbg) {
+    if (dbg & 1) { __syncthreads(); return; }
+    __builtin_amdgcn_s_waitcnt(0);                         // this thread's device-scope stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 255u && wall_clock64() - t0 > patience) {
+                __hip_atomic_store(&g_small_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;                                     // the factors are garbage from here on; the host raises (status word)
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int KP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a) {
+    constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1;
+    const int z = a.z0 + blockIdx.z, p = blockIdx.x, P = gridDim.x;
+    const float* __restrict__ A = a.A + (long)z * a.a_stride;
+    float* __restrict__ W = a.W + (long)z * a.w_stride;
+    float* H = a.H + (long)z * a.h_stride;
+    float* part = a.part + (long)z * a.part_stride;
+    unsigned* bar = a.bar + (long)z * a.bar_stride;
+    const int m = a.m, n = a.n, k = a.k;
+    const float eps = a.eps;
+    const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
+    float* pcs = part + (long)P * KP * NS;                 // [P][KP] column sums of W per slab
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                      // [R][LDA]   the slab of A (zero beyond m / n)
+    float* Hs = As + R * LDA;                              // [KP][LDH]  all of H (zero beyond k / n)
+    float* Ws = Hs + KP * LDH;                             // [R][LDW]   the slab's rows of W (zero beyond m / k)
+    float* xs = Ws + R * LDW;                              // [KP]       row sums of H
+    float* cs = xs + KP;                                   // [NW][KP]   column sums of W per wave
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long r0 = (long)p * R;
+
+    for (int idx = tid; idx < R * NS; idx += T) {
+        const int r = idx / NS, c = idx - r * NS;
+        As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : 0.f;
+    }
+    for (int idx = tid; idx < R * KP; idx += T) {
+        const int r = idx / KP, j = idx - r * KP;
+        Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
+    }
+    auto load_h = [&]() {                                  // H -> LDS, then its row sums (every workgroup the same sums)
+        for (int idx = tid; idx < KP * NS; idx += T) {
+            const int j = idx / NS, c = idx - j * NS;
+            Hs[j * LDH + c] = (j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
+        }
+        __syncthreads();
+        for (int j = wv; j < KP; j += NW) {
+            float s = 0.f;
+            for (int c = lane; c < NS; c += 64) s += Hs[j * LDH + c];
+            s = row16_sum(s);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane == 0) xs[j] = s;
+        }
+        __syncthreads();
+    };
+    load_h();
+    // the wave's rows of W as an MFMA operand: lane (row i, q) holds W[16 wv + i][4 s + q]
+    float wreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+    const bool rowok = r0 + 16 * wv + i < m;
+    unsigned gen = 0;
+
+    for (int it = 0; it < a.itr; ++it) {
+        const bool clamp = (it % 10 == 0);
+        if (a.w_update && !(a.dbg & 2)) {
+            // ---------------------------------------------------------------- W phase: rows 16 wv .. 16 wv + 15
+            // four column tiles at a time: four independent MFMA chains in flight (one tile after the other was a chain of dependent
+            // MFMAs, LDS reads and reciprocals -- 5.9 us of a 21 us step); U H^T accumulates in two registers sets, added at the end
+            f32x4 acc2[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc2[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct0 = 0; ct0 < nct; ct0 += 4) {
+                int c0[4];
+                f32x4 d[4];                                // lane (row i, q) reg r = (W H)[row i][c0 + 4 q + r]
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { c0[t] = 16 * (ct0 + t < nct ? ct0 + t : nct - 1); d[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Hs[(4 * s + q) * LDH + c0[t] + i], wreg[s], d[t]);
+                float u[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0[t] + 4 * q]);
+                    const bool live = ct0 + t < nct;       // (a tile beyond the last one repeats it with U = 0)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) u[t][r] = live ? av[r] * __builtin_amdgcn_rcpf(d[t][r] + eps) : 0.f;
+                }
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)            // lane (j = i, q) reg r = (U H^T)[row 4 q + r][16 jt + i]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + i) * LDH + c0[t] + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc2[t & 1][jt] = SM_MFMA(u[t][r], hv[r], acc2[t & 1][jt]);
+                    }
+            }
+            // U H^T goes through the wave's own rows of Ws into the operand layout (W itself is in wreg)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ws[(16 * wv + 4 * q + r) * LDW + 16 * jt + i] = acc2[0][jt][r] + acc2[1][jt][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the tile is in LDS (same wave reads it back)
+            __builtin_amdgcn_wave_barrier();
+            float tt[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) tt[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                wreg[s] = wreg[s] * (tt[s] * __builtin_amdgcn_rcpf(xs[4 * s + q] + eps));
+                Ws[(16 * wv + i) * LDW + 4 * s + q] = wreg[s];
+            }
+        }
+        // column sums of the slab's W (the H update divides by the sums over all rows, :847-849)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float v = row16_sum(wreg[s]);
+            if (i == 0) cs[wv * KP + 4 * s + q] = v;
+        }
+        __syncthreads();
+        if (tid < KP) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += cs[w * KP + tid];
+            st_dev(&pcs[p * KP + tid], v);
+        }
+        // -------------------------------------------------------------------- H phase: column tiles wv, wv + NW, ...
+        for (int ct = wv; ct < ((a.dbg & 4) ? 0 : nct); ct += NW) {
+            const int c0 = 16 * ct;
+            f32x4 acc3[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc3[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt0 = 0; rt0 < NW; rt0 += 4) {        // four row tiles at a time (independent chains, as in the W phase)
+                f32x4 d[4];                                // lane (col i, q) reg r = (W H)[16 rt + 4 q + r][c0 + i]
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const float hb = Hs[(4 * s + q) * LDH + c0 + i];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
+                }
+                float u[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        u[t][r] = As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] * __builtin_amdgcn_rcpf(d[t][r] + eps);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], u[t][r], acc3[t & 1][jt]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience, a.dbg);
+        // -------------------------------------------------------------------- H update: this workgroup's share of the elements
+        if (tid < KP) {                                    // column sums of W over all slabs, slab order
+            float x = 0.f;
+            for (int g0 = 0; g0 < P; g0 += 8) {
+                float y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = ld_dev(&pcs[(g0 + u < P ? g0 + u : P - 1) * KP + tid]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x += (g0 + u < P) ? y[u] : 0.f;
+            }
+            cs[tid] = x;
+        }
+        __syncthreads();
+        for (int e = p * T + tid; e < KP * NS; e += P * T) {
+            const int j = e / NS, c = e - j * NS;
+            float sum = 0.f;
+            for (int g0 = 0; g0 < P; g0 += 8) {             // eight partials in flight, added in slab order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
+            }
+            float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(cs[j] + eps));
+            if (j < k && c < n) {
+                if (clamp) h = fmaxf(h, eps);
+                st_dev(&H[(long)j * a.ldh + c], h);
+            }
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience, a.dbg);
+        load_h();
+        if (clamp) {                                       // W = max(W, eps) after both updates (pyDNMF.py:155)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (rowok && 4 * s + q < k) wreg[s] = fmaxf(wreg[s], eps);
+                Ws[(16 * wv + i) * LDW + 4 * s + q] = wreg[s];
+            }
+            __syncthreads();
+        }
+    }
+    if (a.w_update || a.itr > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (rowok && 4 * s + q < k) W[(r0 + 16 * wv + i) * a.ldw + 4 * s + q] = wreg[s];
+    }
+}
+
+inline size_t small_kl_lds(int kp, int nw, long n) {
+    const long ns = (n + 15) & ~15L;
+    return ((size_t)(16 * nw) * (ns + 4) + (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + kp + (size_t)nw * kp) * sizeof(float);
+}
+
+}  // namespace

@@ -270,9 +270,10 @@ class HipOps:
         flag = ctypes.c_int(0)
         check(lib.dnmf_hals_sweep_status(ctypes.byref(flag), _stream()))
         if flag.value:
-            raise DnmfError("HALS: a persistent W sweep timed out -- its workgroups were not all resident (is the GPU shared "
-                            "with another process or stream?); the factors are NaN.  Set params.hals_sweep = 'columns' to use "
-                            "the per-column sweep, which needs no co-residency.")
+            raise DnmfError("a persistent kernel (the HALS W sweep, or the whole-fit kernel of a small MU/KL problem) timed out -- "
+                            "its workgroups were not all resident (is the GPU shared with another process or stream?); the "
+                            "factors are invalid.  params.hals_sweep = 'columns' selects the per-column HALS sweep and "
+                            "params.fit_loop = 'python' the step loop, which need no co-residency.")
 
     def hals_update_w_columns(self, W, AH, G, eps):
         """The same sweep as k column launches (what the persistent kernel falls back to; kept callable for A/B tests)."""

@@ -2,7 +2,9 @@
 
   * one library call (`dnmf_*_fit`) against the per-step Python loop it replaces (`params.fit_loop = 'python'`): the same
     kernels in the same order on the same operands -- BIT-identical factors; the two squared norms come from fp64 atomic
-    sums whose order is free, so the error is compared to 1e-12 relative;
+    sums whose order is free, so the error is compared to 1e-12 relative.  SMALL MU/KL problems are the exception: their
+    whole loop is one persistent kernel (csrc/dnmf_small.h) with the same update rule in another association of the fp32
+    sums -- both it and the step loop are held to a float64 run of the reference's loop (2e-4 of the largest entry);
   * a batch of B problems in one call (blockIdx.z = problem) against B calls of their own: bit-identical factors, problem
     by problem -- the property the NMFk sweep relies on when it fits its perturbations together;
   * the NMFk driver with and without batching: identical statistics and the same estimate.
@@ -16,6 +18,9 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 CASES = [  # m, n, k, method, norm, precision, itr
+    (1000, 250, 9, "mu", "kl", "float32", 31),        # persistent small-fit kernel: ragged slab, ragged columns, 128-row slabs
+    (4100, 400, 20, "mu", "kl", "float32", 12),       # ... 64-row slabs, k padded to 32, more slabs than fit one launch with 5 problems
+    (70, 33, 3, "mu", "kl", "float32", 23),           # ... one or two slabs
     (1024, 256, 16, "mu", "kl", "float32", 25),       # the reference's swim example shape, 16-wide kernels
     (1024, 256, 17, "mu", "kl", "float32", 21),       # k = 17: 32-wide kernels on zero-padded factor images
     (1024, 256, 4, "mu", "fro", "float32", 25),
@@ -53,10 +58,41 @@ def _problem(m, n, k, seed, precision):
     return A, torch.rand(m, k, device="cuda", generator=g), torch.rand(k, n, device="cuda", generator=g)
 
 
+def _persistent(m, n, k, method, norm, precision):
+    from pydnmfk_amd._lib import lib
+    return method == "mu" and norm == "kl" and precision == "float32" and lib.dnmf_mu_kl_fit_persistent(m, n, k) != 0
+
+
+def _kl_fit_f64(A, W, H, itr, w_update, eps=1.1920929e-07):
+    """PyNMF.fit with MU/KL on one rank in float64 (pyDNMF.py:151-194, dist_nmf.py:806-849)"""
+    A, W, H = A.double(), W.double().clone(), H.double().clone()
+    for i in range(itr):
+        if w_update:
+            W = W * (((A / (W @ H + eps)) @ H.t()) / (H.sum(1) + eps))
+        H = H * ((W.t() @ (A / (W @ H + eps))) / (W.sum(0)[:, None] + eps))
+        if i % 10 == 0:
+            W, H = torch.clamp(W, min=eps), torch.clamp(H, min=eps)
+    s = W.sum(0)
+    return W / (s + eps), H * s[:, None]
+
+
+def _close(X, Y, tol):
+    return float((X.double() - Y.double()).abs().max()) <= tol * float(Y.double().abs().max())
+
+
 @pytest.mark.parametrize("m,n,k,method,norm,precision,itr", CASES)
 def test_whole_fit_equals_step_loop(m, n, k, method, norm, precision, itr):
     from pydnmfk_amd.pyDNMF import PyNMF
     A, W0, H0 = _problem(m, n, k, 3, precision)
+    if _persistent(m, n, k, method, norm, precision):
+        for w_update in (True, False):
+            W1, H1, e1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update)).fit()
+            W2, H2, e2 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update, fit_loop="python")).fit()
+            Wr, Hr = _kl_fit_f64(A, W0, H0, itr, w_update)
+            for X, Y in ((W1, Wr), (H1, Hr), (W2, Wr), (H2, Hr)):
+                assert _close(X, Y, 2e-4), (w_update, float((X.double() - Y).abs().max()), float(Y.abs().max()))
+            assert abs(e1 - e2) <= 1e-4 * max(1e-3, abs(e2)) and np.isfinite(e1)
+        return
     for w_update in (True, False):
         f1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update))
         assert f1._whole_fit_ok(f1._ops())
