@@ -19,16 +19,20 @@ inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 // The persistent small-problem MU/KL fit (csrc/dnmf_small.h): which shapes take it and with what geometry.  fp32 A, k <= 32, the slab of A +
 // all of H + the slab's W in the 160 KiB of LDS of a CU (8-wave workgroups = 128-row slabs when that fits, else 4-wave = 64-row), at
 // most 64 slabs per problem -- in practice n up to ~500 columns and m up to 8192 rows: the reference's example sizes.
-struct SmallPlan { int kp, nw, P; long ns; size_t lds, part_floats, bytes; bool ok; };
+struct SmallPlan { int kp, nw, P; bool alds; long ns; size_t lds, part_floats, bytes; bool ok; };
 SmallPlan small_kl_plan(long m, long n, int k) {
     SmallPlan s{};
     if (k < 1 || k > 32 || n > 4096 || tune("DNMF_SMALL_FIT", 1) == 0) return s;
     s.kp = k <= 16 ? 16 : 32;
     s.ns = round_up(n, 16);
-    for (int nw : {8, 4}) {
-        const size_t lds = small_kl_lds(s.kp, nw, n);
-        const long P = cdiv(m, 16L * nw);
-        if (lds <= 160 * 1024 && P <= 64 && (nw == 4 || P >= 2)) { s.nw = nw; s.P = (int)P; s.lds = lds; break; }
+    // geometry by shape alone (a batched fit must equal single fits bit for bit): 128-row slabs with A in LDS when that fits; else
+    // 128-row slabs with A streamed from the L2 (H and the slab's W in LDS); else 64-row slabs with A in LDS
+    const struct { int nw; bool alds; } tries[3] = {{8, true}, {8, false}, {4, true}};
+    for (const auto& t : tries) {
+        const size_t lds = small_kl_lds(s.kp, t.nw, n, t.alds);
+        const long P = cdiv(m, 16L * t.nw);
+        if (tune("DNMF_SMALL_NOSTREAM", 0) && !t.alds) continue;
+        if (lds <= 160 * 1024 && P <= 64 && (t.nw == 4 || P >= 2)) { s.nw = t.nw; s.alds = t.alds; s.P = (int)P; s.lds = lds; break; }
     }
     if (!s.nw) return s;
     s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp;
@@ -92,11 +96,11 @@ int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float
 }
 
 // all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
-template <int KP, int NW>
+template <int KP, int NW, bool ALDS>
 int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
     static int cus = 0;
     if (!cus) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kl_fit_kernel<KP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kl_fit_kernel<KP, NW, ALDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
         int dev = 0;
         hipDeviceProp_t prop;
@@ -104,7 +108,7 @@ int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t s
         cus = prop.multiProcessorCount;
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, small_kl_fit_kernel<KP, NW>, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, small_kl_fit_kernel<KP, NW, ALDS>, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
         clear_hip_error();
         return DNMF_OK;                                             // (not taken: the step loop runs)
     }
@@ -116,7 +120,7 @@ int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t s
     for (int z0 = 0; z0 < batch; z0 += each) {
         a.z0 = z0;
         const int nz = std::min(each, batch - z0);
-        hipLaunchKernelGGL((small_kl_fit_kernel<KP, NW>), dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
+        hipLaunchKernelGGL((small_kl_fit_kernel<KP, NW, ALDS>), dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
         int rc = check_launch("small_kl_fit_kernel");
         if (rc) return rc;
     }
@@ -139,8 +143,11 @@ int small_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, f
     a.patience = 200000000ull;                                         // 2 s of the 100 MHz wall clock
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
     if (hipMemset2DAsync(a.bar, f.total, 0, sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
-    if (sp.kp == 16) return sp.nw == 8 ? small_kl_launch<16, 8>(sp, a, batch, st, taken) : small_kl_launch<16, 4>(sp, a, batch, st, taken);
-    return sp.nw == 8 ? small_kl_launch<32, 8>(sp, a, batch, st, taken) : small_kl_launch<32, 4>(sp, a, batch, st, taken);
+#define SMALL_CASE(KP_, NW_, AL_) if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_) return small_kl_launch<KP_, NW_, AL_>(sp, a, batch, st, taken)
+    SMALL_CASE(16, 8, true); SMALL_CASE(16, 8, false); SMALL_CASE(16, 4, true);
+    SMALL_CASE(32, 8, true); SMALL_CASE(32, 8, false); SMALL_CASE(32, 4, true);
+#undef SMALL_CASE
+    return DNMF_OK;
 }
 
 int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,

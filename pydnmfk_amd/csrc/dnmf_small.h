@@ -82,7 +82,10 @@ __device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, un
     __syncthreads();
 }
 
-template <int KP, int NW>
+// ALDS: the slab of A lives in LDS for the whole fit.  !ALDS (k > 16 at the example sizes: slab + H + W do not fit 160 KiB with 128-row
+// slabs, and 64-row slabs of 20 problems do not fit the device in one launch): A streams from the L2 / Infinity Cache -- a problem is
+// ~1 MB -- with the next group's elements requested before this group's MFMAs; LDS then holds H and the slab's W only.
+template <int KP, int NW, bool ALDS>
 __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a) {
     constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1;
     const int z = a.z0 + blockIdx.z, p = blockIdx.x, P = gridDim.x;
@@ -96,8 +99,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
     float* pcs = part + (long)P * KP * NS;                 // [P][KP] column sums of W per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                      // [R][LDA]   the slab of A (zero beyond m / n)
-    float* Hs = As + R * LDA;                              // [KP][LDH]  all of H (zero beyond k / n)
+    float* As = smem;                                      // [R][LDA]   the slab of A (zero beyond m / n); ALDS only
+    float* Hs = As + (ALDS ? R * LDA : 0);                 // [KP][LDH]  all of H (zero beyond k / n)
     float* Ws = Hs + KP * LDH;                             // [R][LDW]   the slab's rows of W (zero beyond m / k)
     float* xs = Ws + R * LDW;                              // [KP]       row sums of H
     float* cs = xs + KP;                                   // [NW][KP]   column sums of W per wave
@@ -105,18 +108,45 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long r0 = (long)p * R;
 
-    for (int idx = tid; idx < R * NS; idx += T) {
-        const int r = idx / NS, c = idx - r * NS;
-        As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : 0.f;
+    if constexpr (ALDS) {
+        for (int idx = tid; idx < R * NS; idx += T) {
+            const int r = idx / NS, c = idx - r * NS;
+            As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : 0.f;
+        }
     }
+    // streamed A (!ALDS): four consecutive elements of the wave's row (W phase) / one element of each of four rows (H phase), zero outside
+    const bool avec = (a.lda % 4 == 0) && (((unsigned long)A & 15) == 0);
+    auto a_row4 = [&](int c) -> f32x4 {                    // A[r0 + 16 wv + i][c .. c + 3]
+        const long row = r0 + 16 * wv + i;
+        if (row < m && c + 4 <= n && avec) return *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (row < m && c + e < n) ? A[row * a.lda + c + e] : 0.f;
+        return v;
+    };
+    auto a_col4 = [&](int rbase, int c) -> f32x4 {         // A[r0 + rbase + r][c], r = 0..3
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r0 + rbase + e < m && c < n) ? A[(r0 + rbase + e) * a.lda + c] : 0.f;
+        return v;
+    };
     for (int idx = tid; idx < R * KP; idx += T) {
         const int r = idx / KP, j = idx - r * KP;
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
     auto load_h = [&]() {                                  // H -> LDS, then its row sums (every workgroup the same sums)
-        for (int idx = tid; idx < KP * NS; idx += T) {
-            const int j = idx / NS, c = idx - j * NS;
-            Hs[j * LDH + c] = (j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
+        for (int idx0 = tid; idx0 < KP * NS; idx0 += 4 * T) {          // four loads in flight per thread
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
+            }
         }
         __syncthreads();
         for (int j = wv; j < KP; j += NW) {
@@ -148,7 +178,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc2[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 apre[4];                                 // (!ALDS) the next group's elements of A
+            if constexpr (!ALDS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (t < nct ? t : nct - 1) + 4 * q);
+            }
             for (int ct0 = 0; ct0 < nct; ct0 += 4) {
+                f32x4 acur[4];
+                if constexpr (!ALDS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acur[t] = apre[t];
+                    if (ct0 + 4 < nct) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (ct0 + 4 + t < nct ? ct0 + 4 + t : nct - 1) + 4 * q);
+                    }
+                }
                 int c0[4];
                 f32x4 d[4];                                // lane (row i, q) reg r = (W H)[row i][c0 + 4 q + r]
 #pragma unroll
@@ -160,7 +204,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 float u[4][4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0[t] + 4 * q]);
+                    f32x4 av;
+                    if constexpr (ALDS) av = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0[t] + 4 * q]);
+                    else av = acur[t];
                     const bool live = ct0 + t < nct;       // (a tile beyond the last one repeats it with U = 0)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) u[t][r] = live ? av[r] * __builtin_amdgcn_rcpf(d[t][r] + eps) : 0.f;
@@ -213,7 +259,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc3[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 hpre[4];
+            if constexpr (!ALDS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * t + 4 * q, c0 + i);
+            }
             for (int rt0 = 0; rt0 < NW; rt0 += 4) {        // four row tiles at a time (independent chains, as in the W phase)
+                f32x4 hcur[4];
+                if constexpr (!ALDS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hcur[t] = hpre[t];
+                    if (rt0 + 4 < NW) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
+                    }
+                }
                 f32x4 d[4];                                // lane (col i, q) reg r = (W H)[16 rt + 4 q + r][c0 + i]
 #pragma unroll
                 for (int t = 0; t < 4; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -228,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        u[t][r] = As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] * __builtin_amdgcn_rcpf(d[t][r] + eps);
+                        u[t][r] = (ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r]) * __builtin_amdgcn_rcpf(d[t][r] + eps);
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
 #pragma unroll
@@ -290,9 +350,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     }
 }
 
-inline size_t small_kl_lds(int kp, int nw, long n) {
+inline size_t small_kl_lds(int kp, int nw, long n, bool alds) {
     const long ns = (n + 15) & ~15L;
-    return ((size_t)(16 * nw) * (ns + 4) + (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + kp + (size_t)nw * kp) * sizeof(float);
+    return ((alds ? (size_t)(16 * nw) * (ns + 4) : 0) + (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + kp + (size_t)nw * kp) * sizeof(float);
 }
 
 }  // namespace
