@@ -31,7 +31,6 @@ SmallPlan small_kl_plan(long m, long n, int k) {
     for (const auto& t : tries) {
         const size_t lds = small_kl_lds(s.kp, t.nw, n, t.alds);
         const long P = cdiv(m, 16L * t.nw);
-        if (tune("DNMF_SMALL_NOSTREAM", 0) && !t.alds) continue;
         if (lds <= 160 * 1024 && P <= 64 && (t.nw == 4 || P >= 2)) { s.nw = t.nw; s.alds = t.alds; s.P = (int)P; s.lds = lds; break; }
     }
     if (!s.nw) return s;
@@ -139,7 +138,6 @@ int small_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, f
     a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = w_update;
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
-    a.dbg = (int)tune("DNMF_SMALL_DBG", 0);
     a.patience = 200000000ull;                                         // 2 s of the 100 MHz wall clock
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
     if (hipMemset2DAsync(a.bar, f.total, 0, sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");

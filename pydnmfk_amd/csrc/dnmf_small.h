@@ -16,8 +16,12 @@
 //   grid barrier over the problem's workgroups; every workgroup sums the partials (fixed order: the same sum for any grid) for its share of
 //     H's elements, updates them (clamped every tenth step, pyDNMF.py:155-156), writes them; second barrier; everybody re-reads H.
 //
-// Two barriers per step among the <= 64 workgroups of ONE problem (an arrival counter per problem + release / acquire fences at
-// device scope); waits are bounded by the wall clock and report through a sticky word, as the persistent HALS sweep does.
+// Two barriers per step among the <= 64 workgroups of ONE problem (an arrival counter per problem; the exchanged data move as
+// device-scope atomic stores / loads, see st_dev); waits are bounded by the wall clock and report through a sticky word, as the
+// persistent HALS sweep does.
+// Measured (20 problems of 1024 x 256, k <= 16, 8 workgroups of 8 waves each; tuning build with phases switched off): a step is 19 us
+// = W phase 6-7 us + H phase 6-7 us (4.2 MFLOP per workgroup and step on one CU's matrix pipe: 160 of the 256 CUs are in use) + 6 us
+// of H update, re-read of H and row / column sums + 2 us for the two barriers; the per-step path needs 90 us for the same step.
 // The sums are fp32 MFMA accumulations in a different association than the big kernels' (dnmf_kl16.h): results agree with the step
 // path to fp32 rounding, not bit for bit (tests/test_gpu_fit.py pins both against float64).
 #pragma once
@@ -38,7 +42,6 @@ struct SmallKlArgs {
     unsigned* bar; long bar_stride;              // per problem: arrival counter (zeroed before the launch)
     unsigned long long patience;                 // ticks of the 100 MHz wall clock a barrier may wait
     int z0;                                      // first problem of this launch
-    int dbg;                                     // tuning build: 1 = no barriers, 2 = no W phase, 4 = no H phase (timing only)
 };
 
 __device__ unsigned int g_small_timeout = 0;     // sticky: a barrier of a persistent fit gave up (dnmf_hals_sweep_status reports it)
@@ -63,8 +66,7 @@ __device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p
 __device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // arrive at / wait for the `gen`-th barrier of the problem's nwg workgroups (counter monotonic: gen nwg arrivals in all)
-__device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, unsigned long long patience, int dbg) {
-    if (dbg & 1) { __syncthreads(); return; }
+__device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, unsigned long long patience) {
     __builtin_amdgcn_s_waitcnt(0);                         // this thread's device-scope stores have completed
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 
     for (int it = 0; it < a.itr; ++it) {
         const bool clamp = (it % 10 == 0);
-        if (a.w_update && !(a.dbg & 2)) {
+        if (a.w_update) {
             // ---------------------------------------------------------------- W phase: rows 16 wv .. 16 wv + 15
             // four column tiles at a time: four independent MFMA chains in flight (one tile after the other was a chain of dependent
             // MFMAs, LDS reads and reciprocals -- 5.9 us of a 21 us step); U H^T accumulates in two registers sets, added at the end
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
             st_dev(&pcs[p * KP + tid], v);
         }
         // -------------------------------------------------------------------- H phase: column tiles wv, wv + NW, ...
-        for (int ct = wv; ct < ((a.dbg & 4) ? 0 : nct); ct += NW) {
+        for (int ct = wv; ct < nct; ct += NW) {
             const int c0 = 16 * ct;
             f32x4 acc3[2][JT];
 #pragma unroll
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience, a.dbg);
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
         // -------------------------------------------------------------------- H update: this workgroup's share of the elements
         if (tid < KP) {                                    // column sums of W over all slabs, slab order
             float x = 0.f;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 st_dev(&H[(long)j * a.ldh + c], h);
             }
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience, a.dbg);
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
         load_h();
         if (clamp) {                                       // W = max(W, eps) after both updates (pyDNMF.py:155)
 #pragma unroll
