@@ -253,15 +253,16 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * are ignored for batch == 1).  `ws` >= dnmf_ws_bytes_fit(m, n, k, batch).  The persistent HALS W sweep then needs the
  * workgroups of ALL problems resident together (it takes the column launches otherwise); `column_sweep` != 0 forces those.
  * After a HALS fit dnmf_hals_sweep_status tells whether a persistent sweep timed out.
- * SMALL MU/KL problems (fp32 A, k <= 32, a 64- or 128-row slab of A + all of H in the 160 KiB of LDS of a CU -- n up to ~500 -- and at
- * most 64 slabs: the reference's example sizes, e.g. swim 1024 x 256) run the whole loop as ONE persistent kernel per batch
- * (csrc/dnmf_small.h): a workgroup per slab keeps its data in LDS across the steps, the problem's workgroups meet at two barriers per
- * step.  Same update rule, fp32 sums in another association than the step kernels: results agree with dnmf_mu_kl_step to fp32
- * rounding (not bit for bit); a batched fit still equals `batch` single fits bit for bit.  All workgroups of a launch must be resident
- * together (the library splits a batch into as many launches as that takes); a barrier that waits longer than 2 s gives up and
- * dnmf_hals_sweep_status reports it.  dnmf_mu_kl_fit_persistent(m, n, k) != 0: this shape takes that kernel. */
+ * SMALL MU problems (MU/KL and MU/FRO, fp32 A, k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
+ * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~500 -- and at most 64 slabs: the reference's example sizes, swim 1024
+ * x 256, wtsi 96 x 21) run the whole loop as ONE persistent kernel per batch (csrc/dnmf_small.h): a workgroup per slab keeps its data in
+ * LDS across the steps, the problem's workgroups meet at two barriers per step.  Same update rules, fp32 sums in another association
+ * than the step kernels: results agree with dnmf_mu_{kl,fro}_step to fp32 rounding (not bit for bit); a batched fit still equals
+ * `batch` single fits bit for bit.  All workgroups of a launch must be resident together (the library splits a batch into as many
+ * launches as that takes; do not share the GPU with another stream meanwhile); a barrier that waits longer than 2 s gives up and
+ * dnmf_hals_sweep_status reports it.  dnmf_mu_fit_persistent(m, n, k) != 0: fits of this shape take that kernel. */
 size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch);
-int dnmf_mu_kl_fit_persistent(long m, long n, int k);
+int dnmf_mu_fit_persistent(long m, long n, int k);
 int dnmf_mu_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
                     int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
                     void* stream);

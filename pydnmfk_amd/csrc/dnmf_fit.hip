@@ -34,7 +34,7 @@ SmallPlan small_kl_plan(long m, long n, int k) {
         if (lds <= 160 * 1024 && P <= 64 && (t.nw == 4 || P >= 2)) { s.nw = t.nw; s.alds = t.alds; s.P = (int)P; s.lds = lds; break; }
     }
     if (!s.nw) return s;
-    s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp;
+    s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;       // W^T U / W^T A partials + (KL) column sums or (FRO) W^T W per slab
     s.bytes = ((s.part_floats * sizeof(float) + 255) & ~size_t(255)) + 256;          // ... + the arrival counter
     s.ok = true;
     return s;
@@ -95,11 +95,12 @@ int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float
 }
 
 // all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
-template <int KP, int NW, bool ALDS>
+template <int KP, int NW, bool ALDS, bool FRO>
 int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    const auto kern = FRO ? small_fro_fit_kernel<KP, NW, ALDS> : small_kl_fit_kernel<KP, NW, ALDS>;
     static int cus = 0;
     if (!cus) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&small_kl_fit_kernel<KP, NW, ALDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
         int dev = 0;
         hipDeviceProp_t prop;
@@ -107,7 +108,7 @@ int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t s
         cus = prop.multiProcessorCount;
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, small_kl_fit_kernel<KP, NW, ALDS>, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
         clear_hip_error();
         return DNMF_OK;                                             // (not taken: the step loop runs)
     }
@@ -119,7 +120,7 @@ int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t s
     for (int z0 = 0; z0 < batch; z0 += each) {
         a.z0 = z0;
         const int nz = std::min(each, batch - z0);
-        hipLaunchKernelGGL((small_kl_fit_kernel<KP, NW, ALDS>), dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
         int rc = check_launch("small_kl_fit_kernel");
         if (rc) return rc;
     }
@@ -127,7 +128,7 @@ int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t s
     return DNMF_OK;
 }
 
-int small_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update, int itr,
+int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update, int itr,
                  int batch, long a_stride, long w_stride, long h_stride, char* ws, const FitWs& f, void* stream, bool* taken) {
     *taken = false;
     const SmallPlan sp = small_kl_plan(m, n, k);
@@ -141,7 +142,9 @@ int small_kl_fit(const float* A, long m, long n, long lda, float* W, long ldw, f
     a.patience = 200000000ull;                                         // 2 s of the 100 MHz wall clock
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
     if (hipMemset2DAsync(a.bar, f.total, 0, sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
-#define SMALL_CASE(KP_, NW_, AL_) if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_) return small_kl_launch<KP_, NW_, AL_>(sp, a, batch, st, taken)
+#define SMALL_CASE(KP_, NW_, AL_)                                                                                                 \
+    if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
+        return fro ? small_kl_launch<KP_, NW_, AL_, true>(sp, a, batch, st, taken) : small_kl_launch<KP_, NW_, AL_, false>(sp, a, batch, st, taken)
     SMALL_CASE(16, 8, true); SMALL_CASE(16, 8, false); SMALL_CASE(16, 4, true);
     SMALL_CASE(32, 8, true); SMALL_CASE(32, 8, false); SMALL_CASE(32, 4, true);
 #undef SMALL_CASE
@@ -180,11 +183,11 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
     char* base = (char*)ws;
     int rc = DNMF_OK;
     bool small = false;
-    if (method == FIT_MU_KL && !bf) {
-        // small problems: the whole loop as one persistent kernel per batch (csrc/dnmf_small.h); launched unbatched -- it indexes the problems itself
+    if ((method == FIT_MU_KL || method == FIT_MU_FRO) && !bf) {
+        // small fp32 problems: the whole loop as one persistent kernel per batch (csrc/dnmf_small.h); launched unbatched -- it indexes the problems itself
         const int B = ctx->B;
         ctx->B = 1;
-        rc = small_kl_fit((const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
+        rc = small_fit(method == FIT_MU_FRO, (const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
         ctx->B = B;
         if (rc) return rc;
     }
@@ -232,7 +235,7 @@ __attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out
 
 extern "C" {
 
-int dnmf_mu_kl_fit_persistent(long m, long n, int k) {
+int dnmf_mu_fit_persistent(long m, long n, int k) {
     return (m >= 1 && n >= 1 && small_kl_plan(m, n, k).ok) ? 1 : 0;
 }
 

@@ -352,9 +352,256 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The Frobenius twin (MU/FRO, dist_nmf.py:716-751): the same slabs, barriers and exchange, without the quotient.
+//   W phase: A H^T over the column tiles (the wave's elements of A are the A operand as they come), G = H H^T by the first JT^2 waves
+//     from the H in LDS (every workgroup the same G), W *= A H^T / (W G + eps) with W G on the matrix cores in the layout A H^T
+//     accumulated in.
+//   H phase: W^T A per column tile + the slab's W^T W (first JT^2 waves) -> global partials; barrier; every workgroup sums the Gram
+//     partials (slab order), then for its share of H's elements the W^T A partials, and H *= W^T A / (G H + eps) with the k-term dot
+//     product from LDS; barrier; re-read H.
+template <int KP, int NW, bool ALDS>
+__global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a) {
+    constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1, LDG = KP + 1;
+    static_assert(JT * JT <= NW, "one wave per Gram tile");
+    const int z = a.z0 + blockIdx.z, p = blockIdx.x, P = gridDim.x;
+    const float* __restrict__ A = a.A + (long)z * a.a_stride;
+    float* __restrict__ W = a.W + (long)z * a.w_stride;
+    float* H = a.H + (long)z * a.h_stride;
+    float* part = a.part + (long)z * a.part_stride;
+    unsigned* bar = a.bar + (long)z * a.bar_stride;
+    const int m = a.m, n = a.n, k = a.k;
+    const float eps = a.eps;
+    const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
+    float* pg = part + (long)P * KP * NS;                  // [P][KP][KP] W^T W of the slabs
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Hs = As + (ALDS ? R * LDA : 0);                 // [KP][LDH]
+    float* Ws = Hs + KP * LDH;                             // [R][LDW]
+    float* Gs = Ws + R * LDW;                              // [KP][LDG]  H H^T (W phase), then W^T W (H update)
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long r0 = (long)p * R;
+    if constexpr (ALDS) {
+        for (int idx = tid; idx < R * NS; idx += T) {
+            const int r = idx / NS, c = idx - r * NS;
+            As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : 0.f;
+        }
+    }
+    const bool avec = (a.lda % 4 == 0) && (((unsigned long)A & 15) == 0);
+    auto a_row4 = [&](int c) -> f32x4 {
+        const long row = r0 + 16 * wv + i;
+        if (row < m && c + 4 <= n && avec) return *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (row < m && c + e < n) ? A[row * a.lda + c + e] : 0.f;
+        return v;
+    };
+    auto a_col4 = [&](int rbase, int c) -> f32x4 {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r0 + rbase + e < m && c < n) ? A[(r0 + rbase + e) * a.lda + c] : 0.f;
+        return v;
+    };
+    for (int idx = tid; idx < R * KP; idx += T) {
+        const int r = idx / KP, j = idx - r * KP;
+        Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
+    }
+    auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
+        for (int idx0 = tid; idx0 < KP * NS; idx0 += 4 * T) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
+            }
+        }
+        __syncthreads();
+        if (wv < JT * JT) {
+            const int j1 = wv / JT, j2 = wv - j1 * JT;
+            f32x4 g[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int ct = 0; ct < nct; ++ct) {             // lane (i, q) reg r = G[16 j1 + 4 q + r][16 j2 + i]
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(&Hs[(16 * j1 + i) * LDH + 16 * ct + 4 * q]);
+                const f32x4 h2 = *reinterpret_cast<const f32x4*>(&Hs[(16 * j2 + i) * LDH + 16 * ct + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[ct & 1] = SM_MFMA(h1[r], h2[r], g[ct & 1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gs[(16 * j1 + 4 * q + r) * LDG + 16 * j2 + i] = g[0][r] + g[1][r];
+        }
+        __syncthreads();
+    };
+    load_h();
+    float wreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+    const bool rowok = r0 + 16 * wv + i < m;
+    unsigned gen = 0;
+
+    for (int it = 0; it < a.itr; ++it) {
+        const bool clamp = (it % 10 == 0);
+        if (a.w_update) {
+            // ---------------------------------------------------------------- W phase: rows 16 wv .. 16 wv + 15
+            f32x4 acc2[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc2[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 apre[4];
+            if constexpr (!ALDS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (t < nct ? t : nct - 1) + 4 * q);
+            }
+            for (int ct0 = 0; ct0 < nct; ct0 += 4) {
+                f32x4 av[4];
+                if constexpr (!ALDS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) av[t] = apre[t];
+                    if (ct0 + 4 < nct) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (ct0 + 4 + t < nct ? ct0 + 4 + t : nct - 1) + 4 * q);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c0 = 16 * (ct0 + t < nct ? ct0 + t : nct - 1);
+                    if constexpr (ALDS) av[t] = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0 + 4 * q]);
+                    if (ct0 + t >= nct) av[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {      // lane (j = i, q) reg r = (A H^T)[row 4 q + r][16 jt + i]
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + i) * LDH + c0 + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc2[t & 1][jt] = SM_MFMA(av[t][r], hv[r], acc2[t & 1][jt]);
+                    }
+                }
+            }
+            // W G in the same layout, then the update through the wave's own rows of Ws
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};            // lane (j = i, q) reg r = (W G)[row 4 q + r][16 jt + i]
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d = SM_MFMA(wreg[s], Gs[(4 * s + q) * LDG + 16 * jt + i], d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* wp = &Ws[(16 * wv + 4 * q + r) * LDW + 16 * jt + i];
+                    *wp = *wp * ((acc2[0][jt][r] + acc2[1][jt][r]) * __builtin_amdgcn_rcpf(d[r] + eps));
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+        }
+        __syncthreads();                                   // every wave's rows of Ws are the updated ones
+        // -------------------------------------------------------------------- H phase: column tiles wv, wv + NW, ...
+        for (int ct = wv; ct < nct; ct += NW) {
+            const int c0 = 16 * ct;
+            f32x4 acc3[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc3[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 hpre[4];
+            if constexpr (!ALDS) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * t + 4 * q, c0 + i);
+            }
+            for (int rt0 = 0; rt0 < NW; rt0 += 4) {
+                f32x4 hcur[4];
+                if constexpr (!ALDS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hcur[t] = hpre[t];
+                    if (rt0 + 4 < NW) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float av = ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r];
+#pragma unroll
+                        for (int jt = 0; jt < JT; ++jt)    // lane (col i, q) reg r = (W^T A)[16 jt + 4 q + r][c0 + i]
+                            acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], av, acc3[t & 1][jt]);
+                    }
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
+        }
+        if (wv < JT * JT) {                                // the slab's W^T W: lane (i, q) reg r = G[16 j1 + 4 q + r][16 j2 + i]
+            const int j1 = wv / JT, j2 = wv - j1 * JT;
+            f32x4 g[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int rt = 0; rt < NW; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    g[rt & 1] = SM_MFMA(Ws[(16 * rt + 4 * q + r) * LDW + 16 * j1 + i], Ws[(16 * rt + 4 * q + r) * LDW + 16 * j2 + i], g[rt & 1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_dev(&pg[((long)p * KP + 16 * j1 + 4 * q + r) * KP + 16 * j2 + i], g[0][r] + g[1][r]);
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        // -------------------------------------------------------------------- H update
+        for (int e = tid; e < KP * KP; e += T) {           // G = W^T W over all slabs, slab order
+            float x = 0.f;
+            for (int g0 = 0; g0 < P; g0 += 8) {
+                float y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = ld_dev(&pg[(long)(g0 + u < P ? g0 + u : P - 1) * KP * KP + e]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x += (g0 + u < P) ? y[u] : 0.f;
+            }
+            Gs[(e / KP) * LDG + e % KP] = x;
+        }
+        __syncthreads();
+        for (int e = p * T + tid; e < KP * NS; e += P * T) {
+            const int j = e / NS, c = e - j * NS;
+            float sum = 0.f;
+            for (int g0 = 0; g0 < P; g0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int l = 0; l < KP; ++l) dot = fmaf(Gs[j * LDG + l], Hs[l * LDH + c], dot);
+            float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(dot + eps));
+            if (j < k && c < n) {
+                if (clamp) h = fmaxf(h, eps);
+                st_dev(&H[(long)j * a.ldh + c], h);
+            }
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        load_h();
+        if (clamp) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (rowok && 4 * s + q < k) wreg[s] = fmaxf(wreg[s], eps);
+                Ws[(16 * wv + i) * LDW + 4 * s + q] = wreg[s];
+            }
+            __syncthreads();
+        }
+    }
+    if (a.itr > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (rowok && 4 * s + q < k) W[(r0 + 16 * wv + i) * a.ldw + 4 * s + q] = wreg[s];
+    }
+}
+
+// LDS of either kernel: [slab of A] + H + the slab's W + (KL: row sums, per-wave column sums; FRO: the k x k Gram matrix)
 inline size_t small_kl_lds(int kp, int nw, long n, bool alds) {
     const long ns = (n + 15) & ~15L;
-    return ((alds ? (size_t)(16 * nw) * (ns + 4) : 0) + (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + kp + (size_t)nw * kp) * sizeof(float);
+    const size_t tail = std::max<size_t>((size_t)kp + (size_t)nw * kp, (size_t)kp * (kp + 1));
+    return ((alds ? (size_t)(16 * nw) * (ns + 4) : 0) + (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + tail) * sizeof(float);
 }
 
 }  // namespace

@@ -21,6 +21,9 @@ CASES = [  # m, n, k, method, norm, precision, itr
     (1000, 250, 9, "mu", "kl", "float32", 31),        # persistent small-fit kernel: ragged slab, ragged columns, 128-row slabs
     (4100, 400, 20, "mu", "kl", "float32", 12),       # ... 64-row slabs, k padded to 32, more slabs than fit one launch with 5 problems
     (70, 33, 3, "mu", "kl", "float32", 23),           # ... one or two slabs
+    (1000, 250, 9, "mu", "fro", "float32", 31),       # the Frobenius twin of the persistent kernel
+    (4100, 400, 20, "mu", "fro", "float32", 12),
+    (96, 21, 4, "mu", "fro", "float32", 40),          # the reference's wtsi example shape
     (1024, 256, 16, "mu", "kl", "float32", 25),       # the reference's swim example shape, 16-wide kernels
     (1024, 256, 17, "mu", "kl", "float32", 21),       # k = 17: 32-wide kernels on zero-padded factor images
     (1024, 256, 4, "mu", "fro", "float32", 25),
@@ -60,16 +63,21 @@ def _problem(m, n, k, seed, precision):
 
 def _persistent(m, n, k, method, norm, precision):
     from pydnmfk_amd._lib import lib
-    return method == "mu" and norm == "kl" and precision == "float32" and lib.dnmf_mu_kl_fit_persistent(m, n, k) != 0
+    return method == "mu" and precision == "float32" and lib.dnmf_mu_fit_persistent(m, n, k) != 0
 
 
-def _kl_fit_f64(A, W, H, itr, w_update, eps=1.1920929e-07):
-    """PyNMF.fit with MU/KL on one rank in float64 (pyDNMF.py:151-194, dist_nmf.py:806-849)"""
+def _mu_fit_f64(A, W, H, itr, w_update, norm, eps=1.1920929e-07):
+    """PyNMF.fit with MU/KL or MU/FRO on one rank in float64 (pyDNMF.py:151-194, dist_nmf.py:716-751, :806-849)"""
     A, W, H = A.double(), W.double().clone(), H.double().clone()
     for i in range(itr):
-        if w_update:
-            W = W * (((A / (W @ H + eps)) @ H.t()) / (H.sum(1) + eps))
-        H = H * ((W.t() @ (A / (W @ H + eps))) / (W.sum(0)[:, None] + eps))
+        if norm == "fro":
+            if w_update:
+                W = W * ((A @ H.t()) / (W @ (H @ H.t()) + eps))
+            H = H * ((W.t() @ A) / ((W.t() @ W) @ H + eps))
+        else:
+            if w_update:
+                W = W * (((A / (W @ H + eps)) @ H.t()) / (H.sum(1) + eps))
+            H = H * ((W.t() @ (A / (W @ H + eps))) / (W.sum(0)[:, None] + eps))
         if i % 10 == 0:
             W, H = torch.clamp(W, min=eps), torch.clamp(H, min=eps)
     s = W.sum(0)
@@ -88,7 +96,7 @@ def test_whole_fit_equals_step_loop(m, n, k, method, norm, precision, itr):
         for w_update in (True, False):
             W1, H1, e1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update)).fit()
             W2, H2, e2 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update, fit_loop="python")).fit()
-            Wr, Hr = _kl_fit_f64(A, W0, H0, itr, w_update)
+            Wr, Hr = _mu_fit_f64(A, W0, H0, itr, w_update, norm)
             for X, Y in ((W1, Wr), (H1, Hr), (W2, Wr), (H2, Hr)):
                 assert _close(X, Y, 2e-4), (w_update, float((X.double() - Y).abs().max()), float(Y.abs().max()))
             assert abs(e1 - e2) <= 1e-4 * max(1e-3, abs(e2)) and np.isfinite(e1)

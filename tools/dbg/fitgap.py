@@ -7,7 +7,7 @@ from pydnmfk_amd.engine import HIP_OPS as ops, stack_alloc
 m, n, k, B, itr = 1024, 256, int(os.environ.get("K", "8")), int(os.environ.get("B", "20")), int(os.environ.get("ITR", "100"))
 method, norm = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("hals", "fro")
 dev = torch.device("cuda")
-A = stack_alloc(B, m, n, torch.float32 if norm == "kl" else torch.bfloat16, dev); A.copy_(torch.rand(B, m, n, device=dev))
+A = stack_alloc(B, m, n, torch.float32 if (norm == "kl" or os.environ.get("DT") == "f32") else torch.bfloat16, dev); A.copy_(torch.rand(B, m, n, device=dev))
 W = stack_alloc(B, m, k, torch.float32, dev); H = stack_alloc(B, k, n, torch.float32, dev)
 out = {}
 for rep in range(3):
