@@ -137,15 +137,15 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
     auto load_h = [&]() {                                  // H -> LDS, then its row sums (every workgroup the same sums)
-        for (int idx0 = tid; idx0 < KP * NS; idx0 += 4 * T) {          // four loads in flight per thread
-            float v[4];
+        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {          // eight loads in flight per thread
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
                 v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
                 if (idx < KP * NS) Hs[j * LDH + c] = v[u];
             }
@@ -306,29 +306,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
         }
         small_barrier(bar, (unsigned)P * ++gen, a.patience);
         // -------------------------------------------------------------------- H update: this workgroup's share of the elements
-        if (tid < KP) {                                    // column sums of W over all slabs, slab order
-            float x = 0.f;
-            for (int g0 = 0; g0 < P; g0 += 8) {
-                float y[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) y[u] = ld_dev(&pcs[(g0 + u < P ? g0 + u : P - 1) * KP + tid]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x += (g0 + u < P) ? y[u] : 0.f;
-            }
-            cs[tid] = x;
-        }
-        __syncthreads();
         for (int e = p * T + tid; e < KP * NS; e += P * T) {
             const int j = e / NS, c = e - j * NS;
-            float sum = 0.f;
-            for (int g0 = 0; g0 < P; g0 += 8) {             // eight partials in flight, added in slab order
-                float v[8];
+            float sum = 0.f, x = 0.f;                      // W^T U and the column sum of W over all slabs, slab order
+            for (int g0 = 0; g0 < P; g0 += 8) {             // eight partials of each in flight
+                float v[8], y[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
+                for (int u = 0; u < 8; ++u) {
+                    const int g = g0 + u < P ? g0 + u : P - 1;
+                    v[u] = ld_dev(&part[((long)g * KP + j) * NS + c]);
+                    y[u] = ld_dev(&pcs[g * KP + j]);
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
+                for (int u = 0; u < 8; ++u) { sum += (g0 + u < P) ? v[u] : 0.f; x += (g0 + u < P) ? y[u] : 0.f; }
             }
-            float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(cs[j] + eps));
+            float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(x + eps));
             if (j < k && c < n) {
                 if (clamp) h = fmaxf(h, eps);
                 st_dev(&H[(long)j * a.ldh + c], h);
@@ -408,15 +400,15 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
     auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
-        for (int idx0 = tid; idx0 < KP * NS; idx0 += 4 * T) {
-            float v[4];
+        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
                 v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
                 if (idx < KP * NS) Hs[j * LDH + c] = v[u];
             }
