@@ -263,6 +263,8 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * dnmf_hals_sweep_status reports it.  dnmf_mu_fit_persistent(m, n, k) != 0: fits of this shape take that kernel. */
 size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch);
 int dnmf_mu_fit_persistent(long m, long n, int k);
+/* seconds a barrier of the persistent small fit may wait before it gives up (default 2; process-wide, read at the next fit call) */
+int dnmf_fit_set_timeout(double seconds);
 int dnmf_mu_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
                     int itr, int batch, long a_stride, long w_stride, long h_stride, double* sq_out, void* ws, size_t ws_bytes,
                     void* stream);

@@ -94,6 +94,8 @@ int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float
     return DNMF_OK;
 }
 
+unsigned long long g_small_patience = 200000000ull;
+
 // all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
 template <int KP, int NW, bool ALDS, bool FRO>
 int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
@@ -139,9 +141,9 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
     a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = w_update;
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
-    a.patience = 200000000ull;                                         // 2 s of the 100 MHz wall clock
+    a.patience = g_small_patience;                                     // ticks of the 100 MHz wall clock (2 s unless dnmf_fit_set_timeout)
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
-    if (hipMemset2DAsync(a.bar, f.total, 0, sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
+    if (hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
 #define SMALL_CASE(KP_, NW_, AL_)                                                                                                 \
     if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
         return fro ? small_kl_launch<KP_, NW_, AL_, true>(sp, a, batch, st, taken) : small_kl_launch<KP_, NW_, AL_, false>(sp, a, batch, st, taken)
@@ -234,6 +236,12 @@ __attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out
 }
 
 extern "C" {
+
+int dnmf_fit_set_timeout(double seconds) {
+    if (!(seconds > 0.0) || seconds > 3600.0) return fail(DNMF_EINVAL, "fit_set_timeout: %g s", seconds);
+    g_small_patience = (unsigned long long)(seconds * 1e8) + 1ull;
+    return DNMF_OK;
+}
 
 int dnmf_mu_fit_persistent(long m, long n, int k) {
     return (m >= 1 && n >= 1 && small_kl_plan(m, n, k).ok) ? 1 : 0;

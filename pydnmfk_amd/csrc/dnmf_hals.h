@@ -209,7 +209,11 @@ __device__ __forceinline__ double hals_poll(const unsigned long long* col, int n
     // "empty" pattern, which is a NaN: the column norm -- and with it W -- turns NaN instead of the GPU hanging.
     bool complete = false;
     const unsigned long long t0 = sys ? wall_clock64() : 0ull;
-    for (unsigned spins = 0; sys || spins < (1u << 21); ++spins) {
+    // a sweep on this device has already given up (sticky word, cleared by dnmf_hals_sweep_status): its factors are lost, and so are
+    // the ones computed since -- do not spend a second per column of every later sweep waiting again (one missing slot then costs one
+    // wait per fit, not k per iteration)
+    const bool lost = __hip_atomic_load(&g_hals_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    for (unsigned spins = 0; !lost && (sys || spins < (1u << 21)); ++spins) {
         unsigned long long v[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {

@@ -65,7 +65,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// arrive at / wait for the `gen`-th barrier of the problem's nwg workgroups (counter monotonic: gen nwg arrivals in all)
+// arrive at / wait for the `gen`-th barrier of the problem's nwg workgroups (counter monotonic: gen nwg arrivals in all).  bar[1] is the
+// problem's abort word (zeroed with the counter before the launch): the first wait that exceeds `patience` sets it and the sticky
+// device word; every wait of the problem -- this one and all later ones, in every workgroup -- then returns at once, so a fit that lost
+// its co-residency ends within one patience instead of one patience per barrier.  Its factors are garbage; the host raises.
 __device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, unsigned long long patience) {
     __builtin_amdgcn_s_waitcnt(0);                         // this thread's device-scope stores have completed
     __syncthreads();
@@ -75,9 +78,11 @@ __device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, un
         unsigned spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 255u && wall_clock64() - t0 > patience) {
+            if ((++spins & 15u) == 15u && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > patience) {          // (the clock is read every round: the round trip of the counter dominates)
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&g_small_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;                                     // the factors are garbage from here on; the host raises (status word)
+                break;
             }
         }
     }

@@ -203,3 +203,72 @@ def test_nmfk_batched_equals_one_by_one(tmp_path, method, norm, precision, io):
             for other in (b, c):
                 np.testing.assert_allclose(np.asarray(a.stats[k][key], dtype=np.float64), np.asarray(other.stats[k][key], dtype=np.float64),
                                            rtol=1e-12, atol=0, err_msg="%s k=%d" % (key, k))
+
+
+def test_persistent_fit_that_loses_its_residency_ends_and_says_so():
+    """Two batched persistent fits on two streams, each wanting most of the device, the first one 2.5 s long: the workgroups of the
+    second cannot all be resident while the first runs.  Whatever the dispatcher does, (a) both calls END -- a barrier that gives up
+    aborts every later wait of its problem, it does not cost one patience per barrier -- and (b) the status word tells the truth: set
+    (then `hals_check` raises) or clear (then the second fit's factors are the ones it computes alone).  Through the C ABI with a
+    workspace per call (the operator set shares one scratch buffer per device, which two concurrent fits must not)."""
+    import ctypes
+    import time
+    from pydnmfk_amd._lib import DnmfError, lib
+    from pydnmfk_amd.engine import HIP_OPS, stack_alloc
+    B, m, n, k = 20, 1024, 256, 16
+    assert lib.dnmf_mu_fit_persistent(m, n, k)
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def stacks():
+        A = stack_alloc(B, m, n, torch.float32, dev); A.copy_(torch.rand(B, m, n, device=dev, generator=g) + 0.01)
+        W = stack_alloc(B, m, k, torch.float32, dev); W.copy_(torch.rand(B, m, k, device=dev, generator=g))
+        H = stack_alloc(B, k, n, torch.float32, dev); H.copy_(torch.rand(B, k, n, device=dev, generator=g))
+        return A, W, H
+    nbytes = lib.dnmf_ws_bytes_fit(m, n, k, B)
+
+    def call(A, W, H, itr, ws, sq, stream):
+        rc = lib.dnmf_mu_kl_fit(A.data_ptr(), m, n, A.stride(1), W.data_ptr(), W.stride(1), H.data_ptr(), H.stride(1), k, 1.1920929e-07, 1, itr, B,
+                                A.stride(0), W.stride(0), H.stride(0), sq.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+        assert rc == 0, lib.dnmf_last_error()
+    A1, W1, H1 = stacks()
+    A2, W2, H2 = stacks()
+    ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+    sq = [torch.empty(B, 2, dtype=torch.float64, device=dev) for _ in range(2)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    Wr, Hr = W2.clone(), H2.clone()
+    call(A2, Wr, Hr, 200, ws[1], sq[1], s2)                  # the second fit alone: its reference
+    torch.cuda.synchronize()
+    HIP_OPS.hals_check()                                     # nothing has timed out so far
+    t0 = time.time()
+    call(A1, W1, H1, 130000, ws[0], sq[0], s1)               # ~2.5 s of barriers on 160 CUs
+    call(A2, W2, H2, 200, ws[1], sq[1], s2)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30.0
+    try:
+        HIP_OPS.hals_check()
+        lost = False
+    except DnmfError as ex:
+        lost = True
+        assert "resident" in str(ex)
+    if not lost:
+        assert torch.equal(W2, Wr) and torch.equal(H2, Hr)
+    flag = ctypes.c_int(7)
+    assert lib.dnmf_hals_sweep_status(ctypes.byref(flag), None) == 0 and flag.value == 0      # cleared by the query above
+    # the abort path for certain: a patience of a tenth of a microsecond -- the first barrier anybody has to wait at gives up, every later
+    # wait of that problem returns at once, the call ends, the status says so, the next fit (default patience) is clean again
+    assert lib.dnmf_fit_set_timeout(1e-7) == 0
+    try:
+        call(A2, W2, H2, 5000, ws[1], sq[1], s2)
+        torch.cuda.synchronize()
+    finally:
+        assert lib.dnmf_fit_set_timeout(2.0) == 0
+    with pytest.raises(DnmfError, match="resident"):
+        HIP_OPS.hals_check()
+    W3, H3 = W2.clone(), H2.clone()
+    W3.copy_(Wr); H3.copy_(Hr)
+    call(A2, W3, H3, 50, ws[1], sq[1], s2)
+    torch.cuda.synchronize()
+    HIP_OPS.hals_check()
+    assert torch.isfinite(W3).all() and torch.isfinite(H3).all()
+    assert lib.dnmf_fit_set_timeout(0.0) == -1
