@@ -232,7 +232,7 @@ class PyNMF:
         """The end of the last iteration (pyDNMF.py:158-166, :173-181): error, un-pruning, save.  `sq`: the device pair
         {sum (A - W H)^2, sum A^2} a whole-fit call left (None: evaluate them here)."""
         ops = self._ops()
-        persistent = self.method.lower() == 'hals' or (sq is not None and str(self.norm).lower() == 'kl')
+        persistent = self.method.lower() == 'hals' or sq is not None       # (whole MU fits of small problems are persistent kernels too)
         if persistent and hasattr(ops, "hals_check"):
             # a persistent kernel (the HALS W sweep; the whole-fit kernel of a small MU/KL problem, csrc/dnmf_small.h) that lost its
             # co-residency raises here -- BEFORE the error's allreduce sees NaN
