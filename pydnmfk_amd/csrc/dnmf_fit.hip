@@ -67,6 +67,7 @@ struct BatchGuard {      // the batch state of this thread is set for the durati
 };
 
 bool overlap(const BatchFam& a, const BatchFam& b) { return a.lo < b.hi && b.lo < a.hi; }
+inline bool wide_fit_k(int k) { return k > DNMF_TUNED_MAX_K; }
 
 template <bool BF>
 int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,
@@ -193,8 +194,24 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
         ctx->B = B;
         if (rc) return rc;
     }
+    // W fixed (the regression fit of an NMFk sweep, pyDNMFk.py:243-247): the Frobenius H updates read A only through W^T A, and W^T A and
+    // W^T W are loop invariants once W has been clamped (the clamp after step 0 is the only thing that can still change W; it is idempotent
+    // from then on).  Steps 0 and 1 run in full -- step 1 leaves W^T A and W^T W of the final W in the workspace --, every later step is
+    // the H update alone on those: the same values the step would recompute, so the same bits, without the two passes over A.
+    const bool h_only = !w_update && method != FIT_MU_KL && !wide_fit_k(k);
+    const long ldatw = method == FIT_MU_FRO ? round_up(n, 4) : n;
     for (int i = 0; i < itr && !rc && !small; ++i) {                                  // pyDNMF.py:151-172
         const int clamp = (i % 10 == 0);
+        if (h_only && i >= 2) {
+            float* G = (float*)(base + f.g_off);
+            float* Sb = (float*)(base + f.s_off);
+            if (method == FIT_MU_FRO) rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream);          // dist_nmf.py:750-751
+            else {
+                rc = dnmf_hals_update_h(H, k, n, ldh, Sb, ldatw, G, eps, stream);                                     // :905-909
+                if (!rc && clamp) rc = dnmf_clamp_min(H, k, n, ldh, eps, stream);
+            }
+            continue;
+        }
         if (method == FIT_MU_FRO)
             rc = bf ? dnmf_mu_fro_step_bf16a(A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream)
                     : dnmf_mu_fro_step((const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, clamp, ws, f.step_total, stream);
