@@ -144,6 +144,26 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
     a.patience = g_small_patience;                                     // ticks of the 100 MHz wall clock (2 s unless dnmf_fit_set_timeout)
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
+    if (!fro && !w_update) {
+        // W fixed: the columns of H are independent -- a workgroup per 16 columns, no barrier, nothing to keep resident (small_kl_hfit_kernel)
+        constexpr int NW = 8;
+        const size_t lds = small_kl_hfit_lds(sp.kp, NW, m);
+        if (lds <= 160 * 1024) {
+            const dim3 grid((unsigned)(sp.ns / 16), 1, (unsigned)batch);
+            a.z0 = 0;
+            static bool once16 = false, once32 = false;
+            if (sp.kp == 16) {
+                if (!once16) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kl_hfit_kernel<16, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit"); once16 = true; }
+                hipLaunchKernelGGL((small_kl_hfit_kernel<16, NW>), grid, dim3(64 * NW), lds, st, a);
+            } else {
+                if (!once32) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kl_hfit_kernel<32, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit"); once32 = true; }
+                hipLaunchKernelGGL((small_kl_hfit_kernel<32, NW>), grid, dim3(64 * NW), lds, st, a);
+            }
+            const int rc = check_launch("small_kl_hfit_kernel");
+            if (!rc) *taken = true;
+            return rc;
+        }
+    }
     if (hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
 #define SMALL_CASE(KP_, NW_, AL_)                                                                                                 \
     if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \

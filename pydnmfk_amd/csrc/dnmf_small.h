@@ -594,6 +594,149 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// MU/KL with W FIXED (w_update = 0: the regression fit of every k of an NMFk sweep, pyDNMFk.py:243-247).  The H update of a column
+// reads nothing but that column of A and of H (and all of W): the columns are independent problems.  A workgroup owns 16 columns for the
+// whole fit -- all of W in LDS, its columns of H in registers / LDS, its 16 columns of A streamed from the L2 (m x 64 bytes per step) -- and
+// iterates on its own: NO grid barrier, no exchange, no residency requirement.  Wave w takes the row tiles w, w + NW, ...: S = W H
+// (B operand = the wave's copy of the H columns), U = A / (S + eps) in the C registers = the B operand of W^T U; the waves' partial
+// k x 16 results are summed in wave order through LDS, H *= W^T U / (colsum(W) + eps), clamp every tenth step.  W is clamped once,
+// after step 0 (pyDNMF.py:155: idempotent afterwards), and its column sums are taken again.
+template <int KP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a) {
+    constexpr int JT = KP / 16, KS = KP / 4, T = 64 * NW, LDW = KP + 1, LDR = 17;
+    const int z = a.z0 + blockIdx.z, c0 = 16 * blockIdx.x;
+    const float* __restrict__ A = a.A + (long)z * a.a_stride;
+    float* W = a.W + (long)z * a.w_stride;
+    float* H = a.H + (long)z * a.h_stride;
+    const int m = a.m, n = a.n, k = a.k;
+    const float eps = a.eps;
+    const int m16 = (m + 15) & ~15, nrt = m16 / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                      // [m16][LDW]     all of W (zero beyond m / k)
+    float* red = Wl + m16 * LDW;                           // [NW][KP][LDR]  the waves' partial W^T U (also scratch of the column sums)
+    float* hs = red + NW * KP * LDR;                       // [KP][LDR]      the 16 columns of H
+    float* xw = hs + KP * LDR;                             // [KP]           column sums of W
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int idx = tid; idx < m16 * KP; idx += T) {
+        const int r = idx / KP, j = idx - r * KP;
+        Wl[r * LDW + j] = (r < m && j < k) ? W[(long)r * a.ldw + j] : 0.f;
+    }
+    for (int idx = tid; idx < KP * 16; idx += T) {
+        const int j = idx >> 4, c = idx & 15;
+        hs[j * LDR + c] = (j < k && c0 + c < n) ? H[(long)j * a.ldh + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    auto colsums = [&]() {                                 // xw[j] = sum_r Wl[r][j]: T / KP strided parts, added in part order
+        constexpr int PARTS = T / KP;
+        static_assert(PARTS <= NW * LDR, "scratch");
+        const int j = tid % KP, part = tid / KP;
+        float v = 0.f;
+        for (int r = part; r < m16; r += PARTS) v += Wl[r * LDW + j];
+        red[part * KP + j] = v;
+        __syncthreads();
+        if (tid < KP) {
+            float x = 0.f;
+            for (int g = 0; g < PARTS; ++g) x += red[g * KP + tid];
+            xw[tid] = x;
+        }
+        __syncthreads();
+    };
+    colsums();
+    float hb[KS];                                          // lane (col i, q): H[4 s + q][c0 + i]
+#pragma unroll
+    for (int s = 0; s < KS; ++s) hb[s] = hs[(4 * s + q) * LDR + i];
+    auto a_col4 = [&](int rt) -> f32x4 {                   // A[16 rt + 4 q + r][c0 + i], r = 0..3 (zero outside)
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 16 * rt + 4 * q + e;
+            v[e] = (rt < nrt && row < m && c0 + i < n) ? A[(long)row * a.lda + c0 + i] : 0.f;
+        }
+        return v;
+    };
+    for (int it = 0; it < a.itr; ++it) {
+        const bool clamp = (it % 10 == 0);
+        f32x4 acc[2][JT];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 apre[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) apre[t] = a_col4(wv + NW * t);
+        for (int g0 = 0; wv + NW * g0 < nrt; g0 += 4) {    // four of the wave's row tiles at a time
+            f32x4 acur[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acur[t] = apre[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) apre[t] = a_col4(wv + NW * (g0 + 4 + t));
+            int rt[4];
+            f32x4 d[4];                                    // lane (col i, q) reg r = (W H)[16 rt + 4 q + r][c0 + i]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int x = wv + NW * (g0 + t);
+                rt[t] = x < nrt ? x : nrt - 1;             // (a tile beyond the last repeats it; its U is zero: A reads as zero there)
+                d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Wl[(16 * rt[t] + i) * LDW + 4 * s + q], hb[s], d[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float u[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = acur[t][r] * __builtin_amdgcn_rcpf(d[t][r] + eps);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t & 1][jt] = SM_MFMA(Wl[(16 * rt[t] + 4 * q + r) * LDW + 16 * jt + i], u[r], acc[t & 1][jt]);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wv * KP + 16 * jt + 4 * q + r) * LDR + i] = acc[0][jt][r] + acc[1][jt][r];
+        __syncthreads();
+        for (int e = tid; e < KP * 16; e += T) {
+            const int j = e >> 4, c = e & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[(w * KP + j) * LDR + c];
+            float h = hs[j * LDR + c] * (sum * __builtin_amdgcn_rcpf(xw[j] + eps));
+            if (clamp && j < k && c0 + c < n) h = fmaxf(h, eps);
+            hs[j * LDR + c] = h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) hb[s] = hs[(4 * s + q) * LDR + i];
+        if (it == 0) {                                     // W = max(W, eps), once (idempotent at the later clamps)
+            for (int idx = tid; idx < m16 * KP; idx += T) {
+                const int r = idx / KP, j = idx - r * KP;
+                if (r < m && j < k) Wl[r * LDW + j] = fmaxf(Wl[r * LDW + j], eps);
+            }
+            __syncthreads();
+            colsums();
+        }
+    }
+    for (int e = tid; e < KP * 16; e += T) {
+        const int j = e >> 4, c = e & 15;
+        if (j < k && c0 + c < n) H[(long)j * a.ldh + c0 + c] = hs[j * LDR + c];
+    }
+    if (blockIdx.x == 0) {
+        for (int idx = tid; idx < m * k; idx += T) {
+            const int r = idx / k, j = idx - r * k;
+            W[(long)r * a.ldw + j] = Wl[r * LDW + j];
+        }
+    }
+}
+inline size_t small_kl_hfit_lds(int kp, int nw, long m) {
+    const long m16 = (m + 15) & ~15L;
+    return ((size_t)m16 * (kp + 1) + (size_t)nw * kp * 17 + (size_t)kp * 17 + kp) * sizeof(float);
+}
+
 // LDS of either kernel: [slab of A] + H + the slab's W + (KL: row sums, per-wave column sums; FRO: the k x k Gram matrix)
 inline size_t small_kl_lds(int kp, int nw, long n, bool alds) {
     const long ns = (n + 15) & ~15L;
