@@ -213,6 +213,8 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
         rc = small_fit(method == FIT_MU_FRO, (const float*)A, m, n, lda, W, ldw, H, ldh, k, eps, w_update, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
         ctx->B = B;
         if (rc) return rc;
+        // (the W-fixed KL kernel leaves W alone; the clamp of pyDNMF.py:155 after step 0 is this launch)
+        if (small && method == FIT_MU_KL && !w_update && (rc = dnmf_clamp_min(W, m, k, ldw, eps, stream))) return rc;
     }
     // W fixed (the regression fit of an NMFk sweep, pyDNMFk.py:243-247): the Frobenius H updates read A only through W^T A, and W^T A and
     // W^T W are loop invariants once W has been clamped (the clamp after step 0 is the only thing that can still change W; it is idempotent

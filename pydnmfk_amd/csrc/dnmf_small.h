@@ -600,14 +600,14 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 // whole fit -- all of W in LDS, its columns of H in registers / LDS, its 16 columns of A streamed from the L2 (m x 64 bytes per step) -- and
 // iterates on its own: NO grid barrier, no exchange, no residency requirement.  Wave w takes the row tiles w, w + NW, ...: S = W H
 // (B operand = the wave's copy of the H columns), U = A / (S + eps) in the C registers = the B operand of W^T U; the waves' partial
-// k x 16 results are summed in wave order through LDS, H *= W^T U / (colsum(W) + eps), clamp every tenth step.  W is clamped once,
-// after step 0 (pyDNMF.py:155: idempotent afterwards), and its column sums are taken again.
+// k x 16 results are summed in wave order through LDS, H *= W^T U / (colsum(W) + eps), clamp every tenth step.  The LDS copy of W is
+// clamped once, after step 0 (pyDNMF.py:155: idempotent afterwards), and its column sums are taken again.
 template <int KP, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a) {
     constexpr int JT = KP / 16, KS = KP / 4, T = 64 * NW, LDW = KP + 1, LDR = 17;
     const int z = a.z0 + blockIdx.z, c0 = 16 * blockIdx.x;
     const float* __restrict__ A = a.A + (long)z * a.a_stride;
-    float* W = a.W + (long)z * a.w_stride;
+    const float* __restrict__ W = a.W + (long)z * a.w_stride;
     float* H = a.H + (long)z * a.h_stride;
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
@@ -725,12 +725,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a
         const int j = e >> 4, c = e & 15;
         if (j < k && c0 + c < n) H[(long)j * a.ldh + c0 + c] = hs[j * LDR + c];
     }
-    if (blockIdx.x == 0) {
-        for (int idx = tid; idx < m * k; idx += T) {
-            const int r = idx / k, j = idx - r * k;
-            W[(long)r * a.ldw + j] = Wl[r * LDW + j];
-        }
-    }
+    // (W itself is only read here: a workgroup that starts late must still find the caller's W, not a clamped one -- the host clamps W
+    // with its own launch after this kernel, csrc/dnmf_fit.hip)
 }
 inline size_t small_kl_hfit_lds(int kp, int nw, long m) {
     const long m16 = (m + 15) & ~15L;
