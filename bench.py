@@ -80,6 +80,7 @@ def parse_args():
                     help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
                          "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
+    ap.add_argument("--no-swim", action="store_true", help="skip the extra measurement of the reference's own example sweep (swim, KL / MU NMFk) in the default run")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic, single GPU: run ONE rank's share of an R-GPU row grid (m / R rows) with the REAL exchange calls on "
                          "a one-rank group (RCCL has no wire to cross: kernels, launch overheads and the collectives' fixed costs are "
@@ -738,6 +739,42 @@ def run_config4(a, job):
     return out
 
 
+def swim_example(npz, dev):
+    """One warm-up sweep + one timed sweep of the reference's swim example (see tools/swimbench.py)."""
+    import contextlib
+    import tempfile
+    import numpy as np
+    import torch
+    from pydnmfk_amd.dist_comm import MPI_comm
+    from pydnmfk_amd.pyDNMFk import PyNMFk
+    from pydnmfk_amd.utils import parse
+    X = torch.from_numpy(np.ascontiguousarray(np.load(npz)["A"].astype(np.float32))).to(dev)
+    itr = 5000
+
+    def sweep():
+        comms = MPI_comm(None, 1, 1)
+        q = parse()
+        q.size, q.rank, q.comm, q.p_r, q.p_c = 1, 0, comms, 1, 1
+        q.row_comm, q.col_comm, q.comm1 = comms.cart_1d_row(), comms.cart_1d_column(), comms.comm
+        q.fpath, q.fname, q.ftype = "../data/", "swim", "mat"
+        q.start_k, q.end_k, q.sill_thr, q.itr, q.init = 14, 18, 0.6, itr, "rand"
+        q.noise_var, q.verbose, q.norm, q.method, q.checkpoint = 0.016, False, "kl", "mu", False
+        q.prune, q.rng, q.results_path = False, "device", tempfile.mkdtemp(prefix="dnmf_swim_") + "/"
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):
+            nopt = PyNMFk(X, factors=None, params=q).fit()
+        torch.cuda.synchronize()
+        return int(nopt), time.perf_counter() - t0
+
+    sweep()
+    nopt, secs = sweep()
+    steps = 5 * 21 * itr
+    return {"workload": "NMFk on swim %d x %d (tests/golden/data_swim.npz = the reference's data/swim.mat): KL/MU, k = 14..18, 20 perturbations + the "
+                        "regression fit per k, %d iterations each, one rank, device resident" % (X.shape[0], X.shape[1], itr),
+            "nopt": nopt, "known_answer": 16, "seconds_per_sweep": secs, "kl_steps_per_sec": steps / secs, "fits_per_sec": 105 / secs,
+            "note": "every fit is ONE persistent kernel (csrc/dnmf_small.h): slab of A, rows of W and H in LDS across the steps"}
+
+
 def run_config5(a, job):
     """BASELINE config 5: the NMFk sweep k = 2..16, 20 perturbations, HALS / Frobenius on bf16-STORED X (reference
     pyDNMFk.py:169-258 over dist_nmf.py:873-934, clustering dist_clustering.py:84-160).  X = 65536 x 4096 of planted rank 6
@@ -1281,6 +1318,16 @@ def main():
             res16["note"] = ("X stored as bfloat16 (half the HBM bytes; a rounded X, not the headline's fp32 X); fp32 factors and "
                              "accumulation; bf16x6 = X times the three bf16 pieces of the fp32 factor")
             out["bf16_stored_x"] = res16
+
+    # Informational: the reference's OWN example next to its headline configuration -- examples/dist_pynmfk_2d_Swim.py (NMFk, KL / MU, k =
+    # 14..18, 20 perturbations x 5000 iterations, 1024 x 256) on one rank, whole sweep incl. clustering and the regression fits; the known
+    # answer is nopt == 16.  Small problems: the whole-fit kernels of csrc/dnmf_small.h (tools/swimbench.py is the stand-alone tool).
+    swim_npz = os.path.join(ROOT, "tests", "golden", "data_swim.npz")
+    if not multi and rank == 0 and not a.no_swim and a.gemm == "fp32" and os.path.exists(swim_npz):
+        try:
+            out["reference_example_swim"] = swim_example(swim_npz, dev)
+        except Exception as ex:  # noqa: BLE001 -- informational: never costs the headline line
+            out["reference_example_swim"] = {"error": str(ex)[:200]}
 
     if not a.no_kernel_timing and a.norm == "fro":
         # Per-kernel HIP-event timings IN SITU: the step is replayed primitive by primitive (same launches, same order
