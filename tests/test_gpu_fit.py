@@ -272,3 +272,46 @@ def test_persistent_fit_that_loses_its_residency_ends_and_says_so():
     HIP_OPS.hals_check()
     assert torch.isfinite(W3).all() and torch.isfinite(H3).all()
     assert lib.dnmf_fit_set_timeout(0.0) == -1
+
+
+@pytest.mark.parametrize("m,n,k", [(17, 5, 1), (33, 300, 2), (130, 47, 16), (2050, 130, 17), (8192, 64, 32), (100, 500, 9), (1500, 16, 5)])
+@pytest.mark.parametrize("norm", ["kl", "fro"])
+def test_persistent_fits_on_padded_operands_through_the_c_abi(m, n, k, norm):
+    """The persistent small-fit kernels behind dnmf_mu_{kl,fro}_fit with leading dimensions larger than the rows (views of wider
+    arrays: every pitch odd or unaligned), a batch of 3 and both settings of w_update, against the float64 loop: ragged slabs, one to
+    64 slabs per problem, k = 1, n < 16, streamed and LDS-resident A."""
+    from pydnmfk_amd._lib import lib
+    from pydnmfk_amd.engine import HIP_OPS
+    if not lib.dnmf_mu_fit_persistent(m, n, k):
+        pytest.skip("shape not on the persistent path")
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(m + 7 * n + k)
+    B, itr, eps = 3, 23, 1.1920929e-07
+    fn = lib.dnmf_mu_kl_fit if norm == "kl" else lib.dnmf_mu_fro_fit
+
+    def pitched(rows, cols, extra):                    # [B][rows][cols] views of wider arrays; the problem stride stays a 16-byte multiple
+        full = torch.rand(B, rows + 4 - rows % 4, cols + extra, device=dev, generator=g) + 0.05
+        return full, full[:, :rows, :cols]
+    for w_update in (1, 0):
+        Af, A = pitched(m, n, 5)
+        Wf, W = pitched(m, k, 3)
+        Hf, H = pitched(k, n, 1)
+        A[:, :, ::3] *= (torch.rand(B, m, (n + 2) // 3, device=dev, generator=g) > 0.3)      # zeros in the data
+        W0, H0 = W.clone(), H.clone()
+        guard_w, guard_h = Wf.clone(), Hf.clone()
+        nbytes = lib.dnmf_ws_bytes_fit(m, n, k, B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sq = torch.empty(B, 2, dtype=torch.float64, device=dev)
+        rc = fn(A.data_ptr(), m, n, A.stride(1), W.data_ptr(), W.stride(1), H.data_ptr(), H.stride(1), k, eps, w_update, itr, B,
+                A.stride(0), W.stride(0), H.stride(0), sq.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.dnmf_last_error()
+        torch.cuda.synchronize()
+        HIP_OPS.hals_check()
+        for b in range(B):
+            Wr, Hr = _mu_fit_f64(A[b], W0[b], H0[b], itr, bool(w_update), norm)
+            assert _close(W[b], Wr, 3e-4) and _close(H[b], Hr, 3e-4), (w_update, b)
+            R = A[b].double() - Wr @ Hr
+            assert abs(float(sq[b, 0]) / float((R * R).sum()) - 1) < 1e-3 and abs(float(sq[b, 1]) / float((A[b].double() ** 2).sum()) - 1) < 1e-5
+        # nothing outside the k columns / n columns of the factor views was written
+        guard_w[:, :m, :k] = W; guard_h[:, :k, :n] = H
+        assert torch.equal(guard_w, Wf) and torch.equal(guard_h, Hf)
