@@ -254,7 +254,7 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * workgroups of ALL problems resident together (it takes the column launches otherwise); `column_sweep` != 0 forces those.
  * After a HALS fit dnmf_hals_sweep_status tells whether a persistent sweep timed out.
  * SMALL MU problems (MU/KL and MU/FRO, fp32 A, k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
- * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~500 -- and at most 64 slabs: the reference's example sizes, swim 1024
+ * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~2400 at k <= 16, ~1200 beyond -- and at most 64 slabs (m <= 8192): the reference's example sizes, swim 1024
  * x 256, wtsi 96 x 21) run the whole loop as ONE persistent kernel per batch (csrc/dnmf_small.h): a workgroup per slab keeps its data in
  * LDS across the steps, the problem's workgroups meet at two barriers per step.  Same update rules, fp32 sums in another association
  * than the step kernels: results agree with dnmf_mu_{kl,fro}_step to fp32 rounding (not bit for bit); a batched fit still equals

@@ -26,8 +26,8 @@ SmallPlan small_kl_plan(long m, long n, int k) {
     s.kp = k <= 16 ? 16 : 32;
     s.ns = round_up(n, 16);
     // geometry by shape alone (a batched fit must equal single fits bit for bit): 128-row slabs with A in LDS when that fits; else
-    // 128-row slabs with A streamed from the L2 (H and the slab's W in LDS); else 64-row slabs with A in LDS
-    const struct { int nw; bool alds; } tries[3] = {{8, true}, {8, false}, {4, true}};
+    // 128-row slabs with A streamed from the L2 (H and the slab's W in LDS); else 64-row slabs with A in LDS, or streamed (short, wide problems)
+    const struct { int nw; bool alds; } tries[4] = {{8, true}, {8, false}, {4, true}, {4, false}};
     for (const auto& t : tries) {
         const size_t lds = small_kl_lds(s.kp, t.nw, n, t.alds);
         const long P = cdiv(m, 16L * t.nw);
@@ -168,8 +168,8 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
 #define SMALL_CASE(KP_, NW_, AL_)                                                                                                 \
     if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
         return fro ? small_kl_launch<KP_, NW_, AL_, true>(sp, a, batch, st, taken) : small_kl_launch<KP_, NW_, AL_, false>(sp, a, batch, st, taken)
-    SMALL_CASE(16, 8, true); SMALL_CASE(16, 8, false); SMALL_CASE(16, 4, true);
-    SMALL_CASE(32, 8, true); SMALL_CASE(32, 8, false); SMALL_CASE(32, 4, true);
+    SMALL_CASE(16, 8, true); SMALL_CASE(16, 8, false); SMALL_CASE(16, 4, true); SMALL_CASE(16, 4, false);
+    SMALL_CASE(32, 8, true); SMALL_CASE(32, 8, false); SMALL_CASE(32, 4, true); SMALL_CASE(32, 4, false);
 #undef SMALL_CASE
     return DNMF_OK;
 }

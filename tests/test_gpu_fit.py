@@ -274,7 +274,7 @@ def test_persistent_fit_that_loses_its_residency_ends_and_says_so():
     assert lib.dnmf_fit_set_timeout(0.0) == -1
 
 
-@pytest.mark.parametrize("m,n,k", [(17, 5, 1), (33, 300, 2), (130, 47, 16), (2050, 130, 17), (8192, 64, 32), (100, 500, 9), (1500, 16, 5)])
+@pytest.mark.parametrize("m,n,k", [(17, 5, 1), (33, 300, 2), (130, 47, 16), (2050, 130, 17), (8192, 64, 32), (100, 500, 9), (1500, 16, 5), (60, 2000, 12), (40, 1100, 30)])
 @pytest.mark.parametrize("norm", ["kl", "fro"])
 def test_persistent_fits_on_padded_operands_through_the_c_abi(m, n, k, norm):
     """The persistent small-fit kernels behind dnmf_mu_{kl,fro}_fit with leading dimensions larger than the rows (views of wider
