@@ -263,6 +263,9 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * dnmf_hals_sweep_status reports it.  dnmf_mu_fit_persistent(m, n, k) != 0: fits of this shape take that kernel. */
 size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch);
 int dnmf_mu_fit_persistent(long m, long n, int k);
+/* != 0: dnmf_hals_fro_fit[_bf16a] with w_update != 0 and column_sweep == 0 runs fits of this shape on the persistent kernel too (A streamed
+ * from the L2, fp32 or bf16-stored; the k column norms of a W sweep cross the problem's workgroups through value-as-flag slots) */
+int dnmf_hals_fit_persistent(long m, long n, int k);
 /* seconds a barrier of the persistent small fit may wait before it gives up (default 2; process-wide, read at the next fit call) */
 int dnmf_fit_set_timeout(double seconds);
 int dnmf_mu_fro_fit(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update,

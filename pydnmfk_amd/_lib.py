@@ -122,6 +122,7 @@ for _n in ("mu_fro_step_1d", "mu_fro_step_2d", "hals_fro_step_1d", "hals_fro_ste
 # sq_out, ws, ws_bytes, stream
 SIGNATURES["dnmf_ws_bytes_fit"] = [c_long, c_long, c_int, c_int]
 SIGNATURES["dnmf_mu_fit_persistent"] = [c_long, c_long, c_int]
+SIGNATURES["dnmf_hals_fit_persistent"] = [c_long, c_long, c_int]
 SIGNATURES["dnmf_fit_set_timeout"] = [ctypes.c_double]
 SIGNATURES["dnmf_mu_fro_fit"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int, c_int,
                                  c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_size_t, c_void_p]

@@ -40,6 +40,28 @@ SmallPlan small_kl_plan(long m, long n, int k) {
     return s;
 }
 
+// HALS on the persistent kernel (small_hals_fit_kernel): A always streamed, so LDS holds H, the slab's W, the Gram matrix and the
+// workgroup's share of W^T A; fp32 or bf16-stored A
+struct HalsPlan { int kp, nw, P, cw; long ns; size_t lds, part_floats, slot_words, bytes; bool ok; };
+HalsPlan small_hals_plan(long m, long n, int k) {
+    HalsPlan s{};
+    if (k < 1 || k > 32 || n > 4096 || tune("DNMF_SMALL_FIT", 1) == 0) return s;
+    s.kp = k <= 16 ? 16 : 32;
+    s.ns = round_up(n, 16);
+    for (int nw : {8, 4}) {
+        const long P = cdiv(m, 16L * nw);
+        const int cw = (int)cdiv(s.ns, P);
+        const size_t lds = small_hals_lds(s.kp, nw, n, cw);
+        if (lds <= 160 * 1024 && P <= 64 && (nw == 4 || P >= 2)) { s.nw = nw; s.P = (int)P; s.cw = cw; s.lds = lds; break; }
+    }
+    if (!s.nw) return s;
+    s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;
+    s.slot_words = (size_t)2 * s.kp * s.P;
+    s.bytes = (((s.part_floats + s.slot_words) * 4 + 255) & ~size_t(255)) + 256;
+    s.ok = true;
+    return s;
+}
+
 // per-problem workspace: [ step workspace | s: KP floats (column sums of W) | ss2: KP doubles | sq: 2 doubles | small-fit partials ]
 struct FitWs { size_t g_off, s_off, part_off, step_total, cs_off, ss2_off, sq_off, small_off, total; };
 
@@ -56,7 +78,7 @@ FitWs fit_layout(long m, long n, int k) {
     f.ss2_off = f.cs_off + al256((size_t)kp * sizeof(float));
     f.sq_off = f.ss2_off + al256((size_t)kp * sizeof(double));
     f.small_off = f.sq_off + 256;
-    f.total = f.small_off + small_kl_plan(m, n, k).bytes;
+    f.total = f.small_off + std::max(small_kl_plan(m, n, k).bytes, small_hals_plan(m, n, k).bytes);
     return f;
 }
 
@@ -174,6 +196,56 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
     return DNMF_OK;
 }
 
+// all `itr` HALS steps of `batch` small problems on the persistent kernel (W updated: with W fixed the hoisted H-only loop of fit_impl is
+// the better path)
+template <int KP, int NW, typename TA>
+int small_hals_launch(const HalsPlan& hp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    const auto kern = small_hals_fit_kernel<KP, NW, TA>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
+    int nb = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: device query failed");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, hp.lds) != hipSuccess || nb < 1) { clear_hip_error(); return DNMF_OK; }
+    const long cap = (long)nb * cus;
+    if (cap < hp.P) return DNMF_OK;
+    const int per_launch = (int)std::min<long>(batch, cap / hp.P);
+    const int each = (int)cdiv(batch, cdiv(batch, per_launch));
+    for (int z0 = 0; z0 < batch; z0 += each) {
+        a.z0 = z0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)hp.P, 1, (unsigned)std::min(each, batch - z0)), dim3(64 * NW), hp.lds, st, a);
+        const int rc = check_launch("small_hals_fit_kernel");
+        if (rc) return rc;
+    }
+    *taken = true;
+    return DNMF_OK;
+}
+
+int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int itr, int batch,
+                   long a_stride, long w_stride, long h_stride, char* ws, const FitWs& f, void* stream, bool* taken) {
+    *taken = false;
+    const HalsPlan hp = small_hals_plan(m, n, k);
+    if (!hp.ok || itr < 1) return DNMF_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SmallKlArgs a{};
+    a.A = (const float*)A; a.lda = lda; a.a_stride = a_stride; a.W = W; a.ldw = ldw; a.w_stride = w_stride; a.H = H; a.ldh = ldh; a.h_stride = h_stride;
+    a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = 1; a.cw = hp.cw;
+    a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
+    a.slots = (unsigned*)(ws + f.small_off) + hp.part_floats; a.slots_stride = (long)(f.total / sizeof(unsigned));
+    a.bar = (unsigned*)(ws + f.small_off + hp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.patience = g_small_patience;
+    if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
+    if (hipMemset2DAsync(a.slots, f.total, 0xff, hp.slot_words * sizeof(unsigned), (size_t)batch, st) != hipSuccess ||
+        hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: memset failed");
+#define HALS_CASE(KP_, NW_)                                                                                                       \
+    if (hp.kp == KP_ && hp.nw == NW_)                                                                                             \
+        return bf ? small_hals_launch<KP_, NW_, bf16_t>(hp, a, batch, st, taken) : small_hals_launch<KP_, NW_, float>(hp, a, batch, st, taken)
+    HALS_CASE(16, 8); HALS_CASE(16, 4); HALS_CASE(32, 8); HALS_CASE(32, 4);
+#undef HALS_CASE
+    return DNMF_OK;
+}
+
 int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
              int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
              void* ws, size_t ws_bytes, void* stream) {
@@ -206,7 +278,15 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
     char* base = (char*)ws;
     int rc = DNMF_OK;
     bool small = false;
-    if ((method == FIT_MU_KL || method == FIT_MU_FRO) && !bf) {
+    if (method == FIT_HALS_FRO && w_update && !column_sweep) {
+        const int B = ctx->B;
+        ctx->B = 1;
+        rc = small_hals_fit(bf, A, m, n, lda, W, ldw, H, ldh, k, eps, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
+        ctx->B = B;
+        if (rc) return rc;
+    }
+    // (Frobenius MU with W fixed: the hoisted H-only loop below beats the barrier kernel)
+    if ((method == FIT_MU_KL || (method == FIT_MU_FRO && w_update)) && !bf) {
         // small fp32 problems: the whole loop as one persistent kernel per batch (csrc/dnmf_small.h); launched unbatched -- it indexes the problems itself
         const int B = ctx->B;
         ctx->B = 1;
@@ -280,6 +360,10 @@ int dnmf_fit_set_timeout(double seconds) {
     if (!(seconds > 0.0) || seconds > 3600.0) return fail(DNMF_EINVAL, "fit_set_timeout: %g s", seconds);
     g_small_patience = (unsigned long long)(seconds * 1e8) + 1ull;
     return DNMF_OK;
+}
+
+int dnmf_hals_fit_persistent(long m, long n, int k) {
+    return (m >= 1 && n >= 1 && small_hals_plan(m, n, k).ok) ? 1 : 0;
 }
 
 int dnmf_mu_fit_persistent(long m, long n, int k) {

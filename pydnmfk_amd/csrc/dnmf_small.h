@@ -42,6 +42,8 @@ struct SmallKlArgs {
     unsigned* bar; long bar_stride;              // per problem: arrival counter (zeroed before the launch)
     unsigned long long patience;                 // ticks of the 100 MHz wall clock a barrier may wait
     int z0;                                      // first problem of this launch
+    unsigned* slots; long slots_stride;          // HALS: per problem [2][KP][P] column-norm partials (float bits; SLOT_EMPTY = not there yet)
+    int cw;                                      // HALS: columns of H a workgroup sweeps (ceil(NS / P))
 };
 
 __device__ unsigned int g_small_timeout = 0;     // sticky: a barrier of a persistent fit gave up (dnmf_hals_sweep_status reports it)
@@ -592,6 +594,328 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         for (int s = 0; s < KS; ++s)
             if (rowok && 4 * s + q < k) W[(r0 + 16 * wv + i) * a.ldw + 4 * s + q] = wreg[s];
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// HALS / Frobenius (dist_nmf.py:873-934) on the same slabs.  A is streamed from the L2 (fp32 or bf16-stored: TA), LDS holds H, the
+// slab's W, the Gram matrix and the workgroup's share of W^T A.
+//   W phase: A H^T as in the Frobenius kernel, T = A H^T - W G' with G' = G masked to l > j (the l = j term of the reference's
+//     W G[:, j] cancels its W[:, j] G[j][j]; the l < j terms are the rank-1 corrections below) on the matrix cores, into the slab's rows
+//     in LDS.  Then the k columns in sequence (:884-891): u = max(T[:, kk], eps); the slab's sum of squares goes to the problem's slot
+//     [parity][kk][slab] -- the value is its own flag -- and every workgroup collects the P slots (the same butterfly sum everywhere);
+//     w = u / norm; T[:, j] -= w G[kk][j] for j > kk.  One exchange per column: the price of the global column norm.
+//   H phase: W^T A + the slab's W^T W as in the Frobenius kernel; barrier; Gram and the workgroup's columns of W^T A summed in slab
+//     order, then a thread per column runs the k rows in sequence (:905-909) on the LDS copy of H; barrier; re-read H.
+//   The slots of a parity are reset by their owner after the first barrier of the step that used them: every reader is done with them
+//   by then, and they are not written again before the step after next.
+constexpr unsigned SLOT_EMPTY = 0xffffffffu;               // (a NaN pattern: a sum of squares never has it)
+template <typename TA> __device__ __forceinline__ float sm_ld(const TA* p);
+template <> __device__ __forceinline__ float sm_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float sm_ld<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+
+template <int KP, int NW, typename TA>
+__global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs a) {
+    constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1, LDG = KP + 1;
+    static_assert(JT * JT <= NW, "one wave per Gram tile");
+    const int z = a.z0 + blockIdx.z, p = blockIdx.x, P = gridDim.x;
+    const TA* __restrict__ A = reinterpret_cast<const TA*>(a.A) + (long)z * a.a_stride;
+    float* __restrict__ W = a.W + (long)z * a.w_stride;
+    float* H = a.H + (long)z * a.h_stride;
+    float* part = a.part + (long)z * a.part_stride;
+    unsigned* bar = a.bar + (long)z * a.bar_stride;
+    unsigned* slots = a.slots + (long)z * a.slots_stride;
+    const int m = a.m, n = a.n, k = a.k, cw = a.cw;
+    const float eps = a.eps;
+    const int NS = (n + 15) & ~15, nct = NS / 16, LDH = NS + 4;
+    float* pg = part + (long)P * KP * NS;                  // [P][KP][KP] W^T W of the slabs
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                      // [KP][LDH]
+    float* Ws = Hs + KP * LDH;                             // [R][LDW]   W; during the W sweep: T
+    float* Gs = Ws + R * LDW;                              // [KP][LDG]  H H^T (W phase), then W^T W (H sweep)
+    float* atw = Gs + KP * LDG;                            // [KP][cw]   this workgroup's columns of W^T A
+    float* red = atw + KP * cw;                            // [NW + 8]   wave sums / the broadcast norm
+    float* Ts = red + NW + 8;                              // [R][LDW]   T of the W sweep (the new columns go straight into Ws)
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long r0 = (long)p * R;
+    const bool avec = (a.lda % 4 == 0) && (((unsigned long)A & (4 * sizeof(TA) - 1)) == 0);
+    auto a_row4 = [&](int c) -> f32x4 {                    // A[r0 + 16 wv + i][c .. c + 3] (zero outside)
+        const long row = r0 + 16 * wv + i;
+        f32x4 v;
+        if (row < m && c + 4 <= n && avec) {               // one 16-byte (fp32) / 8-byte (bf16) access
+            if constexpr (sizeof(TA) == 4) v = *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
+            else {
+                const uint2 raw = *reinterpret_cast<const uint2*>(A + row * a.lda + c);
+                v[0] = __builtin_bit_cast(float, raw.x << 16); v[1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+                v[2] = __builtin_bit_cast(float, raw.y << 16); v[3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+            }
+            return v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (row < m && c + e < n) ? sm_ld<TA>(A + row * a.lda + c + e) : 0.f;
+        return v;
+    };
+    auto a_col4 = [&](int rbase, int c) -> f32x4 {         // A[r0 + rbase + r][c], r = 0..3
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r0 + rbase + e < m && c < n) ? sm_ld<TA>(A + (r0 + rbase + e) * a.lda + c) : 0.f;
+        return v;
+    };
+    for (int idx = tid; idx < R * KP; idx += T) {
+        const int r = idx / KP, j = idx - r * KP;
+        Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
+    }
+    auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
+        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
+                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
+            }
+        }
+        __syncthreads();
+        if (wv < JT * JT) {
+            const int j1 = wv / JT, j2 = wv - j1 * JT;
+            f32x4 g[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int ct = 0; ct < nct; ++ct) {
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(&Hs[(16 * j1 + i) * LDH + 16 * ct + 4 * q]);
+                const f32x4 h2 = *reinterpret_cast<const f32x4*>(&Hs[(16 * j2 + i) * LDH + 16 * ct + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[ct & 1] = SM_MFMA(h1[r], h2[r], g[ct & 1]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gs[(16 * j1 + 4 * q + r) * LDG + 16 * j2 + i] = g[0][r] + g[1][r];
+        }
+        __syncthreads();
+    };
+    load_h();
+    float wreg[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+    const bool rowok = r0 + 16 * wv + i < m;
+    unsigned gen = 0;
+    bool lost = false;                                     // (thread 0 of wave 0: a slot wait gave up -- no more waiting in this fit)
+
+    for (int it = 0; it < a.itr; ++it) {
+        const bool clamp = (it % 10 == 0);
+        unsigned* slot = slots + (long)(it & 1) * KP * P;
+        if (a.w_update) {
+            // ---------------------------------------------------------------- A H^T for rows 16 wv .. 16 wv + 15
+            f32x4 acc2[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc2[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 apre[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (t < nct ? t : nct - 1) + 4 * q);
+            for (int ct0 = 0; ct0 < nct; ct0 += 4) {
+                f32x4 av[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[t] = apre[t];
+                if (ct0 + 4 < nct) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (ct0 + 4 + t < nct ? ct0 + 4 + t : nct - 1) + 4 * q);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c0 = 16 * (ct0 + t < nct ? ct0 + t : nct - 1);
+                    if (ct0 + t >= nct) av[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {      // lane (j = i, q) reg r = (A H^T)[row 4 q + r][16 jt + i]
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(&Hs[(16 * jt + i) * LDH + c0 + 4 * q]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc2[t & 1][jt] = SM_MFMA(av[t][r], hv[r], acc2[t & 1][jt]);
+                    }
+                }
+            }
+            // T = A H^T - W G' (G'[l][j] = G[l][j] for l > j), into the wave's rows of Ws
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) d = SM_MFMA(wreg[s], (4 * s + q > 16 * jt + i) ? Gs[(4 * s + q) * LDG + 16 * jt + i] : 0.f, d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ts[(16 * wv + 4 * q + r) * LDW + 16 * jt + i] = (acc2[0][jt][r] + acc2[1][jt][r]) - d[r];
+            }
+            __syncthreads();
+            // ---------------------------------------------------------------- the k columns in sequence
+            const int srow = tid % R, sgrp = tid / R;      // the rank-1 corrections: T / R threads per row, columns sgrp, sgrp + T / R, ...
+            constexpr int SG = T / R;                      // (= 4)
+            for (int kk = 0; kk < k; ++kk) {                // two workgroup barriers and one exchange per column
+                float sq = 0.f;
+                if (tid < R) {
+                    const float u = fmaxf(Ts[tid * LDW + kk], eps);
+                    sq = (r0 + tid < m) ? u * u : 0.f;
+                }
+                if (wv * 64 < R) {                         // the waves that hold rows: sum of the wave, lane 0 -> red
+                    float v = row16_sum(sq);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (lane == 0) red[wv] = v;
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int w = 0; w < (R + 63) / 64; ++w) mine += red[w];
+                    if (lane == 0) __hip_atomic_store(&slot[kk * P + p], __builtin_bit_cast(unsigned, mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // collect the P slots: lane g polls slot g (P <= 64)
+                    unsigned bits = lane < P ? SLOT_EMPTY : 0u;
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned spins = 0;
+                    while (!lost) {
+                        if (bits == SLOT_EMPTY) bits = __hip_atomic_load(&slot[kk * P + (lane < P ? lane : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!__any(bits == SLOT_EMPTY)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 15u) == 15u && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) lost = true;
+                        if (wall_clock64() - t0 > a.patience) {
+                            if (lane == 0) {
+                                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&g_small_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            lost = true;
+                        }
+                    }
+                    float v = (lane < P && bits != SLOT_EMPTY) ? __builtin_bit_cast(float, bits) : 0.f;
+                    v = row16_sum(v);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (lane == 0) red[NW + (kk & 1)] = v;  // (two cells: the next column's norm never lands on one still being read)
+                }
+                __syncthreads();
+                const float ss = sqrtf(red[NW + (kk & 1)]);  // utils.py:388-391: the 2-norm of the whole column
+                const float u = fmaxf(Ts[srow * LDW + kk], eps);
+                const float w = ss > 0.f ? u / ss : u;
+                for (int j = kk + 1 + sgrp; j < k; j += SG) Ts[srow * LDW + j] = fmaf(-w, Gs[kk * LDG + j], Ts[srow * LDW + j]);
+                if (sgrp == 0) Ws[srow * LDW + kk] = (r0 + srow < m) ? w : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
+        }
+        __syncthreads();
+        // -------------------------------------------------------------------- H phase: W^T A per column tile, the slab's W^T W
+        for (int ct = wv; ct < nct; ct += NW) {
+            const int c0 = 16 * ct;
+            f32x4 acc3[2][JT];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc3[h2][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 hpre[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * t + 4 * q, c0 + i);
+            for (int rt0 = 0; rt0 < NW; rt0 += 4) {
+                f32x4 hcur[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hcur[t] = hpre[t];
+                if (rt0 + 4 < NW) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int jt = 0; jt < JT; ++jt)    // lane (col i, q) reg r = (W^T A)[16 jt + 4 q + r][c0 + i]
+                            acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], hcur[t][r], acc3[t & 1][jt]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
+        }
+        if (wv < JT * JT) {
+            const int j1 = wv / JT, j2 = wv - j1 * JT;
+            f32x4 g[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int rt = 0; rt < NW; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    g[rt & 1] = SM_MFMA(Ws[(16 * rt + 4 * q + r) * LDW + 16 * j1 + i], Ws[(16 * rt + 4 * q + r) * LDW + 16 * j2 + i], g[rt & 1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_dev(&pg[((long)p * KP + 16 * j1 + 4 * q + r) * KP + 16 * j2 + i], g[0][r] + g[1][r]);
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        if (a.w_update && tid < k) __hip_atomic_store(&slot[tid * P + p], SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // -------------------------------------------------------------------- H sweep on this workgroup's columns [cb, ce)
+        for (int e = tid; e < KP * KP; e += T) {
+            float x = 0.f;
+            for (int g0 = 0; g0 < P; g0 += 8) {
+                float y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) y[u] = ld_dev(&pg[(long)(g0 + u < P ? g0 + u : P - 1) * KP * KP + e]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x += (g0 + u < P) ? y[u] : 0.f;
+            }
+            Gs[(e / KP) * LDG + e % KP] = x;
+        }
+        const int cb = p * cw, ce = (cb + cw < NS) ? cb + cw : NS;
+        for (int e = tid; e < KP * cw; e += T) {
+            const int j = e / cw, c = cb + e - j * cw;
+            float sum = 0.f;
+            if (c < ce) {
+                for (int g0 = 0; g0 < P; g0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
+                }
+            }
+            atw[e] = sum;
+        }
+        __syncthreads();
+        // KP lanes per column (lane l holds H[l][c]): the dot product of row kk is a product per lane + a butterfly sum over the 16-lane
+        // DPP row(s); lane kk takes the new value -- rows in sequence, updated rows used at once (:905-909)
+        {
+            constexpr int CPW = 64 / KP;                    // columns per wave: 4 (KP = 16) or 2 (KP = 32)
+            const int l = lane % KP, cl = lane / KP;
+            for (int c = cb + wv * CPW + cl; c < cb + cw; c += NW * CPW) {       // (uniform trip count per wave: cw is the same everywhere)
+                const bool cok = c < ce;
+                float h = (cok && l < k) ? Hs[l * LDH + c] : 0.f;
+                const float aw = (cok && l < k) ? atw[l * cw + (c - cb)] : 0.f;
+                for (int kk = 0; kk < k; ++kk) {
+                    float d = Gs[kk * LDG + l] * h;         // (G rows beyond k are zero)
+                    d = row16_sum(d);
+                    if constexpr (KP == 32) d += __shfl_xor(d, 16, 64);
+                    const float t = fmaxf(h + aw - d, eps);
+                    if (l == kk) h = t;
+                }
+                if (cok && l < k) {
+                    const float v = (c < n) ? h : 0.f;
+                    Hs[l * LDH + c] = v;
+                    if (c < n) st_dev(&H[(long)l * a.ldh + c], v);
+                }
+            }
+        }
+        small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        load_h();
+        if (clamp) {                                       // W = max(W, eps) (pyDNMF.py:170-172; H is >= eps after its sweep)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (rowok && 4 * s + q < k) wreg[s] = fmaxf(wreg[s], eps);
+                Ws[(16 * wv + i) * LDW + 4 * s + q] = wreg[s];
+            }
+            __syncthreads();
+        }
+    }
+    if (a.itr > 0) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (rowok && 4 * s + q < k) W[(r0 + 16 * wv + i) * a.ldw + 4 * s + q] = wreg[s];
+    }
+}
+inline size_t small_hals_lds(int kp, int nw, long n, int cw) {
+    const long ns = (n + 15) & ~15L;
+    return ((size_t)kp * (ns + 4) + 2 * (size_t)(16 * nw) * (kp + 1) + (size_t)kp * (kp + 1) + (size_t)kp * cw + nw + 8) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------

@@ -24,6 +24,9 @@ CASES = [  # m, n, k, method, norm, precision, itr
     (1000, 250, 9, "mu", "fro", "float32", 31),       # the Frobenius twin of the persistent kernel
     (4100, 400, 20, "mu", "fro", "float32", 12),
     (96, 21, 4, "mu", "fro", "float32", 40),          # the reference's wtsi example shape
+    (1024, 256, 9, "hals", "fro", "bfloat16", 21),    # HALS on the persistent kernel: the small NMFk sweep's shape and storage
+    (1000, 250, 20, "hals", "fro", "float32", 13),    # ... ragged, k padded to 32
+    (96, 21, 4, "hals", "fro", "float32", 30),
     (1024, 256, 16, "mu", "kl", "float32", 25),       # the reference's swim example shape, 16-wide kernels
     (1024, 256, 17, "mu", "kl", "float32", 21),       # k = 17: 32-wide kernels on zero-padded factor images
     (1024, 256, 4, "mu", "fro", "float32", 25),
@@ -63,6 +66,8 @@ def _problem(m, n, k, seed, precision):
 
 def _persistent(m, n, k, method, norm, precision):
     from pydnmfk_amd._lib import lib
+    if method == "hals":
+        return lib.dnmf_hals_fit_persistent(m, n, k) != 0
     return method == "mu" and precision == "float32" and lib.dnmf_mu_fit_persistent(m, n, k) != 0
 
 
@@ -70,7 +75,20 @@ def _mu_fit_f64(A, W, H, itr, w_update, norm, eps=1.1920929e-07):
     """PyNMF.fit with MU/KL or MU/FRO on one rank in float64 (pyDNMF.py:151-194, dist_nmf.py:716-751, :806-849)"""
     A, W, H = A.double(), W.double().clone(), H.double().clone()
     for i in range(itr):
-        if norm == "fro":
+        if norm == "hals":                                  # dist_nmf.py:873-934
+            k = W.shape[1]
+            if w_update:
+                G, AH = H @ H.t(), A @ H.t()
+                for kk in range(k):
+                    t = W[:, kk] * G[kk, kk] + AH[:, kk] - W @ G[:, kk]
+                    W[:, kk] = torch.clamp(t, min=eps)
+                    ss = torch.linalg.norm(W[:, kk])
+                    if float(ss) > 0:
+                        W[:, kk] = W[:, kk] / ss
+            G, AtW = W.t() @ W, W.t() @ A
+            for kk in range(k):
+                H[kk] = torch.clamp(H[kk] + AtW[kk] - G[kk] @ H, min=eps)
+        elif norm == "fro":
             if w_update:
                 W = W * ((A @ H.t()) / (W @ (H @ H.t()) + eps))
             H = H * ((W.t() @ A) / ((W.t() @ W) @ H + eps))
@@ -96,9 +114,10 @@ def test_whole_fit_equals_step_loop(m, n, k, method, norm, precision, itr):
         for w_update in (True, False):
             W1, H1, e1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update)).fit()
             W2, H2, e2 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update, fit_loop="python")).fit()
-            Wr, Hr = _mu_fit_f64(A, W0, H0, itr, w_update, norm)
+            Wr, Hr = _mu_fit_f64(A, W0, H0, itr, w_update, "hals" if method == "hals" else norm)
+            tol = 1e-3 if method == "hals" else 2e-4       # (HALS: the sequential sweeps amplify fp32 rounding; the goldens hold 2e-3)
             for X, Y in ((W1, Wr), (H1, Hr), (W2, Wr), (H2, Hr)):
-                assert _close(X, Y, 2e-4), (w_update, float((X.double() - Y).abs().max()), float(Y.abs().max()))
+                assert _close(X, Y, tol), (w_update, float((X.double() - Y).abs().max()), float(Y.abs().max()))
             assert abs(e1 - e2) <= 1e-4 * max(1e-3, abs(e2)) and np.isfinite(e1)
         return
     for w_update in (True, False):
