@@ -291,6 +291,26 @@ def test_persistent_fit_that_loses_its_residency_ends_and_says_so():
     HIP_OPS.hals_check()
     assert torch.isfinite(W3).all() and torch.isfinite(H3).all()
     assert lib.dnmf_fit_set_timeout(0.0) == -1
+    # the same for the HALS kernel, whose column norms wait at slots of their own
+    def call_hals(W, H, itr):
+        rc = lib.dnmf_hals_fro_fit(A2.data_ptr(), m, n, A2.stride(1), W.data_ptr(), W.stride(1), H.data_ptr(), H.stride(1), k, 1.1920929e-07, 1, itr, 0,
+                                   B, A2.stride(0), W.stride(0), H.stride(0), sq[1].data_ptr(), ws[1].data_ptr(), ws[1].numel(), s2.cuda_stream)
+        assert rc == 0, lib.dnmf_last_error()
+    assert lib.dnmf_hals_fit_persistent(m, n, k)
+    assert lib.dnmf_fit_set_timeout(1e-7) == 0
+    try:
+        W3.copy_(Wr); H3.copy_(Hr)
+        call_hals(W3, H3, 3000)
+        torch.cuda.synchronize()
+    finally:
+        assert lib.dnmf_fit_set_timeout(2.0) == 0
+    with pytest.raises(DnmfError, match="resident"):
+        HIP_OPS.hals_check()
+    W3.copy_(Wr); H3.copy_(Hr)
+    call_hals(W3, H3, 30)
+    torch.cuda.synchronize()
+    HIP_OPS.hals_check()
+    assert torch.isfinite(W3).all() and torch.isfinite(H3).all()
 
 
 @pytest.mark.parametrize("m,n,k", [(17, 5, 1), (33, 300, 2), (130, 47, 16), (2050, 130, 17), (8192, 64, 32), (100, 500, 9), (1500, 16, 5), (60, 2000, 12), (40, 1100, 30)])
