@@ -250,8 +250,8 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * W + b w_stride, H + b h_stride (strides in ELEMENTS, multiples of 16 bytes, each spanning at least one problem: e.g. stacked
  * [batch][m][lda] arrays) and its scratch at ws + b (ws_bytes_fit / batch); sq_out is [batch][2].  Problem b of a batched fit
  * runs the same kernels on the same operands as a fit of its own: results are bit-identical to `batch` single fits (strides
- * are ignored for batch == 1).  `ws` >= dnmf_ws_bytes_fit(m, n, k, batch).  The persistent HALS W sweep then needs the
- * workgroups of ALL problems resident together (it takes the column launches otherwise); `column_sweep` != 0 forces those.
+ * are ignored for batch == 1).  `ws` >= dnmf_ws_bytes_fit(m, n, k, batch).  The persistent HALS W sweep runs on as many problems
+ * at a time as the device holds resident (a problem that does not fit on its own takes the column launches); `column_sweep` != 0 forces those.
  * After a HALS fit dnmf_hals_sweep_status tells whether a persistent sweep timed out.
  * SMALL MU problems (MU/KL and MU/FRO, fp32 A, k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
  * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~2400 at k <= 16, ~1200 beyond -- and at most 64 slabs (m <= 8192): the reference's example sizes, swim 1024

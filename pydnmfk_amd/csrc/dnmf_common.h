@@ -54,7 +54,7 @@ __device__ void buf_st_f32x4(f32x4 v, i32x4 rsrc, int voff, int soff, int aux) _
 // n = 0 (and gridDim.z = 1) outside a batched fit: the rebase then adds zero.  Strides are multiples of 16 bytes, so the
 // host's alignment decisions for problem 0 hold for every problem.
 struct BatchFam { unsigned long lo, hi; long stride; };
-struct BatchTab { int n; int pad_; BatchFam f[4]; };
+struct BatchTab { int n; int z0; BatchFam f[4]; };      // z0: first problem of this launch (a batch cut into several launches)
 // the calling thread's batch state (csrc/dnmf.hip owns it; set by the *_fit entry points around their launch sequence)
 struct BatchCtx { int B; BatchTab tab; };
 __attribute__((visibility("hidden"))) BatchCtx* dnmf_batch_();
@@ -65,7 +65,7 @@ __device__ __forceinline__ long batch_off(const void* p, const BatchTab& bt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < bt.n && a >= bt.f[i].lo && a < bt.f[i].hi) d = bt.f[i].stride;
-    return d * (long)blockIdx.z;
+    return d * (long)(blockIdx.z + bt.z0);
 }
 // pointer arithmetic, not integer arithmetic: the kernel-argument pointer keeps its global address space through it
 template <typename T>

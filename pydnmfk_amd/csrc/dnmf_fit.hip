@@ -85,7 +85,7 @@ FitWs fit_layout(long m, long n, int k) {
 struct BatchGuard {      // the batch state of this thread is set for the duration of one fit call, whatever the exit path
     BatchCtx* c;
     explicit BatchGuard(BatchCtx* ctx) : c(ctx) {}
-    ~BatchGuard() { c->B = 1; c->tab.n = 0; }
+    ~BatchGuard() { c->B = 1; c->tab.n = 0; c->tab.z0 = 0; }
 };
 
 bool overlap(const BatchFam& a, const BatchFam& b) { return a.lo < b.hi && b.lo < a.hi; }

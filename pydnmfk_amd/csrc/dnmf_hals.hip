@@ -93,7 +93,14 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
             have[dev] = true;
         }
     }
-    if (grid > HALS_MAX_WG || grid * dnmf_batch_()->B > (vec ? cap_v[dev] : cap_s[dev])) return 1;   // not applicable: the caller takes the column path
+    // a batch whose workgroups do not all fit the device runs the sweep kernel on as many problems at a time as do (round 5: it took the
+    // column launches instead -- 20 problems of 65536 rows, BASELINE config 5: 41 us x k per step -- and a batched fit then differed
+    // from single fits, which do fit)
+    BatchCtx* bc = dnmf_batch_();
+    const int B = bc->B;
+    const long cap = vec ? cap_v[dev] : cap_s[dev];
+    if (grid > HALS_MAX_WG || grid > cap || (pe && B > 1)) return 1;   // not applicable: the caller takes the column path
+    const int per = (int)std::min<long>(B, cap / grid);
     if (ldw >= (1L << 23) || ldah >= (1L << 23)) return 1;                        // beyond the 32-bit tile offsets of pass 1: column path
     if (check_only) return 0;
     if (!pe && batch_memset(slab, 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)
@@ -121,9 +128,17 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
         if (rc) return rc;
     }
     static const int dbg = (int)tune("DNMF_HALS_DBG", 0);     // tuning build: 1 = no grid exchange (timing experiment, wrong norms)
-    if (vec) DNMF_LAUNCH((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
-    else DNMF_LAUNCH((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
-    if (int rc = check_launch("hals_sweep_w")) return rc;
+    int rc_sweep = DNMF_OK;
+    for (int z0 = 0; z0 < B && !rc_sweep; z0 += per) {
+        bc->B = std::min(per, B - z0);
+        bc->tab.z0 = z0;
+        if (vec) DNMF_LAUNCH((hals_w_sweep_kernel<KP, HASVEC>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
+        else DNMF_LAUNCH((hals_w_sweep_kernel<KP, false>), dim3((unsigned)grid), dim3(HALS_WG), lds, st, W, m, k, ldw, (const float*)T, ldt, G, eps, slab, ss2, dbg, peers);
+        rc_sweep = check_launch("hals_sweep_w");
+    }
+    bc->B = B;
+    bc->tab.z0 = 0;
+    if (rc_sweep) return rc_sweep;
     // cross-rank: this rank's slab of this parity goes back to "empty" behind the sweep that used it -- a peer writes the sweep
     // after next into it only after finishing the next one, which needs this rank's next sweep, which is enqueued behind this fill
     if (pe && hipMemsetAsync(pe->slab[pe->rank], 0xff, (size_t)k * HALS_MAX_WG * sizeof(unsigned long long), st) != hipSuccess)

@@ -354,3 +354,19 @@ def test_persistent_fits_on_padded_operands_through_the_c_abi(m, n, k, norm):
         # nothing outside the k columns / n columns of the factor views was written
         guard_w[:, :m, :k] = W; guard_h[:, :k, :n] = H
         assert torch.equal(guard_w, Wf) and torch.equal(guard_h, Hf)
+
+
+def test_batched_hals_sweep_in_several_launches_equals_single_fits():
+    """A batch whose persistent W sweeps do not all fit the device at once (6 problems x 128 workgroups of 512 rows) runs the sweep
+    kernel on as many problems at a time as do: the factors still equal single fits bit for bit (round 4 took the column launches for
+    such a batch: different rounding than the single fits' persistent sweep, and 41 us per column at BASELINE config 5's size)."""
+    from pydnmfk_amd.pyDNMF import PyNMF
+    m, n, k, B, itr = 65536, 64, 8, 6, 4
+    probs = [_problem(m, n, k, 40 + b, "float32") for b in range(B)]
+    single = [PyNMF(A, factors=[W0, H0], params=_args(k, itr, "fro", "hals", "float32")).fit() for A, W0, H0 in probs]
+    fits = [PyNMF(A, factors=[W0, H0], params=_args(k, itr, "fro", "hals", "float32")) for A, W0, H0 in probs]
+    batched = PyNMF.fit_batch(fits)
+    assert getattr(fits[0], "_stack", None) is not None and fits[0]._stack.shape[0] == B
+    for b in range(B):
+        assert torch.equal(batched[b][0], single[b][0]) and torch.equal(batched[b][1], single[b][1]), b
+    assert not torch.equal(batched[0][0], batched[5][0])
