@@ -1,9 +1,10 @@
-// dnmf_small.h -- a whole MU/KL fit of a SMALL problem as ONE persistent kernel (round 5).
-// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf_fit.hip launches this one).
+// dnmf_small.h -- whole fits of SMALL problems as ONE persistent kernel per batch (round 5): MU/KL (small_kl_fit_kernel, described first;
+// small_kl_hfit_kernel when W is fixed), MU/FRO (small_fro_fit_kernel) and HALS (small_hals_fit_kernel).
+// Part of libdnmf_hip.so (kernels live in anonymous namespaces of the headers; csrc/dnmf_fit.hip plans and launches them).
 //
 // Why: the reference's own examples factorise 1024 x 256 matrices (examples/dist_pynmfk_2d_Swim.py: k = 14..18, 5000 KL steps per
 // fit, 20 perturbations per k).  At that size a step is ~11 dependent launches of 4-12 us each, whatever the batch: 90 us per
-// batched step, host-bound and latency-bound at once (profiles/r05_fitgap_*).  Here a problem's rows are cut into slabs of R = 16 NW
+// batched step, host-bound and latency-bound at once (tools/dbg/fitgap.py under rocprofv3).  Here a problem's rows are cut into slabs of R = 16 NW
 // rows, one workgroup per slab, all workgroups of all problems of a batch resident at once; a workgroup keeps its slab of A, its
 // rows of W and the whole of H in LDS for the entire fit and runs the iterations itself:
 //
