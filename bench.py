@@ -1326,6 +1326,19 @@ def main():
     if not multi and rank == 0 and not a.no_swim and a.gemm == "fp32" and os.path.exists(swim_npz):
         try:
             out["reference_example_swim"] = swim_example(swim_npz, dev)
+            if not a.no_cpu_baseline:
+                # the oracle's MU/KL step on a problem of the example's size, in the reference's process model (1 BLAS thread per process)
+                cores, model = host_cpu()
+                P = min(8, cores)
+                got = _cpu_pool(_cpu_kl_rank, [(r, 1024, 256, 16, 200) for r in range(P)], timeout=120)
+                if got:
+                    sec = max(got.values())
+                    steps = 5 * 21 * 5000
+                    out["reference_example_swim"]["cpu_baseline"] = {
+                        "value": P / sec, "unit": "KL steps/s", "cores": P, "kind": "port", "host_cpu": model, "seconds_per_step_per_core": sec,
+                        "sweep_seconds_if_spread_over_the_cores": steps * sec / P,
+                        "sample": "oracle kl_mu_step_local on a 1024 x 256, k = 16 problem: %d processes x 1 BLAS thread, 1 warm-up + 200 timed steps "
+                                  "each (slowest process); the sweep is 525 000 such steps" % P}
         except Exception as ex:  # noqa: BLE001 -- informational: never costs the headline line
             out["reference_example_swim"] = {"error": str(ex)[:200]}
 
