@@ -1319,29 +1319,6 @@ def main():
                              "accumulation; bf16x6 = X times the three bf16 pieces of the fp32 factor")
             out["bf16_stored_x"] = res16
 
-    # Informational: the reference's OWN example next to its headline configuration -- examples/dist_pynmfk_2d_Swim.py (NMFk, KL / MU, k =
-    # 14..18, 20 perturbations x 5000 iterations, 1024 x 256) on one rank, whole sweep incl. clustering and the regression fits; the known
-    # answer is nopt == 16.  Small problems: the whole-fit kernels of csrc/dnmf_small.h (tools/swimbench.py is the stand-alone tool).
-    swim_npz = os.path.join(ROOT, "tests", "golden", "data_swim.npz")
-    if not multi and rank == 0 and not a.no_swim and a.gemm == "fp32" and os.path.exists(swim_npz):
-        try:
-            out["reference_example_swim"] = swim_example(swim_npz, dev)
-            if not a.no_cpu_baseline:
-                # the oracle's MU/KL step on a problem of the example's size, in the reference's process model (1 BLAS thread per process)
-                cores, model = host_cpu()
-                P = min(8, cores)
-                got = _cpu_pool(_cpu_kl_rank, [(r, 1024, 256, 16, 200) for r in range(P)], timeout=120)
-                if got:
-                    sec = max(got.values())
-                    steps = 5 * 21 * 5000
-                    out["reference_example_swim"]["cpu_baseline"] = {
-                        "value": P / sec, "unit": "KL steps/s", "cores": P, "kind": "port", "host_cpu": model, "seconds_per_step_per_core": sec,
-                        "sweep_seconds_if_spread_over_the_cores": steps * sec / P,
-                        "sample": "oracle kl_mu_step_local on a 1024 x 256, k = 16 problem: %d processes x 1 BLAS thread, 1 warm-up + 200 timed steps "
-                                  "each (slowest process); the sweep is 525 000 such steps" % P}
-        except Exception as ex:  # noqa: BLE001 -- informational: never costs the headline line
-            out["reference_example_swim"] = {"error": str(ex)[:200]}
-
     if not a.no_kernel_timing and a.norm == "fro":
         # Per-kernel HIP-event timings IN SITU: the step is replayed primitive by primitive (same launches, same order
         # as dnmf_mu_fro_step / the 1D-row choreography) with an event pair around every library call, so each kernel
@@ -1471,6 +1448,28 @@ def main():
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(n, k, m)
             out["cpu_baseline_allcores"] = cpu_baseline_allcores(n, k, m)
+        # LAST (it must not disturb the clocks of the measurements above).  Informational: the reference's OWN example next to its headline
+        # configuration -- examples/dist_pynmfk_2d_Swim.py (NMFk, KL / MU, k = 14..18, 20 perturbations x 5000 iterations, 1024 x 256) on one rank, whole sweep incl. clustering and the regression fits; the known
+        # answer is nopt == 16.  Small problems: the whole-fit kernels of csrc/dnmf_small.h (tools/swimbench.py is the stand-alone tool).
+        swim_npz = os.path.join(ROOT, "tests", "golden", "data_swim.npz")
+        if not multi and not a.no_swim and a.gemm == "fp32" and os.path.exists(swim_npz):
+            try:
+                out["reference_example_swim"] = swim_example(swim_npz, dev)
+                if not a.no_cpu_baseline:
+                    # the oracle's MU/KL step on a problem of the example's size, in the reference's process model (1 BLAS thread per process)
+                    cores, model = host_cpu()
+                    P = min(8, cores)
+                    got = _cpu_pool(_cpu_kl_rank, [(r, 1024, 256, 16, 200) for r in range(P)], timeout=120)
+                    if got:
+                        sec = max(got.values())
+                        steps = 5 * 21 * 5000
+                        out["reference_example_swim"]["cpu_baseline"] = {
+                            "value": P / sec, "unit": "KL steps/s", "cores": P, "kind": "port", "host_cpu": model, "seconds_per_step_per_core": sec,
+                            "sweep_seconds_if_spread_over_the_cores": steps * sec / P,
+                            "sample": "oracle kl_mu_step_local on a 1024 x 256, k = 16 problem: %d processes x 1 BLAS thread, 1 warm-up + 200 timed steps "
+                                      "each (slowest process); the sweep is 525 000 such steps" % P}
+            except Exception as ex:  # noqa: BLE001 -- informational: never costs the headline line
+                out["reference_example_swim"] = {"error": str(ex)[:200]}
         flush_c_stdio()                                           # (RCCL's version banner sits in C stdio until here)
         print(json.dumps(out), flush=True)
     if world > 1:
