@@ -106,7 +106,8 @@ def test_f64_primitives_match_torch(ops, m, n, k):
     assert rel(Hh, Hr) < 1e-11
 
 
-@pytest.mark.parametrize("m,n,k", [(200, 150, 6), (2100, 333, 20), (4200, 131, 64), (9000, 70, 100)])
+@pytest.mark.parametrize("m,n,k", [(200, 150, 6), (2100, 333, 20), (4200, 131, 64), (9000, 70, 100),
+                                   (20000, 200, 40), (17000, 130, 100), (16500, 77, 20)])      # (tall: the LDS-staged A H^T kernel)
 def test_f64_products_on_unaligned_views(ops, m, n, k):
     """The big products on operands that rule out the 16-byte accesses: odd pitches, bases 8 bytes off (views of larger tensors) --
     the kernels fall back to 8-byte accesses lane by lane, same sums."""
@@ -123,6 +124,9 @@ def test_f64_products_on_unaligned_views(ops, m, n, k):
     assert rel(ops.kl_wtu(A, W, H, EPS, torch.empty(k, n, dtype=torch.float64, device=dev)), W.t() @ U) < tol
     R = A - W @ H
     assert abs(float(ops.resid_sqnorm(A, W, H)) / float((R * R).sum()) - 1) < tol
+    Ac, Hc = A.contiguous(), H.contiguous()                          # the same products on aligned operands (the 16-byte accesses)
+    assert rel(ops.aht(Ac, Hc, torch.empty(m, k, dtype=torch.float64, device=dev)), A @ H.t()) < tol
+    assert rel(ops.wta(Ac, W.contiguous(), torch.empty(k, n, dtype=torch.float64, device=dev)), W.t() @ A) < tol
 
 
 def _args(k, itr, norm, W_update=True, method="mu", prune=False):
