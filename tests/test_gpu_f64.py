@@ -107,7 +107,7 @@ def test_f64_primitives_match_torch(ops, m, n, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(200, 150, 6), (2100, 333, 20), (4200, 131, 64), (9000, 70, 100),
-                                   (20000, 200, 40), (17000, 130, 100), (16500, 77, 20)])      # (tall: the LDS-staged A H^T kernel)
+                                   (20000, 200, 40), (17000, 130, 100), (16500, 77, 20)])      # (tall shapes: four row tiles per wave)
 def test_f64_products_on_unaligned_views(ops, m, n, k):
     """The big products on operands that rule out the 16-byte accesses: odd pitches, bases 8 bytes off (views of larger tensors) --
     the kernels fall back to 8-byte accesses lane by lane, same sums."""
