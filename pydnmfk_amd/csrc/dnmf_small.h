@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     unsigned* bar = a.bar + (long)z * a.bar_stride;
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
+    const int ksteps = (k + 3) >> 2;                      // contraction steps of 4 that hold real columns of W
     const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
     float* pcs = part + (long)P * KP * NS;                 // [P][KP] column sums of W per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -208,9 +209,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { c0[t] = 16 * (ct0 + t < nct ? ct0 + t : nct - 1); d[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KS; ++s) {
+                    if (s >= ksteps) break;                // (the zero-padded steps beyond k: uniform)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Hs[(4 * s + q) * LDH + c0[t] + i], wreg[s], d[t]);
+                }
                 float u[4][4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 for (int t = 0; t < 4; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
+                    if (s >= ksteps) break;
                     const float hb = Hs[(4 * s + q) * LDH + c0 + i];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
@@ -936,6 +940,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a
     float* H = a.H + (long)z * a.h_stride;
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
+    const int ksteps = (k + 3) >> 2;
     const int m16 = (m + 15) & ~15, nrt = m16 / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                      // [m16][LDW]     all of W (zero beyond m / k)
@@ -1006,9 +1011,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a
                 d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s) {
+                if (s >= ksteps) break;                    // (the zero-padded steps beyond k: uniform)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Wl[(16 * rt[t] + i) * LDW + 4 * s + q], hb[s], d[t]);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float u[4];
