@@ -42,7 +42,7 @@ SmallPlan small_kl_plan(long m, long n, int k) {
 
 // HALS on the persistent kernel (small_hals_fit_kernel): A always streamed, so LDS holds H, the slab's W, the Gram matrix and the
 // workgroup's share of W^T A; fp32 or bf16-stored A
-struct HalsPlan { int kp, nw, P, cw; long ns; size_t lds, part_floats, slot_words, bytes; bool ok; };
+struct HalsPlan { int kp, nw, P, cw; long ns; size_t lds, lds_bf16_resident, part_floats, slot_words, bytes; bool ok; };
 HalsPlan small_hals_plan(long m, long n, int k) {
     HalsPlan s{};
     if (k < 1 || k > 32 || n > 4096 || tune("DNMF_SMALL_FIT", 1) == 0) return s;
@@ -51,8 +51,12 @@ HalsPlan small_hals_plan(long m, long n, int k) {
     for (int nw : {8, 4}) {
         const long P = cdiv(m, 16L * nw);
         const int cw = (int)cdiv(s.ns, P);
-        const size_t lds = small_hals_lds(s.kp, nw, n, cw);
-        if (lds <= 160 * 1024 && P <= 64 && (nw == 4 || P >= 2)) { s.nw = nw; s.P = (int)P; s.cw = cw; s.lds = lds; break; }
+        const size_t lds = small_hals_lds(s.kp, nw, n, cw, 0);
+        if (lds <= 160 * 1024 && P <= 64 && (nw == 4 || P >= 2)) {
+            s.nw = nw; s.P = (int)P; s.cw = cw; s.lds = lds;
+            s.lds_bf16_resident = small_hals_lds(s.kp, nw, n, cw, 2);       // (the geometry never depends on the storage: only where A is read from)
+            break;
+        }
     }
     if (!s.nw) return s;
     s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;
@@ -198,9 +202,11 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
 
 // all `itr` HALS steps of `batch` small problems on the persistent kernel (W updated: with W fixed the hoisted H-only loop of fit_impl is
 // the better path)
-template <int KP, int NW, typename TA>
-int small_hals_launch(const HalsPlan& hp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
-    const auto kern = small_hals_fit_kernel<KP, NW, TA>;
+template <int KP, int NW, typename TA, bool ALDS>
+int small_hals_launch(const HalsPlan& hp0, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    HalsPlan hp = hp0;
+    if (ALDS) hp.lds = hp.lds_bf16_resident;
+    const auto kern = small_hals_fit_kernel<KP, NW, TA, ALDS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
     int nb = 0, dev = 0, cus = 0;
@@ -240,7 +246,9 @@ int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, l
         return fail(DNMF_EHIP, "small fit: memset failed");
 #define HALS_CASE(KP_, NW_)                                                                                                       \
     if (hp.kp == KP_ && hp.nw == NW_)                                                                                             \
-        return bf ? small_hals_launch<KP_, NW_, bf16_t>(hp, a, batch, st, taken) : small_hals_launch<KP_, NW_, float>(hp, a, batch, st, taken)
+        return !bf ? small_hals_launch<KP_, NW_, float, false>(hp, a, batch, st, taken)                                           \
+                   : (hp.lds_bf16_resident <= 160 * 1024 ? small_hals_launch<KP_, NW_, bf16_t, true>(hp, a, batch, st, taken)         \
+                                                         : small_hals_launch<KP_, NW_, bf16_t, false>(hp, a, batch, st, taken))
     HALS_CASE(16, 8); HALS_CASE(16, 4); HALS_CASE(32, 8); HALS_CASE(32, 4);
 #undef HALS_CASE
     return DNMF_OK;

@@ -618,7 +618,8 @@ template <typename TA> __device__ __forceinline__ float sm_ld(const TA* p);
 template <> __device__ __forceinline__ float sm_ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float sm_ld<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
 
-template <int KP, int NW, typename TA>
+// ALDS: the slab of A in LDS in its storage type (bf16: 66 KiB for 128 rows x 256 columns -- it fits beside the rest; fp32 slabs stream)
+template <int KP, int NW, typename TA, bool ALDS>
 __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs a) {
     constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1, LDG = KP + 1;
     static_assert(JT * JT <= NW, "one wave per Gram tile");
@@ -640,6 +641,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
     float* atw = Gs + KP * LDG;                            // [KP][cw]   this workgroup's columns of W^T A
     float* red = atw + KP * cw;                            // [NW + 8]   wave sums / the broadcast norm
     float* Ts = red + NW + 8;                              // [R][LDW]   T of the W sweep (the new columns go straight into Ws)
+    TA* As = reinterpret_cast<TA*>(Ts + R * LDW);          // [R][LDA]   ALDS: the slab of A as stored (zero beyond m / n)
+    const int LDA = NS + 8;
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long r0 = (long)p * R;
@@ -647,6 +650,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
     auto a_row4 = [&](int c) -> f32x4 {                    // A[r0 + 16 wv + i][c .. c + 3] (zero outside)
         const long row = r0 + 16 * wv + i;
         f32x4 v;
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sm_ld<TA>(&As[(16 * wv + i) * LDA + c + e]);
+            return v;
+        }
         if (row < m && c + 4 <= n && avec) {               // one 16-byte (fp32) / 8-byte (bf16) access
             if constexpr (sizeof(TA) == 4) v = *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
             else {
@@ -662,6 +670,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
     };
     auto a_col4 = [&](int rbase, int c) -> f32x4 {         // A[r0 + rbase + r][c], r = 0..3
         f32x4 v;
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sm_ld<TA>(&As[(rbase + e) * LDA + c]);
+            return v;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (r0 + rbase + e < m && c < n) ? sm_ld<TA>(A + (r0 + rbase + e) * a.lda + c) : 0.f;
         return v;
@@ -669,6 +682,12 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
     for (int idx = tid; idx < R * KP; idx += T) {
         const int r = idx / KP, j = idx - r * KP;
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
+    }
+    if constexpr (ALDS) {
+        for (int idx = tid; idx < R * NS; idx += T) {
+            const int r = idx / NS, c = idx - r * NS;
+            As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : TA(0);
+        }
     }
     auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
         for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {
@@ -918,9 +937,10 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
             if (rowok && 4 * s + q < k) W[(r0 + 16 * wv + i) * a.ldw + 4 * s + q] = wreg[s];
     }
 }
-inline size_t small_hals_lds(int kp, int nw, long n, int cw) {
+inline size_t small_hals_lds(int kp, int nw, long n, int cw, size_t a_elem /* bytes per element of an LDS-resident A slab, 0: streamed */) {
     const long ns = (n + 15) & ~15L;
-    return ((size_t)kp * (ns + 4) + 2 * (size_t)(16 * nw) * (kp + 1) + (size_t)kp * (kp + 1) + (size_t)kp * cw + nw + 8) * sizeof(float);
+    return ((size_t)kp * (ns + 4) + 2 * (size_t)(16 * nw) * (kp + 1) + (size_t)kp * (kp + 1) + (size_t)kp * cw + nw + 8) * sizeof(float) +
+           (size_t)(16 * nw) * (ns + 8) * a_elem;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
