@@ -253,7 +253,7 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * are ignored for batch == 1).  `ws` >= dnmf_ws_bytes_fit(m, n, k, batch).  The persistent HALS W sweep runs on as many problems
  * at a time as the device holds resident (a problem that does not fit on its own takes the column launches); `column_sweep` != 0 forces those.
  * After a HALS fit dnmf_hals_sweep_status tells whether a persistent sweep timed out.
- * SMALL MU problems (MU/KL and MU/FRO, fp32 A, k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
+ * SMALL MU problems (MU/KL on fp32 A; MU/FRO on fp32 or bf16-stored A; k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
  * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~2400 at k <= 16, ~1200 beyond -- and at most 64 slabs (m <= 8192): the reference's example sizes, swim 1024
  * x 256, wtsi 96 x 21) run the whole loop as ONE persistent kernel per batch (csrc/dnmf_small.h): a workgroup per slab keeps its data in
  * LDS across the steps, the problem's workgroups meet at two barriers per step.  Same update rules, fp32 sums in another association

@@ -66,6 +66,27 @@ HalsPlan small_hals_plan(long m, long n, int k) {
     return s;
 }
 
+// MU/FRO on bf16-stored data (params.precision = 'bfloat16'): the Frobenius kernel with TA = bf16_t, its own plan (the slab is half the
+// size: it fits LDS where the fp32 one streams)
+struct FroBfPlan { int kp, nw, P; bool alds; long ns; size_t lds, part_floats, bytes; bool ok; };
+FroBfPlan small_fro_bf16_plan(long m, long n, int k) {
+    FroBfPlan s{};
+    if (k < 1 || k > 32 || n > 4096 || tune("DNMF_SMALL_FIT", 1) == 0) return s;
+    s.kp = k <= 16 ? 16 : 32;
+    s.ns = round_up(n, 16);
+    const struct { int nw; bool alds; } tries[4] = {{8, true}, {8, false}, {4, true}, {4, false}};
+    for (const auto& t : tries) {
+        const size_t lds = small_fro_lds(s.kp, t.nw, n, t.alds, 2);
+        const long P = cdiv(m, 16L * t.nw);
+        if (lds <= 160 * 1024 && P <= 64 && (t.nw == 4 || P >= 2)) { s.nw = t.nw; s.alds = t.alds; s.P = (int)P; s.lds = lds; break; }
+    }
+    if (!s.nw) return s;
+    s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;
+    s.bytes = ((s.part_floats * sizeof(float) + 255) & ~size_t(255)) + 256;
+    s.ok = true;
+    return s;
+}
+
 // per-problem workspace: [ step workspace | s: KP floats (column sums of W) | ss2: KP doubles | sq: 2 doubles | small-fit partials ]
 struct FitWs { size_t g_off, s_off, part_off, step_total, cs_off, ss2_off, sq_off, small_off, total; };
 
@@ -82,7 +103,7 @@ FitWs fit_layout(long m, long n, int k) {
     f.ss2_off = f.cs_off + al256((size_t)kp * sizeof(float));
     f.sq_off = f.ss2_off + al256((size_t)kp * sizeof(double));
     f.small_off = f.sq_off + 256;
-    f.total = f.small_off + std::max(small_kl_plan(m, n, k).bytes, small_hals_plan(m, n, k).bytes);
+    f.total = f.small_off + std::max(std::max(small_kl_plan(m, n, k).bytes, small_hals_plan(m, n, k).bytes), small_fro_bf16_plan(m, n, k).bytes);
     return f;
 }
 
@@ -126,7 +147,7 @@ unsigned long long g_small_patience = 200000000ull;
 // all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
 template <int KP, int NW, bool ALDS, bool FRO>
 int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
-    const auto kern = FRO ? small_fro_fit_kernel<KP, NW, ALDS> : small_kl_fit_kernel<KP, NW, ALDS>;
+    const auto kern = FRO ? small_fro_fit_kernel<KP, NW, ALDS, float> : small_kl_fit_kernel<KP, NW, ALDS>;
     static int cus = 0;
     if (!cus) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -254,6 +275,51 @@ int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, l
     return DNMF_OK;
 }
 
+// a launch (or as few as keep every workgroup resident) of a persistent small-fit kernel
+int resident_launch(void (*kern)(SmallKlArgs), int threads, size_t lds, int P, SmallKlArgs a, int batch, hipStream_t st, bool* taken, const char* what) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
+    int nb = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: device query failed");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) { clear_hip_error(); return DNMF_OK; }
+    const long cap = (long)nb * cus;
+    if (cap < P) return DNMF_OK;
+    const int per_launch = (int)std::min<long>(batch, cap / P);
+    const int each = (int)cdiv(batch, cdiv(batch, per_launch));
+    for (int z0 = 0; z0 < batch; z0 += each) {
+        a.z0 = z0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)P, 1, (unsigned)std::min(each, batch - z0)), dim3(threads), lds, st, a);
+        const int rc = check_launch(what);
+        if (rc) return rc;
+    }
+    *taken = true;
+    return DNMF_OK;
+}
+
+int small_fro_bf16_fit(const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int itr, int batch,
+                       long a_stride, long w_stride, long h_stride, char* ws, const FitWs& f, void* stream, bool* taken) {
+    *taken = false;
+    const FroBfPlan sp = small_fro_bf16_plan(m, n, k);
+    if (!sp.ok || itr < 1) return DNMF_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SmallKlArgs a{};
+    a.A = (const float*)A; a.lda = lda; a.a_stride = a_stride; a.W = W; a.ldw = ldw; a.w_stride = w_stride; a.H = H; a.ldh = ldh; a.h_stride = h_stride;
+    a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = 1;
+    a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
+    a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.patience = g_small_patience;
+    if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
+    if (hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
+#define FROBF_CASE(KP_, NW_, AL_)                                                                                                 \
+    if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
+        return resident_launch(small_fro_fit_kernel<KP_, NW_, AL_, bf16_t>, 64 * NW_, sp.lds, sp.P, a, batch, st, taken, "small_fro_fit_kernel(bf16)")
+    FROBF_CASE(16, 8, true); FROBF_CASE(16, 8, false); FROBF_CASE(16, 4, true); FROBF_CASE(16, 4, false);
+    FROBF_CASE(32, 8, true); FROBF_CASE(32, 8, false); FROBF_CASE(32, 4, true); FROBF_CASE(32, 4, false);
+#undef FROBF_CASE
+    return DNMF_OK;
+}
+
 int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps,
              int w_update, int itr, int column_sweep, int batch, long a_stride, long w_stride, long h_stride, double* sq_out,
              void* ws, size_t ws_bytes, void* stream) {
@@ -290,6 +356,13 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
         const int B = ctx->B;
         ctx->B = 1;
         rc = small_hals_fit(bf, A, m, n, lda, W, ldw, H, ldh, k, eps, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
+        ctx->B = B;
+        if (rc) return rc;
+    }
+    if (method == FIT_MU_FRO && bf && w_update) {
+        const int B = ctx->B;
+        ctx->B = 1;
+        rc = small_fro_bf16_fit(A, m, n, lda, W, ldw, H, ldh, k, eps, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
         ctx->B = B;
         if (rc) return rc;
     }

@@ -68,6 +68,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// one element of A as stored -> fp32 (bf16 -> fp32 is a 16-bit shift)
+template <typename TA> __device__ __forceinline__ float sm_ld(const TA* p);
+template <> __device__ __forceinline__ float sm_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float sm_ld<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+
 // arrive at / wait for the `gen`-th barrier of the problem's nwg workgroups (counter monotonic: gen nwg arrivals in all).  bar[1] is the
 // problem's abort word (zeroed with the counter before the launch): the first wait that exceeds `patience` sets it and the sticky
 // device word; every wait of the problem -- this one and all later ones, in every workgroup -- then returns at once, so a fit that lost
@@ -364,47 +369,67 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 //   H phase: W^T A per column tile + the slab's W^T W (first JT^2 waves) -> global partials; barrier; every workgroup sums the Gram
 //     partials (slab order), then for its share of H's elements the W^T A partials, and H *= W^T A / (G H + eps) with the k-term dot
 //     product from LDS; barrier; re-read H.
-template <int KP, int NW, bool ALDS>
+// TA: the storage type of A (float, or bf16_t for params.precision = 'bfloat16'); ALDS: the slab in LDS as stored, else streamed from the L2
+template <int KP, int NW, bool ALDS, typename TA>
 __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a) {
     constexpr int JT = KP / 16, KS = KP / 4, R = 16 * NW, T = 64 * NW, LDW = KP + 1, LDG = KP + 1;
     static_assert(JT * JT <= NW, "one wave per Gram tile");
     const int z = a.z0 + blockIdx.z, p = blockIdx.x, P = gridDim.x;
-    const float* __restrict__ A = a.A + (long)z * a.a_stride;
+    const TA* __restrict__ A = reinterpret_cast<const TA*>(a.A) + (long)z * a.a_stride;
     float* __restrict__ W = a.W + (long)z * a.w_stride;
     float* H = a.H + (long)z * a.h_stride;
     float* part = a.part + (long)z * a.part_stride;
     unsigned* bar = a.bar + (long)z * a.bar_stride;
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
-    const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
+    const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + (sizeof(TA) == 4 ? 4 : 8), LDH = NS + 4;
     float* pg = part + (long)P * KP * NS;                  // [P][KP][KP] W^T W of the slabs
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Hs = As + (ALDS ? R * LDA : 0);                 // [KP][LDH]
+    float* Hs = smem;                                      // [KP][LDH]
     float* Ws = Hs + KP * LDH;                             // [R][LDW]
     float* Gs = Ws + R * LDW;                              // [KP][LDG]  H H^T (W phase), then W^T W (H update)
+    TA* As = reinterpret_cast<TA*>(Gs + ((KP * LDG + 3) & ~3));       // [R][LDA]   ALDS: the slab of A as stored (16-byte aligned rows)
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long r0 = (long)p * R;
     if constexpr (ALDS) {
         for (int idx = tid; idx < R * NS; idx += T) {
             const int r = idx / NS, c = idx - r * NS;
-            As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : 0.f;
+            As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : TA(0);
         }
     }
-    const bool avec = (a.lda % 4 == 0) && (((unsigned long)A & 15) == 0);
-    auto a_row4 = [&](int c) -> f32x4 {
-        const long row = r0 + 16 * wv + i;
-        if (row < m && c + 4 <= n && avec) return *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
+    const bool avec = (a.lda % 4 == 0) && (((unsigned long)A & (4 * sizeof(TA) - 1)) == 0);
+    auto a_row4 = [&](int c) -> f32x4 {                    // A[r0 + 16 wv + i][c .. c + 3] (zero outside)
         f32x4 v;
+        if constexpr (ALDS) {
+            if constexpr (sizeof(TA) == 4) v = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c]);
+            else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (row < m && c + e < n) ? A[row * a.lda + c + e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = sm_ld<TA>(&As[(16 * wv + i) * LDA + c + e]);
+            }
+            return v;
+        }
+        const long row = r0 + 16 * wv + i;
+        if (row < m && c + 4 <= n && avec) {
+            if constexpr (sizeof(TA) == 4) v = *reinterpret_cast<const f32x4*>(A + row * a.lda + c);
+            else {
+                const uint2 raw = *reinterpret_cast<const uint2*>(A + row * a.lda + c);
+                v[0] = __builtin_bit_cast(float, raw.x << 16); v[1] = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+                v[2] = __builtin_bit_cast(float, raw.y << 16); v[3] = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+            }
+            return v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (row < m && c + e < n) ? sm_ld<TA>(A + row * a.lda + c + e) : 0.f;
         return v;
     };
-    auto a_col4 = [&](int rbase, int c) -> f32x4 {
+    auto a_col4 = [&](int rbase, int c) -> f32x4 {         // A[r0 + rbase + r][c], r = 0..3
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (r0 + rbase + e < m && c < n) ? A[(r0 + rbase + e) * a.lda + c] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (ALDS) v[e] = sm_ld<TA>(&As[(rbase + e) * LDA + c]);
+            else v[e] = (r0 + rbase + e < m && c < n) ? sm_ld<TA>(A + (r0 + rbase + e) * a.lda + c) : 0.f;
+        }
         return v;
     };
     for (int idx = tid; idx < R * KP; idx += T) {
@@ -474,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int c0 = 16 * (ct0 + t < nct ? ct0 + t : nct - 1);
-                    if constexpr (ALDS) av[t] = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0 + 4 * q]);
+                    if constexpr (ALDS) av[t] = a_row4(c0 + 4 * q);
                     if (ct0 + t >= nct) av[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt) {      // lane (j = i, q) reg r = (A H^T)[row 4 q + r][16 jt + i]
@@ -524,12 +549,15 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 #pragma unroll
                         for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
                     }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hcur[t] = a_col4(16 * (rt0 + t) + 4 * q, c0 + i);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float av = ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r];
+                        const float av = hcur[t][r];
 #pragma unroll
                         for (int jt = 0; jt < JT; ++jt)    // lane (col i, q) reg r = (W^T A)[16 jt + 4 q + r][c0 + i]
                             acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], av, acc3[t & 1][jt]);
@@ -614,9 +642,6 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 //   The slots of a parity are reset by their owner after the first barrier of the step that used them: every reader is done with them
 //   by then, and they are not written again before the step after next.
 constexpr unsigned SLOT_EMPTY = 0xffffffffu;               // (a NaN pattern: a sum of squares never has it)
-template <typename TA> __device__ __forceinline__ float sm_ld(const TA* p);
-template <> __device__ __forceinline__ float sm_ld<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float sm_ld<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
 
 // ALDS: the slab of A in LDS in its storage type (bf16: 66 KiB for 128 rows x 256 columns -- it fits beside the rest; fp32 slabs stream)
 template <int KP, int NW, typename TA, bool ALDS>
@@ -1086,6 +1111,11 @@ inline size_t small_kl_hfit_lds(int kp, int nw, long m) {
 }
 
 // LDS of either kernel: [slab of A] + H + the slab's W + (KL: row sums, per-wave column sums; FRO: the k x k Gram matrix)
+inline size_t small_fro_lds(int kp, int nw, long n, bool alds, size_t a_elem) {
+    const long ns = (n + 15) & ~15L;
+    const size_t f = (size_t)kp * (ns + 4) + (size_t)(16 * nw) * (kp + 1) + (((size_t)kp * (kp + 1) + 3) & ~size_t(3));
+    return f * sizeof(float) + (alds ? (size_t)(16 * nw) * (ns + (a_elem == 4 ? 4 : 8)) * a_elem : 0);
+}
 inline size_t small_kl_lds(int kp, int nw, long n, bool alds) {
     const long ns = (n + 15) & ~15L;
     const size_t tail = std::max<size_t>((size_t)kp + (size_t)nw * kp, (size_t)kp * (kp + 1));

@@ -27,6 +27,8 @@ CASES = [  # m, n, k, method, norm, precision, itr
     (1024, 256, 9, "hals", "fro", "bfloat16", 21),    # HALS on the persistent kernel: the small NMFk sweep's shape and storage
     (1000, 250, 20, "hals", "fro", "float32", 13),    # ... ragged, k padded to 32
     (96, 21, 4, "hals", "fro", "float32", 30),
+    (1024, 256, 5, "mu", "fro", "bfloat16", 21),      # MU/FRO on bf16-stored data: the Frobenius kernel with the slab in LDS as stored
+    (1000, 250, 20, "mu", "fro", "bfloat16", 13),
     (1024, 256, 16, "mu", "kl", "float32", 25),       # the reference's swim example shape, 16-wide kernels
     (1024, 256, 17, "mu", "kl", "float32", 21),       # k = 17: 32-wide kernels on zero-padded factor images
     (1024, 256, 4, "mu", "fro", "float32", 25),
@@ -68,6 +70,8 @@ def _persistent(m, n, k, method, norm, precision):
     from pydnmfk_amd._lib import lib
     if method == "hals":
         return lib.dnmf_hals_fit_persistent(m, n, k) != 0
+    if method == "mu" and norm == "fro" and precision == "bfloat16":     # (the bf16 slab is half the size: every fp32-eligible shape is eligible)
+        return lib.dnmf_mu_fit_persistent(m, n, k) != 0
     return method == "mu" and precision == "float32" and lib.dnmf_mu_fit_persistent(m, n, k) != 0
 
 
