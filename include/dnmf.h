@@ -295,6 +295,13 @@ int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, l
  * error evaluation through the materialised squared residual (dnmf_f64_sqdiff) and the ordered sums.  Host sequencing of these
  * primitives (1D and 2D grids, exchanges over torch.distributed): pydnmfk_amd/dist_nmf.py with engine.HipOpsF64. ---- */
 size_t dnmf_f64_ws_bytes(long m, long n, int k);
+/* A whole float64 fit on one rank (PyNMF.fit, pyDNMF.py:138-182): `itr` steps of method 0 = MU/FRO (dist_nmf.py:716-751), 1 = MU/KL
+ * (:806-849), 2 = HALS/FRO (:873-934) with the clamp after the steps i % 10 == 0, then normalize_features and the two squared norms
+ * {sum (A - W H)^2, sum A^2} -> sq_out (device) -- the primitives below in the order pydnmfk_amd/dist_nmf.py issues them, enqueued by
+ * ONE call (bit-identical to that step loop).  ws >= dnmf_f64_ws_bytes_fit(m, n, k): it holds the m x n quotient / residual image too. */
+size_t dnmf_f64_ws_bytes_fit(long m, long n, int k);
+int dnmf_f64_fit(int method, const double* A, long m, long n, long lda, double* W, long ldw, double* H, long ldh, int k, double eps,
+                 int w_update, int itr, double* sq_out, void* ws, size_t ws_bytes, void* stream);
 /* C[m x kc] = X[m x n] Y[kc x n]^T   (A H^T: dist_nmf.py:730; H H^T = global_gram(H.T), :729, with X = Y = H) */
 int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int kc, long ldy, double* C, long ldc, void* ws,
                  size_t ws_bytes, void* stream);

@@ -135,6 +135,9 @@ c_double = ctypes.c_double
 SIGNATURES["dnmf_f64_ws_bytes"] = [c_long, c_long, c_int]
 SIGNATURES["dnmf_f64_aht"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_wta"] = SIGNATURES["dnmf_f64_aht"]
+SIGNATURES["dnmf_f64_ws_bytes_fit"] = [c_long, c_long, c_int]
+SIGNATURES["dnmf_f64_fit"] = [c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
+                              c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_mu_update_w"] = [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_void_p]
 SIGNATURES["dnmf_f64_mu_update_h"] = [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_int, c_void_p]
 SIGNATURES["dnmf_f64_kl_quot"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_double, c_void_p, c_long, c_void_p]
@@ -147,7 +150,7 @@ SIGNATURES["dnmf_f64_hals_w_col"] = [c_void_p, c_long, c_int, c_long, c_void_p, 
                                      c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_hals_w_scale"] = [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p]
 SIGNATURES["dnmf_f64_hals_update_h"] = [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_void_p]
-_RESTYPES = {"dnmf_ws_bytes_fit": c_size_t, "dnmf_f64_ws_bytes": c_size_t, "dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
+_RESTYPES = {"dnmf_ws_bytes_fit": c_size_t, "dnmf_f64_ws_bytes": c_size_t, "dnmf_f64_ws_bytes_fit": c_size_t, "dnmf_last_error": ctypes.c_char_p, "dnmf_ws_bytes": c_size_t, "dnmf_ws_bytes_bf16x6": c_size_t,
              "dnmf_ws_bytes_1d": c_size_t, "dnmf_ws_bytes_hblocks": c_size_t, "dnmf_ws_bytes_2d": c_size_t}
 
 

@@ -728,4 +728,87 @@ int dnmf_f64_hals_update_h(double* H, int k, long n, long ldh, const double* AtW
     return check_launch("f64 hals_update_h");
 }
 
+
+// ---- whole fits in float64 on one rank (PyNMF.fit, pyDNMF.py:138-182 with p_r = p_c = 1): the primitives above in the order the
+// choreography (pydnmfk_amd/dist_nmf.py over engine.HipOpsF64) issues them -- same kernels, same operands, so the same bits -- without a
+// Python frame and a ctypes call per launch (about 15 per step: 150-200 us of host time against 60-80 us of kernels on the reference's own
+// test sizes).  method: 0 = MU/FRO, 1 = MU/KL, 2 = HALS/FRO.  sq_out (device): {sum (A - W H)^2, sum A^2}.
+size_t dnmf_f64_ws_bytes_fit(long m, long n, int k) {
+    const size_t prim = dnmf_f64_ws_bytes(m, n, k);
+    if (!prim) return 0;
+    const size_t D = sizeof(double);
+    return al256(prim) + al256((size_t)k * k * D) + al256((size_t)std::max(m * k, (long)k * n) * D) + 2 * al256((size_t)k * D) + al256((size_t)m * n * D) + 256;
+}
+
+int dnmf_f64_fit(int method, const double* A, long m, long n, long lda, double* W, long ldw, double* H, long ldh, int k, double eps, int w_update,
+                 int itr, double* sq_out, void* ws, size_t ws_bytes, void* stream) {
+    REQ(method >= 0 && method <= 2 && A && W && H && sq_out && ws && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && itr >= 0 && lda >= n &&
+            ldw >= k && ldh >= n, "f64 fit: bad arguments");
+    const size_t need = dnmf_f64_ws_bytes_fit(m, n, k);
+    if (ws_bytes < need) return fail(DNMF_EWS, "f64 fit: workspace %zu < %zu", ws_bytes, need);
+    const size_t D = sizeof(double), prim_bytes = dnmf_f64_ws_bytes(m, n, k);
+    char* b = (char*)ws;
+    void* prim = b;                                   b += al256(prim_bytes);
+    double* G = (double*)b;                           b += al256((size_t)k * k * D);
+    double* S = (double*)b;                           b += al256((size_t)std::max(m * k, (long)k * n) * D);
+    double* x = (double*)b;                           b += al256((size_t)k * D);
+    double* ss2 = (double*)b;                         b += al256((size_t)k * D);
+    double* U = (double*)b;                           b += al256((size_t)m * n * D);
+    double* sq = (double*)b;
+    int rc = DNMF_OK;
+#define F64(call) do { if ((rc = (call))) return rc; } while (0)
+    for (int i = 0; i < itr; ++i) {
+        const int clamp = (i % 10 == 0);                                              // pyDNMF.py:155 / :170
+        if (method == 0) {                                                            // dist_nmf.py:716-751
+            if (w_update) {
+                F64(dnmf_f64_aht(H, k, n, ldh, H, k, ldh, G, k, prim, prim_bytes, stream));
+                F64(dnmf_f64_aht(A, m, n, lda, H, k, ldh, S, k, prim, prim_bytes, stream));
+                F64(dnmf_f64_mu_update_w(W, m, k, ldw, S, k, G, k, eps, stream));
+            }
+            F64(dnmf_f64_wta(W, m, k, ldw, W, k, ldw, G, k, prim, prim_bytes, stream));
+            F64(dnmf_f64_wta(A, m, n, lda, W, k, ldw, S, n, prim, prim_bytes, stream));
+            F64(dnmf_f64_mu_update_h(H, k, n, ldh, S, n, G, k, eps, clamp, stream));
+            if (clamp) F64(dnmf_f64_ew(0, W, m, k, ldw, nullptr, 0, nullptr, eps, 0, stream));
+        } else if (method == 1) {                                                     // dist_nmf.py:806-849
+            if (w_update) {
+                F64(dnmf_f64_rowsum(H, k, n, ldh, x, stream));
+                F64(dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream));
+                F64(dnmf_f64_aht(U, m, n, n, H, k, ldh, S, k, prim, prim_bytes, stream));
+                F64(dnmf_f64_ew(4, W, m, k, ldw, S, k, x, eps, 0, stream));
+            }
+            F64(dnmf_f64_colsum(W, m, k, ldw, 0, x, prim, prim_bytes, stream));
+            F64(dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream));
+            F64(dnmf_f64_wta(U, m, n, n, W, k, ldw, S, n, prim, prim_bytes, stream));
+            F64(dnmf_f64_ew(3, H, k, n, ldh, S, n, x, eps, clamp, stream));
+            if (clamp) F64(dnmf_f64_ew(0, W, m, k, ldw, nullptr, 0, nullptr, eps, 0, stream));
+        } else {                                                                      // dist_nmf.py:873-934
+            if (w_update) {
+                F64(dnmf_f64_aht(H, k, n, ldh, H, k, ldh, G, k, prim, prim_bytes, stream));
+                F64(dnmf_f64_aht(A, m, n, lda, H, k, ldh, S, k, prim, prim_bytes, stream));
+                if (hipMemsetAsync(ss2, 0, (size_t)k * D, ST(stream)) != hipSuccess) return fail(DNMF_EHIP, "f64 fit: memset failed");
+                for (int kk = 0; kk < k; ++kk)
+                    F64(dnmf_f64_hals_w_col(W, m, k, ldw, S, k, G, k, kk, kk > 0 ? ss2 + kk - 1 : nullptr, eps, ss2 + kk, prim, prim_bytes, stream));
+                F64(dnmf_f64_hals_w_scale(W, m, ldw, k - 1, ss2 + k - 1, stream));
+            }
+            F64(dnmf_f64_wta(W, m, k, ldw, W, k, ldw, G, k, prim, prim_bytes, stream));
+            F64(dnmf_f64_wta(A, m, n, lda, W, k, ldw, S, n, prim, prim_bytes, stream));
+            F64(dnmf_f64_hals_update_h(H, k, n, ldh, S, n, G, k, eps, stream));
+            if (clamp) {
+                F64(dnmf_f64_ew(0, H, k, n, ldh, nullptr, 0, nullptr, eps, 0, stream));
+                F64(dnmf_f64_ew(0, W, m, k, ldw, nullptr, 0, nullptr, eps, 0, stream));
+            }
+        }
+    }
+    // normalize_features (pyDNMF.py:185-194), then the two squared norms of relative_err (:205-218)
+    F64(dnmf_f64_colsum(W, m, k, ldw, 0, x, prim, prim_bytes, stream));
+    F64(dnmf_f64_ew(1, W, m, k, ldw, nullptr, 0, x, eps, 0, stream));
+    F64(dnmf_f64_ew(2, H, k, n, ldh, nullptr, 0, x, 0.0, 0, stream));
+    F64(dnmf_f64_sqdiff(A, m, n, lda, W, ldw, H, ldh, k, U, n, stream));
+    F64(dnmf_f64_sum(U, m, n, n, 0, sq, prim, prim_bytes, stream));
+    F64(dnmf_f64_sum(A, m, n, lda, 1, sq + 1, prim, prim_bytes, stream));
+#undef F64
+    if (hipMemcpyAsync(sq_out, sq, 2 * D, hipMemcpyDeviceToDevice, ST(stream)) != hipSuccess) return fail(DNMF_EHIP, "f64 fit: copy of the squared norms failed");
+    return DNMF_OK;
+}
+
 }  // extern "C"

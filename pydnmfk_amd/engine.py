@@ -551,8 +551,8 @@ HIP_OPS_BF16X6 = HipOpsBf16x6()
 class HipOpsF64:
     """The operator set in float64 (csrc/dnmf_f64.hip: the fp64 matrix cores, one plain tile shape per kernel family).  The
     reference computes in the dtype of A_ij (pyDNMF.py:68): float64 data are factorised in float64, eps = 2.22e-16.  The same
-    method surface as HipOps for the primitives the choreography (dist_nmf.py) sequences; no whole-step / whole-fit entry points
-    (the choreography's generic path runs), no bf16 storage, no block-column products."""
+    method surface as HipOps for the primitives the choreography (dist_nmf.py) sequences, plus the whole one-rank fit (`fit`); no
+    whole-step entry points (the choreography's generic path runs), no bf16 storage, no block-column products."""
 
     name = "hip-f64"
     aht_hblocks = None
@@ -589,6 +589,30 @@ class HipOpsF64:
             t = torch.empty(m * n, dtype=torch.float64, device=device)
             cls._img[key] = t
         return t[: m * n].view(m, n)
+
+    def fit(self, method, norm, A, W, H, eps, w_update, itr, column_sweep=False):
+        """`itr` steps, normalize_features and the squared norms of relative_err in ONE library call (dnmf_f64_fit: the primitives
+        of this class in the choreography's order -- the same bits as the step loop, without its Python frames).  Matrices, or
+        stacks [B][m][n] / [B][m][k] / [B][k][n] fitted one after the other.  W, H are updated in place; returns the device tensor
+        [B][2] of {sum (A - W H)^2, sum A^2}."""
+        code = {("mu", "fro"): 0, ("mu", "kl"): 1, ("hals", "fro"): 2}.get((method.lower(), norm.lower()))
+        if code is None:
+            raise ValueError("fit: no whole-fit entry point for method %r / norm %r" % (method, norm))
+        A3, W3, H3 = (A, W, H) if A.dim() == 3 else (A[None], W[None], H[None])
+        B, m, n = A3.shape
+        k = W3.shape[2]
+        if W3.shape != (B, m, k) or H3.shape != (B, k, n):
+            raise ValueError("fit: shapes A %s, W %s, H %s do not match" % (tuple(A3.shape), tuple(W3.shape), tuple(H3.shape)))
+        nbytes = lib.dnmf_f64_ws_bytes_fit(int(m), int(n), int(k))
+        if nbytes == 0:
+            raise ValueError("fit: bad problem shape m=%d n=%d k=%d" % (m, n, k))
+        ws = _scratch(nbytes, A.device)
+        sq = torch.empty(B, 2, dtype=torch.float64, device=A.device)
+        for b in range(B):
+            self._r(A3[b], "A"); self._r(W3[b], "W"); self._r(H3[b], "H")
+            check(lib.dnmf_f64_fit(code, A3[b].data_ptr(), m, n, _ld(A3[b]), W3[b].data_ptr(), _ld(W3[b]), H3[b].data_ptr(), _ld(H3[b]), k,
+                                   float(eps), int(bool(w_update)), int(itr), sq[b].data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return sq
 
     # ---- grams and the two big contractions
     def gram_hht(self, H, out):

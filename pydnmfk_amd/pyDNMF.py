@@ -223,7 +223,8 @@ class PyNMF:
         """One rank, the product's own fp32-MFMA operator set, a method / norm pair the library has a whole-fit entry point for
         (anything else keeps the step loop, which raises the reference's messages for invalid pairs).  `params.fit_loop =
         'python'` keeps the step loop (A/B runs, tests of the per-step API)."""
-        return (self.p == 1 and self.topo == '1d' and self.itr >= 1 and getattr(ops, "name", "") == "hip" and hasattr(ops, "fit")
+        return (self.p == 1 and self.topo == '1d' and self.itr >= 1 and getattr(ops, "name", "") in ("hip", "hip-f64") and hasattr(ops, "fit")
+                and not (getattr(ops, "name", "") == "hip-f64" and self.k > 128)
                 and (str(self.method).lower(), str(self.norm).lower()) in _NATIVE_FITS
                 and getattr(self.params, "fit_loop", None) != "python"
                 and not getattr(self.params, "native_always", False))

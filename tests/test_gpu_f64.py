@@ -271,3 +271,30 @@ def test_nmfk_sweep_in_float64(tmp_path, golden_dir):
         assert np.asarray(st["L_err"]).dtype == np.float64
         assert np.allclose(st["clusterSilhouetteCoefficients"], z["k%d_clusterSilhouetteCoefficients" % k], atol=0.08), k
         assert abs(st["avgErr"] / float(z["k%d_avgErr" % k]) - 1) < 2e-2, k      # (a float64 trajectory against the fixture's float32 one)
+
+
+@pytest.mark.parametrize("m,n,k,method,norm,itr", [(300, 200, 7, "mu", "fro", 23), (300, 200, 7, "mu", "kl", 23), (300, 200, 7, "hals", "fro", 12),
+                                                   (1024, 256, 16, "mu", "kl", 11), (2100, 333, 40, "mu", "fro", 11), (513, 129, 3, "hals", "fro", 21)])
+def test_f64_whole_fit_equals_step_loop(m, n, k, method, norm, itr):
+    """dnmf_f64_fit enqueues the float64 primitives in the order the choreography issues them: the factors of a whole-fit call equal
+    the Python step loop's (`params.fit_loop = 'python'`) BIT FOR BIT, with and without W updates; a batch of fits equals single fits."""
+    from pydnmfk_amd.pyDNMF import PyNMF
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(m + n + k)
+    A = torch.rand(m, n, dtype=torch.float64, device=dev, generator=g)
+    A[:, ::6] = 0.0
+    W0 = torch.rand(m, k, dtype=torch.float64, device=dev, generator=g)
+    H0 = torch.rand(k, n, dtype=torch.float64, device=dev, generator=g)
+    for w_update in (True, False):
+        a1, a2 = _args(k, itr, norm, W_update=w_update, method=method), _args(k, itr, norm, W_update=w_update, method=method)
+        a2.fit_loop = "python"
+        f1, f2 = PyNMF(A, factors=[W0, H0], params=a1), PyNMF(A, factors=[W0, H0], params=a2)
+        assert f1._whole_fit_ok(f1._ops()) and not f2._whole_fit_ok(f2._ops())
+        W1, H1, e1 = f1.fit()
+        W2, H2, e2 = f2.fit()
+        assert W1.dtype == torch.float64 and torch.equal(W1, W2) and torch.equal(H1, H2), (w_update, float((W1 - W2).abs().max()))
+        assert abs(e1 - e2) <= 1e-14 * max(1.0, abs(e2))
+    fits = [PyNMF(A * (1.0 + 0.01 * b), factors=[W0, H0], params=_args(k, itr, norm, method=method)) for b in range(3)]
+    single = [PyNMF(A * (1.0 + 0.01 * b), factors=[W0, H0], params=_args(k, itr, norm, method=method)).fit() for b in range(3)]
+    for o, r in zip(PyNMF.fit_batch(fits), single):
+        assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1]) and o[2] == r[2]
