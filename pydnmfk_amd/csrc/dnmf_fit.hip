@@ -144,38 +144,33 @@ int hals_step(const void* A, long m, long n, long lda, float* W, long ldw, float
 
 unsigned long long g_small_patience = 200000000ull;
 
-// all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
-template <int KP, int NW, bool ALDS, bool FRO>
-int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
-    const auto kern = FRO ? small_fro_fit_kernel<KP, NW, ALDS, float> : small_kl_fit_kernel<KP, NW, ALDS>;
-    static int cus = 0;
-    if (!cus) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(DNMF_EHIP, "small fit: device query failed");
-        cus = prop.multiProcessorCount;
-    }
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, sp.lds) != hipSuccess || nb < 1) {
-        clear_hip_error();
-        return DNMF_OK;                                             // (not taken: the step loop runs)
-    }
+// a launch (or as few as keep every workgroup resident) of a persistent small-fit kernel
+int resident_launch(void (*kern)(SmallKlArgs), int threads, size_t lds, int P, SmallKlArgs a, int batch, hipStream_t st, bool* taken, const char* what) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
+    int nb = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(DNMF_EHIP, "small fit: device query failed");
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) { clear_hip_error(); return DNMF_OK; }
     const long cap = (long)nb * cus;
-    if (cap < sp.P) return DNMF_OK;
-    const int per_launch = (int)std::min<long>(batch, cap / sp.P);
-    const int launches = (int)cdiv(batch, per_launch);
-    const int each = (int)cdiv(batch, launches);                       // balanced: 20 problems, room for 16 -> 10 + 10
+    if (cap < P) return DNMF_OK;
+    const int per_launch = (int)std::min<long>(batch, cap / P);
+    const int each = (int)cdiv(batch, cdiv(batch, per_launch));
     for (int z0 = 0; z0 < batch; z0 += each) {
         a.z0 = z0;
-        const int nz = std::min(each, batch - z0);
-        hipLaunchKernelGGL(kern, dim3((unsigned)sp.P, 1, (unsigned)nz), dim3(64 * NW), sp.lds, st, a);
-        int rc = check_launch("small_kl_fit_kernel");
+        hipLaunchKernelGGL(kern, dim3((unsigned)P, 1, (unsigned)std::min(each, batch - z0)), dim3(threads), lds, st, a);
+        const int rc = check_launch(what);
         if (rc) return rc;
     }
     *taken = true;
     return DNMF_OK;
+}
+
+// all `itr` MU/KL steps of `batch` small problems: as few launches as keep every workgroup of a launch resident at once
+template <int KP, int NW, bool ALDS, bool FRO>
+int small_kl_launch(const SmallPlan& sp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    return resident_launch(FRO ? small_fro_fit_kernel<KP, NW, ALDS, float> : small_kl_fit_kernel<KP, NW, ALDS>, 64 * NW, sp.lds, sp.P, a, batch, st, taken,
+                           FRO ? "small_fro_fit_kernel" : "small_kl_fit_kernel");
 }
 
 int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int w_update, int itr,
@@ -198,14 +193,10 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
         if (lds <= 160 * 1024) {
             const dim3 grid((unsigned)(sp.ns / 16), 1, (unsigned)batch);
             a.z0 = 0;
-            static bool once16 = false, once32 = false;
-            if (sp.kp == 16) {
-                if (!once16) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kl_hfit_kernel<16, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit"); once16 = true; }
-                hipLaunchKernelGGL((small_kl_hfit_kernel<16, NW>), grid, dim3(64 * NW), lds, st, a);
-            } else {
-                if (!once32) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_kl_hfit_kernel<32, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit"); once32 = true; }
-                hipLaunchKernelGGL((small_kl_hfit_kernel<32, NW>), grid, dim3(64 * NW), lds, st, a);
-            }
+            const auto kern = sp.kp == 16 ? small_kl_hfit_kernel<16, NW> : small_kl_hfit_kernel<32, NW>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
             const int rc = check_launch("small_kl_hfit_kernel");
             if (!rc) *taken = true;
             return rc;
@@ -224,28 +215,8 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
 // all `itr` HALS steps of `batch` small problems on the persistent kernel (W updated: with W fixed the hoisted H-only loop of fit_impl is
 // the better path)
 template <int KP, int NW, typename TA, bool ALDS>
-int small_hals_launch(const HalsPlan& hp0, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
-    HalsPlan hp = hp0;
-    if (ALDS) hp.lds = hp.lds_bf16_resident;
-    const auto kern = small_hals_fit_kernel<KP, NW, TA, ALDS>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
-    int nb = 0, dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return fail(DNMF_EHIP, "small fit: device query failed");
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, hp.lds) != hipSuccess || nb < 1) { clear_hip_error(); return DNMF_OK; }
-    const long cap = (long)nb * cus;
-    if (cap < hp.P) return DNMF_OK;
-    const int per_launch = (int)std::min<long>(batch, cap / hp.P);
-    const int each = (int)cdiv(batch, cdiv(batch, per_launch));
-    for (int z0 = 0; z0 < batch; z0 += each) {
-        a.z0 = z0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)hp.P, 1, (unsigned)std::min(each, batch - z0)), dim3(64 * NW), hp.lds, st, a);
-        const int rc = check_launch("small_hals_fit_kernel");
-        if (rc) return rc;
-    }
-    *taken = true;
-    return DNMF_OK;
+int small_hals_launch(const HalsPlan& hp, SmallKlArgs a, int batch, hipStream_t st, bool* taken) {
+    return resident_launch(small_hals_fit_kernel<KP, NW, TA, ALDS>, 64 * NW, ALDS ? hp.lds_bf16_resident : hp.lds, hp.P, a, batch, st, taken, "small_hals_fit_kernel");
 }
 
 int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh, int k, float eps, int itr, int batch,
@@ -272,28 +243,6 @@ int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, l
                                                          : small_hals_launch<KP_, NW_, bf16_t, false>(hp, a, batch, st, taken))
     HALS_CASE(16, 8); HALS_CASE(16, 4); HALS_CASE(32, 8); HALS_CASE(32, 4);
 #undef HALS_CASE
-    return DNMF_OK;
-}
-
-// a launch (or as few as keep every workgroup resident) of a persistent small-fit kernel
-int resident_launch(void (*kern)(SmallKlArgs), int threads, size_t lds, int P, SmallKlArgs a, int batch, hipStream_t st, bool* taken, const char* what) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return fail(DNMF_EHIP, "small fit: cannot raise the dynamic LDS limit");
-    int nb = 0, dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return fail(DNMF_EHIP, "small fit: device query failed");
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) { clear_hip_error(); return DNMF_OK; }
-    const long cap = (long)nb * cus;
-    if (cap < P) return DNMF_OK;
-    const int per_launch = (int)std::min<long>(batch, cap / P);
-    const int each = (int)cdiv(batch, cdiv(batch, per_launch));
-    for (int z0 = 0; z0 < batch; z0 += each) {
-        a.z0 = z0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)P, 1, (unsigned)std::min(each, batch - z0)), dim3(threads), lds, st, a);
-        const int rc = check_launch(what);
-        if (rc) return rc;
-    }
-    *taken = true;
     return DNMF_OK;
 }
 
