@@ -37,6 +37,8 @@ SIGNATURES = {
                           c_float, c_void_p],
     "dnmf_mu_fro_step": [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_int,
                          c_int, c_void_p, c_size_t, c_void_p],
+    "dnmf_mu_fro_onepass": [c_long, c_long, c_int],
+    "dnmf_set_onepass": [c_int],
     "dnmf_hals_w_col": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_float, c_void_p,
                         c_void_p],
     "dnmf_hals_w_scale": [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p],

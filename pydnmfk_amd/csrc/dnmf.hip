@@ -202,6 +202,14 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
     return check_launch(what);
 }
 
+}  // namespace
+// csrc/dnmf_team.hip: the one-pass MU/Frobenius step (16 < k <= 32, n a multiple of 512 up to 4096)
+__attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n, int k);
+__attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
+                                                          const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
+                                                          const float** P_out, int* nparts);
+namespace {
+
 struct WsLayout {
     size_t g_off, s_off, x_off, part_off, total;  // G [KP*KP] | S = AtW / AH / UHT / WTU | x [KP] | partials
 };
@@ -247,6 +255,7 @@ size_t partial_bytes(long m, long n, int k) {
         }
     }
     b = std::max(b, (size_t)1024 * kp * sizeof(float));  // colsum partials (at most 1024 slabs)
+    b = std::max(b, dnmf_team_ws_bytes_(m, n, k));       // one-pass MU/FRO step: the teams' partials + the granule ring (csrc/dnmf_team.hip)
     // HALS W sweep: slots + norms + the m x KP block T of its first pass (only when the sweep is asked for a factor of
     // this shape, i.e. n == k: dnmf_hals_sweep_w is called with dnmf_ws_bytes(m, k, k))
     b = std::max(b, align256((size_t)kp * HALS_MAX_WG * sizeof(unsigned long long) + (size_t)kp * sizeof(double)) +
@@ -821,8 +830,29 @@ int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, 
     void* part = base + L.part_off;
     const size_t part_bytes = L.total - L.part_off;
     int rc;
+    if constexpr (std::is_same<TA, float>::value) {
+        // 16 < k <= 32 on whole 512-column pieces: ONE pass over A (csrc/dnmf_team.h) -- the W update of a row block and its share of
+        // W^T A while the block is on chip; H H^T before, W^T W after and the H update are the launches of the two-pass sequence
+        if (w_update && dnmf_team_ws_bytes_(m, n, k)) {
+            if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
+            const float* P = nullptr;
+            int nparts = 0;
+            rc = dnmf_team_fro_(A, m, n, lda, W, ldw, H, ldh, G, k, eps, part, part_bytes, stream, &P, &nparts);
+            if (rc < 0) return rc;
+            if (rc == DNMF_OK) {
+                const long ldatw = round_up(n, 4);
+                if ((rc = launch_reduce(P, (long)32 * n, n, nparts, Sb, ldatw, k, n, k, n, nullptr, S(stream)))) return rc;
+                // (the Gram launch uses `part` as its scratch: after the reduction has read the partials -- same stream)
+                if ((rc = dnmf_gram_wtw(W, m, k, ldw, G, part, part_bytes, stream))) return rc;
+                if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
+                if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);
+                return DNMF_OK;
+            }
+            w_update = -1;                                                            // H H^T is in G already
+        }
+    }
     if (w_update) {                                                                   // dist_nmf.py:716-732
-        if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
+        if (w_update > 0 && (rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
         if (wide_k(k)) {                                             // beyond the fused kernel's rank: the product, then the update
             const long ldah = round_up(k, 4);
             if ((rc = aht_impl<TA>(A, m, n, lda, H, k, ldh, Sb, ldah, stream, 0))) return rc;

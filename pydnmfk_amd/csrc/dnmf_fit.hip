@@ -384,11 +384,14 @@ __attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out
     return DNMF_OK;
 }
 
+__attribute__((visibility("hidden"))) void dnmf_team_set_patience_(unsigned long long ticks);   // csrc/dnmf_team.hip
+
 extern "C" {
 
 int dnmf_fit_set_timeout(double seconds) {
     if (!(seconds > 0.0) || seconds > 3600.0) return fail(DNMF_EINVAL, "fit_set_timeout: %g s", seconds);
     g_small_patience = (unsigned long long)(seconds * 1e8) + 1ull;
+    dnmf_team_set_patience_(g_small_patience);
     return DNMF_OK;
 }
 

@@ -198,6 +198,7 @@ int dnmf_hals_sweep_w_peers_(float* W, long m, int k, long ldw, const float* AH,
 }
 
 __attribute__((visibility("hidden"))) int dnmf_small_timeout_take_(unsigned* out);      // csrc/dnmf_fit.hip
+__attribute__((visibility("hidden"))) int dnmf_team_timeout_take_(unsigned* out);       // csrc/dnmf_team.hip
 
 extern "C" {
 
@@ -213,7 +214,9 @@ int dnmf_hals_sweep_status(int* timed_out, void* stream) {
         return fail(DNMF_EHIP, "hals_sweep_status: clear failed");
     unsigned int v2 = 0;                                   // the persistent small-problem fit (csrc/dnmf_small.h) reports through the same call
     if (dnmf_small_timeout_take_(&v2) != DNMF_OK) return fail(DNMF_EHIP, "hals_sweep_status: read of the small-fit word failed");
-    *timed_out = (v != 0) || (v2 != 0);
+    unsigned int v3 = 0;                                   // ... and so does the one-pass MU/Frobenius team kernel (csrc/dnmf_team.h)
+    if (dnmf_team_timeout_take_(&v3) != DNMF_OK) return fail(DNMF_EHIP, "hals_sweep_status: read of the team kernel's word failed");
+    *timed_out = (v != 0) || (v2 != 0) || (v3 != 0);
     return DNMF_OK;
 }
 

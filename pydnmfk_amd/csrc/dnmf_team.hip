@@ -1,0 +1,128 @@
+// dnmf_team.hip -- plan and launch of the one-pass MU/Frobenius team kernel (csrc/dnmf_team.h); part of libdnmf_hip.so.
+// csrc/dnmf.hip (mu_fro_step_impl) asks dnmf_team_plan_ whether a step of this shape takes it, sizes the workspace with
+// dnmf_team_ws_bytes_ and calls dnmf_team_fro_; the reduction of the teams' partials and the H update stay where they were.
+#include "dnmf_team.h"
+#include "dnmf_host.h"
+
+namespace {
+
+struct TeamPlan {
+    bool ok;
+    int T, tpx, teams, teams_used;
+    long rpt;
+    size_t p_bytes, ctl_off, ring_off, total;
+};
+
+int g_team_on = 1;                       // dnmf_set_onepass
+int g_team_cus = -1;                     // CUs of the device the census may count on (queried once per process)
+unsigned long long g_team_patience = 200000000ull;
+
+int team_cus() {
+    if (g_team_cus >= 0) return g_team_cus;
+    int dev = 0, cus = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        clear_hip_error();
+        return 0;                        // no device (the CPU tier loads the library for its symbol checks): plans say no
+    }
+    const auto kern = team_fro_kernel<2, 2>;
+    allow_lds(kern, TM_LDS_BYTES + 64);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * TM_NW, TM_LDS_BYTES) != hipSuccess || nb < 1) { clear_hip_error(); cus = 0; }
+    g_team_cus = cus;
+    return cus;
+}
+
+// shape-only part of the decision (the workspace query has no pointers); `cus` = 0: ask the device
+TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
+    TeamPlan p{};
+    if ((!g_team_on && !sizing) || k <= 16 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
+    if (cus <= 0) cus = team_cus();
+    p.T = (int)(n / TM_C);
+    p.tpx = (cus / 8) / p.T;
+    if (p.tpx < 1) return p;
+    p.teams = 8 * p.tpx;
+    p.rpt = round_up(cdiv(m, p.teams), TM_R);
+    p.teams_used = (int)cdiv(m, p.rpt);
+    if (p.teams_used > 64) return p;                                   // one-stage reduction of the partials
+    p.p_bytes = align256((size_t)p.teams * TM_KP * n * sizeof(float));
+    p.ctl_off = p.p_bytes;
+    p.ring_off = p.ctl_off + 256;
+    p.total = p.ring_off + (size_t)p.teams * TM_D * (p.T + 2) * (TM_R * TM_KP) * sizeof(unsigned long long);
+    p.ok = true;
+    return p;
+}
+
+}  // namespace
+
+__attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n, int k) {
+    // sized for the largest device this library is built for (256 CUs), so that the answer does not depend on a device query
+    const TeamPlan p = team_plan(m, n, k, 256, true);
+    return p.ok ? p.total : 0;
+}
+
+// 1: not taken (the caller keeps the two-pass sequence); DNMF_OK: W is updated, the teams' partials of W^T A are in
+// *P_out ([*nparts][32][n], part of `part`) for the caller's reduction
+__attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
+                                                          const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
+                                                          const float** P_out, int* nparts) {
+    const TeamPlan p = team_plan(m, n, k);
+    if (!p.ok || dnmf_batch_()->B != 1) return 1;
+    if (!(aligned16(A) && lda % 4 == 0 && lda >= n && aligned16(H) && ldh % 4 == 0 && ldh >= n && ldw >= k && aligned16(part))) return 1;
+    if ((double)p.rpt * lda * 4.0 >= 2147483648.0 || part_bytes < p.total) return 1;
+    hipStream_t st = S(stream);
+    char* base = (char*)part;
+    TeamArgs a{};
+    a.A = A; a.lda = lda; a.m = m; a.n = (int)n; a.k = k;
+    a.H = H; a.ldh = ldh; a.G = G; a.W = W; a.ldw = ldw; a.eps = eps;
+    a.P = (float*)base;
+    a.ctl = (unsigned*)(base + p.ctl_off);
+    a.ring = (unsigned long long*)(base + p.ring_off);
+    a.T = p.T; a.tpx = p.tpx; a.rpt = p.rpt;
+    a.patience = g_team_patience;
+    if (hipMemsetAsync(base + p.ctl_off, 0, p.total - p.ctl_off, st) != hipSuccess) return fail(DNMF_EHIP, "team: memset of the granule ring failed");
+    static const int sd = (int)tune("DNMF_TEAM_SD", 2), nt = (int)tune("DNMF_TEAM_NT", 2);
+    const dim3 grid((unsigned)(8 * p.tpx * p.T)), block(64 * TM_NW);
+#define TEAM_LAUNCH(SD, NT)                                                          \
+    do {                                                                             \
+        static bool once = false;                                                    \
+        if (!once) { allow_lds(team_fro_kernel<SD, NT>, TM_LDS_BYTES + 64); once = true; } \
+        hipLaunchKernelGGL((team_fro_kernel<SD, NT>), grid, block, TM_LDS_BYTES, st, a); \
+    } while (0)
+#ifdef DNMF_TUNING
+    if (sd == 1 && nt == 2) TEAM_LAUNCH(1, 2);
+    else if (sd == 4 && nt == 2) TEAM_LAUNCH(4, 2);
+    else if (sd == 2 && nt == 0) TEAM_LAUNCH(2, 0);
+    else if (sd == 4 && nt == 0) TEAM_LAUNCH(4, 0);
+    else
+#endif
+        TEAM_LAUNCH(2, 2);
+#undef TEAM_LAUNCH
+    (void)sd; (void)nt;
+    if (int rc = check_launch("team_fro_kernel")) return rc;
+    *P_out = a.P;
+    *nparts = p.teams_used;
+    return DNMF_OK;
+}
+
+// read-and-clear of the team kernel's sticky time-out word (csrc/dnmf_hals.hip: dnmf_hals_sweep_status reports it)
+__attribute__((visibility("hidden"))) int dnmf_team_timeout_take_(unsigned* out) {
+    unsigned v = 0;
+    const unsigned zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_team_timeout), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return DNMF_EHIP;
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_team_timeout), &zero, sizeof(zero), 0, hipMemcpyHostToDevice) != hipSuccess) return DNMF_EHIP;
+    *out = v;
+    return DNMF_OK;
+}
+
+__attribute__((visibility("hidden"))) void dnmf_team_set_patience_(unsigned long long ticks) { g_team_patience = ticks; }
+
+extern "C" {
+
+int dnmf_set_onepass(int on) {
+    const int was = g_team_on;
+    g_team_on = on ? 1 : 0;
+    return was;
+}
+
+int dnmf_mu_fro_onepass(long m, long n, int k) { return (m >= 1 && n >= 1 && team_plan(m, n, k).ok) ? 1 : 0; }
+
+}  // extern "C"
