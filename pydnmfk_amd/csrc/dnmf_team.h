@@ -46,11 +46,11 @@ constexpr int TM_C = 512;                // columns per team member
 constexpr int TM_NW = 8;                 // waves per workgroup, 64 columns each
 constexpr int TM_KP = 32;                // padded rank
 constexpr int TM_LDA = TM_C + 8;         // LDS row pitch of a slab piece: 130 sixteen-byte chunks = 2 (mod 16) -> the row-per-lane ds_read_b128 is conflict free
-constexpr int TM_NBUF = 4;               // slabs in the LDS ring: t (Q), t + 1, t + 2 (P), t + 3 (being written)
-constexpr int TM_D = 8;                  // granule ring depth (a member is at most three slabs ahead of the slowest reader: >= 6)
+constexpr int TM_NBUF = 3;               // slabs in the LDS ring: t (Q), t + 1, t + 2 (written and read by P in the same stage)
+constexpr int TM_D = 8;                  // granule ring depth (slabs s - 1 .. s + 2 are live while a member publishes s + 2: >= 4)
 constexpr int TM_LDW = 48;               // pitch of the new W rows in LDS (the two 16-lane halves of a scalar read land on different banks)
 constexpr int TM_MAXT = 8;               // members per team at most (n <= 4096)
-constexpr size_t TM_LDS_BYTES = (size_t)(TM_NBUF * TM_R * TM_LDA + TM_NW * TM_R * TM_KP + 4 * TM_R * TM_KP + TM_R * TM_LDW) * sizeof(float);
+constexpr size_t TM_LDS_BYTES = (size_t)(TM_NBUF * TM_R * TM_LDA + 2 * TM_NW * TM_R * TM_KP + 2 * 4 * TM_R * TM_KP + 2 * TM_R * TM_LDW) * sizeof(float);
 
 struct TeamArgs {
     const void* A; long lda;             // the data block (fp32), rows 16-byte aligned
@@ -65,19 +65,27 @@ struct TeamArgs {
     int T, tpx;                          // members per team, teams per XCD-residue class (grid = 8 tpx T)
     long rpt;                            // rows per team (a multiple of 16)
     unsigned long long patience;         // ticks of the 100 MHz wall clock a wait may last
+    int xflags;                          // tuning build only (0 in the shipped library): 1 = take granules as they are, 2 = no exchange at all (timing ablations, wrong results)
 };
 
-__device__ __forceinline__ void tm_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long tm_ld64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// SD: slabs in flight in registers ahead of the LDS ring (1, 2 or 4); NT: cache policy bits of the loads of A (2 = streaming)
+// SD: slabs in flight in registers ahead of the LDS ring (1, 2 or 3); NT: cache policy bits of the loads of A (2 = streaming)
+//
+// Memory instructions and the in-order counter.  A wave's loads and stores retire in issue order (s_waitcnt vmcnt(N) = "all but my N
+// youngest"), and this kernel has three streams per wave with very different latencies: the slab pieces of A (HBM, SD stages ahead),
+// the granules (fabric, one stage ahead) and the owner's W elements.  The stage body therefore issues every one of them UNCONDITIONALLY
+// and in the order they are consumed -- a member that is not the owner of a slab still executes the owner's loads and stores, with the
+// lane offset BUF_OOB (the hardware drops such an access), the gather always reads TM_MAXT + 2 planes (plane min(j, T - 1) for j >= T) --
+// so that the compiler's counts are exact and a wait for the granules leaves the younger loads of A in flight.  The first version had
+// these accesses under `if (owner)` / `if (j < T)`: the counts became path dependent, every wait degenerated to vmcnt(0..3) and each
+// stage paid a full fabric round trip (0.46 ms per launch at 65536 x 4096 against 0.22 ms of matrix time; profiles/r06a_team_*).
 template <int SD, int NT>
 __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tm_smem[];
+    constexpr int EL = TM_R * TM_KP;                       // elements of a slab's tile = granules of a plane = threads
     float* Ab = tm_smem;                                   // [NBUF][R][LDA]
-    float* red = Ab + TM_NBUF * TM_R * TM_LDA;             // [NW][R * KP]   the waves' partials of A H^T
-    float* dred = red + TM_NW * TM_R * TM_KP;              // [4][R * KP]    partial denominators (two waves fill one plane)
-    float* Wn = dred + 4 * TM_R * TM_KP;                   // [R][LDW]       the slab's new W rows
+    float* red = Ab + TM_NBUF * TM_R * TM_LDA;             // [2][NW][EL]   the waves' partials of A H^T (by stage parity)
+    float* dred = red + 2 * TM_NW * EL;                    // [2][4][EL]    partial denominators (two waves fill one plane)
+    float* Wn = dred + 2 * 4 * EL;                         // [2][R][LDW]   the slab's new W rows
     __shared__ unsigned s_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q4 = lane >> 4;
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     const long row0 = (long)team * a.rpt;
     const long rows = min(a.rpt, m - row0);
     const int nsl = rows > 0 ? (int)((rows + TM_R - 1) / TM_R) : 0;
+    const int nfull = rows > 0 ? (int)(rows / TM_R) : 0;   // slabs with all 16 rows
     const int cw = 64 * wv;                                // the wave's first column inside the member's piece
     const int cb = member * TM_C + cw;                     // ... inside the matrix
 
@@ -110,38 +119,27 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) gden[u] = a.G[(4 * (dks + u) + q4) * TM_KP + 16 * dtk + i];
 
-    // the slab pieces stream through a MUBUF descriptor at the team's first row: lane offset + scalar slab offset
+    // MUBUF descriptors at the team's first row / the team's granules: one lane offset per stream, everything else scalar
     const i32x4 arsrc = buf_rsrc((const float*)a.A + row0 * a.lda);
     const int avoff = (int)(((long)q4 * a.lda + cb + 4 * i) * 4);          // row q4 of a group of four, the lane's four columns
     const int arow4 = (int)(a.lda * 16);                                   // bytes between groups of four rows
-    f32x4 stg[SD][4];
-    auto load_slab = [&](int t, f32x4 (&d)[4]) {                           // 16 x 64 floats of slab t: four rows x 256 bytes per instruction
-        const int soff = t * 4 * arow4;
-        if ((long)(t + 1) * TM_R <= rows) {
+    const i32x4 wrsrc = buf_rsrc(a.W + row0 * a.ldw);
+    const int er = tid >> 5, ekk = tid & 31;                               // thread e = element (er, ekk) of a slab's 16 x 32 tile
+    const int wevoff = ekk < k ? (int)((er * a.ldw + ekk) * 4) : BUF_OOB;  // thread e's element of a slab of W
+    int wdvoff[2];                                                         // the wave's two A fragments of the product W G
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) d[ks] = buf_ld_f32x4(arsrc, avoff, soff + ks * arow4, NT);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                d[ks] = buf_ld_f32x4(arsrc, (long)t * TM_R + 4 * ks + q4 < rows ? avoff : BUF_OOB, soff + ks * arow4, NT);
-        }
-    };
-#pragma unroll
-    for (int u = 0; u + 1 < SD; ++u)
-        if (u < nsl) load_slab(u, stg[u]);
+    for (int u = 0; u < 2; ++u) wdvoff[u] = 4 * (dks + u) + q4 < k ? (int)((i * a.ldw + 4 * (dks + u) + q4) * 4) : BUF_OOB;
+    const int wslab = (int)(a.ldw * 4 * TM_R);                             // bytes between slabs of W
+    const i32x4 rrsrc = buf_rsrc(a.ring + (long)team * TM_D * (T + 2) * EL);
+    const int gvoff = tid * 8;
+    constexpr int PLANE = EL * 8;
+    const int slotb = (T + 2) * PLANE;                                     // bytes of a ring slot
 
-    // W as it is before the update, read by the slab's OWNER only: thread e's own element, and the wave's two A fragments of W G
-    const int er = tid >> 5, ekk = tid & 31;               // thread e = element (er, ekk) of a slab's 16 x 32 tile
+    f32x4 stg[SD][4];
     float wold[2] = {0.f, 0.f}, wdn[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    auto load_w = [&](int t, float& wo, float (&wd)[2]) {
-        const long r = row0 + (long)t * TM_R;
-        wo = (r + er < m && ekk < k) ? a.W[(r + er) * a.ldw + ekk] : 0.f;
+    f32x2 gat[TM_MAXT + 2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = 4 * (dks + u) + q4;
-            wd[u] = (r + i < m && j < k) ? a.W[(r + i) * a.ldw + j] : 0.f;
-        }
-    };
+    for (int j = 0; j < TM_MAXT + 2; ++j) gat[j] = f32x2{0.f, 0.f};
 
     // ---- census, second half
     if (tid == 0) {
@@ -168,142 +166,203 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) qacc[tk][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int EL = TM_R * TM_KP;                       // elements of a slab's tile = granules of a plane = threads
-    unsigned long long gat[TM_MAXT + 2];
-    unsigned long long* const ring_team = a.ring + (long)team * TM_D * (T + 2) * EL;
-    auto issue_gather = [&](int t) {                       // planes 0 .. T - 1: the members' partials; T: w_old; T + 1: den
-        const unsigned long long* src = ring_team + (long)(t & (TM_D - 1)) * (T + 2) * EL + tid;
+    // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
+    auto regather = [&](int t) {
+        const unsigned want = (unsigned)(t + 1);
+        const int slot = (t & (TM_D - 1)) * slotb;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-        for (int j = 0; j < TM_MAXT; ++j)
-            if (j < T) gat[j] = tm_ld64(src + j * EL);
-        gat[TM_MAXT] = tm_ld64(src + T * EL);
-        gat[TM_MAXT + 1] = tm_ld64(src + (T + 1) * EL);
+            for (int j = 0; j < TM_MAXT + 2; ++j) {
+                const int pl = j < TM_MAXT ? (j < T ? j : T - 1) : T + (j - TM_MAXT);
+                gat[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TM_MAXT + 2; ++j) ok = ok && __float_as_uint(gat[j][1]) == want;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 15u) == 15u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > a.patience) {
+                __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g_team_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
     };
-    // a granule that is not there yet (a late member): read again, bounded by the wall clock
-    auto granule = [&](unsigned long long g, const unsigned long long* src, unsigned want) -> float {
-        if ((unsigned)(g >> 32) != want) {
-            const unsigned long long t0 = wall_clock64();
-            unsigned spins = 0;
-            for (;;) {
-                g = tm_ld64(src);
-                if ((unsigned)(g >> 32) == want) break;
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 15u) == 15u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > a.patience) {
-                    __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&g_team_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+
+    float tmask[TM_MAXT];                                                  // 1 for the planes of real members (uniform values)
+#pragma unroll
+    for (int j = 0; j < TM_MAXT; ++j) tmask[j] = j < T ? 1.f : 0.f;
+    // owners without a division per stage: o3 / o2 / o0 = (s + 3) / (s + 2) / s modulo T, stepped with s
+    int o3 = (3 * T - 3) % T, o2 = (4 * T - 4) % T, o0 = (6 * T - 6) % T;  // s = -6
+    // One stage.  U = s mod 6 fixes every LDS slot and staging register at compile time; GD: the guarded form (first and last
+    // stages of a team's rows: slabs that do not exist, a last slab with fewer than 16 rows) -- the steady form has no such test.
+    // ONE barrier per stage: before it the wave stages slab s + 2 and forms its partial (matrix work that needs nothing from the
+    // team), then finishes the W update of slab s from the granules it asked for a stage ago; after it the partial is published,
+    // the next slab's granules are requested and the product W_new^T A of slab s runs.
+    auto stage = [&](int s, auto uc, auto gc) {
+        constexpr int U = decltype(uc)::value, PAR = U & 1;
+        constexpr bool GD = decltype(gc)::value;
+        float* const redp = red + PAR * (TM_NW * EL);
+        float* const dredp = dred + PAR * (4 * EL);
+        float* const Wnp = Wn + PAR * (TM_R * TM_LDW);
+        const bool pub = !GD || (s + 2 >= 0 && s + 2 < nsl);
+        const bool cur = !GD || (s >= 0 && s < nsl);
+        // S: slab s + 2 from the staging registers into its ring slot (the wave's own 64 columns)
+        if (pub) {
+            float* dst = Ab + ((U + 2) % 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<f32x4*>(dst + 4 * ks * TM_LDA) = stg[(U + 2) % SD][ks];
+        }
+        // L: slab s + 2 + SD into the registers just freed (four rows x 256 bytes per instruction)
+        {
+            const int t = s + 2 + SD;
+            if (!GD || (t >= 0 && t < nsl)) {
+                const int soff = t * 4 * arow4;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int vo = (!GD || (long)t * TM_R + 4 * ks + q4 < rows) ? avoff : BUF_OOB;
+                    stg[(U + 2) % SD][ks] = buf_ld_f32x4(arsrc, vo, soff + ks * arow4, NT);
                 }
             }
         }
-        return __uint_as_float((unsigned)g);
-    };
-    auto pack = [](float v, int t) { return ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(v); };
-
-    // one stage: u = s mod 4 fixes every LDS ring slot and staging register at compile time
-    // owners without a division per stage: o3 / o2 / o0 = (s + 3) / (s + 2) / s modulo T, stepped with s
-    int o3 = (T - 1) % T, o2 = (2 * T - 2) % T, o0 = (4 * T - 4) % T;      // s = -4
-    auto stage = [&](int s, auto uc) {
-        constexpr int u = decltype(uc)::value;
-        // S: slab s + 3 from the staging registers into its ring slot (the wave's own 64 columns)
-        if (s + 3 >= 0 && s + 3 < nsl) {
-            float* dst = Ab + ((u + 3) & 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
+        // the old W of slab s + 3, for its owner (used by the next stage; everybody else reads nothing: BUF_OOB)
+        {
+            const int t = s + 3;
+            if (!GD || (t >= 0 && t < nsl)) {
+                const bool mine = o3 == member;
+                const int soff = t * wslab;
+                wold[(U + 3) & 1] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + er < rows)) ? wevoff : BUF_OOB, soff, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<f32x4*>(dst + 4 * ks * TM_LDA) = stg[(u + 3) % SD][ks];
+                for (int u = 0; u < 2; ++u)
+                    wdn[(U + 3) & 1][u] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + i < rows)) ? wdvoff[u] : BUF_OOB, soff, 0);
+            }
         }
-        // L: slab s + 3 + SD into the registers just freed; the owner of slab s + 3 reads its old W (used by the next stage)
-        if (s + 3 + SD < nsl) load_slab(s + 3 + SD, stg[(u + 3) % SD]);
-        if (s + 3 >= 0 && s + 3 < nsl && o3 == member) load_w(s + 3, wold[(u + 3) & 1], wdn[(u + 3) & 1]);
-        // P: the wave's partial of A H^T for slab s + 2
-        const bool pub = s + 2 >= 0 && s + 2 < nsl;
-        const bool own = pub && o2 == member;
-        if (pub) {
-            const float* src = Ab + ((u + 2) & 3) * (TM_R * TM_LDA) + i * TM_LDA + cw + 4 * q4;
-            f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // P, first half: the wave's partial of A H^T for slab s + 2 over its first 32 columns
+        f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const float* psrc = Ab + ((U + 2) % 3) * (TM_R * TM_LDA) + i * TM_LDA + cw + 4 * q4;
+        auto p_half = [&](int g0) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(src + 16 * g);
+            for (int g = g0; g < g0 + 2; ++g) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(psrc + 16 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pacc[0] = TM_MFMA(av[e], hreg[0][g][e], pacc[0]);
                     pacc[1] = TM_MFMA(av[e], hreg[1][g][e], pacc[1]);
                 }
             }
-            float* dst = red + wv * EL + 4 * q4 * TM_KP + i;
+        };
+        if (pub) p_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // W update of slab s from the granules read a stage ago -- between the two halves of P, so that neither the wait for the granules nor
+        // the LDS round trip behind it leaves the matrix pipe without queued work.  All tags right <=> their sum is (TM_MAXT + 2) x the tag:
+        // a slot's earlier contents carry SMALLER tags (zero after the launch's memset, then s + 1 - 8, s + 1 - 16, ...), never larger ones.
+        if (cur) {
+            const unsigned want = (unsigned)(s + 1);
+            unsigned tsum = __float_as_uint(gat[0][1]);
+#pragma unroll
+            for (int j = 1; j < TM_MAXT + 2; ++j) tsum += __float_as_uint(gat[j][1]);
+            if (tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s);
+            float ah = gat[0][0];
+#pragma unroll
+            for (int j = 1; j < TM_MAXT; ++j) ah = fmaf(tmask[j], gat[j][0], ah);      // planes j >= T: x 0 (a re-read of plane T - 1)
+            const float wn = div_pos(gat[TM_MAXT][0] * ah, gat[TM_MAXT + 1][0]);
+            Wnp[er * TM_LDW + ekk] = wn;
+            const bool st = o0 == member && (!GD || (long)s * TM_R + er < rows);
+            buf_st_f32(wn, wrsrc, st ? wevoff : BUF_OOB, s * wslab, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pub) {
+            p_half(2);
+            float* dst = redp + wv * EL + 4 * q4 * TM_KP + i;
 #pragma unroll
             for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[r * TM_KP + 16 * tk] = pacc[tk][r];
-        }
-        // the owner's W G for slab s + 2: this wave's tile and contraction steps
-        if (own) {
-            f32x4 dacc = TM_MFMA(wdn[u & 1][0], gden[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-            dacc = TM_MFMA(wdn[u & 1][1], gden[1], dacc);
-            float* dst = dred + (wv >> 1) * EL + 4 * q4 * TM_KP + 16 * dtk + i;
+            // the owner's W G for slab s + 2: this wave's tile and contraction steps
+            if (o2 == member) {
+                f32x4 dacc = TM_MFMA(wdn[U & 1][0], gden[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+                dacc = TM_MFMA(wdn[U & 1][1], gden[1], dacc);
+                float* dd = dredp + (wv >> 1) * EL + 4 * q4 * TM_KP + 16 * dtk + i;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[r * TM_KP] = dacc[r];
-        }
-        __syncthreads();
-        // publish slab s + 2: thread e sums the eight waves' values of element e (the owner adds w_old and den)
-        if (pub) {
-            float v = red[tid];
-#pragma unroll
-            for (int w = 1; w < TM_NW; ++w) v += red[w * EL + tid];
-            unsigned long long* dst = ring_team + (long)((s + 2) & (TM_D - 1)) * (T + 2) * EL + tid;
-            tm_st64(dst + member * EL, pack(v, s + 2));
-            if (own) {
-                const float den = (((dred[tid] + dred[EL + tid]) + dred[2 * EL + tid]) + dred[3 * EL + tid]) + a.eps;
-                tm_st64(dst + T * EL, pack(wold[u & 1], s + 2));
-                tm_st64(dst + (T + 1) * EL, pack(den, s + 2));
+                for (int r = 0; r < 4; ++r) dd[r * TM_KP] = dacc[r];
             }
         }
-        // W update of slab s, then the reads of slab s + 1's granules (consumed by the next stage)
-        const bool cur = s >= 0 && s < nsl;
-        if (cur) {
-            const unsigned want = (unsigned)(s + 1);
-            const unsigned long long* src = ring_team + (long)(s & (TM_D - 1)) * (T + 2) * EL + tid;
-            float ah = 0.f;
-#pragma unroll
-            for (int j = 0; j < TM_MAXT; ++j)
-                if (j < T) ah += granule(gat[j], src + j * EL, want);
-            const float wo = granule(gat[TM_MAXT], src + T * EL, want);
-            const float den = granule(gat[TM_MAXT + 1], src + (T + 1) * EL, want);
-            const float wn = (wo * ah) / den;
-            Wn[er * TM_LDW + ekk] = wn;
-            const long r = row0 + (long)s * TM_R + er;
-            if (o0 == member && r < m && ekk < k) a.W[r * a.ldw + ekk] = wn;
-        }
-        if (s + 1 >= 0 && s + 1 < nsl) issue_gather(s + 1);
         __syncthreads();
-        // Q: the team's W^T A gains the slab (this wave: its 64 columns, from the LDS copy)
+        // after the barrier: every LDS read of this half first (the eight partials and four denominator parts of element e, the new W rows
+        // as A operand, the slab piece as B operand), then half of Q, the publication and the request for the next granules, the other half
+        float rr[TM_NW], dd[4], wop[2][4];
+        f32x4 bv[4];
+        const float* qsrc = Ab + (U % 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
         if (cur) {
-            float wop[2][4];
 #pragma unroll
             for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wop[tk][ks] = Wn[(4 * ks + q4) * TM_LDW + 16 * tk + i];
-            const float* src = Ab + u * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
+                for (int ks = 0; ks < 4; ++ks) wop[tk][ks] = Wnp[(4 * ks + q4) * TM_LDW + 16 * tk + i];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(src + 4 * ks * TM_LDA);
+            for (int ks = 0; ks < 4; ++ks) bv[ks] = *reinterpret_cast<const f32x4*>(qsrc + 4 * ks * TM_LDA);
+        }
+        if (pub) {
+#pragma unroll
+            for (int w = 0; w < TM_NW; ++w) rr[w] = redp[w * EL + tid];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dd[w] = dredp[w * EL + tid];
+        }
+        auto q_half = [&](int k0) {                        // Q: the team's W^T A gains slab s (this wave: its 64 columns, from the LDS copy)
+#pragma unroll
+            for (int ks = k0; ks < k0 + 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    qacc[0][j] = TM_MFMA(wop[0][ks], bv[j], qacc[0][j]);
-                    qacc[1][j] = TM_MFMA(wop[1][ks], bv[j], qacc[1][j]);
+                    qacc[0][j] = TM_MFMA(wop[0][ks], bv[ks][j], qacc[0][j]);
+                    qacc[1][j] = TM_MFMA(wop[1][ks], bv[ks][j], qacc[1][j]);
                 }
+        };
+        if (cur) q_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // publish slab s + 2: thread e sums the eight waves' values of element e (the owner adds w_old and den)
+        if (pub) {
+            float v = rr[0];
+#pragma unroll
+            for (int w = 1; w < TM_NW; ++w) v += rr[w];
+            const float den = (((dd[0] + dd[1]) + dd[2]) + dd[3]) + a.eps;
+            const float tag = __uint_as_float((unsigned)(s + 3));
+            const int slot = ((s + 2) & (TM_D - 1)) * slotb;
+            const int ov = (o2 == member && !(a.xflags & 2)) ? gvoff : BUF_OOB;
+            buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 16);
+            buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 16);
+            buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 16);
+        }
+        // the reads of slab s + 1's granules (published a stage ago, used by the next stage)
+        if ((!GD || (s + 1 >= 0 && s + 1 < nsl)) && !(a.xflags & 2)) {
+            const int slot = ((s + 1) & (TM_D - 1)) * slotb;
+#pragma unroll
+            for (int j = 0; j < TM_MAXT + 2; ++j) {
+                const int pl = j < TM_MAXT ? (j < T ? j : T - 1) : T + (j - TM_MAXT);
+                gat[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur) q_half(2);
         o3 = o3 + 1 == T ? 0 : o3 + 1;
         o2 = o2 + 1 == T ? 0 : o2 + 1;
         o0 = o0 + 1 == T ? 0 : o0 + 1;
     };
+    auto group = [&](int sb, auto gc) {
+        stage(sb, std::integral_constant<int, 0>{}, gc);
+        stage(sb + 1, std::integral_constant<int, 1>{}, gc);
+        stage(sb + 2, std::integral_constant<int, 2>{}, gc);
+        stage(sb + 3, std::integral_constant<int, 3>{}, gc);
+        stage(sb + 4, std::integral_constant<int, 4>{}, gc);
+        stage(sb + 5, std::integral_constant<int, 5>{}, gc);
+    };
 
-    for (int sb = -4; sb < nsl; sb += 4) {
-        stage(sb, std::integral_constant<int, 0>{});
-        stage(sb + 1, std::integral_constant<int, 1>{});
-        stage(sb + 2, std::integral_constant<int, 2>{});
-        stage(sb + 3, std::integral_constant<int, 3>{});
-    }
+    int sb = -6;
+    group(sb, std::true_type{});                                           // stages -6 .. -1: the pipeline fills
+    sb = 0;
+    for (; sb + 5 + 2 + SD < nfull; sb += 6) group(sb, std::false_type{}); // every slab a stage touches exists and is whole
+    for (; sb < nsl; sb += 6) group(sb, std::true_type{});                 // the pipeline drains
 
     // the team's partial: accumulator register r of tile (tk, j) is row 16 tk + 4 q4 + r, column cb + 4 i + j
     float* Pt = a.P + (long)team * TM_KP * n + cb + 4 * i;

@@ -88,10 +88,10 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
         hipLaunchKernelGGL((team_fro_kernel<SD, NT>), grid, block, TM_LDS_BYTES, st, a); \
     } while (0)
 #ifdef DNMF_TUNING
+    a.xflags = (int)tune("DNMF_TEAM_X", 0);
     if (sd == 1 && nt == 2) TEAM_LAUNCH(1, 2);
-    else if (sd == 4 && nt == 2) TEAM_LAUNCH(4, 2);
+    else if (sd == 3 && nt == 2) TEAM_LAUNCH(3, 2);
     else if (sd == 2 && nt == 0) TEAM_LAUNCH(2, 0);
-    else if (sd == 4 && nt == 0) TEAM_LAUNCH(4, 0);
     else
 #endif
         TEAM_LAUNCH(2, 2);

@@ -68,7 +68,8 @@ def timeit(on):
 
 
 for rnd in range(2):
-    out["two_pass_ms_%d" % rnd] = round(timeit(0), 4)
+    if not os.environ.get("NOTWO"):
+        out["two_pass_ms_%d" % rnd] = round(timeit(0), 4)
     out["one_pass_ms_%d" % rnd] = round(timeit(1), 4)
 lib.dnmf_hals_sweep_status(ctypes.byref(flag), None)
 out["timed_out_after_timing"] = int(flag.value)
