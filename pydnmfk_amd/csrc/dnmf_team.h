@@ -165,6 +165,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
         for (int j = 0; j < 4; ++j) qacc[tk][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool plain = (a.xflags & 4) != 0;
 
     // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
     auto regather = [&](int t) {
@@ -330,9 +331,15 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
             const float tag = __uint_as_float((unsigned)(s + 3));
             const int slot = ((s + 2) & (TM_D - 1)) * slotb;
             const int ov = (o2 == member && !(a.xflags & 2)) ? gvoff : BUF_OOB;
-            buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 16);
-            buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 16);
-            buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 16);
+            if (plain) {        // the whole team on one XCD: its L2 is the point of coherence, the granules need not leave it
+                buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 0);
+                buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 0);
+                buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 0);
+            } else {
+                buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 16);
+                buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 16);
+                buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 16);
+            }
         }
         // the reads of slab s + 1's granules (published a stage ago, used by the next stage)
         if ((!GD || (s + 1 >= 0 && s + 1 < nsl)) && !(a.xflags & 2)) {

@@ -2,6 +2,9 @@
 // csrc/dnmf.hip (mu_fro_step_impl) asks dnmf_team_plan_ whether a step of this shape takes it, sizes the workspace with
 // dnmf_team_ws_bytes_ and calls dnmf_team_fro_; the reduction of the teams' partials and the H update stay where they were.
 #include "dnmf_team.h"
+#ifdef DNMF_TUNING
+#include "dnmf_team2.h"       // the role-split variant: measured slower (profiles/r06b_team2_*), kept for the A/B only
+#endif
 #include "dnmf_host.h"
 
 namespace {
@@ -13,7 +16,7 @@ struct TeamPlan {
     size_t p_bytes, ctl_off, ring_off, total;
 };
 
-int g_team_on = 1;                       // dnmf_set_onepass
+int g_team_on = 1;                       // dnmf_set_onepass: 0 never, 1 where it measured faster (team_pays), 2 wherever the shape allows
 int g_team_cus = -1;                     // CUs of the device the census may count on (queried once per process)
 unsigned long long g_team_patience = 200000000ull;
 
@@ -31,10 +34,17 @@ int team_cus() {
     return cus;
 }
 
+// Where the one-pass step measured faster than the two passes on an MI355X (tools/team_shapes.sh, profiles/r06b_team_shapes.txt):
+// short blocks (two passes are launch- and latency-bound there: 10-35 % at m <= 16384), ranks that are not a whole 32-wide tile (the
+// two-pass kernels take their edge paths: 4 % at 65536 x 4096, k = 24; 33 % at 16384 x 4096, k = 17) and very tall blocks (3-5 %);
+// at k = 32 in between the two are within 2 % of each other either way, and the two-pass sequence needs no residency.
+bool team_pays(long m, long n, int k) { return n >= 2048 && (k < 32 || m <= 24576 || m >= 196608); }
+
 // shape-only part of the decision (the workspace query has no pointers); `cus` = 0: ask the device
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     TeamPlan p{};
-    if ((!g_team_on && !sizing) || k <= 16 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
+    if ((!g_team_on || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
+    if (k <= 16 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
     if (cus <= 0) cus = team_cus();
     p.T = (int)(n / TM_C);
     p.tpx = (cus / 8) / p.T;
@@ -81,6 +91,14 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     if (hipMemsetAsync(base + p.ctl_off, 0, p.total - p.ctl_off, st) != hipSuccess) return fail(DNMF_EHIP, "team: memset of the granule ring failed");
     static const int sd = (int)tune("DNMF_TEAM_SD", 2), nt = (int)tune("DNMF_TEAM_NT", 2);
     const dim3 grid((unsigned)(8 * p.tpx * p.T)), block(64 * TM_NW);
+#ifdef DNMF_TUNING
+#define TEAM2_LAUNCH(SD, NT)                                                         \
+    do {                                                                             \
+        static bool once = false;                                                    \
+        if (!once) { allow_lds(team_split_kernel<SD, NT>, TM2_LDS_BYTES + 64); once = true; } \
+        hipLaunchKernelGGL((team_split_kernel<SD, NT>), grid, block, TM2_LDS_BYTES, st, a); \
+    } while (0)
+#endif
 #define TEAM_LAUNCH(SD, NT)                                                          \
     do {                                                                             \
         static bool once = false;                                                    \
@@ -89,6 +107,12 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     } while (0)
 #ifdef DNMF_TUNING
     a.xflags = (int)tune("DNMF_TEAM_X", 0);
+    static const int ver = (int)tune("DNMF_TEAM_V", 1);
+    if (ver == 2) {
+        if (sd == 1) TEAM2_LAUNCH(1, 2);
+        else if (sd == 3) TEAM2_LAUNCH(3, 2);
+        else TEAM2_LAUNCH(2, 2);
+    } else
     if (sd == 1 && nt == 2) TEAM_LAUNCH(1, 2);
     else if (sd == 3 && nt == 2) TEAM_LAUNCH(3, 2);
     else if (sd == 2 && nt == 0) TEAM_LAUNCH(2, 0);
@@ -119,7 +143,7 @@ extern "C" {
 
 int dnmf_set_onepass(int on) {
     const int was = g_team_on;
-    g_team_on = on ? 1 : 0;
+    g_team_on = on < 0 ? 0 : (on > 2 ? 2 : on);
     return was;
 }
 

@@ -16,11 +16,13 @@ A = torch.rand(m, n, device=dev, generator=g)
 W0 = torch.rand(m, k, device=dev, generator=g)
 H0 = torch.rand(k, n, device=dev, generator=g)
 eps = 1.1920929e-07
-out = {"m": m, "n": n, "k": k, "onepass_shape": int(lib.dnmf_mu_fro_onepass(m, n, k))}
+out = {"m": m, "n": n, "k": k, "onepass_auto": int(lib.dnmf_mu_fro_onepass(m, n, k))}
+lib.dnmf_set_onepass(2)
+out["onepass_shape"] = int(lib.dnmf_mu_fro_onepass(m, n, k))
 
 
 def step(on, W, H, clamp=False):
-    lib.dnmf_set_onepass(int(on))
+    lib.dnmf_set_onepass(2 if on else 0)
     ops.mu_fro_step(A, W, H, eps, True, clamp)
 
 
