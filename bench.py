@@ -46,10 +46,6 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_CLOCK_GHZ = 2.4            # the clock that peak is quoted at (256 CUs x 256 flop per CU and clock)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
-# measured on an MI355X with tools/ceilbench.hip (profiles/r01d_ceilings.txt): what the matrix pipe sustains while the
-# contraction's HBM stream (128 B per 32x32x2 MFMA at k = 64) runs beside it, and plain streaming reads
-MEASURED_MFMA_WITH_STREAM_TFLOPS = {128: 138.9, 64: 126.2, 32: 108.4}
-MEASURED_STREAM_GBS = 6760.0
 
 
 def parse_args():
@@ -80,6 +76,10 @@ def parse_args():
                     help="arithmetic of A.H^T and W^T.A in the measured step: fp32 MFMA (default, the parity reference) or six "
                          "bf16 piece products per fp32 product (fp32-grade, csrc/dnmf_split.h)")
     ap.add_argument("--no-bf16x6", action="store_true", help="skip the extra bf16x6 measurement of the default run")
+    ap.add_argument("--onepass", default="auto", choices=["auto", "on", "off"], help="MU/FRO at 16 < k <= 32 on one rank: the one-pass team kernel where it "
+                    "measured faster (auto, the library's default), wherever the shape allows it (on), never (off) -- dnmf_set_onepass")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (2, 4 on one emulated rank, 5 at the example size) "
+                    "that the default run measures after the headline and reports in `configs`")
     ap.add_argument("--no-swim", action="store_true", help="skip the extra measurement of the reference's own example sweep (swim, KL / MU NMFk) in the default run")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="diagnostic, single GPU: run ONE rank's share of an R-GPU row grid (m / R rows) with the REAL exchange calls on "
@@ -109,6 +109,50 @@ CONFIGS = {
     4: dict(m=131072, n=65536, k=128, norm="kl", steps=30, warmup=3, label="BASELINE config 4"),
     5: dict(m=65536, n=4096, k=16, norm="fro", steps=1, warmup=1, label="BASELINE config 5"),
 }
+
+
+def other_configs():
+    """The other BASELINE configurations next to the headline, each as a CHILD process of this one (a fresh `python bench.py --config N`:
+    its own context, its own clocks; this process only waits) with a bounded workload:
+      2  MU/FRO 65536 x 4096, k = 32, 1000 steps;
+      4  MU/KL, ONE rank's 32768 x 32768 block of the 4 x 2 grid with the real collective calls on one-rank groups (--emulate-ranks 8;
+         not a whole-job number: the workload string says so), 10 steps;
+      5  the NMFk sweep k = 2..16 x 20 perturbations, HALS/FRO on bf16-stored X at the reference's example size 1024 x 256, one sweep.
+    Returns {name: {metric, value, unit, ms_per_step, steps, config.workload, roofline{kernel, bound, achieved, peak, unit, frac}}}; a child
+    that fails or takes more than two minutes is reported as {"error": ...} and never costs the headline line."""
+    import subprocess
+    runs = {
+        "config2": ["--config", "2", "--steps", "1000", "--warmup", "20", "--no-cpu-baseline", "--no-sustained", "--no-bf16x6", "--no-swim"],
+        "config4_one_emulated_rank": ["--config", "4", "--emulate-ranks", "8", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"],
+        "config5_example_size": ["--config", "5", "--rows", "1024", "--cols", "256", "--no-cpu-baseline", "--no-kernel-timing"],
+    }
+    env = dict(os.environ)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    out = {}
+    for name, args in runs.items():
+        t0 = time.time()
+        try:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-configs"] + args, capture_output=True, text=True,
+                                 timeout=120, env=env)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode != 0 or not line:
+                out[name] = {"error": ("exit %d: " % res.returncode) + (res.stderr.strip().splitlines() or [""])[-1][:200]}
+                continue
+            d = json.loads(line[-1])
+            e = {key: d.get(key) for key in ("metric", "value", "unit", "ms_per_step", "steps", "dtype")}
+            e["config"] = {"workload": d.get("config", {}).get("workload")}
+            r = d.get("roofline")
+            if r:
+                e["roofline"] = {key: r.get(key) for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch")}
+            for key in ("estimated_k", "fits_per_step", "onepass"):
+                if key in d:
+                    e[key] = d[key]
+            e["wall_s"] = round(time.time() - t0, 1)
+            out[name] = e
+        except Exception as ex:  # noqa: BLE001
+            out[name] = {"error": str(ex)[:200]}
+    return out
 
 
 def flush_c_stdio():
@@ -888,8 +932,7 @@ def run_config5(a, job):
             def entry(kernel, ms_):
                 ach = by / ms_ / 1e6
                 return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                        "traffic": None, "bytes_per_launch": by, "ms_per_launch": ms_, "measured_ceiling": MEASURED_STREAM_GBS,
-                        "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS, "note": "algorithmic bytes = one read of the bf16 block"}
+                        "traffic": None, "bytes_per_launch": by, "ms_per_launch": ms_, "note": "algorithmic bytes = one read of the bf16 block"}
             out["roofline"] = entry("nt16_kernel<bf16 X> (dnmf_aht_bf16a, k=%d: A H^T of the HALS W phase, dist_nmf.py:884)" % kk, t_nt)
             out["rooflines"] = [out["roofline"], entry("tn16_kernel<bf16 X> + reduce_partials (dnmf_wta_bf16a, k=%d: W^T A of the H phase, dist_nmf.py:903)" % kk, t_tn)]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -988,6 +1031,8 @@ def main():
     from pydnmfk_amd.utils import determine_block_params, parse
 
     m, n, k = a.m, a.n, a.k
+    from pydnmfk_amd._lib import lib as _lib
+    _lib.dnmf_set_onepass({"auto": 1, "on": 2, "off": 0}[a.onepass])
     comms = MPI_comm(None, world, 1)
     grid_r = emu or world                       # rows of the process grid the step is written for
     multi = world > 1 or emu > 1
@@ -1233,6 +1278,8 @@ def main():
             "step_mfma_frac": (flops_iter / world / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if a.gemm == "fp32" else None,
             "step_algorithmic_hbm_gbs_per_gpu": (4.0 * m_l * n + 12.0 * (m_l + n) * k) / (ms * 1e-3) / 1e9,
         }
+        if not multi and a.gemm == "fp32":
+            out["onepass"] = bool(_lib.dnmf_mu_fro_onepass(m_l, n, k))   # the step read A once (csrc/dnmf_team.h) instead of twice
         if mg is not None:
             out["multi_gpu"] = mg
 
@@ -1373,9 +1420,6 @@ def main():
             ach = flops / ms_ / 1e9
             e = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                  "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops, "ms_per_launch": ms_}
-            if k in MEASURED_MFMA_WITH_STREAM_TFLOPS:       # informational: fraction of the MEASURED mixed ceiling
-                e["measured_ceiling"] = MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
-                e["frac_of_measured_ceiling"] = ach / MEASURED_MFMA_WITH_STREAM_TFLOPS[k]
             tr = pmc_traffic(role) if (m, n, k, world) == (262144, 8192, 64, 1) else None
             if tr is not None:
                 e["traffic"] = tr["bytes"]
@@ -1391,7 +1435,6 @@ def main():
             ach = nbytes / ms_ / 1e6
             e = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                  "frac": ach / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": nbytes, "ms_per_launch": ms_,
-                 "measured_ceiling": MEASURED_STREAM_GBS, "frac_of_measured_ceiling": ach / MEASURED_STREAM_GBS,
                  "note": note}
             tr = pmc_traffic(role, workload) if (role and (m, n, k, world) == (262144, 8192, 64, 1)) else None
             if tr is not None:
@@ -1470,6 +1513,9 @@ def main():
                                       "each (slowest process); the sweep is 525 000 such steps" % P}
             except Exception as ex:  # noqa: BLE001 -- informational: never costs the headline line
                 out["reference_example_swim"] = {"error": str(ex)[:200]}
+        if not multi and not a.no_configs and a.config == 3 and a.gemm == "fp32" and (m, n, k) == (262144, 8192, 64):
+            torch.cuda.synchronize()
+            out["configs"] = other_configs()
         flush_c_stdio()                                           # (RCCL's version banner sits in C stdio until here)
         print(json.dumps(out), flush=True)
     if world > 1:
