@@ -99,6 +99,11 @@ int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, 
  * launch starts with a census and writes nothing unless every workgroup has been seen (a shared GPU: dnmf_hals_sweep_status reports the
  * time-out, W is untouched by that launch).  dnmf_mu_fro_onepass(m, n, k) != 0: steps of this shape take it on this device;
  * dnmf_set_onepass(0) switches it off process-wide (returns the previous setting). */
+/* Process-wide switch of every kernel whose workgroups wait for each other (the whole fits of small problems, the persistent HALS W sweep
+ * -- local and across ranks --, the one-pass MU/FRO step): on (default) / off = their launch-chain forms everywhere (same update rules, no
+ * co-residency needed: for a GPU shared with another process or stream).  Returns the previous setting.  PyNMF switches it off for the
+ * rest of the process, and fits again from the initial factors, when dnmf_hals_sweep_status reports a time-out. */
+int dnmf_set_persistent(int on);
 int dnmf_mu_fro_onepass(long m, long n, int k);
 int dnmf_set_onepass(int on);
 int dnmf_mu_fro_step(const float* A, long m, long n, long lda, float* W, long ldw, float* H, long ldh,
@@ -408,6 +413,11 @@ int dnmf_comm_direct_teardown(dnmf_comm_t* comm);
 /* how long a wait of a direct allreduce may see no progress before it gives up (default 30 s; rank skew of seconds is ordinary:
  * result I/O on rank 0, first-call module loads) */
 int dnmf_comm_set_direct_timeout(dnmf_comm_t* comm, double seconds);
+/* Call on EVERY rank before the first step of a fit on new data (PyNMF.fit does): the next HALS W sweep over the ranks then agrees anew
+ * on whether the one-launch cross-rank sweep applies (a host-synchronous 16-float allreduce).  The ranks re-open that agreement only at
+ * events all of them see -- this call, another k, dnmf_set_persistent -- because a rank's local row count may change on some ranks only;
+ * a step whose local row count differs from the agreed one without this call returns DNMF_EINVAL. */
+int dnmf_comm_fit_begin(dnmf_comm_t* comm);
 /* on != 0: allreduces over ALL ranks that fit the regions (the packed exchange of the 1D steps, dnmf_comm_allreduce with
  * group 0) take the direct path; everything else stays on RCCL / the hosted function */
 int dnmf_comm_set_direct(dnmf_comm_t* comm, int on);

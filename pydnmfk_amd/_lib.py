@@ -39,6 +39,7 @@ SIGNATURES = {
                          c_int, c_void_p, c_size_t, c_void_p],
     "dnmf_mu_fro_onepass": [c_long, c_long, c_int],
     "dnmf_set_onepass": [c_int],
+    "dnmf_set_persistent": [c_int],
     "dnmf_hals_w_col": [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_float, c_void_p,
                         c_void_p],
     "dnmf_hals_w_scale": [c_void_p, c_long, c_long, c_int, c_void_p, c_void_p],
@@ -98,6 +99,7 @@ SIGNATURES["dnmf_comm_set_direct"] = [c_void_p, c_int]
 SIGNATURES["dnmf_comm_direct_teardown"] = [c_void_p]
 SIGNATURES["dnmf_comm_hals_xsweeps"] = [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
 SIGNATURES["dnmf_comm_set_direct_timeout"] = [c_void_p, ctypes.c_double]
+SIGNATURES["dnmf_comm_fit_begin"] = [c_void_p]
 DIRECT_HANDLE_BYTES = 80           # DNMF_DIRECT_HANDLE_BYTES
 SIGNATURES["dnmf_comm_allreduce_direct"] = [c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_comm_allreduce_direct_f64"] = [c_void_p, c_void_p, c_size_t, c_void_p]
@@ -174,6 +176,11 @@ lib = load()
 
 class DnmfError(RuntimeError):
     pass
+
+
+class PersistentTimeout(DnmfError):
+    """A kernel whose workgroups wait for each other gave up (dnmf_hals_sweep_status): its workgroups were not all resident -- the GPU is
+    shared with another process or stream.  The factors it was working on are invalid."""
 
 
 def check(rc):

@@ -279,6 +279,12 @@ WsLayout ws_layout(long m, long n, int k) {
 }  // namespace
 
 // =============================================================================================== C ABI
+// Process-wide: may kernels whose workgroups WAIT FOR EACH OTHER run (the whole fits of small problems, the persistent HALS W sweep
+// -- local and across ranks --, the one-pass MU/FRO team kernel)?  They need every workgroup of a launch resident at once, i.e. the GPU
+// to themselves; off, every path takes its launch-chain form (same update rules, no residency needed).  dnmf_set_persistent.
+static int g_persistent_on = 1;
+__attribute__((visibility("hidden"))) int dnmf_persistent_on_() { return g_persistent_on; }
+__attribute__((visibility("hidden"))) void dnmf_persistent_set_(int on) { g_persistent_on = on; }
 __attribute__((visibility("hidden"))) void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]);
 void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]) {   // library-internal (csrc/dnmf_split.hip)
     const WsLayout L = ws_layout(m, n, k);
@@ -288,6 +294,11 @@ void dnmf_ws_offsets_(long m, long n, int k, size_t out[5]) {   // library-inter
 extern "C" {
 
 const char* dnmf_last_error(void) { return dnmf_errbuf_(); }
+int dnmf_set_persistent(int on) {
+    const int was = dnmf_persistent_on_();
+    dnmf_persistent_set_(on != 0);
+    return was;
+}
 int dnmf_version(void) { return 100; }
 int dnmf_kp(int k) { return kp_of(k); }
 

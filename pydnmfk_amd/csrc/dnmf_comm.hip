@@ -88,6 +88,12 @@ struct dnmf_comm {
     // cross-rank persistent HALS W sweep over the peer regions (hals_sweep_exchanged): the ranks' agreement for the last shape seen
     unsigned long long hals_seq = 0;                             // sweeps issued: its parity selects the slot slab
     long xs_m = -1; int xs_k = -1, xs_ok = 0, xs_first = 0, xs_total = 0;
+    // WHEN the ranks agree again is a function of things every rank sees alike -- the fit counter (dnmf_comm_fit_begin: PyNMF calls it on
+    // every rank at the start of every fit), the rank k, the process-wide persistent switch -- never of a rank's LOCAL row count: with
+    // an asymmetric split two fits of different global m can change the row count on some ranks only, and an agreement
+    // that only those ranks enter is a collective mismatch
+    int xs_epoch = 0, xs_seen_epoch = -1, xs_pers = -1;
+    float* agree_buf = nullptr;                                  // DNMF_DIRECT_MAX_RANKS device floats of the comm's own (the caller's workspace may be absent)
 };
 
 namespace {
@@ -308,13 +314,15 @@ int allreduce_f64(dnmf_comm* cm, int g, double* buf, size_t count, hipStream_t s
 // give each rank its first slot.  (Host-synchronous, once per shape.)
 int hals_xsweep_agree(dnmf_comm* cm, float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps, void* ws,
                       size_t ws_bytes, hipStream_t st) {
-    cm->xs_m = m; cm->xs_k = k; cm->xs_ok = 0;
+    cm->xs_m = m; cm->xs_k = k; cm->xs_ok = 0; cm->xs_seen_epoch = cm->xs_epoch; cm->xs_pers = dnmf_persistent_on_();
     int nwg = 0;
     const bool mine = ws && ws_bytes >= 64 * sizeof(float) &&
                       dnmf_hals_sweep_w_peers_(W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, nullptr, &nwg, (void*)st) == 0;
     float host[DNMF_DIRECT_MAX_RANKS] = {};
     host[cm->rank] = mine ? (float)nwg : -1.0e6f;                  // (a rank that cannot poisons the sum of its own slot)
-    float* dev = (float*)ws;
+    // the comm's own buffer: a rank that cannot take the sweep (no workspace, too small a one) still joins the allreduce
+    if (!cm->agree_buf) HIP_OK(hipMalloc((void**)&cm->agree_buf, sizeof(host)), "hals sweep: agreement buffer");
+    float* dev = cm->agree_buf;
     HIP_OK(hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, st), "hals sweep: agreement");
     HIP_OK(hipStreamSynchronize(st), "hals sweep: agreement");
     if (int rc = allreduce_f32(cm, G_WORLD, dev, DNMF_DIRECT_MAX_RANKS, st)) return rc;
@@ -338,8 +346,11 @@ int hals_sweep_exchanged(dnmf_comm* cm, float* W, long m, int k, long ldw, const
     // ONE persistent launch when the direct peer regions are up (dnmf_comm_set_direct) and every rank can keep its rows resident:
     // the column partials cross the ranks through the slot slabs in the exported regions (csrc/dnmf_hals.h, HalsPeers)
     if (cm->direct_on && !cm->null_exchange && k <= DNMF_TUNED_MAX_K && cm->nranks <= DNMF_DIRECT_MAX_RANKS) {
-        if (cm->xs_m != m || cm->xs_k != k)
+        if (cm->xs_seen_epoch != cm->xs_epoch || cm->xs_k != k || cm->xs_pers != dnmf_persistent_on_()) {
             if (int rc = hals_xsweep_agree(cm, W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, st)) return rc;
+        } else if (cm->xs_m != m)                                   // a rank cannot re-open the agreement on its own
+            return fail(DNMF_EINVAL, "hals sweep: the row count of rank %d changed (%ld -> %ld) inside one fit: call dnmf_comm_fit_begin on every rank "
+                                     "before the first step on new data", cm->rank, cm->xs_m, m);
         if (cm->xs_ok) {
             HalsPeers pe{};
             pe.P = cm->nranks; pe.rank = cm->rank; pe.first = cm->xs_first; pe.total = cm->xs_total; pe.patience = cm->direct_patience;
@@ -806,12 +817,19 @@ int dnmf_comm_destroy(dnmf_comm_t* c) {
         if (c->done[q]) (void)hipEventDestroy(c->done[q]);
     }
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (c->agree_buf) (void)hipFree(c->agree_buf);
     if (r) {
         if (c->row) r->CommDestroy(c->row);
         if (c->col) r->CommDestroy(c->col);
         if (c->world) r->CommDestroy(c->world);
     }
     delete c;
+    return DNMF_OK;
+}
+
+int dnmf_comm_fit_begin(dnmf_comm_t* c) {
+    REQUIRE(c, "comm_fit_begin: null communicator");
+    ++c->xs_epoch;
     return DNMF_OK;
 }
 

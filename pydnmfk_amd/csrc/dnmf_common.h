@@ -58,6 +58,9 @@ struct BatchTab { int n; int z0; BatchFam f[4]; };      // z0: first problem of 
 // the calling thread's batch state (csrc/dnmf.hip owns it; set by the *_fit entry points around their launch sequence)
 struct BatchCtx { int B; BatchTab tab; };
 __attribute__((visibility("hidden"))) BatchCtx* dnmf_batch_();
+// process-wide switch of the kernels that need co-residency (csrc/dnmf.hip owns it; dnmf_set_persistent)
+__attribute__((visibility("hidden"))) int dnmf_persistent_on_();
+__attribute__((visibility("hidden"))) void dnmf_persistent_set_(int on);
 
 __device__ __forceinline__ long batch_off(const void* p, const BatchTab& bt) {
     const unsigned long a = (unsigned long)p;

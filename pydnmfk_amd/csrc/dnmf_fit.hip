@@ -301,14 +301,16 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
     char* base = (char*)ws;
     int rc = DNMF_OK;
     bool small = false;
-    if (method == FIT_HALS_FRO && w_update && !column_sweep) {
+    const bool pers = dnmf_persistent_on_() != 0;
+    if (!pers) column_sweep = 1;                                       // (the HALS steps below take the column launches)
+    if (pers && method == FIT_HALS_FRO && w_update && !column_sweep) {
         const int B = ctx->B;
         ctx->B = 1;
         rc = small_hals_fit(bf, A, m, n, lda, W, ldw, H, ldh, k, eps, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
         ctx->B = B;
         if (rc) return rc;
     }
-    if (method == FIT_MU_FRO && bf && w_update) {
+    if (pers && method == FIT_MU_FRO && bf && w_update) {
         const int B = ctx->B;
         ctx->B = 1;
         rc = small_fro_bf16_fit(A, m, n, lda, W, ldw, H, ldh, k, eps, itr, batch, a_stride, w_stride, h_stride, base, f, stream, &small);
@@ -316,7 +318,7 @@ int fit_impl(int method, bool bf, const void* A, long m, long n, long lda, float
         if (rc) return rc;
     }
     // (Frobenius MU with W fixed: the hoisted H-only loop below beats the barrier kernel)
-    if ((method == FIT_MU_KL || (method == FIT_MU_FRO && w_update)) && !bf) {
+    if (pers && (method == FIT_MU_KL || (method == FIT_MU_FRO && w_update)) && !bf) {
         // small fp32 problems: the whole loop as one persistent kernel per batch (csrc/dnmf_small.h); launched unbatched -- it indexes the problems itself
         const int B = ctx->B;
         ctx->B = 1;
@@ -396,11 +398,11 @@ int dnmf_fit_set_timeout(double seconds) {
 }
 
 int dnmf_hals_fit_persistent(long m, long n, int k) {
-    return (m >= 1 && n >= 1 && small_hals_plan(m, n, k).ok) ? 1 : 0;
+    return (dnmf_persistent_on_() && m >= 1 && n >= 1 && small_hals_plan(m, n, k).ok) ? 1 : 0;
 }
 
 int dnmf_mu_fit_persistent(long m, long n, int k) {
-    return (m >= 1 && n >= 1 && small_kl_plan(m, n, k).ok) ? 1 : 0;
+    return (dnmf_persistent_on_() && m >= 1 && n >= 1 && small_kl_plan(m, n, k).ok) ? 1 : 0;
 }
 
 size_t dnmf_ws_bytes_fit(long m, long n, int k, int batch) {

@@ -99,7 +99,7 @@ int launch_hals_sweep(float* W, long m, int k, long ldw, const float* AH, long l
     BatchCtx* bc = dnmf_batch_();
     const int B = bc->B;
     const long cap = vec ? cap_v[dev] : cap_s[dev];
-    if (grid > HALS_MAX_WG || grid > cap || (pe && B > 1)) return 1;   // not applicable: the caller takes the column path
+    if (grid > HALS_MAX_WG || grid > cap || (pe && B > 1) || !dnmf_persistent_on_()) return 1;   // not applicable (or switched off): the caller takes the column path
     const int per = (int)std::min<long>(B, cap / grid);
     if (ldw >= (1L << 23) || ldah >= (1L << 23)) return 1;                        // beyond the 32-bit tile offsets of pass 1: column path
     if (check_only) return 0;

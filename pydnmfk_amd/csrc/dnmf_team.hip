@@ -43,7 +43,7 @@ bool team_pays(long m, long n, int k) { return n >= 2048 && (k < 32 || m <= 2457
 // shape-only part of the decision (the workspace query has no pointers); `cus` = 0: ask the device
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     TeamPlan p{};
-    if ((!g_team_on || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
+    if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
     if (k <= 16 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
     if (cus <= 0) cus = team_cus();
     p.T = (int)(n / TM_C);

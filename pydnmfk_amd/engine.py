@@ -8,7 +8,7 @@ exception is the data matrix A of the Frobenius paths, which may be STORED as bf
 """
 import torch
 
-from ._lib import DnmfError, check, lib
+from ._lib import DnmfError, PersistentTimeout, check, lib
 
 _ws_cache = {}
 
@@ -66,6 +66,21 @@ def _req_g(G, k, name="G"):
     if G.shape[0] < n or G.shape[1] != n or G.stride(0) != n:
         raise ValueError("%s: rank %d needs the contiguous %d x %d Gram buffer (dnmf_kp), got %s with pitch %d" % (name, k, n, n, tuple(G.shape), G.stride(0)))
     return G
+
+
+_downgraded = False
+
+
+def persistent_off(reason=""):
+    """For the rest of this process every path takes its launch-chain kernels (dnmf_set_persistent(0)): called by PyNMF when a kernel
+    that needs the GPU to itself has timed out.  Warns once."""
+    global _downgraded
+    lib.dnmf_set_persistent(0)
+    if not _downgraded:
+        _downgraded = True
+        import warnings
+        warnings.warn("pydnmfk_amd: a persistent kernel lost its residency (%s); this process continues on the launch-chain kernels "
+                      "-- same results, no co-residency needed (dnmf_set_persistent(1) switches back)" % (reason or "shared GPU"), RuntimeWarning, stacklevel=3)
 
 
 def kp(k):
@@ -270,10 +285,10 @@ class HipOps:
         flag = ctypes.c_int(0)
         check(lib.dnmf_hals_sweep_status(ctypes.byref(flag), _stream()))
         if flag.value:
-            raise DnmfError("a persistent kernel (the HALS W sweep, or the whole-fit kernel of a small MU/KL problem) timed out -- "
-                            "its workgroups were not all resident (is the GPU shared with another process or stream?); the "
-                            "factors are invalid.  params.hals_sweep = 'columns' selects the per-column HALS sweep and "
-                            "params.fit_loop = 'python' the step loop, which need no co-residency.")
+            raise PersistentTimeout("a persistent kernel (the HALS W sweep, the whole-fit kernel of a small problem, the one-pass MU/FRO step) "
+                                    "timed out -- its workgroups were not all resident (is the GPU shared with another process or stream?); the "
+                                    "factors are invalid.  PyNMF fits again on the launch-chain kernels (dnmf_set_persistent(0)); through the C ABI: "
+                                    "dnmf_set_persistent(0), or hals_sweep = 'columns' / fit_loop = 'python' per fit.")
 
     def hals_update_w_columns(self, W, AH, G, eps):
         """The same sweep as k column launches (what the persistent kernel falls back to; kept callable for A/B tests)."""
@@ -946,6 +961,10 @@ class NativeComm:
 
     def set_direct_timeout(self, seconds):
         check(lib.dnmf_comm_set_direct_timeout(self.handle, float(seconds)))
+
+    def fit_begin(self):
+        """every rank, before the first step of a fit: the cross-rank HALS sweep agrees anew on the first sweep (dnmf_comm_fit_begin)"""
+        check(lib.dnmf_comm_fit_begin(self.handle))
 
     def direct_self_check(self, host_comm, count=4096):
         """First contact: the same random vector summed by the direct allreduce and by the communicator's own allreduce (RCCL or

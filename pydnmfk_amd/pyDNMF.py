@@ -194,7 +194,40 @@ class PyNMF:
         return a.astype(np.float64) if self.prune else a        # the reference's dtype after unprune (utils.py:195,198)
 
     def fit(self):
-        """pyDNMF.py:138-182.  Returns (W, H, recon_err)."""
+        """pyDNMF.py:138-182.  Returns (W, H, recon_err).
+
+        Several kernels behind this loop need the GPU to themselves (their workgroups wait for each other: the whole fits of small
+        problems, the persistent HALS W sweep, the one-pass MU/FRO step).  When one of them gives up -- another process or stream holds
+        CUs -- the fit is NOT lost: the initial factors are kept until the end, the ranks agree on the time-out, every rank switches its
+        process to the launch-chain kernels (engine.persistent_off: same update rules, no co-residency) and the fit runs again from them."""
+        from ._lib import PersistentTimeout
+        keep = self._initial_factors()
+        nc = getattr(self.params, "_native_comm", None)
+        if nc is not None and hasattr(nc, "fit_begin"):
+            nc.fit_begin()
+        try:
+            return self._fit_once()
+        except PersistentTimeout as ex:
+            from .engine import persistent_off
+            persistent_off(str(ex).split(" -- ")[0])
+            self._restore_factors(keep)
+            if nc is not None and hasattr(nc, "fit_begin"):
+                nc.fit_begin()
+            return self._fit_once()
+
+    def _initial_factors(self):
+        W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
+        return W.clone(), H.clone()
+
+    def _restore_factors(self, keep):
+        W, H = (self.W_ij, self.H_ij) if self.topo == '2d' else (self.W_i, self.H_j)
+        W.copy_(keep[0])
+        H.copy_(keep[1])
+        for name in ("W_i", "H_j") if self.topo == '2d' else ():       # (the gathered copies relative_err made)
+            if hasattr(self, name):
+                delattr(self, name)
+
+    def _fit_once(self):
         if self.method.lower() not in ('mu', 'hals'):
             raise NotImplementedError("method '%s' is not part of the MI355X engine (mu / hals)" % self.method)
         ops = self._ops()
@@ -233,21 +266,21 @@ class PyNMF:
         """The end of the last iteration (pyDNMF.py:158-166, :173-181): error, un-pruning, save.  `sq`: the device pair
         {sum (A - W H)^2, sum A^2} a whole-fit call left (None: evaluate them here)."""
         ops = self._ops()
-        persistent = self.method.lower() == 'hals' or sq is not None       # (whole MU fits of small problems are persistent kernels too)
+        persistent = self.method.lower() == 'hals' or sq is not None or self.p == 1     # (paths that may have run a kernel of that kind)
         if persistent and hasattr(ops, "hals_check"):
-            # a persistent kernel (the HALS W sweep; the whole-fit kernel of a small MU/KL problem, csrc/dnmf_small.h) that lost its
-            # co-residency raises here -- BEFORE the error's allreduce sees NaN
-            # factors, and on EVERY rank (the word is per device: the ranks agree on it first, or the others would
-            # walk into the next collective alone)
+            # a persistent kernel (the HALS W sweep; the whole-fit kernel of a small problem, csrc/dnmf_small.h; the one-pass MU/FRO step,
+            # csrc/dnmf_team.h) that lost its co-residency raises here -- BEFORE the error's allreduce sees NaN factors, and on EVERY rank
+            # (the word is per device: the ranks agree on it first, or the others would walk into the next collective alone); fit() then
+            # runs the fit again on the launch-chain kernels
+            from ._lib import PersistentTimeout
             bad = None
             try:
                 ops.hals_check()
-            except Exception as ex:  # noqa: BLE001
+            except PersistentTimeout as ex:
                 bad = ex
             nbad = int(self.params.comm1.allreduce(1 if bad is not None else 0))
             if nbad:
-                raise bad if bad is not None else RuntimeError(
-                    "HALS W sweep timed out on %d other rank(s) (params.hals_sweep = 'columns' selects the per-column sweep)" % nbad)
+                raise bad if bad is not None else PersistentTimeout("a persistent kernel timed out on %d other rank(s)" % nbad)
         nc = getattr(self.params, "_native_comm", None)
         if nc is not None and getattr(nc, "direct_ready", False) and nc._get_direct_on():
             # a direct allreduce that gave up waiting for a peer has produced garbage since: fatal, on every rank together
@@ -300,8 +333,23 @@ class PyNMF:
         for b, f in enumerate(fits):
             W[b].copy_(f.W_i)
             H[b].copy_(f.H_j)
-        sq = f0._ops().fit(f0.method, f0.norm, A, W, H, f0.eps, f0.W_update, f0.itr,
-                           column_sweep=(getattr(f0.params, "hals_sweep", None) == "columns"))
+        from ._lib import PersistentTimeout
+        ops = f0._ops()
+        for attempt in (0, 1):
+            sq = ops.fit(f0.method, f0.norm, A, W, H, f0.eps, f0.W_update, f0.itr,
+                         column_sweep=(getattr(f0.params, "hals_sweep", None) == "columns"))
+            try:
+                if hasattr(ops, "hals_check"):
+                    ops.hals_check()
+                break
+            except PersistentTimeout as ex:                 # (one rank per problem here: nobody to agree with)
+                if attempt:
+                    raise
+                from .engine import persistent_off
+                persistent_off(str(ex).split(" -- ")[0])
+                for b, f in enumerate(fits):                # the fits still hold their initial factors
+                    W[b].copy_(f.W_i)
+                    H[b].copy_(f.H_j)
         out = []
         sq_host = sq.cpu()                                  # ONE synchronisation for the whole batch
         for b, f in enumerate(fits):
