@@ -315,6 +315,11 @@ size_t dnmf_f64_ws_bytes(long m, long n, int k);
  * {sum (A - W H)^2, sum A^2} -> sq_out (device) -- the primitives below in the order pydnmfk_amd/dist_nmf.py issues them, enqueued by
  * ONE call (bit-identical to that step loop).  ws >= dnmf_f64_ws_bytes_fit(m, n, k): it holds the m x n quotient / residual image too. */
 size_t dnmf_f64_ws_bytes_fit(long m, long n, int k);
+/* != 0: a fit of this shape and method runs as ONE single-workgroup launch with A, W, H in LDS for all its steps (csrc/dnmf_f64_tiny.hip:
+ * k <= 16 and everything within 160 KiB of LDS -- the reference's own test sizes, 24 x 12 with k = 2 over 2000 iterations,
+ * tests/test_dist_nmf_1d.py:14-46): same update rules in plain float64 FMA chains (index-order sums: a few ulp from the primitives'
+ * MFMA sums, so such a fit equals the step loop to ~1e-13, not bit for bit); no workgroup waits for another one (nothing to keep resident) */
+int dnmf_f64_fit_tiny(long m, long n, int k, int method);
 int dnmf_f64_fit(int method, const double* A, long m, long n, long lda, double* W, long ldw, double* H, long ldh, int k, double eps,
                  int w_update, int itr, double* sq_out, void* ws, size_t ws_bytes, void* stream);
 /* C[m x kc] = X[m x n] Y[kc x n]^T   (A H^T: dist_nmf.py:730; H H^T = global_gram(H.T), :729, with X = Y = H) */

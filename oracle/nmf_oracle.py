@@ -152,13 +152,15 @@ class SimGrid:
     on every rank; `fit(itr)` = `PyNMF.fit()` (pyDNMF.py:138-182).
     """
 
-    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True, method="mu", prune=False):
+    def __init__(self, A, W0, H0, p_r=1, p_c=1, norm="fro", W_update=True, method="mu", prune=False, eps=None):
         self.method = method
         self.prune = prune
         self.p_r, self.p_c, self.P = p_r, p_c, p_r * p_c
         self.m, self.n = A.shape
         self.dtype = A.dtype
-        self.eps = np.finfo(A.dtype).eps                     # pyDNMF.py:68
+        # pyDNMF.py:68: the machine epsilon of the data's dtype.  `eps` overrides it for ONE use: a float64 evaluation of a float32
+        # run (tests of fp32 kernels against the same loop without fp32 rounding keep the fp32 epsilon in the denominators)
+        self.eps = np.finfo(A.dtype).eps if eps is None else eps
         self.norm = norm
         self.W_update = W_update
         self.topo = "2d" if (p_r != 1 and p_c != 1) else "1d"  # pyDNMF.py:83-87
@@ -446,8 +448,8 @@ class SimGrid:
         raise ValueError("itr must be >= 1")
 
 
-def fit_single(A, W0, H0, itr, norm="fro", W_update=True, method="mu"):
+def fit_single(A, W0, H0, itr, norm="fro", W_update=True, method="mu", eps=None):
     """Single-rank convenience wrapper: returns (W, H, err)."""
-    g = SimGrid(A, W0, H0, 1, 1, norm=norm, W_update=W_update, method=method)
+    g = SimGrid(A, W0, H0, 1, 1, norm=norm, W_update=W_update, method=method, eps=eps)
     W, H, err = g.fit(itr)
     return W[0], H[0], err

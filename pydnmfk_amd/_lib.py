@@ -140,6 +140,7 @@ SIGNATURES["dnmf_f64_ws_bytes"] = [c_long, c_long, c_int]
 SIGNATURES["dnmf_f64_aht"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_wta"] = SIGNATURES["dnmf_f64_aht"]
 SIGNATURES["dnmf_f64_ws_bytes_fit"] = [c_long, c_long, c_int]
+SIGNATURES["dnmf_f64_fit_tiny"] = [c_long, c_long, c_int, c_int]
 SIGNATURES["dnmf_f64_fit"] = [c_int, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
                               c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_mu_update_w"] = [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_void_p]

@@ -733,6 +733,11 @@ int dnmf_f64_hals_update_h(double* H, int k, long n, long ldh, const double* AtW
 // choreography (pydnmfk_amd/dist_nmf.py over engine.HipOpsF64) issues them -- same kernels, same operands, so the same bits -- without a
 // Python frame and a ctypes call per launch (about 15 per step: 150-200 us of host time against 60-80 us of kernels on the reference's own
 // test sizes).  method: 0 = MU/FRO, 1 = MU/KL, 2 = HALS/FRO.  sq_out (device): {sum (A - W H)^2, sum A^2}.
+}  // extern "C"
+__attribute__((visibility("hidden"))) int dnmf_f64_tiny_fit_(int method, const double* A, long m, long n, long lda, long a_stride, double* W, long ldw,
+                                                              long w_stride, double* H, long ldh, long h_stride, int k, double eps, int w_update, int itr,
+                                                              int batch, double* sq_out, long sq_stride, void* stream);
+extern "C" {
 size_t dnmf_f64_ws_bytes_fit(long m, long n, int k) {
     const size_t prim = dnmf_f64_ws_bytes(m, n, k);
     if (!prim) return 0;
@@ -746,6 +751,11 @@ int dnmf_f64_fit(int method, const double* A, long m, long n, long lda, double* 
             ldw >= k && ldh >= n, "f64 fit: bad arguments");
     const size_t need = dnmf_f64_ws_bytes_fit(m, n, k);
     if (ws_bytes < need) return fail(DNMF_EWS, "f64 fit: workspace %zu < %zu", ws_bytes, need);
+    static const bool tiny_on = tune("DNMF_F64_TINY", 1) != 0;     // (tuning build: 0 = the chain of primitives, for the before / after timing)
+    if (itr >= 1 && tiny_on) {      // tiny problems (the reference's own test sizes): the whole fit as ONE single-workgroup launch (csrc/dnmf_f64_tiny.hip)
+        const int rc_tiny = dnmf_f64_tiny_fit_(method, A, m, n, lda, 0, W, ldw, 0, H, ldh, 0, k, eps, w_update, itr, 1, sq_out, 2, stream);
+        if (rc_tiny != 1) return rc_tiny;
+    }
     const size_t D = sizeof(double), prim_bytes = dnmf_f64_ws_bytes(m, n, k);
     char* b = (char*)ws;
     void* prim = b;                                   b += al256(prim_bytes);

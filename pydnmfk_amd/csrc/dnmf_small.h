@@ -62,6 +62,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Ordering contract of the in-kernel exchanges of this file: none of the atomics below carries release / acquire semantics --
+// the hand-off is the form MI355X_MICROARCH.md lists as measured-valid on gfx950 ("Valid forms", row 1 of its table): EVERY handed-off
+// byte is written by a write-through (sc1) store and read by an L1-bypassing (sc1) load (st_dev / ld_dev), every storing wave drains its
+// stores (s_waitcnt 0) before the workgroup barrier behind which ONE lane adds to the arrival counter, the consumer's polling lane reads
+// only after its poll has matched and the other waves only after the workgroup barrier it then joins; hipMalloc memory, one workgroup
+// per CU.  An agent-scope acquire after each barrier (buffer_inv sc1, ~1.7 us) would make the form architectural at +20 % per step; the
+// guard below keeps the kernels from being built for a target the form has not been measured on.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "csrc/dnmf_small.h: the sc1 store / sc1 load hand-off of the persistent kernels is validated on gfx950 (and gfx942) only"
+#endif
 // The data that cross workgroups inside the kernel (the partials, the updated H) move as relaxed DEVICE-scope atomic stores / loads:
 // coherent at the device level by themselves (write-through, no stale lines), so the barrier needs no cache write-back / invalidate
 // -- the first version bracketed the barriers with __threadfence() (an L2 write-back + invalidate each) and a step took 107 us.
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 //     order, then a thread per column runs the k rows in sequence (:905-909) on the LDS copy of H; barrier; re-read H.
 //   The slots of a parity are reset by their owner after the first barrier of the step that used them: every reader is done with them
 //   by then, and they are not written again before the step after next.
-constexpr unsigned SLOT_EMPTY = 0xffffffffu;               // (a NaN pattern: a sum of squares never has it)
+constexpr unsigned SLOT_EMPTY = 0xffffffffu;               // (a NaN pattern: a sum of squares of finite data never has it; NaN data would read as "not there yet" until the wait times out and the fit reports it)
 
 // ALDS: the slab of A in LDS in its storage type (bf16: 66 KiB for 128 rows x 256 columns -- it fits beside the rest; fp32 slabs stream)
 template <int KP, int NW, typename TA, bool ALDS>

@@ -302,7 +302,7 @@ class PyNMFk:
         operators -- as many as fit next to each other in the GPU's free memory (each holds its perturbed copy of the data) --
         else 1.  `params.nmfk_batch` = False / 0 / 1 keeps the one-by-one fits, an integer caps the batch."""
         want = getattr(self.params, "nmfk_batch", True)
-        if want is False or self.params.p_r * self.params.p_c != 1 or self.ops is not None or not torch.cuda.is_available():
+        if want is False or self.p != 1 or self.ops is not None or not torch.cuda.is_available():
             return 1
         cap = self.perturbations if want is True else max(1, int(want))
         try:
@@ -310,7 +310,11 @@ class PyNMFk:
         except Exception:  # noqa: BLE001
             return 1
         m, n = self.A_ij.shape
-        per = m * n * 4 * 1.25 + (m + n) * max(int(self.end_k), 1) * 4 * 8 + (64 << 20)
+        # per problem: its perturbed copy of the data in the data's own element size (float64 data are 8 bytes; fp32 data that the fit stores as
+        # bf16 still pass through a full-size copy first), the float64 operator set's m x n quotient image (one per call, counted per problem to
+        # stay on the safe side), the factors and their workspaces
+        esz = self.A_ij.element_size() if isinstance(self.A_ij, torch.Tensor) else int(np.dtype(getattr(self.A_ij, "dtype", np.float32)).itemsize)
+        per = m * n * esz * (2.25 if esz == 8 else 1.25) + (m + n) * max(int(self.end_k), 1) * esz * 8 + (64 << 20)
         return int(max(1, min(cap, self.perturbations, (0.6 * free) // per)))
 
     def pvalueAnalysis(self):

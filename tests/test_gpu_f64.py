@@ -298,3 +298,34 @@ def test_f64_whole_fit_equals_step_loop(m, n, k, method, norm, itr):
     single = [PyNMF(A * (1.0 + 0.01 * b), factors=[W0, H0], params=_args(k, itr, norm, method=method)).fit() for b in range(3)]
     for o, r in zip(PyNMF.fit_batch(fits), single):
         assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1]) and o[2] == r[2]
+
+
+@pytest.mark.parametrize("m,n,k", [(24, 12, 2), (96, 21, 4), (100, 60, 16), (1, 9, 1), (300, 20, 5)])
+@pytest.mark.parametrize("method,norm", [("mu", "fro"), ("mu", "kl"), ("hals", "fro")])
+def test_f64_tiny_fit_equals_the_step_loop(m, n, k, method, norm):
+    """Tiny float64 problems (the reference's own test sizes) run their whole fit as ONE single-workgroup launch (csrc/dnmf_f64_tiny.hip:
+    A, W, H in LDS, plain FMA chains in index order); the step loop over the float64 primitives sums through MFMAs.  Same update rules
+    (dist_nmf.py:716-751, :806-849, :873-934): the factors agree to 1e-11 of the largest entry after 60 steps (HALS: 1e-12 after 2 sweeps), with and without W updates, and both agree with the checker's loop in float64."""
+    from oracle import nmf_oracle as orc
+    from pydnmfk_amd._lib import lib
+    from pydnmfk_amd.pyDNMF import PyNMF
+    code = {("mu", "fro"): 0, ("mu", "kl"): 1, ("hals", "fro"): 2}[(method, norm)]
+    assert lib.dnmf_f64_fit_tiny(m, n, k, code) == 1
+    rs = np.random.RandomState(m + 3 * n + k)
+    A = rs.rand(m, n)
+    A[:, ::5] = 0.0
+    W0, H0 = rs.rand(m, k), rs.rand(k, n)
+    # (HALS on over-parameterised random data is chaotic once entries sit on the eps clamp: at 100 x 60, k = 16 the checker's loop, the step
+    # loop and this kernel agree to 1e-16 for two sweeps and all three part ways at the third -- one flipped comparison -- so its sweeps
+    # are compared over two; the float64 goldens hold the long HALS runs)
+    itr = 2 if method == "hals" else 60
+    tol = 1e-12 if method == "hals" else 1e-11
+    for w_update in (True, False):
+        a1, a2 = _args(k, itr, norm, W_update=w_update, method=method), _args(k, itr, norm, W_update=w_update, method=method)
+        a2.fit_loop = "python"
+        W1, H1, e1 = PyNMF(A, factors=[W0, H0], params=a1).fit()
+        W2, H2, e2 = PyNMF(A, factors=[W0, H0], params=a2).fit()
+        Wr, Hr, er = orc.fit_single(A, W0, H0, itr, norm=norm, W_update=w_update, method=method)
+        for X, Y in ((W1, W2), (H1, H2), (W1, Wr), (H1, Hr)):
+            assert W1.dtype == np.float64 and np.abs(X - Y).max() <= tol * np.abs(Y).max(), (w_update, np.abs(X - Y).max())
+        assert abs(e1 - e2) <= 1e-10 * max(1.0, abs(e2)) and abs(e1 - er) <= 1e-9 * max(1.0, abs(er))

@@ -4,7 +4,7 @@
     kernels in the same order on the same operands -- BIT-identical factors; the two squared norms come from fp64 atomic
     sums whose order is free, so the error is compared to 1e-12 relative.  SMALL MU/KL problems are the exception: their
     whole loop is one persistent kernel (csrc/dnmf_small.h) with the same update rule in another association of the fp32
-    sums -- both it and the step loop are held to a float64 run of the reference's loop (2e-4 of the largest entry);
+    sums -- both it and the step loop are held to the checker's loop (oracle.fit_single) run in float64 (2e-4 of the largest entry);
   * a batch of B problems in one call (blockIdx.z = problem) against B calls of their own: bit-identical factors, problem
     by problem -- the property the NMFk sweep relies on when it fits its perturbations together;
   * the NMFk driver with and without batching: identical statistics and the same estimate.
@@ -75,35 +75,14 @@ def _persistent(m, n, k, method, norm, precision):
     return method == "mu" and precision == "float32" and lib.dnmf_mu_fit_persistent(m, n, k) != 0
 
 
-def _mu_fit_f64(A, W, H, itr, w_update, norm, eps=1.1920929e-07):
-    """PyNMF.fit with MU/KL or MU/FRO on one rank in float64 (pyDNMF.py:151-194, dist_nmf.py:716-751, :806-849)"""
-    A, W, H = A.double(), W.double().clone(), H.double().clone()
-    for i in range(itr):
-        if norm == "hals":                                  # dist_nmf.py:873-934
-            k = W.shape[1]
-            if w_update:
-                G, AH = H @ H.t(), A @ H.t()
-                for kk in range(k):
-                    t = W[:, kk] * G[kk, kk] + AH[:, kk] - W @ G[:, kk]
-                    W[:, kk] = torch.clamp(t, min=eps)
-                    ss = torch.linalg.norm(W[:, kk])
-                    if float(ss) > 0:
-                        W[:, kk] = W[:, kk] / ss
-            G, AtW = W.t() @ W, W.t() @ A
-            for kk in range(k):
-                H[kk] = torch.clamp(H[kk] + AtW[kk] - G[kk] @ H, min=eps)
-        elif norm == "fro":
-            if w_update:
-                W = W * ((A @ H.t()) / (W @ (H @ H.t()) + eps))
-            H = H * ((W.t() @ A) / ((W.t() @ W) @ H + eps))
-        else:
-            if w_update:
-                W = W * (((A / (W @ H + eps)) @ H.t()) / (H.sum(1) + eps))
-            H = H * ((W.t() @ (A / (W @ H + eps))) / (W.sum(0)[:, None] + eps))
-        if i % 10 == 0:
-            W, H = torch.clamp(W, min=eps), torch.clamp(H, min=eps)
-    s = W.sum(0)
-    return W / (s + eps), H * s[:, None]
+def _checker_fit_f64(A, W, H, itr, w_update, norm, method):
+    """The checker's fit loop (oracle/nmf_oracle.py: fit_single -- pyDNMF.py:151-194 with dist_nmf.py:716-751, :806-849, :873-934 --
+    pinned to the reference's vectors by tests/test_oracle_golden.py) on float64 copies of the device operands, with the float32
+    epsilon the kernels under test use: ONE restatement of the reference's loop holds the persistent kernels and the step loop alike."""
+    from oracle import nmf_oracle as orc
+    Wr, Hr, _ = orc.fit_single(A.float().double().cpu().numpy(), W.double().cpu().numpy(), H.double().cpu().numpy(), itr, norm=norm,
+                               W_update=w_update, method=method, eps=1.1920929e-07)
+    return torch.from_numpy(Wr).cuda(), torch.from_numpy(Hr).cuda()
 
 
 def _close(X, Y, tol):
@@ -118,7 +97,7 @@ def test_whole_fit_equals_step_loop(m, n, k, method, norm, precision, itr):
         for w_update in (True, False):
             W1, H1, e1 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update)).fit()
             W2, H2, e2 = PyNMF(A, factors=[W0, H0], params=_args(k, itr, norm, method, precision, W_update=w_update, fit_loop="python")).fit()
-            Wr, Hr = _mu_fit_f64(A, W0, H0, itr, w_update, "hals" if method == "hals" else norm)
+            Wr, Hr = _checker_fit_f64(A, W0, H0, itr, w_update, norm, method)
             tol = 1e-3 if method == "hals" else 2e-4       # (HALS: the sequential sweeps amplify fp32 rounding; the goldens hold 2e-3)
             for X, Y in ((W1, Wr), (H1, Hr), (W2, Wr), (H2, Hr)):
                 assert _close(X, Y, tol), (w_update, float((X.double() - Y).abs().max()), float(Y.abs().max()))
@@ -321,7 +300,7 @@ def test_persistent_fit_that_loses_its_residency_ends_and_says_so():
 @pytest.mark.parametrize("norm", ["kl", "fro"])
 def test_persistent_fits_on_padded_operands_through_the_c_abi(m, n, k, norm):
     """The persistent small-fit kernels behind dnmf_mu_{kl,fro}_fit with leading dimensions larger than the rows (views of wider
-    arrays: every pitch odd or unaligned), a batch of 3 and both settings of w_update, against the float64 loop: ragged slabs, one to
+    arrays: every pitch odd or unaligned), a batch of 3 and both settings of w_update, against the checker's loop in float64: ragged slabs, one to
     64 slabs per problem, k = 1, n < 16, streamed and LDS-resident A."""
     from pydnmfk_amd._lib import lib
     from pydnmfk_amd.engine import HIP_OPS
@@ -351,7 +330,7 @@ def test_persistent_fits_on_padded_operands_through_the_c_abi(m, n, k, norm):
         torch.cuda.synchronize()
         HIP_OPS.hals_check()
         for b in range(B):
-            Wr, Hr = _mu_fit_f64(A[b], W0[b], H0[b], itr, bool(w_update), norm)
+            Wr, Hr = _checker_fit_f64(A[b].contiguous(), W0[b].contiguous(), H0[b].contiguous(), itr, bool(w_update), norm, "mu")
             assert _close(W[b], Wr, 3e-4) and _close(H[b], Hr, 3e-4), (w_update, b)
             R = A[b].double() - Wr @ Hr
             assert abs(float(sq[b, 0]) / float((R * R).sum()) - 1) < 1e-3 and abs(float(sq[b, 1]) / float((A[b].double() ** 2).sum()) - 1) < 1e-5

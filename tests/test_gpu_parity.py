@@ -40,14 +40,19 @@ def _args(k, itr, norm, W_update=True, method="mu", prune=False):
     return args
 
 
+@pytest.mark.parametrize("fit_loop", ["native", "python"])
 @pytest.mark.parametrize("name", SINGLE)
-def test_fit_matches_reference_golden(name):
+def test_fit_matches_reference_golden(name, fit_loop):
+    """Both ways a one-rank fit can run are held to the reference's vectors: the whole-fit entry points (`native`, the default: for the
+    small goldens the persistent kernels of csrc/dnmf_small.h) and the per-step loop over nmf_algorithms_1D.update (`python`)."""
     from pydnmfk_amd.pyDNMF import PyNMF
     meta, A, W0, H0, z = load_case(name)
     _, tol_fit, tol_err = _tols(meta)
     for itr in meta["itrs"]:
-        W, H, err = PyNMF(A, factors=[W0, H0], params=_args(meta["k"], itr, meta["norm"], meta["W_update"],
-                                                             meta.get("method", "mu"), meta.get("prune", False))).fit()
+        args = _args(meta["k"], itr, meta["norm"], meta["W_update"], meta.get("method", "mu"), meta.get("prune", False))
+        if fit_loop == "python":
+            args.fit_loop = "python"
+        W, H, err = PyNMF(A, factors=[W0, H0], params=args).fit()
         # numpy in -> numpy out, in the dtype the reference hands back (float64 after unprune, utils.py:195,198)
         assert isinstance(W, np.ndarray) and W.dtype == z["r0_fit%d_W" % itr].dtype and H.dtype == z["r0_fit%d_H" % itr].dtype
         assert rel_fro(W, z["r0_fit%d_W" % itr]) <= tol_fit, itr
