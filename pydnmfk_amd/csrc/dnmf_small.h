@@ -292,40 +292,40 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * t + 4 * q, c0 + i);
             }
-            for (int rt0 = 0; rt0 < NW; rt0 += 4) {        // four row tiles at a time (independent chains, as in the W phase)
+            static_for<0, (NW + 3) / 4>([&](auto gc) {     // four row tiles at a time (independent chains, as in the W phase); NW = 6: four, then two
+                constexpr int rt0 = 4 * decltype(gc)::value, C = NW - rt0 < 4 ? NW - rt0 : 4;
                 f32x4 hcur[4];
                 if constexpr (!ALDS) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) hcur[t] = hpre[t];
-                    if (rt0 + 4 < NW) {
+                    for (int t = 0; t < C; ++t) hcur[t] = hpre[t];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
-                    }
+                    for (int t = 0; t < 4; ++t)
+                        if (rt0 + 4 + t < NW) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
                 }
                 f32x4 d[4];                                // lane (col i, q) reg r = (W H)[16 rt + 4 q + r][c0 + i]
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < C; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s >= ksteps) break;
                     const float hb = Hs[(4 * s + q) * LDH + c0 + i];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
+                    for (int t = 0; t < C; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
                 }
                 float u[4][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < C; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         u[t][r] = (ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r]) * __builtin_amdgcn_rcpf(d[t][r] + eps);
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < C; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], u[t][r], acc3[t & 1][jt]);
-            }
+            });
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -550,21 +550,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 #pragma unroll
                 for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * t + 4 * q, c0 + i);
             }
-            for (int rt0 = 0; rt0 < NW; rt0 += 4) {
+            static_for<0, (NW + 3) / 4>([&](auto gc) {     // four row tiles at a time; NW = 6: four, then two
+                constexpr int rt0 = 4 * decltype(gc)::value, C = NW - rt0 < 4 ? NW - rt0 : 4;
                 f32x4 hcur[4];
                 if constexpr (!ALDS) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) hcur[t] = hpre[t];
-                    if (rt0 + 4 < NW) {
+                    for (int t = 0; t < C; ++t) hcur[t] = hpre[t];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
-                    }
+                    for (int t = 0; t < 4; ++t)
+                        if (rt0 + 4 + t < NW) hpre[t] = a_col4(16 * (rt0 + 4 + t) + 4 * q, c0 + i);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) hcur[t] = a_col4(16 * (rt0 + t) + 4 * q, c0 + i);
+                    for (int t = 0; t < C; ++t) hcur[t] = a_col4(16 * (rt0 + t) + 4 * q, c0 + i);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < C; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float av = hcur[t][r];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
                         for (int jt = 0; jt < JT; ++jt)    // lane (col i, q) reg r = (W^T A)[16 jt + 4 q + r][c0 + i]
                             acc3[t & 1][jt] = SM_MFMA(Ws[(16 * (rt0 + t) + 4 * q + r) * LDW + 16 * jt + i], av, acc3[t & 1][jt]);
                     }
-            }
+            });
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
