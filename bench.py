@@ -43,9 +43,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_CLOCK_GHZ = 2.4            # the clock that peak is quoted at (256 CUs x 256 flop per CU and clock)
-PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+from benchlib.common import (CONFIGS, PEAK_CLOCK_GHZ, PEAK_FP32_MFMA_TFLOPS, PEAK_HBM_GBS, Job, event_time_ms, flush_c_stdio,  # noqa: E402
+                             parse_grid, pmc_traffic, rccl_record)
+from benchlib.config4 import run_config4  # noqa: E402
+from benchlib.config5 import run_config5, swim_example  # noqa: E402
+from benchlib.cpu_baseline import (_cpu_hals_rank, _cpu_kl_rank, _cpu_pool, cpu_baseline, cpu_baseline_allcores,  # noqa: E402
+                                   host_cpu)
 
 
 def parse_args():
@@ -103,12 +106,6 @@ def parse_args():
 
 
 # BASELINE.json `configs` (1 = the reference's own CPU case: a parity test, tests/test_gpu_parity.py, not a bench line)
-CONFIGS = {
-    2: dict(m=65536, n=4096, k=32, norm="fro", steps=2000, warmup=20, label="BASELINE config 2"),
-    3: dict(m=262144, n=8192, k=64, norm="fro", steps=500, warmup=5, label="BASELINE config 3"),
-    4: dict(m=131072, n=65536, k=128, norm="kl", steps=30, warmup=3, label="BASELINE config 4"),
-    5: dict(m=65536, n=4096, k=16, norm="fro", steps=1, warmup=1, label="BASELINE config 5"),
-}
 
 
 def other_configs():
@@ -153,187 +150,6 @@ def other_configs():
         except Exception as ex:  # noqa: BLE001
             out[name] = {"error": str(ex)[:200]}
     return out
-
-
-def flush_c_stdio():
-    """RCCL 2.26 writes a version banner to C stdout when its first communicator comes up; on a pipe that text stays in the C
-    buffer until the process exits, i.e. it would land AFTER rank 0's JSON line.  Flushing the C streams before the line is
-    printed keeps the JSON the last line of stdout."""
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-
-
-def event_time_ms(fn, reps=5, warm=2):
-    import torch
-    for _ in range(warm):
-        fn()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for s, e in evs:
-        s.record()
-        fn()
-        e.record()
-    torch.cuda.synchronize()
-    ts = sorted(s.elapsed_time(e) for s, e in evs)
-    return sum(ts) / len(ts), ts[0]
-
-
-def _cpu_rank(rank, P, m_l, n, k, steps, q):
-    """One rank of the reference's process model: single BLAS thread (main.py:3 pins OMP_NUM_THREADS=1), its own row
-    slab of X, the oracle's step (the numpy calls of dist_nmf.py:716-751)."""
-    os.environ["OMP_NUM_THREADS"] = "1"
-    import numpy as np
-    from oracle import nmf_oracle as orc
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except ImportError:
-        ctx = None
-    rng = np.random.default_rng(1234 + rank)
-    A = rng.random((m_l, n), dtype=np.float32)
-    W = rng.random((m_l, k), dtype=np.float32)
-    H = np.random.default_rng(99).random((k, n), dtype=np.float32)
-    eps = np.finfo(np.float32).eps
-    orc.fro_mu_step_local(A, W, H, eps)                      # warm-up (page faults, BLAS init)
-    q.put(("ready", rank))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        orc.fro_mu_step_local(A, W, H, eps)
-    q.put(("done", rank, (time.perf_counter() - t0) / steps))
-    del ctx
-
-
-def cpu_baseline(n, k, m_full, steps=3):
-    """The reference's CPU path beside the GPU number: P = min(8, host cores) processes x 1 thread, each
-    holding the 1/P row slab a rank of the p_r = P grid would hold, each running the oracle's MU/FRO step; the iteration
-    time of the job is the slowest rank's (the 2 MiB allreduce the reference adds is not simulated: it only makes the
-    CPU figure slightly optimistic).  Bounded: 1 warm-up + `steps` timed steps per process."""
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    P = min(8, cores)
-    m_l = m_full // P
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_rank, args=(r, P, m_l, n, k, steps, q)) for r in range(P)]
-    for pr in procs:
-        pr.start()
-    import queue
-    times, deadline = {}, time.time() + 600
-    try:
-        while len(times) < P and time.time() < deadline:
-            try:
-                msg = q.get(timeout=2)
-            except queue.Empty:
-                if any(pr.exitcode not in (None, 0) for pr in procs):
-                    break                                    # a rank died: report that instead of waiting
-                continue
-            if msg[0] == "done":
-                times[msg[1]] = msg[2]
-    finally:
-        for pr in procs:
-            pr.join(timeout=5)
-            if pr.is_alive():
-                pr.kill()
-    if len(times) < P:
-        return {"value": None, "unit": "iter/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
-                "sample": "FAILED: %d of %d CPU ranks finished (exit codes %s)" % (len(times), P, [pr.exitcode for pr in procs])}
-    t = max(times.values())
-    flops = 4.0 * m_full * n * k + 4.0 * (m_full + n * P) * k * k          # every rank forms its own k x k products
-    return {"value": 1.0 / t, "unit": "iter/s", "cores": P, "kind": "port",
-            "sample": "oracle fro_mu_step_local in the reference's process model: %d processes x 1 BLAS thread, each on "
-                      "its %dx%d row slab (1/%d of X), k=%d, 1 warm-up + %d timed steps; iteration time = slowest rank "
-                      "(%.2f s; fastest %.2f s), no allreduce simulated" % (P, m_l, n, P, k, steps, t, min(times.values())),
-            "host_cores": cores, "host_cpu": model, "seconds_per_iter": t, "gflops_whole_job": flops / t / 1e9}
-
-
-def _cpu_allcores_rank(m_s, n, k, steps, q):
-    """The non-reference threading variant: ONE process, the BLAS library free to use every host core."""
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.pop(v, None)
-    import numpy as np
-    from oracle import nmf_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        nthreads = max([int(d.get("num_threads", 1)) for d in threadpool_info()] or [1])
-    except ImportError:
-        nthreads = os.cpu_count() or 1
-    rng = np.random.default_rng(1234)
-    A = rng.random((m_s, n), dtype=np.float32)
-    W = rng.random((m_s, k), dtype=np.float32)
-    H = np.random.default_rng(99).random((k, n), dtype=np.float32)
-    eps = np.finfo(np.float32).eps
-    orc.fro_mu_step_local(A, W, H, eps)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        orc.fro_mu_step_local(A, W, H, eps)
-    q.put(((time.perf_counter() - t0) / steps, nthreads))
-
-
-def cpu_baseline_allcores(n, k, m_full, steps=3):
-    """One process with all host cores' BLAS threads on a 1/8 row slab of X (the oracle's step; the whole-X iteration time
-    is 8 x the slab's: the step is linear in the rows).  Labelled non-reference: the reference pins one BLAS thread per
-    rank (main.py:3)."""
-    import multiprocessing as mp
-    import queue
-    frac = 8
-    m_s = m_full // frac
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    saved = {v: os.environ.pop(v) for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS") if v in os.environ}
-    try:
-        pr = ctx.Process(target=_cpu_allcores_rank, args=(m_s, n, k, steps, q))
-        pr.start()
-    finally:
-        os.environ.update(saved)
-    try:
-        t, nthreads = q.get(timeout=300)
-    except queue.Empty:
-        pr.kill()
-        return {"value": None, "unit": "iter/s", "kind": "port", "sample": "FAILED: no result within 300 s"}
-    pr.join(timeout=5)
-    t_full = t * frac
-    flops = 4.0 * m_full * n * k + 4.0 * (m_full + n) * k * k
-    return {"value": 1.0 / t_full, "unit": "iter/s", "cores": nthreads, "kind": "port", "threading": "non-reference",
-            "sample": "oracle fro_mu_step_local, ONE process with %d BLAS threads on a %dx%d row slab (1/%d of X), k=%d, 1 warm-up "
-                      "+ %d timed steps: %.3f s per slab step, x %d = %.2f s per iteration of the whole X (the step is linear in "
-                      "the rows); non-reference threading (the reference pins one BLAS thread per rank)" % (
-                          nthreads, m_s, n, frac, k, steps, t, frac, t_full),
-            "seconds_per_iter": t_full, "gflops_whole_job": flops / t_full / 1e9}
-
-
-def pmc_traffic(role, workload="bench"):
-    """HBM bytes per launch of a kernel from the NEWEST committed PMC pass of the given profiled workload
-    (profiles/<tag>_<workload>_pmc.json: separate --pmc runs of tools/collect_profiles.sh, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md; older rounds: profiles/<tag>_pmc.json) -- a constant of the committed profile, not a live counter:
-    the driver's run has no profiler attached.  Kernels are picked by role (template argument lists change between
-    rounds): 'nt' = the k = 64 NT instantiation with the most bytes (the fused A H^T + W update; the gram launch only
-    reads H), 'tn' = likewise for the TN form, otherwise a name prefix.  None if absent."""
-    import glob
-    best = None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    files = [f for f in files if ("_%s_pmc" % workload) in f or os.path.basename(f).count("_") == 1]
-    for f in files:
-        try:
-            d = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        prefix = {"nt": "nt_kernel<2,", "tn": "tn_kernel<2,"}.get(role, role)
-        cand = [(c["hbm_bytes"], name) for name, c in d.items()
-                if name.startswith(prefix) and isinstance(c, dict) and "hbm_bytes" in c]
-        if cand:
-            by, name = max(cand)
-            best = {"bytes": by, "source": os.path.basename(f), "kernel": name}
-    return best
 
 
 def launch_ranks(a):
@@ -388,577 +204,6 @@ def count_gpus():
         return n
     import torch
     return torch.cuda.device_count()
-
-
-def rccl_record():
-    """What the N > 1 line says about the transport: the RCCL the library bound (version code, where it was found) and the
-    NCCL_* / RCCL_* environment in effect (algorithm / protocol overrides change what an allreduce of 2 MiB costs)."""
-    rec = {"env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) or k == "HSA_ENABLE_IPC_MODE_LEGACY"}}
-    try:
-        import ctypes
-        from pydnmfk_amd._lib import lib
-        v, buf = ctypes.c_int(0), ctypes.create_string_buffer(256)
-        if lib.dnmf_comm_rccl_version(ctypes.byref(v), buf, 256) == 0:
-            rec["version_code"], rec["found"] = int(v.value), buf.value.decode()
-    except Exception as exc:  # noqa: BLE001
-        rec["version_error"] = repr(exc)
-    try:
-        import torch
-        rec["torch_nccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
-    except Exception:  # noqa: BLE001
-        pass
-    return rec
-
-
-class Job:
-    """What every configuration's timed region needs: the ranks, the barrier and the max-over-ranks clock of the contract."""
-
-    def __init__(self, a, world, rank, local, dev, ctl, emu, rccl_ranks_seen):
-        self.a, self.world, self.rank, self.local, self.dev, self.ctl = a, world, rank, local, dev, ctl
-        self.emu, self.rccl_ranks_seen = emu, rccl_ranks_seen
-
-    def barrier(self):
-        import torch.distributed as dist
-        if self.a.backend == "nccl":
-            dist.barrier(device_ids=[self.local])
-        else:
-            dist.barrier()
-
-    def max_over_ranks(self, x):
-        import torch
-        import torch.distributed as dist
-        if self.world == 1:
-            return x
-        tt = torch.tensor([x], dtype=torch.float64, device=self.ctl)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-
-    def timed(self, nsteps, step):
-        """EXACTLY nsteps steps between barrier + device sync on both sides; max over ranks."""
-        import torch
-        if self.world > 1:
-            self.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(nsteps):
-            step(i)
-        torch.cuda.synchronize()
-        if self.world > 1:
-            self.barrier()
-        torch.cuda.synchronize()
-        return self.max_over_ranks(time.perf_counter() - t0)
-
-
-def parse_grid(text, world, default):
-    if not text:
-        return default
-    r, c = (int(x) for x in text.lower().split("x"))
-    if r * c != world:
-        sys.exit("bench.py: --grid %s needs %d ranks, the job has %d" % (text, r * c, world))
-    return r, c
-
-
-def _cpu_kl_rank(rank, rows_s, n_l, k, steps, q):
-    """One rank of the reference's process model for config 4 (single BLAS thread, main.py:3): the oracle's MU/KL step
-    (dist_nmf.py:806-849) on a ROW SLAB of the rank's block -- the step is linear in the rows."""
-    os.environ["OMP_NUM_THREADS"] = "1"
-    import numpy as np
-    from oracle import nmf_oracle as orc
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except ImportError:
-        ctx = None
-    rng = np.random.default_rng(1234 + rank)
-    A = rng.random((rows_s, n_l), dtype=np.float32)
-    W = rng.random((rows_s, k), dtype=np.float32)
-    H = np.random.default_rng(99).random((k, n_l), dtype=np.float32)
-    eps = np.finfo(np.float32).eps
-    orc.kl_mu_step_local(A, W, H, eps)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        orc.kl_mu_step_local(A, W, H, eps)
-    q.put((rank, (time.perf_counter() - t0) / steps))
-    del ctx
-
-
-def _cpu_hals_rank(rank, m_l, n_l, ks, steps, q):
-    """One rank of the reference's process model for config 5: the oracle's HALS/FRO step (dist_nmf.py:873-934) on the rank's
-    block (float32: numpy has no bfloat16) for a few ranks k."""
-    os.environ["OMP_NUM_THREADS"] = "1"
-    import numpy as np
-    from oracle import nmf_oracle as orc
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except ImportError:
-        ctx = None
-    rng = np.random.default_rng(1234 + rank)
-    A = rng.random((m_l, n_l), dtype=np.float32)
-    eps = np.finfo(np.float32).eps
-    res = {}
-    for k in ks:
-        W = rng.random((m_l, k), dtype=np.float32)
-        H = rng.random((k, n_l), dtype=np.float32)
-        orc.fro_hals_step_local(A, W, H, eps)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            orc.fro_hals_step_local(A, W, H, eps)
-        res[k] = (time.perf_counter() - t0) / steps
-    q.put((rank, res))
-    del ctx
-
-
-def _cpu_pool(target, argsets, timeout=600):
-    """P single-thread processes, one result each (rank, value); None when any of them fails."""
-    import multiprocessing as mp
-    import queue
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=target, args=tuple(args) + (q,)) for args in argsets]
-    for pr in procs:
-        pr.start()
-    got, deadline = {}, time.time() + timeout
-    try:
-        while len(got) < len(procs) and time.time() < deadline:
-            try:
-                r, v = q.get(timeout=2)
-                got[r] = v
-            except queue.Empty:
-                if any(pr.exitcode not in (None, 0) for pr in procs):
-                    break
-    finally:
-        for pr in procs:
-            pr.join(timeout=5)
-            if pr.is_alive():
-                pr.kill()
-    return got if len(got) == len(procs) else None
-
-
-def host_cpu():
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return os.cpu_count() or 1, model
-
-
-def run_config4(a, job):
-    """BASELINE config 4: MU/KL, X = 131072 x 65536 fp32, k = 128, on the p_r x p_c grid of the job (8 ranks: 4 x 2; reference
-    dist_nmf.py:268-407 over the grid of dist_comm.py:16-56).  Strong scaling: the global X is fixed.  A step = one
-    nmf_algorithms_2D(...).update() (1D class on 1 x 1 / N x 1 grids), clamp on every 10th; `--emulate-ranks R` = this
-    process is rank 0 of the R-rank grid on one GPU, its sub-communicators EmulatedGroup objects (dist_comm.py)."""
-    import torch
-    import torch.distributed as dist
-    from pydnmfk_amd.dist_comm import EmulatedGroup, MPI_comm, NullExchange
-    from pydnmfk_amd.dist_nmf import nmf_algorithms_1D, nmf_algorithms_2D
-    from pydnmfk_amd.engine import ops_for
-    from pydnmfk_amd.utils import determine_block_params, parse
-
-    world, rank, dev, emu = job.world, job.rank, job.dev, job.emu
-    nr = emu or world
-    p_r, p_c = parse_grid(a.grid, nr, {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(nr, (nr, 1)))
-    m, n, k = a.m, a.n, a.k
-    two_d = p_r > 1 and p_c > 1
-    p = parse()
-    if emu:
-        base = MPI_comm(None, 1, 1)
-        p.comm1, p.comm = base.comm, base
-        p.row_comm, p.col_comm = EmulatedGroup(base.comm, p_r), EmulatedGroup(base.comm, p_c)
-    else:
-        comms = MPI_comm(None, p_r, p_c)
-        p.comm1, p.comm, p.row_comm, p.col_comm = comms.comm, comms, comms.cart_1d_row(), comms.cart_1d_column()
-    p.p_r, p.p_c, p.k, p.m, p.n = p_r, p_c, k, m, n
-    p.norm, p.method, p.W_update, p.eps, p.gemm = a.norm, "mu", True, 1.1920929e-07, "fp32"
-    ops = ops_for(p)
-    i, j = divmod(rank, p_c)
-    m_l, n_l = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_shape_asymm()
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    A = torch.rand(m_l, n_l, device=dev, generator=g)
-    if two_d:      # the rank's SLICES of the factors (utils.py:99-103): W_ij = rows of W_i split over the p_c ranks of grid row i
-        m_w = determine_block_params(j, (p_c, 1), (m_l, k)).determine_block_shape_asymm()[0]
-        n_h = determine_block_params(i, (1, p_r), (k, n_l)).determine_block_shape_asymm()[1]
-    else:          # 1D (and 1 x 1): the sharded factor whole, the other one replicated
-        m_w, n_h = m_l, n_l
-    g.manual_seed(4321 + rank)
-    W = torch.rand(m_w, k, device=dev, generator=g)
-    g.manual_seed(99 + (rank if two_d else (j if p_c > 1 else 0)))
-    H = torch.rand(k, n_h, device=dev, generator=g)
-    if not two_d and world > 1:
-        H = p.comm1.bcast(H, root=0) if p_c == 1 else H
-        W = p.comm1.bcast(W, root=0) if p_r == 1 else W
-    cls = nmf_algorithms_2D if two_d else nmf_algorithms_1D
-
-    if getattr(a, "overlap_2d", False) and two_d:
-        p.overlap_2d = True
-
-    def step(it, params=p):
-        if two_d:
-            cls(A, W, H, params=params).update(clamp=(it % 10 == 0), more=True)
-        else:
-            cls(A, W, H, params=params).update(clamp=(it % 10 == 0))
-
-    multi = world > 1 or emu > 1
-    mg = None
-    if multi:
-        mg = {"rccl_ranks_seen": job.rccl_ranks_seen, "backend": a.backend, "grid": [p_r, p_c],
-              "rccl": rccl_record() if a.backend == "nccl" else None}
-        if emu:
-            mg["emulated"] = ("rank 0 of a %d x %d grid on a single GPU: its own %d x %d block, real kernels and launches, the collectives of the "
-                              "step issued on one-rank groups -- no wire time -- by torch.distributed between the launches (EmulatedGroup) or inside "
-                              "the library (dnmf_comm_create_emulated: one call per step)" % (p_r, p_c, m_l, n_l))
-        modes = ["torch"] if a.exchange in ("auto", "torch") else []
-        if emu and a.backend == "nccl" and a.exchange in ("auto", "native"):
-            # the library-sequenced step of the emulated member: the same kernels, every collective issued inside libdnmf_hip.so on a
-            # one-rank RCCL communicator -- what `params.exchange = 'native'` runs on the real grid, minus the wire
-            try:
-                from pydnmfk_amd.engine import NativeComm
-                p._native_comm = NativeComm.emulated(p_r, p_c, 0)
-                p.exchange = "native"
-                step(1)
-                torch.cuda.synchronize()
-                if p._native_comm.steps < 1:
-                    raise RuntimeError("the step did not run inside the library")
-                modes.append("native")
-            except Exception as exc:  # noqa: BLE001
-                mg["native_exchange_unavailable"] = repr(exc)
-            p.exchange = "torch"
-        if world > 1 and a.backend == "nccl" and a.exchange in ("auto", "native"):
-            p.exchange = "native"
-            from pydnmfk_amd.engine import native_comm_for
-            ok = 1
-            try:
-                ok = int(native_comm_for(p) is not None)           # collective-safe: raises / returns None on every rank together
-                if ok:
-                    step(1)
-                    torch.cuda.synchronize()
-            except Exception as exc:  # noqa: BLE001
-                ok, mg["native_exchange_unavailable"] = 0, repr(exc)
-            if int(-job.max_over_ranks(-float(ok))):
-                modes.append("native")
-            p.exchange = "torch"
-        if not modes:
-            sys.exit("bench.py: --exchange %s is not available (backend %s%s)" % (a.exchange, a.backend, ", emulated" if emu else ""))
-        if len(modes) > 1:
-            ab, nab = {}, max(3, min(10, a.steps))
-            for mode in modes:
-                p.exchange = mode
-                for it in range(2):
-                    step(it)
-                ab[mode] = job.timed(nab, step) / nab * 1e3
-            mg["exchange_ab_ms_per_step"], mg["exchange_ab_steps"] = ab, nab
-            p.exchange = min(ab, key=ab.get)
-        else:
-            p.exchange = modes[0]
-        mg["exchange_used"] = p.exchange
-        mg["overlap_2d"] = bool(getattr(p, "overlap_2d", False)) and p.exchange == "torch"
-
-    for it in range(a.warmup):
-        step(it)
-    elapsed = job.timed(a.steps, step)
-    assert torch.isfinite(W).all() and torch.isfinite(H).all()
-    ms = elapsed / a.steps * 1e3
-
-    if multi:      # the same step with every exchange stubbed out (timing only): this rank's compute
-        pn = parse()
-        pn.__dict__.update(vars(p))
-        native_used = p.exchange == "native"
-        if native_used:
-            p._native_comm.set_null_exchange(True)
-        else:
-            pn.comm1, pn.row_comm, pn.col_comm = NullExchange(p.comm1), NullExchange(p.row_comm), NullExchange(p.col_comm)
-        keep = (W.clone(), H.clone())
-        for it in range(2):
-            step(it, pn)
-        nn = max(3, min(20, a.steps))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for it in range(nn):
-            step(it, pn)
-        torch.cuda.synchronize()
-        mine = (time.perf_counter() - t0) / nn * 1e3
-        if native_used:
-            p._native_comm.set_null_exchange(False)
-        per = [mine]
-        if world > 1:
-            per = [None] * world
-            dist.all_gather_object(per, mine)
-        W.copy_(keep[0]); H.copy_(keep[1])
-        del keep
-        mg["compute_only_ms_per_rank"], mg["compute_only_ms"] = per, max(per)
-        mg["full_step_ms"], mg["exposed_comm_ms"] = ms, ms - max(per)
-        kb = 4 * k
-        if two_d:
-            mg["exchange_bytes_per_step"] = {"allgather_H_recv": kb * n_l, "allgather_W_recv": 2 * kb * m_l, "reduce_scatter_W_send": kb * m_l,
-                                             "reduce_scatter_H_send": kb * n_l, "allreduce_k_vectors": 2 * kb}
-        else:      # 1D grid: the sharded factor's phase is local, the replicated one's product is allreduced (dist_nmf.py:776-869)
-            mg["exchange_bytes_per_step"] = {"allreduce_product": kb * (n_l if p_c == 1 else m_l), "allreduce_k_vectors": 2 * kb}
-        mg["note"] = ("compute_only = the same step with every exchange stubbed out (NullExchange / the library's null mode; timing only); "
-                      "exposed_comm_ms = full step - slowest rank's compute-only step")
-
-    out = None
-    flops_iter = 8.0 * m * n * k + 6.0 * (m + n) * k                  # SURVEY 8d, whole job
-    if rank == 0:
-        out = {
-            "metric": "mu_iterations_per_sec", "value": a.steps / elapsed, "unit": "iter/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MU/%s X=%dx%d fp32 k=%d, %s grid p_r=%d p_c=%d (%s)%s" % (
-                a.norm.upper(), m, n, k, "2D" if two_d else "1D", p_r, p_c, CONFIGS[4]["label"],
-                " -- EMULATED: one rank's block on one GPU, not a whole-job number" if emu else ""),
-                "m": m, "n": n, "k": k, "block_per_gpu": [m_l, n_l], "gemm": "fp32",
-                "parallelism": ("%d x %d blocks of X; per step: allreduce of k-vectors, allgather of the H / W slices in the size-p_r / size-p_c "
-                                "groups, reduce-scatter of U H^T / W^T U over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend + " (host staged)"))
-                if multi else "single GPU"},
-            "step_tflops_per_gpu": flops_iter / nr / (ms * 1e-3) / 1e12,
-            "step_mfma_frac": flops_iter / nr / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "step_algorithmic_hbm_gbs_per_gpu": 4.0 * m_l * n_l / (ms * 1e-3) / 1e9,          # ONE read of the block (SURVEY 8d; the step makes two)
-        }
-        if mg is not None:
-            out["multi_gpu"] = mg
-
-    if not a.no_kernel_timing:
-        # the two KL products in situ (HIP events on the stream the launches go to), on this rank's block with the gathered factors
-        W_i = torch.rand(m_l, k, device=dev, generator=g)
-        H_j = torch.rand(k, n_l, device=dev, generator=g)
-        V = torch.empty(m_l, k, device=dev)
-        Y = torch.empty(k, n_l, device=dev)
-        t_uht, _ = event_time_ms(lambda: ops.kl_uht(A, W_i, H_j, p.eps, V), reps=10, warm=3)
-        t_wtu, _ = event_time_ms(lambda: ops.kl_wtu(A, W_i, H_j, p.eps, Y), reps=10, warm=3)
-        del W_i, H_j, V, Y
-        if rank == 0:
-            fl = 4.0 * m_l * n_l * k
-            kt = max(1, (k + 31) // 32)
-            pipe = k > 16 and m_l >= 128 and n_l % 32 == 0
-
-            def entry(kernel, ms_, role):
-                ach = fl / ms_ / 1e9
-                e = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": fl, "ms_per_launch": ms_,
-                     "algorithmic_bytes_per_launch": 4.0 * m_l * n_l}
-                tr = pmc_traffic(role, "kl") if (m_l, n_l, k) == (32768, 32768, 128) else None
-                if tr is not None:
-                    e["traffic"] = tr["bytes"]
-                    e["traffic_note"] = ("HBM bytes per launch from the committed PMC pass %s, kernel %s (FETCH_SIZE x2 + WRITE_SIZE); a "
-                                         "constant of that profile, not a live counter" % (tr["source"], tr["kernel"]))
-                return e
-
-            r_uht = entry(("kl_uht_pipe_kernel<KT=%d>" if pipe else "kl_uht_kernel<KT=%d>") % kt +
-                          " + reduce_partials (dnmf_kl_uht: U H^T, the W phase's product, dist_nmf.py:806,810)", t_uht,
-                          "kl_uht_pipe_kernel<4" if pipe else "kl_uht_kernel<4")
-            r_wtu = entry("kl_wtu_kernel<KT=%d> + reduce_partials (dnmf_kl_wtu: W^T U, the H phase's product, dist_nmf.py:806,808)" % kt,
-                          t_wtu, "kl_wtu_kernel<4")
-            out["roofline"], out["rooflines"] = r_uht, [r_uht, r_wtu]
-            out["kernels"] = {"dnmf_kl_uht": {"ms": t_uht, "tflops": fl / t_uht / 1e9}, "dnmf_kl_wtu": {"ms": t_wtu, "tflops": fl / t_wtu / 1e9},
-                              "rest_of_step_ms": ms - t_uht - t_wtu}
-
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        # the reference's process model for this config: the 4 x 2 grid = 8 ranks x 1 BLAS thread, each with a 32768 x 32768 block;
-        # bounded sample = a row slab of every rank's block (the KL step is linear in the rows)
-        cores, model = host_cpu()
-        P = min(8, cores)
-        pr_, pc_ = (4, 2) if P == 8 else (P, 1)
-        mb, nb = m // pr_, n // pc_
-        rows_s = max(32, min(mb, int(2.4e10 / (8.0 * nb * k))))            # ~1-2 s per slab step on one core
-        got = _cpu_pool(_cpu_kl_rank, [(r, rows_s, nb, k, 2) for r in range(P)])
-        if got is None:
-            out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": P, "kind": "port", "sample": "FAILED: a CPU rank died or timed out"}
-        else:
-            t_slab = max(got.values())
-            t_it = t_slab * (mb / rows_s)
-            out["cpu_baseline"] = {
-                "value": 1.0 / t_it, "unit": "iter/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
-                "seconds_per_iter": t_it, "gflops_whole_job": flops_iter / t_it / 1e9,
-                "sample": "oracle kl_mu_step_local in the reference's process model: %d processes x 1 BLAS thread = the ranks of a %d x %d grid, "
-                          "each on a %d x %d row slab of its %d x %d block, k=%d, 1 warm-up + 2 timed steps; slab step %.2f s (slowest rank) x %.0f "
-                          "= %.1f s per iteration (the step is linear in the rows); no exchange simulated" % (
-                              P, pr_, pc_, rows_s, nb, mb, nb, k, t_slab, mb / rows_s, t_it)}
-    if multi and getattr(p, "_native_comm", None) is not None:
-        p._native_comm.close()
-    return out
-
-
-def swim_example(npz, dev):
-    """One warm-up sweep + one timed sweep of the reference's swim example (see tools/swimbench.py)."""
-    import contextlib
-    import tempfile
-    import numpy as np
-    import torch
-    from pydnmfk_amd.dist_comm import MPI_comm
-    from pydnmfk_amd.pyDNMFk import PyNMFk
-    from pydnmfk_amd.utils import parse
-    X = torch.from_numpy(np.ascontiguousarray(np.load(npz)["A"].astype(np.float32))).to(dev)
-    itr = 5000
-
-    def sweep():
-        comms = MPI_comm(None, 1, 1)
-        q = parse()
-        q.size, q.rank, q.comm, q.p_r, q.p_c = 1, 0, comms, 1, 1
-        q.row_comm, q.col_comm, q.comm1 = comms.cart_1d_row(), comms.cart_1d_column(), comms.comm
-        q.fpath, q.fname, q.ftype = "../data/", "swim", "mat"
-        q.start_k, q.end_k, q.sill_thr, q.itr, q.init = 14, 18, 0.6, itr, "rand"
-        q.noise_var, q.verbose, q.norm, q.method, q.checkpoint = 0.016, False, "kl", "mu", False
-        q.prune, q.rng, q.results_path = False, "device", tempfile.mkdtemp(prefix="dnmf_swim_") + "/"
-        t0 = time.perf_counter()
-        with contextlib.redirect_stdout(sys.stderr):
-            nopt = PyNMFk(X, factors=None, params=q).fit()
-        torch.cuda.synchronize()
-        return int(nopt), time.perf_counter() - t0
-
-    sweep()
-    nopt, secs = sweep()
-    steps = 5 * 21 * itr
-    return {"workload": "NMFk on swim %d x %d (tests/golden/data_swim.npz = the reference's data/swim.mat): KL/MU, k = 14..18, 20 perturbations + the "
-                        "regression fit per k, %d iterations each, one rank, device resident" % (X.shape[0], X.shape[1], itr),
-            "nopt": nopt, "known_answer": 16, "seconds_per_sweep": secs, "kl_steps_per_sec": steps / secs, "fits_per_sec": 105 / secs,
-            "note": "every fit is ONE persistent kernel (csrc/dnmf_small.h): slab of A, rows of W and H in LDS across the steps"}
-
-
-def run_config5(a, job):
-    """BASELINE config 5: the NMFk sweep k = 2..16, 20 perturbations, HALS / Frobenius on bf16-STORED X (reference
-    pyDNMFk.py:169-258 over dist_nmf.py:873-934, clustering dist_clustering.py:84-160).  X = 65536 x 4096 of planted rank 6
-    (+ 1 % noise), per-rank blocks of the 1 x N grid (the grid for HALS: W is replicated there, its column norms are local).
-    A "step" is one WHOLE sweep: (end_k - start_k + 1) x perturbations fits of `itr` HALS iterations + the regression fit,
-    clustering and statistics of every k, device resident (params.rng = 'device'); value = fits per second."""
-    import contextlib
-    import torch
-    from pydnmfk_amd.dist_comm import MPI_comm
-    from pydnmfk_amd.engine import ops_for
-    from pydnmfk_amd.pyDNMFk import PyNMFk
-    from pydnmfk_amd.utils import determine_block_params, parse
-
-    world, rank, dev = job.world, job.rank, job.dev
-    # N GPUs share the sweep the MI355X way unless a grid is asked for: every GPU holds the WHOLE X (0.5 GB of bf16 here, 288 GB of
-    # HBM) and fits its share of the perturbations as one-rank problems -- no exchange inside a fit (params.nmfk_split =
-    # 'perturbations', pydnmfk_amd/pyDNMFk.py); --grid RxC cuts X into the reference's blocks instead (every fit on all ranks)
-    shared = world > 1 and not a.grid
-    m, n = a.m, a.n
-    if shared:
-        from pydnmfk_amd.dist_comm import COMM_WORLD, SoloGrid
-        p_r = p_c = 1
-        comms, whole = SoloGrid(rank), COMM_WORLD()
-        s, e = determine_block_params(0, (1, 1), (m, n)).determine_block_index_range_asymm()
-    else:
-        p_r, p_c = parse_grid(a.grid, world, (1, world))
-        comms = MPI_comm(None, p_r, p_c)
-        whole = comms.comm
-        s, e = determine_block_params(rank, (p_r, p_c), (m, n)).determine_block_index_range_asymm()
-    # planted rank 6, identifiable (the recipe of tests/test_gpu_nmfk_sweep.py at this size): six Gaussian bumps along the rows,
-    # sparse uniform mixing, 0.5 % noise -- the sweep must come back with estimated_k = 6
-    g = torch.Generator(device=dev)
-    g.manual_seed(7)                                                   # the planted factors: the same on every rank
-    x = torch.arange(m, device=dev, dtype=torch.float32)[:, None]
-    cen = torch.linspace(0.075 * m, m - 0.075 * m, 6, device=dev)[None, :]
-    Wt = torch.exp(-(x - cen) ** 2 / (2 * (0.044 * m) ** 2))
-    Ht = torch.rand(6, n, device=dev, generator=g) * (torch.rand(6, n, device=dev, generator=g) < 0.7)
-    g.manual_seed(1234 + (0 if shared else rank))                      # (shared sweep: the same X on every rank)
-    X = (Wt[s[0]:e[0] + 1] @ Ht[:, s[1]:e[1] + 1])
-    X += 0.005 * torch.rand(X.shape, device=dev, generator=g)
-    del x, cen
-    Xb = X.to(torch.bfloat16)
-    del X, Wt, Ht
-    import tempfile
-    tmp = tempfile.mkdtemp(prefix="dnmf_c5_") if rank == 0 else None
-    tmp = whole.bcast(tmp, root=0) if world > 1 else tmp
-
-    def params(start_k, end_k, pert, itr):
-        q = parse()
-        q.comm1, q.comm, q.p_r, q.p_c = (whole if shared else comms.comm), comms, p_r, p_c
-        q.row_comm, q.col_comm = comms.cart_1d_row(), comms.cart_1d_column()
-        q.size, q.rank = world, rank
-        if shared:
-            q.nmfk_split = "perturbations"
-        q.norm, q.method, q.init, q.itr, q.verbose, q.prune = "fro", "hals", "rand", itr, False, False
-        q.start_k, q.end_k, q.step_k, q.fname, q.checkpoint = start_k, end_k, 1, "c5", False
-        q.perturbations, q.noise_var, q.sampling, q.sill_thr = pert, 0.03, "uniform", 0.8
-        q.precision, q.results_path, q.timing_stats, q.rng = "bfloat16", tmp + "/", False, "device"
-        q.nmfk_batch = True if a.nmfk_batch == "auto" else int(a.nmfk_batch)
-        if a.fit_loop == "python":
-            q.fit_loop = "python"
-        return q
-
-    nopt = [None]
-
-    def sweep(_i, small=False):
-        q = params(2, 3, 2, 10) if small else params(a.start_k, a.end_k, a.perturbations, a.itr)
-        with contextlib.redirect_stdout(sys.stderr):                   # PyNMFk reports progress on stdout: the JSON line stays alone there
-            nopt[0] = PyNMFk(Xb, factors=None, params=q).fit()
-
-    for i in range(max(1, a.warmup)):
-        sweep(i, small=True)                                           # loads every kernel class of the sweep; not a full sweep
-    elapsed = job.timed(a.steps, sweep)
-    nk = a.end_k - a.start_k + 1
-    fits = nk * a.perturbations
-    ms = elapsed / a.steps * 1e3
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "nmfk_fits_per_sec", "value": fits * a.steps / elapsed, "unit": "fits/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16 storage of X, f32 arithmetic and factors", "data": "synthetic",
-            "config": {"workload": "NMFk k=%d..%d x %d perturbations, HALS/FRO %d iterations per fit, X=%dx%d stored bf16 (planted rank 6: estimated_k must be 6), "
-                                   "%d x %d grid (%s); a step = one whole sweep (fits + regression fit + clustering per k)" % (
-                                       a.start_k, a.end_k, a.perturbations, a.itr, m, n, p_r, p_c, CONFIGS[5]["label"]),
-                       "m": m, "n": n, "k_range": [a.start_k, a.end_k], "perturbations": a.perturbations, "itr": a.itr,
-                       "block_per_gpu": [e[0] - s[0] + 1, e[1] - s[1] + 1],
-                       "parallelism": "single GPU" if world == 1 else (
-                           "perturbations over %d ranks, the whole X on every GPU (no exchange inside a fit; factors gathered per k over %s)" % (
-                               world, "RCCL" if a.backend == "nccl" else a.backend) if shared else
-                           "%d x %d blocks of X over %s" % (p_r, p_c, "RCCL" if a.backend == "nccl" else a.backend))},
-            "fits_per_step": fits, "estimated_k": int(nopt[0]), "seconds_per_sweep": elapsed / a.steps,
-            "nmfk_batch": a.nmfk_batch, "fit_loop": a.fit_loop,
-            "hals_iterations_per_sec": (fits + nk) * a.itr * a.steps / elapsed,
-        }
-    if not a.no_kernel_timing:
-        # the kernel the sweep spends most of its time in: A H^T on the bf16-stored block at the top rank of the sweep (HBM bound)
-        ops = ops_for(None)
-        kk = min(16, a.end_k)
-        m_l, n_l = Xb.shape
-        Hk = torch.rand(kk, n_l, device=dev, generator=g)
-        Wk = torch.rand(m_l, kk, device=dev, generator=g)
-        V = torch.empty(m_l, kk, device=dev)
-        Y = torch.empty(kk, n_l, device=dev)
-        t_nt, _ = event_time_ms(lambda: ops.aht(Xb, Hk, V), reps=20, warm=5)
-        t_tn, _ = event_time_ms(lambda: ops.wta(Xb, Wk, Y), reps=20, warm=5)
-        if rank == 0:
-            by = 2.0 * m_l * n_l
-
-            def entry(kernel, ms_):
-                ach = by / ms_ / 1e6
-                return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                        "traffic": None, "bytes_per_launch": by, "ms_per_launch": ms_, "note": "algorithmic bytes = one read of the bf16 block"}
-            out["roofline"] = entry("nt16_kernel<bf16 X> (dnmf_aht_bf16a, k=%d: A H^T of the HALS W phase, dist_nmf.py:884)" % kk, t_nt)
-            out["rooflines"] = [out["roofline"], entry("tn16_kernel<bf16 X> + reduce_partials (dnmf_wta_bf16a, k=%d: W^T A of the H phase, dist_nmf.py:903)" % kk, t_tn)]
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cores, model = host_cpu()
-        P = min(8, cores)
-        ks = sorted({a.start_k, (a.start_k + a.end_k) // 2, a.end_k})
-        got = _cpu_pool(_cpu_hals_rank, [(r, m, n // P, ks, 3) for r in range(P)])
-        if got is None:
-            out["cpu_baseline"] = {"value": None, "unit": "fits/s", "cores": P, "kind": "port", "sample": "FAILED: a CPU rank died or timed out"}
-        else:
-            import numpy as np
-            t_k = {k_: max(v[k_] for v in got.values()) for k_ in ks}                      # iteration time = slowest rank
-            t_all = np.interp(np.arange(a.start_k, a.end_k + 1), ks, [t_k[k_] for k_ in ks])
-            t_sweep = float(np.sum(t_all) * (a.perturbations + 1) * a.itr)
-            out["cpu_baseline"] = {
-                "value": fits / t_sweep, "unit": "fits/s", "cores": P, "kind": "port", "host_cores": cores, "host_cpu": model,
-                "seconds_per_sweep": t_sweep,
-                "sample": "oracle fro_hals_step_local (float32: numpy has no bfloat16) in the reference's process model: %d processes x 1 BLAS "
-                          "thread = the ranks of a 1 x %d grid, each on its %d x %d column block; 1 warm-up + 3 timed HALS iterations at k = %s "
-                          "(%s s, slowest rank), interpolated over k = %d..%d and multiplied by (%d perturbations + 1 regression fit) x %d "
-                          "iterations = %.0f s per sweep; no exchange, no clustering counted" % (
-                              P, P, m, n // P, ks, [round(t_k[k_], 4) for k_ in ks], a.start_k, a.end_k, a.perturbations, a.itr, t_sweep)}
-    import shutil
-    if rank == 0:
-        shutil.rmtree(tmp, ignore_errors=True)
-    return out
 
 
 def main():

@@ -7,66 +7,53 @@ import numpy as np
 from .utils import determine_block_params
 
 
-class data_read:
-    """Read a dense matrix and return this rank's block -- reference data_io.py:12-105.
+def _load_npy(path):
+    return np.load(path, mmap_mode='r')                      # only the rank's block is paged in
 
-    args.fpath + args.fname + '.' + args.ftype with ftype in {npy, csv, txt, mat}; ftype == 'folder' reads the
-    pre-split block fpath + fname + <rank> + '.npy' as is.  The block is rows/cols
-    determine_block_params(rank, [p_r, p_c], shape) (data_io.py:81-83), cast to args.precision (default float32).
-    Like the reference every rank opens the file; .npy files are memory-mapped here so only the block is paged in
-    (the reference loads the whole matrix on every rank, data_io.py:57)."""
+
+def _load_text(path):
+    return np.loadtxt(path, delimiter=',', ndmin=2)
+
+
+def _load_mat(path):
+    from scipy.io import loadmat
+    return loadmat(path)['X']
+
+
+# ftype -> (reader, the file holds the WHOLE matrix: cut this rank's block out of it)
+_READERS = {'npy': (_load_npy, True), 'csv': (_load_text, True), 'txt': (_load_text, True), 'mat': (_load_mat, True),
+            'folder': (_load_npy, False)}
+
+
+class data_read:
+    """This rank's block of a dense matrix on disk -- what reference data_io.py:12-105 returns.
+
+    File: args.fpath + args.fname + '.' + args.ftype for ftype in {npy, csv, txt, mat}; ftype == 'folder' names the pre-split
+    block fpath + fname + <rank> + '.npy', taken as is.  Whole-matrix files are cut by determine_block_params(rank, [p_r, p_c],
+    shape) (data_io.py:81-83); the block is cast to args.precision (default float32).  Like the reference every rank opens the
+    file; .npy files are memory-mapped here (the reference loads the whole matrix on every rank, data_io.py:57)."""
 
     def __init__(self, args):
-        self.fpath = args.fpath
-        if "grid" in vars(args) and args.grid:
-            self.pgrid = args.grid
-        else:
-            self.pgrid = [args.p_r, args.p_c]
+        opts = vars(args)
         self.ftype = args.ftype
-        self.fname = args.fname
-        self.comm = args.comm1
-        self.rank = self.comm.rank
-        self.precision = getattr(args, "precision", None) or 'float32'
-        self.data = 0
-        if self.ftype == 'folder':
-            self.file_path = self.fpath + self.fname + str(self.comm.rank) + '.npy'
-        else:
-            self.file_path = self.fpath + self.fname + '.' + self.ftype
+        if self.ftype not in _READERS:
+            raise ValueError("unknown ftype '%s' (npy/csv/txt/mat/folder)" % self.ftype)
+        self.pgrid = opts.get("grid") or [args.p_r, args.p_c]
+        self.rank = args.comm1.rank
+        self.precision = opts.get("precision") or 'float32'
+        whole = _READERS[self.ftype][1]
+        self.file_path = args.fpath + args.fname + ('.' + self.ftype if whole else '%d.npy' % self.rank)
 
     def read(self):
-        return self.read_dat()
-
-    def read_file_npy(self):
-        self.data = np.load(self.file_path, mmap_mode='r')
-
-    def read_file_csv(self):
-        self.data = np.loadtxt(self.file_path, delimiter=',', ndmin=2)
-
-    def read_file_mat(self):
-        from scipy.io import loadmat
-        self.data = loadmat(self.file_path)['X']
-
-    def data_partition(self):
-        blk = determine_block_params(self.rank, self.pgrid, self.data.shape)
-        s, e = blk.determine_block_index_range_asymm()
-        self.data = self.data[s[0]:e[0] + 1, s[1]:e[1] + 1]
-
-    def read_dat(self):
-        if self.ftype == 'npy':
-            self.read_file_npy()
-            self.data_partition()
-        elif self.ftype in ('csv', 'txt'):
-            self.read_file_csv()
-            self.data_partition()
-        elif self.ftype == 'mat':
-            self.read_file_mat()
-            self.data_partition()
-        elif self.ftype == 'folder':
-            self.read_file_npy()
-        else:
-            raise ValueError("unknown ftype '%s' (npy/csv/txt/mat/folder)" % self.ftype)
+        load, whole = _READERS[self.ftype]
+        data = load(self.file_path)
+        if whole:
+            s, e = determine_block_params(self.rank, self.pgrid, data.shape).determine_block_index_range_asymm()
+            data = data[s[0]:e[0] + 1, s[1]:e[1] + 1]
         prec = 'float32' if str(self.precision).lower() in ('bfloat16', 'bf16') else self.precision
-        return np.ascontiguousarray(self.data).astype(prec)   # bf16: numpy has no such dtype; PyNMF rounds on upload
+        return np.ascontiguousarray(data).astype(prec)       # bf16: numpy has no such dtype; PyNMF rounds on upload
+
+    read_dat = read                                          # (the reference's name for the same call)
 
 
 class read_factors:
@@ -106,44 +93,32 @@ class read_factors:
 
 
 class data_write:
-    """Writes per-rank factor blocks as plain .npy under params.results_paths (data_io.py:158-196):
-    p_c == 1: every rank W_factors/W_<rank>.npy, rank 0 H_factors/H.npy; p_r == 1: rank 0 W_factors/W.npy,
-    every rank H_factors/H_<rank>.npy; 2D (and 1x1): every rank both.  reg=True -> W_reg_factors/H_reg_factors."""
+    """Per-rank factor blocks as plain .npy under params.results_paths -- the layout of reference data_io.py:158-196, which
+    read_factors, the CLI and downstream scripts rely on: a factor that is REPLICATED over the ranks (H on a p_r x 1 grid, W on a
+    1 x p_c grid) is written once, by rank 0, without a rank suffix; every other block as <name>_<rank>.npy by its owner.
+    reg=True -> W_reg_factors / H_reg_factors (the regression fits of an NMFk sweep)."""
 
     def __init__(self, args):
+        self.params = args
         self.p_r, self.p_c = args.p_r, args.p_c
         self.pgrid = [self.p_r, self.p_c]
         self.ftype = getattr(args, "ftype", None)
-        self.comm = args.comm1
-        self.params = args
-        self.fpath = self.params.results_paths
-        self.rank = self.comm.rank
+        self.rank = args.comm1.rank
+        self.fpath = args.results_paths
 
     @staticmethod
     def create_folder_dir(fpath):
-        try:
-            os.mkdir(fpath)
-        except OSError:
-            pass
+        os.makedirs(fpath, exist_ok=True)
 
     def save_factors(self, factors, reg=False):
-        self.create_folder_dir(self.fpath)
-        sub = ('W_reg_factors/', 'H_reg_factors/') if reg else ('W_factors/', 'H_factors/')
-        W_pth, H_pth = self.fpath + sub[0], self.fpath + sub[1]
-        self.create_folder_dir(W_pth)
-        self.create_folder_dir(H_pth)
-        W, H = np.asarray(factors[0]), np.asarray(factors[1])
-        if self.p_r == 1 and self.p_c != 1:
-            if self.rank == 0:
-                np.save(W_pth + 'W.npy', W)
-            np.save(H_pth + 'H_' + str(self.rank) + '.npy', H)
-        elif self.p_c == 1 and self.p_r != 1:
-            if self.rank == 0:
-                np.save(H_pth + 'H.npy', H)
-            np.save(W_pth + 'W_' + str(self.rank) + '.npy', W)
-        else:
-            np.save(H_pth + 'H_' + str(self.rank) + '.npy', H)
-            np.save(W_pth + 'W_' + str(self.rank) + '.npy', W)
+        replicated = {'W': self.p_r == 1 and self.p_c != 1, 'H': self.p_c == 1 and self.p_r != 1}
+        for name, block in zip(('W', 'H'), factors):
+            folder = self.fpath + name + ('_reg_factors/' if reg else '_factors/')
+            self.create_folder_dir(folder)
+            if not replicated[name]:
+                np.save(folder + '%s_%d.npy' % (name, self.rank), np.asarray(block))
+            elif self.rank == 0:
+                np.save(folder + name + '.npy', np.asarray(block))
 
     def save_cluster_results(self, params):
         """Rank 0 writes the per-k NMFk statistics (data_io.py:199-209).  Dataset names are the reference's
