@@ -341,11 +341,12 @@ int hals_xsweep_agree(dnmf_comm* cm, float* W, long m, int k, long ldw, const fl
 }
 
 int hals_sweep_exchanged(dnmf_comm* cm, float* W, long m, int k, long ldw, const float* AH, long ldah, const float* G, float eps,
-                         double* ss2, void* ws, size_t ws_bytes, void* stream) {
+                         double* ss2, void* ws, size_t ws_bytes, void* stream, int column_sweep = 0) {
     hipStream_t st = S(stream);
     // ONE persistent launch when the direct peer regions are up (dnmf_comm_set_direct) and every rank can keep its rows resident:
     // the column partials cross the ranks through the slot slabs in the exported regions (csrc/dnmf_hals.h, HalsPeers)
-    if (cm->direct_on && !cm->null_exchange && k <= DNMF_TUNED_MAX_K && cm->nranks <= DNMF_DIRECT_MAX_RANKS) {
+    // (`column_sweep`: the caller asked for the column launches -- every rank passes the same value, params.hals_sweep = 'columns')
+    if (!column_sweep && cm->direct_on && !cm->null_exchange && k <= DNMF_TUNED_MAX_K && cm->nranks <= DNMF_DIRECT_MAX_RANKS) {
         if (cm->xs_seen_epoch != cm->xs_epoch || cm->xs_k != k || cm->xs_pers != dnmf_persistent_on_()) {
             if (int rc = hals_xsweep_agree(cm, W, m, k, ldw, AH, ldah, G, eps, ws, ws_bytes, st)) return rc;
         } else if (cm->xs_m != m)                                   // a rank cannot re-open the agreement on its own
@@ -1129,7 +1130,7 @@ int hals_fro_step_1d_impl(const TA* A, long m_l, long n_l, long lda, float* W, l
         if ((rc = dnmf_gram_hht(H, k, n_l, ldh, Gx, ws, kws, stream))) return rc;                 // :882
         if ((rc = AOps<TA>::aht(A, m_l, n_l, lda, H, k, ldh, AH, k, stream))) return rc;               // :883
         if (c->p_c != 1 && (rc = allreduce_f32(c, G_WORLD, X, off + (size_t)kp * kp, st))) return rc;
-        if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, ws, kws, stream);   // :884-891
+        if ((c->p_r != 1 && c->nranks > 1) || c->always) rc = hals_sweep_exchanged(c, W, m_l, k, ldw, AH, k, Gx, eps, ss2, ws, kws, stream, column_sweep);   // :884-891
         else rc = hals_sweep_local(W, m_l, k, ldw, AH, k, Gx, eps, column_sweep, ss2, ws, kws, stream);
         if (rc) return rc;
     }

@@ -26,8 +26,9 @@
 //
 // A is read ONCE (streamed into registers two slabs ahead, written to the LDS ring by the wave that will read it: the pieces are wave
 // private, no barrier guards them); what crosses the team per slab is (T + 2) x 4 KiB of granules against 32 KiB of A per member.  The k x n
-// partials of the teams (at most 32) go through the existing fixed-order reduction (launch_reduce) into W^T A; H H^T before and
-// W^T W after are the existing Gram launches.
+// partials of the teams (at most 32) go through the existing fixed-order reduction (launch_reduce) into W^T A; H H^T before is the
+// existing Gram launch; W_new^T W_new rides along (the slab's owner adds 16 MFMAs on operands that are in registers anyway; the members'
+// sums meet once at the end of the launch, the reduction launch's Gram tail adds the teams').
 // Residency: every workgroup waits for its team mates, so all of them must be on the device at once.  The launch takes one workgroup per
 // CU at most and begins with a CENSUS (an arrival counter all workgroups wait on, bounded by the wall clock): nothing is written before
 // every workgroup has been seen running, so a launch that cannot become resident (a co-tenant holds CUs) leaves W untouched, sets the
@@ -60,6 +61,8 @@ struct TeamArgs {
     float* W; long ldw;                  // m x k, updated in place
     float eps;
     float* P;                            // [teams][32][n] partial W^T A per team
+    float* Pg;                           // [teams][32][32] partial W_new^T W_new per team (NULL: the caller forms the Gram matrix itself)
+    unsigned long long* gx;              // [teams][T][1024] granules: the members' Gram partials meet here at the end (zeroed with the ring)
     unsigned long long* ring;            // [teams][TM_D][T + 2][512] granules (T partials, the owner's w_old and den), zeroed before the launch
     unsigned* ctl;                       // ctl[0] census counter, ctl[1] abort word; zeroed before the launch
     int T, tpx;                          // members per team, teams per XCD-residue class (grid = 8 tpx T)
@@ -166,6 +169,11 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) qacc[tk][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool plain = (a.xflags & 4) != 0;
+    // W_new^T W_new (the Gram matrix of the H phase, dist_nmf.py:748) rides along: the new rows of a slab are in every member's LDS, and as
+    // the A operand of Q they ARE both operands of the product -- the slab's owner adds its 16 MFMAs (two per wave: tile (wv >> 1 & 1,
+    // wv & 1), contraction steps 2 (wv >> 2), + 1), no loads
+    f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool gt1 = (wv >> 1) & 1, gt2 = wv & 1, gkh = (wv >> 2) != 0;
 
     // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
     auto regather = [&](int t) {
@@ -352,6 +360,14 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (cur) q_half(2);
+        if (cur && a.Pg && o0 == member) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float x1 = gkh ? (gt1 ? wop[1][2 + u] : wop[0][2 + u]) : (gt1 ? wop[1][u] : wop[0][u]);
+                const float x2 = gkh ? (gt2 ? wop[1][2 + u] : wop[0][2 + u]) : (gt2 ? wop[1][u] : wop[0][u]);
+                gacc = TM_MFMA(x1, x2, gacc);
+            }
+        }
         o3 = o3 + 1 == T ? 0 : o3 + 1;
         o2 = o2 + 1 == T ? 0 : o2 + 1;
         o0 = o0 + 1 == T ? 0 : o0 + 1;
@@ -378,6 +394,61 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             *reinterpret_cast<f32x4*>(Pt + (long)(16 * tk + 4 * q4 + r) * n) = f32x4{qacc[tk][0][r], qacc[tk][1][r], qacc[tk][2][r], qacc[tk][3][r]};
+
+    // the Gram partials: the two contraction halves of a tile meet in LDS, the members' sums in the team's granule planes (once per
+    // launch), member 0 adds them in member order and writes the team's 32 x 32 partial for the reduction launch's Gram tail
+    if (a.Pg) {
+        __syncthreads();
+        float* gl = red;                                   // [2][32 * 32]
+        {
+            float* dst = gl + (wv >> 2) * (TM_KP * TM_KP) + (16 * (int)gt1 + 4 * q4) * TM_KP + 16 * (int)gt2 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r * TM_KP] = gacc[r];
+        }
+        __syncthreads();
+        const i32x4 grsrc = buf_rsrc(a.gx + (long)team * T * (TM_KP * TM_KP));
+        const float gtag = __uint_as_float(0x7fffffffu);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = tid + 512 * h;
+            buf_st_f32x2(f32x2{gl[e] + gl[TM_KP * TM_KP + e], gtag}, grsrc, e * 8, member * (TM_KP * TM_KP * 8), 16);
+        }
+        if (member == 0) {
+            const unsigned long long t0 = wall_clock64();
+            f32x2 g[2][TM_MAXT];
+            auto fetch = [&]() {                           // all planes of both elements in flight together
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < TM_MAXT; ++j)
+                        g[h][j] = buf_ld_f32x2(grsrc, (tid + 512 * h) * 8, (j < T ? j : T - 1) * (TM_KP * TM_KP * 8), 16);
+            };
+            unsigned spins = 0;
+            for (;;) {
+                fetch();
+                bool ok = true;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < TM_MAXT; ++j) ok = ok && __float_as_uint(g[h][j][1]) == 0x7fffffffu;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 15u) == 15u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > a.patience) {
+                    __hip_atomic_store(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&g_team_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float sum = g[h][0][0];
+#pragma unroll
+                for (int j = 1; j < TM_MAXT; ++j) sum = fmaf(tmask[j], g[h][j][0], sum);
+                a.Pg[(long)team * (TM_KP * TM_KP) + tid + 512 * h] = sum;
+            }
+        }
+    }
 }
 
 }  // namespace

@@ -13,7 +13,7 @@ struct TeamPlan {
     bool ok;
     int T, tpx, teams, teams_used;
     long rpt;
-    size_t p_bytes, ctl_off, ring_off, total;
+    size_t p_bytes, pg_off, ctl_off, ring_off, gx_off, total;
 };
 
 int g_team_on = 1;                       // dnmf_set_onepass: 0 never, 1 where it measured faster (team_pays), 2 wherever the shape allows
@@ -54,9 +54,11 @@ TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     p.teams_used = (int)cdiv(m, p.rpt);
     if (p.teams_used > 64) return p;                                   // one-stage reduction of the partials
     p.p_bytes = align256((size_t)p.teams * TM_KP * n * sizeof(float));
-    p.ctl_off = p.p_bytes;
-    p.ring_off = p.ctl_off + 256;
-    p.total = p.ring_off + (size_t)p.teams * TM_D * (p.T + 2) * (TM_R * TM_KP) * sizeof(unsigned long long);
+    p.pg_off = p.p_bytes;                                              // the teams' partial Gram tiles
+    p.ctl_off = p.pg_off + align256((size_t)p.teams * TM_KP * TM_KP * sizeof(float));
+    p.ring_off = p.ctl_off + 256;                                      // ctl | ring | gx: zeroed by ONE memset per launch
+    p.gx_off = p.ring_off + (size_t)p.teams * TM_D * (p.T + 2) * (TM_R * TM_KP) * sizeof(unsigned long long);
+    p.total = p.gx_off + (size_t)p.teams * p.T * (TM_KP * TM_KP) * sizeof(unsigned long long);
     p.ok = true;
     return p;
 }
@@ -73,7 +75,7 @@ __attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n,
 // *P_out ([*nparts][32][n], part of `part`) for the caller's reduction
 __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
                                                           const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
-                                                          const float** P_out, int* nparts) {
+                                                          const float** P_out, int* nparts, const float** Pg_out) {
     const TeamPlan p = team_plan(m, n, k);
     if (!p.ok || dnmf_batch_()->B != 1) return 1;
     if (!(aligned16(A) && lda % 4 == 0 && lda >= n && aligned16(H) && ldh % 4 == 0 && ldh >= n && ldw >= k && aligned16(part))) return 1;
@@ -84,6 +86,8 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     a.A = A; a.lda = lda; a.m = m; a.n = (int)n; a.k = k;
     a.H = H; a.ldh = ldh; a.G = G; a.W = W; a.ldw = ldw; a.eps = eps;
     a.P = (float*)base;
+    a.Pg = (float*)(base + p.pg_off);
+    a.gx = (unsigned long long*)(base + p.gx_off);
     a.ctl = (unsigned*)(base + p.ctl_off);
     a.ring = (unsigned long long*)(base + p.ring_off);
     a.T = p.T; a.tpx = p.tpx; a.rpt = p.rpt;
@@ -123,6 +127,7 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     (void)sd; (void)nt;
     if (int rc = check_launch("team_fro_kernel")) return rc;
     *P_out = a.P;
+    *Pg_out = a.Pg;
     *nparts = p.teams_used;
     return DNMF_OK;
 }
