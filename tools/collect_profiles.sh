@@ -10,7 +10,7 @@ WL=${@:-bench kl hals16 hals64 k16 bf16 elt c2}
 cd /tmp && export TMPDIR=/tmp
 prog() {   # the command line of a workload: "full" (stats pass) or "short" (PMC passes)
   case $1 in
-    bench)  if [ "$2" = full ]; then echo "$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sustained"; else echo "$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sustained"; fi ;;
+    bench)  if [ "$2" = full ]; then echo "$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sustained --no-configs"; else echo "$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sustained --no-configs"; fi ;;
     kl)     echo "$R/tools/klbench.py 32768 32768 128" ;;
     kl16)   echo "$R/tools/klbench.py 32768 16384 16" ;;
     kl32)   echo "$R/tools/klbench.py 32768 16384 32" ;;
