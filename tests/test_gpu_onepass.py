@@ -156,3 +156,23 @@ def test_policy_and_switch(env):
         assert lib.dnmf_mu_fro_onepass(8192, 4096, 32) == 0
     finally:
         lib.dnmf_set_onepass(2)
+
+
+def test_three_hundred_steps_twice_are_bit_identical(env):
+    """The exchange hands 16 x k partials between workgroups through tagged granules with no fence: a stale or torn read would change a
+    sum somewhere.  300 steps (every slab of every team exchanges 300 times: 1.2 million hand-offs of 4 KiB) run twice from the same
+    factors must end in the same bits, and stay finite; the status word stays clear."""
+    lib, ops = env
+    m, n, k = 16384, 4096, 32
+    A, W0, H0 = _mk(m, n, k, seed=21)
+    Ad = _d(A)
+    ends = []
+    for _ in range(2):
+        W, H = _d(W0), _d(H0)
+        for it in range(300):
+            ops.mu_fro_step(Ad, W, H, EPS, True, it % 10 == 0)
+        torch.cuda.synchronize()
+        ends.append((W, H))
+    ops.hals_check()
+    assert torch.equal(ends[0][0], ends[1][0]) and torch.equal(ends[0][1], ends[1][1])
+    assert bool(torch.isfinite(ends[0][0]).all()) and bool(torch.isfinite(ends[0][1]).all())
