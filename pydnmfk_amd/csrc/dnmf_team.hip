@@ -17,20 +17,23 @@ struct TeamPlan {
 };
 
 int g_team_on = 1;                       // dnmf_set_onepass: 0 never, 1 where it measured faster (team_pays), 2 wherever the shape allows
-int g_team_cus = -1;                     // CUs of the device the census may count on (queried once per process)
 unsigned long long g_team_patience = 200000000ull;
 
+// CUs the census may count on, per device (a process may drive several GPUs): the kernel takes one workgroup per CU; 0 = no device (the
+// CPU tier loads the library for its symbol checks) or the kernel cannot be resident at all -- plans then say no
+constexpr int TEAM_MAX_DEVICES = 64;
 int team_cus() {
-    if (g_team_cus >= 0) return g_team_cus;
+    static int cus_of[TEAM_MAX_DEVICES];
+    static bool have[TEAM_MAX_DEVICES] = {};
     int dev = 0, cus = 0, nb = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-        clear_hip_error();
-        return 0;                        // no device (the CPU tier loads the library for its symbol checks): plans say no
-    }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TEAM_MAX_DEVICES) { clear_hip_error(); return 0; }
+    if (have[dev]) return cus_of[dev];
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { clear_hip_error(); return 0; }
     const auto kern = team_fro_kernel<2, 2>;
     allow_lds(kern, TM_LDS_BYTES + 64);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * TM_NW, TM_LDS_BYTES) != hipSuccess || nb < 1) { clear_hip_error(); cus = 0; }
-    g_team_cus = cus;
+    cus_of[dev] = cus;
+    have[dev] = true;
     return cus;
 }
 
