@@ -37,11 +37,14 @@ int team_cus() {
     return cus;
 }
 
-// Where the one-pass step measured faster than the two passes on an MI355X (tools/team_shapes.sh, profiles/r06b_team_shapes.txt):
-// short blocks (two passes are launch- and latency-bound there: 10-35 % at m <= 16384), ranks that are not a whole 32-wide tile (the
-// two-pass kernels take their edge paths: 4 % at 65536 x 4096, k = 24; 33 % at 16384 x 4096, k = 17) and very tall blocks (3-5 %);
-// at k = 32 in between the two are within 2 % of each other either way, and the two-pass sequence needs no residency.
-bool team_pays(long m, long n, int k) { return n >= 2048 && (k < 32 || m <= 24576 || m >= 196608); }
+// Where the one-pass step measured faster than the two passes on an MI355X (tools/team_shapes.sh on the final kernel, third block of
+// profiles/r06b_team_shapes.txt): short blocks (two passes are launch- and latency-bound there: 48 / 39 / 26 / 17 % at m = 4096 / 8192 /
+// 16384 / 24576, n = 4096; 5-10 % up to 49152), ranks that are not a whole 32-wide tile (the two-pass kernels take their edge paths: 7 % at
+// 65536 x 4096, k = 24; 41 % at 16384 x 4096, k = 17) and very tall blocks (1.4-2.9 % from 196608 rows); at k = 32 in between the two
+// are within 1 % of each other either way, and the two-pass sequence needs no residency.
+bool team_pays(long m, long n, int k) {
+    return n >= 2048 && (k < 32 || m <= 24576 || (n >= 4096 && m <= 49152) || m >= 196608);
+}
 
 // shape-only part of the decision (the workspace query has no pointers); `cus` = 0: ask the device
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {

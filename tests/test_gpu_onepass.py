@@ -145,6 +145,7 @@ def test_policy_and_switch(env):
     lib.dnmf_set_onepass(1)
     try:
         assert lib.dnmf_mu_fro_onepass(8192, 4096, 32) == 1               # short blocks: measured faster
+        assert lib.dnmf_mu_fro_onepass(49152, 4096, 32) == 1 and lib.dnmf_mu_fro_onepass(49152, 2048, 32) == 0
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 32) == 0              # parity with two passes: stays on the launch sequence
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 24) == 1
         assert lib.dnmf_mu_fro_onepass(8192, 4096, 16) == 0 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 0
