@@ -44,6 +44,7 @@ def build_lib(force=False, report=False, tuning=False):
              "-I" + os.path.join(HERE, "csrc")]
     if tuning:
         flags.append("-DDNMF_TUNING")
+        flags += os.environ.get("DNMF_EXTRA_FLAGS", "").split()      # experiments: extra -D switches for the tuning build only
     if report:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     srcs = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
