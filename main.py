@@ -52,6 +52,7 @@ FLAGS = [
     ('rng', str, 'device', False, 'where random numbers are drawn: device (the data block goes to the GPU once, perturbations and the rand init are drawn there) or numpy (the reference\'s host stream: every fit draws and uploads host arrays)'),
     ('exchange', str, 'auto', False, 'who sequences the exchanges of a multi-rank step: torch (torch.distributed between the kernel launches), native (whole steps inside libdnmf_hip.so over its own RCCL communicators: one call per step) or auto (native for hals on grids with p_r > 1, where the per-column norm exchanges make the Python-sequenced step host-bound; torch otherwise)'),
     ('direct_allreduce', _flag, False, False, 'with --exchange native on one node: the packed allreduce of a 1D step goes through IPC-mapped peer buffers (two-shot, rank-ordered sums) instead of RCCL, and the HALS W sweep on p_r > 1 runs as ONE persistent launch whose column norms cross the ranks through slots in those buffers; checked against RCCL on first contact, all ranks fall back together'),
+    ('shared_gpu', _flag, False, False, 'the GPU is shared with other processes or streams: never use the kernels whose workgroups wait for each other (whole fits of small problems, the one-launch HALS W sweep, the one-pass MU/FRO step) -- dnmf_set_persistent(0); without it a fit that loses its residency is detected and fitted again on the launch-chain kernels, at the cost of one time-out'),
     ('hals_sweep', str, 'persistent', False, 'W sweep of method hals on a rank with local norms: persistent (one launch; needs the GPU to itself) or columns'),
     # NMFk
     ('perturbations', int, 20, False, 'perturbed copies per rank'),

@@ -70,6 +70,11 @@ class PyNMF:
         else:
             device = A_ij.device if isinstance(A_ij, torch.Tensor) else torch.device("cpu")
         self.device = device
+        if ops is None and getattr(params, "shared_gpu", False):
+            # (main.py --shared_gpu / params.shared_gpu = True) the launch-chain kernels from the start: no kernel of this process waits
+            # for co-resident workgroups, so none can time out behind a co-tenant
+            from ._lib import lib
+            lib.dnmf_set_persistent(0)
         self.a_dtype = storage_dtype(A_ij, params)
         self.c_dtype = torch.float64 if self.a_dtype == torch.float64 else torch.float32      # factors, products, eps
         self.A_ij = _to_device(A_ij, device, self.a_dtype)

@@ -104,3 +104,22 @@ def test_two_processes_share_the_gpu_and_both_finish():
     for rank, err, worst, down in res:
         assert err is None, "process %d failed:\n%s" % (rank, err)
         assert worst < 2e-3, (rank, worst, down)
+
+
+def test_shared_gpu_option_keeps_the_process_on_the_launch_chains():
+    """`params.shared_gpu = True` (main.py --shared_gpu True): PyNMF switches the process to the launch-chain kernels before the first
+    fit -- no kernel that waits for co-resident workgroups runs, so none can time out; same factors as the persistent kernels give."""
+    from pydnmfk_amd._lib import lib
+    from pydnmfk_amd.pyDNMF import PyNMF
+    from tests.test_gpu_parity import _args
+    A, W0, H0 = _problem(5, k=8)
+    try:
+        Wr, Hr, er = PyNMF(A, factors=[W0, H0], params=_args(8, 100, "kl")).fit()
+        assert lib.dnmf_mu_fit_persistent(1024, 256, 8) == 1
+        args = _args(8, 100, "kl")
+        args.shared_gpu = True
+        W, H, err = PyNMF(A, factors=[W0, H0], params=args).fit()
+        assert lib.dnmf_mu_fit_persistent(1024, 256, 8) == 0 and lib.dnmf_mu_fro_onepass(8192, 4096, 32) == 0
+        assert _rel(W, Wr) < 2e-3 and _rel(H, Hr) < 2e-3 and abs(err - er) < 1e-4
+    finally:
+        _restore(lib)
