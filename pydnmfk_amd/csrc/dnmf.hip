@@ -207,7 +207,7 @@ int launch_ew(float* X, long rows, long cols, long ldx, const float* Sm, long ld
 __attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n, int k);
 __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
                                                           const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
-                                                          const float** P_out, int* nparts, const float** Pg_out);
+                                                          const float** P_out, int* nparts, const float** Pg_out, int* kp_out);
 namespace {
 
 struct WsLayout {
@@ -847,15 +847,15 @@ int mu_fro_step_impl(const TA* A, long m, long n, long lda, float* W, long ldw, 
         if (w_update && dnmf_team_ws_bytes_(m, n, k)) {
             if ((rc = dnmf_gram_hht(H, k, n, ldh, G, part, part_bytes, stream))) return rc;
             const float *P = nullptr, *Pg = nullptr;
-            int nparts = 0;
-            rc = dnmf_team_fro_(A, m, n, lda, W, ldw, H, ldh, G, k, eps, part, part_bytes, stream, &P, &nparts, &Pg);
+            int nparts = 0, tkp = 32;
+            rc = dnmf_team_fro_(A, m, n, lda, W, ldw, H, ldh, G, k, eps, part, part_bytes, stream, &P, &nparts, &Pg, &tkp);
             if (rc < 0) return rc;
             if (rc == DNMF_OK) {
                 // the teams' partials of W^T A -> S, and in the same launch the teams' partial Gram tiles -> G = W_new^T W_new (:748; the
                 // kernel read H H^T from G: it has finished -- same stream)
                 const long ldatw = round_up(n, 4);
-                const GramTail gt{Pg, G, 32, k, 32, nparts};
-                if ((rc = launch_reduce(P, (long)32 * n, n, nparts, Sb, ldatw, k, n, k, n, nullptr, S(stream), &gt))) return rc;
+                const GramTail gt{Pg, G, tkp, k, 32, nparts};
+                if ((rc = launch_reduce(P, (long)tkp * n, n, nparts, Sb, ldatw, k, n, k, n, nullptr, S(stream), &gt))) return rc;
                 if ((rc = dnmf_mu_update_h(H, k, n, ldh, Sb, ldatw, G, eps, clamp, stream))) return rc;
                 if (clamp) return dnmf_clamp_min(W, m, k, ldw, eps, stream);
                 return DNMF_OK;

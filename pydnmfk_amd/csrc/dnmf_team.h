@@ -45,13 +45,14 @@ __device__ unsigned int g_team_timeout = 0;   // sticky: a wait of the team kern
 constexpr int TM_R = 16;                 // rows per slab (one MFMA tile of 16x16x4)
 constexpr int TM_C = 512;                // columns per team member
 constexpr int TM_NW = 8;                 // waves per workgroup, 64 columns each
-constexpr int TM_KP = 32;                // padded rank
+constexpr int TM_KP = 32;                // padded rank at 16 < k <= 32 (the kernel's KT = 2; KT = 1: 16), and the pitch of the Gram buffers at every k <= 32
 constexpr int TM_LDA = TM_C + 8;         // LDS row pitch of a slab piece: 130 sixteen-byte chunks = 2 (mod 16) -> the row-per-lane ds_read_b128 is conflict free
 constexpr int TM_NBUF = 3;               // slabs in the LDS ring: t (Q), t + 1, t + 2 (written and read by P in the same stage)
 constexpr int TM_D = 8;                  // granule ring depth (slabs s - 1 .. s + 2 are live while a member publishes s + 2: >= 4)
 constexpr int TM_LDW = 48;               // pitch of the new W rows in LDS (the two 16-lane halves of a scalar read land on different banks)
 constexpr int TM_MAXT = 8;               // members per team at most (n <= 4096)
-constexpr size_t TM_LDS_BYTES = (size_t)(TM_NBUF * TM_R * TM_LDA + 2 * TM_NW * TM_R * TM_KP + 2 * 4 * TM_R * TM_KP + 2 * TM_R * TM_LDW) * sizeof(float);
+constexpr size_t tm_lds_bytes(int kp) { return (size_t)(TM_NBUF * TM_R * TM_LDA + 2 * TM_NW * TM_R * kp + 2 * 4 * TM_R * kp + 2 * TM_R * TM_LDW) * sizeof(float); }
+constexpr size_t TM_LDS_BYTES = tm_lds_bytes(TM_KP);
 
 struct TeamArgs {
     const void* A; long lda;             // the data block (fp32), rows 16-byte aligned
@@ -60,10 +61,10 @@ struct TeamArgs {
     const float* G;                      // H H^T, 32 x 32 zero padded
     float* W; long ldw;                  // m x k, updated in place
     float eps;
-    float* P;                            // [teams][32][n] partial W^T A per team
-    float* Pg;                           // [teams][32][32] partial W_new^T W_new per team (NULL: the caller forms the Gram matrix itself)
-    unsigned long long* gx;              // [teams][T][1024] granules: the members' Gram partials meet here at the end (zeroed with the ring)
-    unsigned long long* ring;            // [teams][TM_D][T + 2][512] granules (T partials, the owner's w_old and den), zeroed before the launch
+    float* P;                            // [teams][KP][n] partial W^T A per team (KP = 16 for k <= 16, else 32)
+    float* Pg;                           // [teams][KP][KP] partial W_new^T W_new per team (NULL: the caller forms the Gram matrix itself)
+    unsigned long long* gx;              // [teams][T][KP * KP] granules: the members' Gram partials meet here at the end (zeroed with the ring)
+    unsigned long long* ring;            // [teams][TM_D][T + 2][16 KP] granules (T partials, the owner's w_old and den), zeroed before the launch
     unsigned* ctl;                       // ctl[0] census counter, ctl[1] abort word; zeroed before the launch
     int T, tpx;                          // members per team, teams per XCD-residue class (grid = 8 tpx T)
     long rpt;                            // rows per team (a multiple of 16)
@@ -81,10 +82,13 @@ struct TeamArgs {
 // so that the compiler's counts are exact and a wait for the granules leaves the younger loads of A in flight.  The first version had
 // these accesses under `if (owner)` / `if (j < T)`: the counts became path dependent, every wait degenerated to vmcnt(0..3) and each
 // stage paid a full fabric round trip (0.46 ms per launch at 65536 x 4096 against 0.22 ms of matrix time; profiles/r06a_team_*).
-template <int SD, int NT>
+// KT = 16-wide tiles of the padded rank: 2 for 16 < k <= 32; 1 for k <= 16, where the two-pass kernels are HBM-bound (AI = k / 2 flop per byte
+// against a balance of 20) and reading A once pays most
+template <int SD, int NT, int KT = 2>
 __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tm_smem[];
-    constexpr int EL = TM_R * TM_KP;                       // elements of a slab's tile = granules of a plane = threads
+    constexpr int KP = 16 * KT;
+    constexpr int EL = TM_R * KP;                          // elements of a slab's tile = granules of a plane (512 = one per thread; KT = 1: 256, waves 0-3)
     float* Ab = tm_smem;                                   // [NBUF][R][LDA]
     float* red = Ab + TM_NBUF * TM_R * TM_LDA;             // [2][NW][EL]   the waves' partials of A H^T (by stage parity)
     float* dred = red + 2 * TM_NW * EL;                    // [2][4][EL]    partial denominators (two waves fill one plane)
@@ -109,37 +113,42 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     if (tid == 0) __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // loop invariants in registers: the wave's block of H (B operand: k-slot q4, kk = lane & 15), two fragments of G for the denominator
-    f32x4 hreg[2][4];
+    f32x4 hreg[KT][4];
 #pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
+    for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int kk = 16 * tk + i;
             hreg[tk][g] = kk < k ? *reinterpret_cast<const f32x4*>(a.H + (long)kk * a.ldh + cb + 16 * g + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    const int dtk = wv & 1, dks = 2 * (wv >> 1);           // this wave's share of W G: tile dtk, contraction steps dks, dks + 1
-    float gden[2];
+    // this wave's share of the owner's W G (16 x KP, contraction over KP): KT = 2: tile wv & 1, steps 2 (wv >> 1), + 1 -> plane wv >> 1;
+    // KT = 1: one tile, step wv of four (waves 0-3) -> plane wv.  The four planes add up to the product either way.
+    constexpr int ND = KT;                                 // MFMAs of this share
+    const bool dact = KT == 2 || wv < 4;
+    const int dtk = KT == 2 ? (wv & 1) : 0, dks = KT == 2 ? 2 * (wv >> 1) : (wv & 3), dpl = KT == 2 ? (wv >> 1) : (wv & 3);
+    float gden[ND];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) gden[u] = a.G[(4 * (dks + u) + q4) * TM_KP + 16 * dtk + i];
+    for (int u = 0; u < ND; ++u) gden[u] = a.G[(4 * (dks + u) + q4) * TM_KP + 16 * dtk + i];
 
     // MUBUF descriptors at the team's first row / the team's granules: one lane offset per stream, everything else scalar
     const i32x4 arsrc = buf_rsrc((const float*)a.A + row0 * a.lda);
     const int avoff = (int)(((long)q4 * a.lda + cb + 4 * i) * 4);          // row q4 of a group of four, the lane's four columns
     const int arow4 = (int)(a.lda * 16);                                   // bytes between groups of four rows
     const i32x4 wrsrc = buf_rsrc(a.W + row0 * a.ldw);
-    const int er = tid >> 5, ekk = tid & 31;                               // thread e = element (er, ekk) of a slab's 16 x 32 tile
-    const int wevoff = ekk < k ? (int)((er * a.ldw + ekk) * 4) : BUF_OOB;  // thread e's element of a slab of W
-    int wdvoff[2];                                                         // the wave's two A fragments of the product W G
+    const bool eon = tid < EL;                                             // thread e = element (er, ekk) of a slab's 16 x KP tile (KT = 1: waves 0-3)
+    const int er = tid / KP, ekk = tid % KP, te = eon ? tid : 0;
+    const int wevoff = (eon && ekk < k) ? (int)((er * a.ldw + ekk) * 4) : BUF_OOB;   // thread e's element of a slab of W
+    int wdvoff[ND];                                                        // the wave's A fragments of the product W G
 #pragma unroll
-    for (int u = 0; u < 2; ++u) wdvoff[u] = 4 * (dks + u) + q4 < k ? (int)((i * a.ldw + 4 * (dks + u) + q4) * 4) : BUF_OOB;
+    for (int u = 0; u < ND; ++u) wdvoff[u] = (dact && 4 * (dks + u) + q4 < k) ? (int)((i * a.ldw + 4 * (dks + u) + q4) * 4) : BUF_OOB;
     const int wslab = (int)(a.ldw * 4 * TM_R);                             // bytes between slabs of W
     const i32x4 rrsrc = buf_rsrc(a.ring + (long)team * TM_D * (T + 2) * EL);
-    const int gvoff = tid * 8;
+    const int gvoff = eon ? tid * 8 : BUF_OOB;                             // (threads without an element: every granule access is dropped)
     constexpr int PLANE = EL * 8;
     const int slotb = (T + 2) * PLANE;                                     // bytes of a ring slot
 
     f32x4 stg[SD][4];
-    float wold[2] = {0.f, 0.f}, wdn[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float wold[2] = {0.f, 0.f}, wdn[2][ND] = {};
     f32x2 gat[TM_MAXT + 2];
 #pragma unroll
     for (int j = 0; j < TM_MAXT + 2; ++j) gat[j] = f32x2{0.f, 0.f};
@@ -163,17 +172,17 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     __syncthreads();
     if (s_flag == 0u || nsl == 0) return;                  // nothing has been written
 
-    f32x4 qacc[2][4];
+    f32x4 qacc[KT][4];
 #pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
+    for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
         for (int j = 0; j < 4; ++j) qacc[tk][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool plain = (a.xflags & 4) != 0;
     // W_new^T W_new (the Gram matrix of the H phase, dist_nmf.py:748) rides along: the new rows of a slab are in every member's LDS, and as
-    // the A operand of Q they ARE both operands of the product -- the slab's owner adds its 16 MFMAs (two per wave: tile (wv >> 1 & 1,
-    // wv & 1), contraction steps 2 (wv >> 2), + 1), no loads
+    // the A operand of Q they ARE both operands of the product -- the slab's owner adds its 16 MFMAs (KT = 2, two per wave: tile (wv >> 1 & 1,
+    // wv & 1), contraction steps 2 (wv >> 2), + 1; KT = 1: four MFMAs, one in each of the waves 0-3: step wv), no loads
     f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool gt1 = (wv >> 1) & 1, gt2 = wv & 1, gkh = (wv >> 2) != 0;
+    const bool gt1 = KT == 2 && ((wv >> 1) & 1), gt2 = KT == 2 && (wv & 1), gkh = (wv >> 2) != 0;
 
     // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
     auto regather = [&](int t) {
@@ -245,22 +254,23 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
                 const int soff = t * wslab;
                 wold[(U + 3) & 1] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + er < rows)) ? wevoff : BUF_OOB, soff, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < ND; ++u)
                     wdn[(U + 3) & 1][u] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + i < rows)) ? wdvoff[u] : BUF_OOB, soff, 0);
             }
         }
         // P, first half: the wave's partial of A H^T for slab s + 2 over its first 32 columns
-        f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 pacc[KT];
+#pragma unroll
+        for (int tk = 0; tk < KT; ++tk) pacc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* psrc = Ab + ((U + 2) % 3) * (TM_R * TM_LDA) + i * TM_LDA + cw + 4 * q4;
         auto p_half = [&](int g0) {
 #pragma unroll
             for (int g = g0; g < g0 + 2; ++g) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(psrc + 16 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pacc[0] = TM_MFMA(av[e], hreg[0][g][e], pacc[0]);
-                    pacc[1] = TM_MFMA(av[e], hreg[1][g][e], pacc[1]);
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tk = 0; tk < KT; ++tk) pacc[tk] = TM_MFMA(av[e], hreg[tk][g][e], pacc[tk]);
             }
         };
         if (pub) p_half(0);
@@ -273,41 +283,42 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
             unsigned tsum = __float_as_uint(gat[0][1]);
 #pragma unroll
             for (int j = 1; j < TM_MAXT + 2; ++j) tsum += __float_as_uint(gat[j][1]);
-            if (tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s);
+            if (eon && tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s);
             float ah = gat[0][0];
 #pragma unroll
             for (int j = 1; j < TM_MAXT; ++j) ah = fmaf(tmask[j], gat[j][0], ah);      // planes j >= T: x 0 (a re-read of plane T - 1)
             const float wn = div_pos(gat[TM_MAXT][0] * ah, gat[TM_MAXT + 1][0]);
-            Wnp[er * TM_LDW + ekk] = wn;
+            if (eon) Wnp[er * TM_LDW + ekk] = wn;
             const bool st = o0 == member && (!GD || (long)s * TM_R + er < rows);
             buf_st_f32(wn, wrsrc, st ? wevoff : BUF_OOB, s * wslab, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (pub) {
             p_half(2);
-            float* dst = redp + wv * EL + 4 * q4 * TM_KP + i;
+            float* dst = redp + wv * EL + 4 * q4 * KP + i;
 #pragma unroll
-            for (int tk = 0; tk < 2; ++tk)
+            for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * TM_KP + 16 * tk] = pacc[tk][r];
+                for (int r = 0; r < 4; ++r) dst[r * KP + 16 * tk] = pacc[tk][r];
             // the owner's W G for slab s + 2: this wave's tile and contraction steps
-            if (o2 == member) {
-                f32x4 dacc = TM_MFMA(wdn[U & 1][0], gden[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-                dacc = TM_MFMA(wdn[U & 1][1], gden[1], dacc);
-                float* dd = dredp + (wv >> 1) * EL + 4 * q4 * TM_KP + 16 * dtk + i;
+            if (o2 == member && dact) {
+                f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dd[r * TM_KP] = dacc[r];
+                for (int u = 0; u < ND; ++u) dacc = TM_MFMA(wdn[U & 1][u], gden[u], dacc);
+                float* dd = dredp + dpl * EL + 4 * q4 * KP + 16 * dtk + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dd[r * KP] = dacc[r];
             }
         }
         __syncthreads();
         // after the barrier: every LDS read of this half first (the eight partials and four denominator parts of element e, the new W rows
         // as A operand, the slab piece as B operand), then half of Q, the publication and the request for the next granules, the other half
-        float rr[TM_NW], dd[4], wop[2][4];
+        float rr[TM_NW], dd[4], wop[KT][4];
         f32x4 bv[4];
         const float* qsrc = Ab + (U % 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
         if (cur) {
 #pragma unroll
-            for (int tk = 0; tk < 2; ++tk)
+            for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) wop[tk][ks] = Wnp[(4 * ks + q4) * TM_LDW + 16 * tk + i];
 #pragma unroll
@@ -315,18 +326,17 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         }
         if (pub) {
 #pragma unroll
-            for (int w = 0; w < TM_NW; ++w) rr[w] = redp[w * EL + tid];
+            for (int w = 0; w < TM_NW; ++w) rr[w] = redp[w * EL + te];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) dd[w] = dredp[w * EL + tid];
+            for (int w = 0; w < 4; ++w) dd[w] = dredp[w * EL + te];
         }
         auto q_half = [&](int k0) {                        // Q: the team's W^T A gains slab s (this wave: its 64 columns, from the LDS copy)
 #pragma unroll
             for (int ks = k0; ks < k0 + 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    qacc[0][j] = TM_MFMA(wop[0][ks], bv[ks][j], qacc[0][j]);
-                    qacc[1][j] = TM_MFMA(wop[1][ks], bv[ks][j], qacc[1][j]);
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tk = 0; tk < KT; ++tk) qacc[tk][j] = TM_MFMA(wop[tk][ks], bv[ks][j], qacc[tk][j]);
         };
         if (cur) q_half(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -361,11 +371,16 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (cur) q_half(2);
         if (cur && a.Pg && o0 == member) {
+            if constexpr (KT == 2) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float x1 = gkh ? (gt1 ? wop[1][2 + u] : wop[0][2 + u]) : (gt1 ? wop[1][u] : wop[0][u]);
-                const float x2 = gkh ? (gt2 ? wop[1][2 + u] : wop[0][2 + u]) : (gt2 ? wop[1][u] : wop[0][u]);
-                gacc = TM_MFMA(x1, x2, gacc);
+                for (int u = 0; u < 2; ++u) {
+                    const float x1 = gkh ? (gt1 ? wop[1][2 + u] : wop[0][2 + u]) : (gt1 ? wop[1][u] : wop[0][u]);
+                    const float x2 = gkh ? (gt2 ? wop[1][2 + u] : wop[0][2 + u]) : (gt2 ? wop[1][u] : wop[0][u]);
+                    gacc = TM_MFMA(x1, x2, gacc);
+                }
+            } else if (wv < 4) {
+                const float x = (wv & 2) ? ((wv & 1) ? wop[0][3] : wop[0][2]) : ((wv & 1) ? wop[0][1] : wop[0][0]);
+                gacc = TM_MFMA(x, x, gacc);
             }
         }
         o3 = o3 + 1 == T ? 0 : o3 + 1;
@@ -388,9 +403,9 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     for (; sb < nsl; sb += 6) group(sb, std::true_type{});                 // the pipeline drains
 
     // the team's partial: accumulator register r of tile (tk, j) is row 16 tk + 4 q4 + r, column cb + 4 i + j
-    float* Pt = a.P + (long)team * TM_KP * n + cb + 4 * i;
+    float* Pt = a.P + (long)team * KP * n + cb + 4 * i;
 #pragma unroll
-    for (int tk = 0; tk < 2; ++tk)
+    for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             *reinterpret_cast<f32x4*>(Pt + (long)(16 * tk + 4 * q4 + r) * n) = f32x4{qacc[tk][0][r], qacc[tk][1][r], qacc[tk][2][r], qacc[tk][3][r]};
@@ -399,36 +414,40 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     // launch), member 0 adds them in member order and writes the team's 32 x 32 partial for the reduction launch's Gram tail
     if (a.Pg) {
         __syncthreads();
-        float* gl = red;                                   // [2][32 * 32]
-        {
-            float* dst = gl + (wv >> 2) * (TM_KP * TM_KP) + (16 * (int)gt1 + 4 * q4) * TM_KP + 16 * (int)gt2 + i;
+        constexpr int GE = KP * KP, NPL = KT == 2 ? 2 : 4, GH = (GE + 511) / 512;      // elements of the tile, partial planes, elements per thread
+        float* gl = red;                                   // [NPL][GE]
+        if (KT == 2 || wv < 4) {
+            float* dst = gl + (KT == 2 ? (wv >> 2) : wv) * GE + (16 * (int)gt1 + 4 * q4) * KP + 16 * (int)gt2 + i;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[r * TM_KP] = gacc[r];
+            for (int r = 0; r < 4; ++r) dst[r * KP] = gacc[r];
         }
         __syncthreads();
-        const i32x4 grsrc = buf_rsrc(a.gx + (long)team * T * (TM_KP * TM_KP));
+        const i32x4 grsrc = buf_rsrc(a.gx + (long)team * T * GE);
         const float gtag = __uint_as_float(0x7fffffffu);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < GH; ++h) {
             const int e = tid + 512 * h;
-            buf_st_f32x2(f32x2{gl[e] + gl[TM_KP * TM_KP + e], gtag}, grsrc, e * 8, member * (TM_KP * TM_KP * 8), 16);
-        }
-        if (member == 0) {
-            const unsigned long long t0 = wall_clock64();
-            f32x2 g[2][TM_MAXT];
-            auto fetch = [&]() {                           // all planes of both elements in flight together
+            float v = gl[e < GE ? e : 0];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+            for (int pl = 1; pl < NPL; ++pl) v += gl[pl * GE + (e < GE ? e : 0)];
+            buf_st_f32x2(f32x2{v, gtag}, grsrc, e < GE ? e * 8 : BUF_OOB, member * (GE * 8), 16);
+        }
+        if (member == 0 && tid < GE) {                       // (GE < 512: whole waves drop out)
+            const unsigned long long t0 = wall_clock64();
+            f32x2 g[GH][TM_MAXT];
+            auto fetch = [&]() {                           // all planes of the thread's elements in flight together
+#pragma unroll
+                for (int h = 0; h < GH; ++h)
 #pragma unroll
                     for (int j = 0; j < TM_MAXT; ++j)
-                        g[h][j] = buf_ld_f32x2(grsrc, (tid + 512 * h) * 8, (j < T ? j : T - 1) * (TM_KP * TM_KP * 8), 16);
+                        g[h][j] = buf_ld_f32x2(grsrc, (tid + 512 * h) * 8, (j < T ? j : T - 1) * (GE * 8), 16);
             };
             unsigned spins = 0;
             for (;;) {
                 fetch();
                 bool ok = true;
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < GH; ++h)
 #pragma unroll
                     for (int j = 0; j < TM_MAXT; ++j) ok = ok && __float_as_uint(g[h][j][1]) == 0x7fffffffu;
                 if (ok) break;
@@ -441,11 +460,11 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < GH; ++h) {
                 float sum = g[h][0][0];
 #pragma unroll
                 for (int j = 1; j < TM_MAXT; ++j) sum = fmaf(tmask[j], g[h][j][0], sum);
-                a.Pg[(long)team * (TM_KP * TM_KP) + tid + 512 * h] = sum;
+                a.Pg[(long)team * GE + tid + 512 * h] = sum;
             }
         }
     }

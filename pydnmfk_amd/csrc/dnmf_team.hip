@@ -11,7 +11,7 @@ namespace {
 
 struct TeamPlan {
     bool ok;
-    int T, tpx, teams, teams_used;
+    int T, tpx, teams, teams_used, kp;
     long rpt;
     size_t p_bytes, pg_off, ctl_off, ring_off, gx_off, total;
 };
@@ -42,6 +42,8 @@ int team_cus() {
 // 16384 / 24576, n = 4096; 5-10 % up to 49152), ranks that are not a whole 32-wide tile (the two-pass kernels take their edge paths: 7 % at
 // 65536 x 4096, k = 24; 41 % at 16384 x 4096, k = 17) and very tall blocks (1.4-2.9 % from 196608 rows); at k = 32 in between the two
 // are within 1 % of each other either way, and the two-pass sequence needs no residency.
+// k <= 16 (round 6, KT = 1): the two-pass kernels are HBM-bound there and the one-pass step won at every shape of the sweep (fourth and fifth
+// block of the file: 2-46 %, 17-22 % at 65536 ... 262144 x 4096).
 bool team_pays(long m, long n, int k) {
     return n >= 2048 && (k < 32 || m <= 24576 || (n >= 4096 && m <= 49152) || m >= 196608);
 }
@@ -50,7 +52,8 @@ bool team_pays(long m, long n, int k) {
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     TeamPlan p{};
     if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
-    if (k <= 16 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
+    if (k < 1 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
+    p.kp = k <= 16 ? 16 : 32;
     if (cus <= 0) cus = team_cus();
     p.T = (int)(n / TM_C);
     p.tpx = (cus / 8) / p.T;
@@ -59,12 +62,12 @@ TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     p.rpt = round_up(cdiv(m, p.teams), TM_R);
     p.teams_used = (int)cdiv(m, p.rpt);
     if (p.teams_used > 64) return p;                                   // one-stage reduction of the partials
-    p.p_bytes = align256((size_t)p.teams * TM_KP * n * sizeof(float));
+    p.p_bytes = align256((size_t)p.teams * p.kp * n * sizeof(float));
     p.pg_off = p.p_bytes;                                              // the teams' partial Gram tiles
-    p.ctl_off = p.pg_off + align256((size_t)p.teams * TM_KP * TM_KP * sizeof(float));
+    p.ctl_off = p.pg_off + align256((size_t)p.teams * p.kp * p.kp * sizeof(float));
     p.ring_off = p.ctl_off + 256;                                      // ctl | ring | gx: zeroed by ONE memset per launch
-    p.gx_off = p.ring_off + (size_t)p.teams * TM_D * (p.T + 2) * (TM_R * TM_KP) * sizeof(unsigned long long);
-    p.total = p.gx_off + (size_t)p.teams * p.T * (TM_KP * TM_KP) * sizeof(unsigned long long);
+    p.gx_off = p.ring_off + (size_t)p.teams * TM_D * (p.T + 2) * (TM_R * p.kp) * sizeof(unsigned long long);
+    p.total = p.gx_off + (size_t)p.teams * p.T * (p.kp * p.kp) * sizeof(unsigned long long);
     p.ok = true;
     return p;
 }
@@ -81,7 +84,7 @@ __attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n,
 // *P_out ([*nparts][32][n], part of `part`) for the caller's reduction
 __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
                                                           const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
-                                                          const float** P_out, int* nparts, const float** Pg_out) {
+                                                          const float** P_out, int* nparts, const float** Pg_out, int* kp_out) {
     const TeamPlan p = team_plan(m, n, k);
     if (!p.ok || dnmf_batch_()->B != 1) return 1;
     if (!(aligned16(A) && lda % 4 == 0 && lda >= n && aligned16(H) && ldh % 4 == 0 && ldh >= n && ldw >= k && aligned16(part))) return 1;
@@ -112,8 +115,9 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
 #define TEAM_LAUNCH(SD, NT)                                                          \
     do {                                                                             \
         static bool once = false;                                                    \
-        if (!once) { allow_lds(team_fro_kernel<SD, NT>, TM_LDS_BYTES + 64); once = true; } \
-        hipLaunchKernelGGL((team_fro_kernel<SD, NT>), grid, block, TM_LDS_BYTES, st, a); \
+        if (!once) { allow_lds(team_fro_kernel<SD, NT, 2>, TM_LDS_BYTES + 64); allow_lds(team_fro_kernel<SD, NT, 1>, tm_lds_bytes(16) + 64); once = true; } \
+        if (p.kp == 16) hipLaunchKernelGGL((team_fro_kernel<SD, NT, 1>), grid, block, tm_lds_bytes(16), st, a); \
+        else hipLaunchKernelGGL((team_fro_kernel<SD, NT, 2>), grid, block, TM_LDS_BYTES, st, a); \
     } while (0)
 #ifdef DNMF_TUNING
     a.xflags = (int)tune("DNMF_TEAM_X", 0);
@@ -134,6 +138,7 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     if (int rc = check_launch("team_fro_kernel")) return rc;
     *P_out = a.P;
     *Pg_out = a.Pg;
+    *kp_out = p.kp;
     *nparts = p.teams_used;
     return DNMF_OK;
 }

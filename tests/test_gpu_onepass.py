@@ -15,8 +15,10 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 EPS = float(np.finfo(np.float32).eps)
-# (m, n, k): whole teams, a ragged last slab, rows that leave teams empty, k on both sides of 24, every team size 512 n' allows
-SHAPES = [(4096, 2048, 32), (5000, 2048, 17), (4100, 4096, 24), (8192, 2560, 32), (6007, 3072, 31), (16384, 3584, 20)]
+# (m, n, k): whole teams, a ragged last slab, rows that leave teams empty, ranks on both sides of the tile sizes, every team size 512 n' allows
+SHAPES = [(4096, 2048, 32), (5000, 2048, 17), (4100, 4096, 24), (8192, 2560, 32), (6007, 3072, 31), (16384, 3584, 20),
+          # k <= 16: the 16-wide instantiation (half the threads carry the 16 x 16 tile's elements)
+          (4096, 2048, 16), (5003, 3072, 9), (8192, 4096, 1), (6000, 2560, 13)]
 
 
 @pytest.fixture(scope="module")
@@ -93,7 +95,7 @@ def test_padded_views_and_w_fixed(env):
     assert torch.equal(W1, _d(W0)) and _maxrel(H1.cpu().numpy(), Hf) < 1e-5
 
 
-@pytest.mark.parametrize("m,n,k", [(4096, 2048, 24), (6007, 3072, 31)])
+@pytest.mark.parametrize("m,n,k", [(4096, 2048, 24), (6007, 3072, 31), (5003, 2048, 11)])
 def test_fit_through_pynmf_matches_the_checker(env, m, n, k):
     """PyNMF.fit (whole-fit entry point -> mu_fro_step_impl -> the team kernel every step) against oracle.fit_single."""
     from oracle import nmf_oracle as orc
@@ -148,7 +150,7 @@ def test_policy_and_switch(env):
         assert lib.dnmf_mu_fro_onepass(49152, 4096, 32) == 1 and lib.dnmf_mu_fro_onepass(49152, 2048, 32) == 0
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 32) == 0              # parity with two passes: stays on the launch sequence
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 24) == 1
-        assert lib.dnmf_mu_fro_onepass(8192, 4096, 16) == 0 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 0
+        assert lib.dnmf_mu_fro_onepass(65536, 4096, 16) == 1 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 0
         assert lib.dnmf_mu_fro_onepass(8192, 8192, 32) == 0               # more than eight 512-column pieces
     finally:
         lib.dnmf_set_onepass(2)
