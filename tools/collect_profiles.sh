@@ -30,6 +30,7 @@ prog() {   # the command line of a workload: "full" (stats pass) or "short" (PMC
     wide)   echo "$R/tools/kbench.py 65536 4096 192" ;;
     c2)     echo "$R/tools/config_bench.py c2" ;;
     team)   echo "$R/tools/teambench.py" ;;
+    team16) echo "$R/tools/teambench.py 65536 4096 16" ;;
     split)  echo "$R/tools/splitbench.py 262144 8192 64 --nocheck" ;;
     klsplit) echo "$R/tools/klsplitbench.py 32768 16384 16 --nocheck" ;;
     klsplit128) echo "$R/tools/klsplitbench.py 32768 32768 128 --nocheck" ;;
@@ -39,7 +40,7 @@ for w in $WL; do
   OUT=$R/gpurun_out/prof_${TAG}_$w
   rm -rf $OUT; mkdir -p $OUT
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $(prog $w full) > $OUT/stdout.json 2> $OUT/stats.log
-  case $w in team|bench|kl|kl16|kl32|kl64|elt|elt128|c4|hals64|c2|split|klsplit|klsplit128|f64|wide|swim)
+  case $w in team|team16|bench|kl|kl16|kl32|kl64|elt|elt128|c4|hals64|c2|split|klsplit|klsplit128|f64|wide|swim)
     timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $(prog $w short) > /dev/null 2> $OUT/pmc_sq.log
     timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $(prog $w short) > /dev/null 2> $OUT/pmc_fetch.log
     timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $(prog $w short) > /dev/null 2> $OUT/pmc_write.log ;;
