@@ -47,12 +47,15 @@ constexpr int TM_C = 512;                // columns per team member
 constexpr int TM_NW = 8;                 // waves per workgroup, 64 columns each
 constexpr int TM_KP = 32;                // padded rank at 16 < k <= 32 (the kernel's KT = 2; KT = 1: 16), and the pitch of the Gram buffers at every k <= 32
 constexpr int TM_LDA = TM_C + 8;         // LDS row pitch of a slab piece: 130 sixteen-byte chunks = 2 (mod 16) -> the row-per-lane ds_read_b128 is conflict free
-constexpr int TM_NBUF = 3;               // slabs in the LDS ring: t (Q), t + 1, t + 2 (written and read by P in the same stage)
+constexpr int TM_NBUF = 3;               // slabs in the LDS ring at lookahead 2: t (Q), t + 1, t + 2 (written and read by P in the same stage); LA + 1 in general
 constexpr int TM_D = 8;                  // granule ring depth (slabs s - 1 .. s + 2 are live while a member publishes s + 2: >= 4)
-constexpr int TM_LDW = 48;               // pitch of the new W rows in LDS (the two 16-lane halves of a scalar read land on different banks)
+constexpr int tm_ldw(int kp) { return kp == 16 ? 40 : 48; }   // pitch of the new W rows in LDS: 48 puts the two 16-lane halves of a scalar read on different banks; 40 at k <= 16, whose four-slab ring fills the 160 KiB to the last KiB
 constexpr int TM_MAXT = 8;               // members per team at most (n <= 4096)
-constexpr size_t tm_lds_bytes(int kp) { return (size_t)(TM_NBUF * TM_R * TM_LDA + 2 * TM_NW * TM_R * kp + 2 * 4 * TM_R * kp + 2 * TM_R * TM_LDW) * sizeof(float); }
-constexpr size_t TM_LDS_BYTES = tm_lds_bytes(TM_KP);
+constexpr int tm_la(int kp) { return kp == 16 ? 3 : 2; }      // lookahead: slabs between the partial (P) and its use (Q); k <= 16 has the LDS for 3
+constexpr size_t tm_lds_bytes(int kp, int la = 0) {
+    return (size_t)(((la ? la : tm_la(kp)) + 1) * TM_R * TM_LDA + 2 * TM_NW * TM_R * kp + 2 * 4 * TM_R * kp + 2 * TM_R * tm_ldw(kp)) * sizeof(float);
+}
+constexpr size_t TM_LDS_BYTES = tm_lds_bytes(TM_KP, 2);
 
 struct TeamArgs {
     const void* A; long lda;             // the data block (fp32), rows 16-byte aligned
@@ -84,13 +87,19 @@ struct TeamArgs {
 // stage paid a full fabric round trip (0.46 ms per launch at 65536 x 4096 against 0.22 ms of matrix time; profiles/r06a_team_*).
 // KT = 16-wide tiles of the padded rank: 2 for 16 < k <= 32; 1 for k <= 16, where the two-pass kernels are HBM-bound (AI = k / 2 flop per byte
 // against a balance of 20) and reading A once pays most
-template <int SD, int NT, int KT = 2>
+// LA = lookahead: the partial of slab s + LA is formed and published in stage s, i.e. LA stages before the slab's W update and Q: the
+// team's granules have LA - 1 stages to arrive (requested one stage after their publication).  LA + 1 slabs live in LDS: 2 at k > 16 (the
+// ring fills the LDS), 3 at k <= 16 -- there a stage is short (0.9 us of MFMA) and one stage did not cover the fabric round trip: the
+// exchange cost 0.074 of 0.29 ms (profiles/r06_team_ab.txt)
+template <int SD, int NT, int KT = 2, int LA = 2>
 __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tm_smem[];
-    constexpr int KP = 16 * KT;
+    constexpr int TM_LDW = tm_ldw(16 * KT);
+    constexpr int KP = 16 * KT, NB = LA + 1, NG = LA - 1, PER = NB % 2 ? 2 * NB : NB;   // ring slots, granule register sets, stages per unrolled group
+    static_assert(PER % SD == 0 && PER % NB == 0 && PER % 2 == 0 && (NG == 1 || PER % NG == 0), "the unrolled group must return every ring to its start");
     constexpr int EL = TM_R * KP;                          // elements of a slab's tile = granules of a plane (512 = one per thread; KT = 1: 256, waves 0-3)
     float* Ab = tm_smem;                                   // [NBUF][R][LDA]
-    float* red = Ab + TM_NBUF * TM_R * TM_LDA;             // [2][NW][EL]   the waves' partials of A H^T (by stage parity)
+    float* red = Ab + NB * TM_R * TM_LDA;             // [2][NW][EL]   the waves' partials of A H^T (by stage parity)
     float* dred = red + 2 * TM_NW * EL;                    // [2][4][EL]    partial denominators (two waves fill one plane)
     float* Wn = dred + 2 * 4 * EL;                         // [2][R][LDW]   the slab's new W rows
     __shared__ unsigned s_flag;
@@ -149,9 +158,11 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 
     f32x4 stg[SD][4];
     float wold[2] = {0.f, 0.f}, wdn[2][ND] = {};
-    f32x2 gat[TM_MAXT + 2];
+    f32x2 gat[NG][TM_MAXT + 2];                                           // granules of the slabs s + 1 .. s + LA - 1 on their way
 #pragma unroll
-    for (int j = 0; j < TM_MAXT + 2; ++j) gat[j] = f32x2{0.f, 0.f};
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < TM_MAXT + 2; ++j) gat[g][j] = f32x2{0.f, 0.f};
 
     // ---- census, second half
     if (tid == 0) {
@@ -185,9 +196,9 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     const bool gt1 = KT == 2 && ((wv >> 1) & 1), gt2 = KT == 2 && (wv & 1), gkh = (wv >> 2) != 0;
 
     // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
-    auto regather = [&](int t) {
+    auto regather = [&](int t, f32x2 (&gat)[TM_MAXT + 2]) __attribute__((always_inline)) {
         const unsigned want = (unsigned)(t + 1);
-        const int slot = (t & (TM_D - 1)) * slotb;
+        const int slot = __builtin_amdgcn_readfirstlane((t & (TM_D - 1)) * slotb);
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         for (;;) {
@@ -213,56 +224,60 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     float tmask[TM_MAXT];                                                  // 1 for the planes of real members (uniform values)
 #pragma unroll
     for (int j = 0; j < TM_MAXT; ++j) tmask[j] = j < T ? 1.f : 0.f;
-    // owners without a division per stage: o3 / o2 / o0 = (s + 3) / (s + 2) / s modulo T, stepped with s
-    int o3 = (3 * T - 3) % T, o2 = (4 * T - 4) % T, o0 = (6 * T - 6) % T;  // s = -6
-    // One stage.  U = s mod 6 fixes every LDS slot and staging register at compile time; GD: the guarded form (first and last
+    // owners without a division per stage: o3 / o2 / o0 = (s + LA + 1) / (s + LA) / s modulo T, stepped with s
+    constexpr int S0 = -2 * PER;                                           // first stage: the pipeline fills in the two guarded groups
+    int o3 = ((S0 + LA + 1) % T + T) % T, o2 = ((S0 + LA) % T + T) % T, o0 = (S0 % T + T) % T;
+    // One stage.  U = s mod PER fixes every LDS slot and staging register at compile time; GD: the guarded form (first and last
     // stages of a team's rows: slabs that do not exist, a last slab with fewer than 16 rows) -- the steady form has no such test.
-    // ONE barrier per stage: before it the wave stages slab s + 2 and forms its partial (matrix work that needs nothing from the
+    // ONE barrier per stage: before it the wave stages slab s + LA and forms its partial (matrix work that needs nothing from the
     // team), then finishes the W update of slab s from the granules it asked for a stage ago; after it the partial is published,
     // the next slab's granules are requested and the product W_new^T A of slab s runs.
-    auto stage = [&](int s, auto uc, auto gc) {
+    auto stage = [&](int s, auto uc, auto gc) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value, PAR = U & 1;
         constexpr bool GD = decltype(gc)::value;
         float* const redp = red + PAR * (TM_NW * EL);
         float* const dredp = dred + PAR * (4 * EL);
         float* const Wnp = Wn + PAR * (TM_R * TM_LDW);
-        const bool pub = !GD || (s + 2 >= 0 && s + 2 < nsl);
+        const bool pub = !GD || (s + LA >= 0 && s + LA < nsl);
+        f32x2 (&gcur)[TM_MAXT + 2] = gat[U % NG];                           // slab s's granules (requested LA - 1 stages ago); refilled below for slab s + LA - 1
         const bool cur = !GD || (s >= 0 && s < nsl);
-        // S: slab s + 2 from the staging registers into its ring slot (the wave's own 64 columns)
+        // S: slab s + LA from the staging registers into its ring slot (the wave's own 64 columns)
         if (pub) {
-            float* dst = Ab + ((U + 2) % 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
+            float* dst = Ab + ((U + LA) % NB) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<f32x4*>(dst + 4 * ks * TM_LDA) = stg[(U + 2) % SD][ks];
+            for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<f32x4*>(dst + 4 * ks * TM_LDA) = stg[(U + LA) % SD][ks];
         }
-        // L: slab s + 2 + SD into the registers just freed (four rows x 256 bytes per instruction)
+        // L: slab s + LA + SD into the registers just freed (four rows x 256 bytes per instruction)
         {
-            const int t = s + 2 + SD;
+            const int t = s + LA + SD;
             if (!GD || (t >= 0 && t < nsl)) {
-                const int soff = t * 4 * arow4;
+                const int soff = __builtin_amdgcn_readfirstlane(t * 4 * arow4);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int vo = (!GD || (long)t * TM_R + 4 * ks + q4 < rows) ? avoff : BUF_OOB;
-                    stg[(U + 2) % SD][ks] = buf_ld_f32x4(arsrc, vo, soff + ks * arow4, NT);
+                    stg[(U + LA) % SD][ks] = buf_ld_f32x4(arsrc, vo, soff + ks * arow4, NT);
                 }
             }
         }
-        // the old W of slab s + 3, for its owner (used by the next stage; everybody else reads nothing: BUF_OOB)
+        // the old W of slab s + LA + 1, for its owner (used by the next stage; everybody else reads nothing: BUF_OOB)
         {
-            const int t = s + 3;
+            const int t = s + LA + 1;
             if (!GD || (t >= 0 && t < nsl)) {
                 const bool mine = o3 == member;
-                const int soff = t * wslab;
-                wold[(U + 3) & 1] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + er < rows)) ? wevoff : BUF_OOB, soff, 0);
+                // (scalar offsets are pinned to SGPRs: under scalar-register pressure hipcc kept these induction values in vector registers and
+                // wrapped every access in a waterfall loop -- 0.385 -> 0.414 ms per step at config 2 when the kernel gained its KT parameter)
+                const int soff = __builtin_amdgcn_readfirstlane(t * wslab);
+                wold[(U + LA + 1) & 1] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + er < rows)) ? wevoff : BUF_OOB, soff, 0);
 #pragma unroll
                 for (int u = 0; u < ND; ++u)
-                    wdn[(U + 3) & 1][u] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + i < rows)) ? wdvoff[u] : BUF_OOB, soff, 0);
+                    wdn[(U + LA + 1) & 1][u] = buf_ld_f32(wrsrc, (mine && (!GD || (long)t * TM_R + i < rows)) ? wdvoff[u] : BUF_OOB, soff, 0);
             }
         }
-        // P, first half: the wave's partial of A H^T for slab s + 2 over its first 32 columns
+        // P, first half: the wave's partial of A H^T for slab s + LA over its first 32 columns
         f32x4 pacc[KT];
 #pragma unroll
         for (int tk = 0; tk < KT; ++tk) pacc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* psrc = Ab + ((U + 2) % 3) * (TM_R * TM_LDA) + i * TM_LDA + cw + 4 * q4;
+        const float* psrc = Ab + ((U + LA) % NB) * (TM_R * TM_LDA) + i * TM_LDA + cw + 4 * q4;
         auto p_half = [&](int g0) {
 #pragma unroll
             for (int g = g0; g < g0 + 2; ++g) {
@@ -280,17 +295,17 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         // a slot's earlier contents carry SMALLER tags (zero after the launch's memset, then s + 1 - 8, s + 1 - 16, ...), never larger ones.
         if (cur) {
             const unsigned want = (unsigned)(s + 1);
-            unsigned tsum = __float_as_uint(gat[0][1]);
+            unsigned tsum = __float_as_uint(gcur[0][1]);
 #pragma unroll
-            for (int j = 1; j < TM_MAXT + 2; ++j) tsum += __float_as_uint(gat[j][1]);
-            if (eon && tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s);
-            float ah = gat[0][0];
+            for (int j = 1; j < TM_MAXT + 2; ++j) tsum += __float_as_uint(gcur[j][1]);
+            if (eon && tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s, gcur);
+            float ah = gcur[0][0];
 #pragma unroll
-            for (int j = 1; j < TM_MAXT; ++j) ah = fmaf(tmask[j], gat[j][0], ah);      // planes j >= T: x 0 (a re-read of plane T - 1)
-            const float wn = div_pos(gat[TM_MAXT][0] * ah, gat[TM_MAXT + 1][0]);
+            for (int j = 1; j < TM_MAXT; ++j) ah = fmaf(tmask[j], gcur[j][0], ah);     // planes j >= T: x 0 (a re-read of plane T - 1)
+            const float wn = div_pos(gcur[TM_MAXT][0] * ah, gcur[TM_MAXT + 1][0]);
             if (eon) Wnp[er * TM_LDW + ekk] = wn;
             const bool st = o0 == member && (!GD || (long)s * TM_R + er < rows);
-            buf_st_f32(wn, wrsrc, st ? wevoff : BUF_OOB, s * wslab, 0);
+            buf_st_f32(wn, wrsrc, st ? wevoff : BUF_OOB, __builtin_amdgcn_readfirstlane(s * wslab), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (pub) {
@@ -300,11 +315,11 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
             for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[r * KP + 16 * tk] = pacc[tk][r];
-            // the owner's W G for slab s + 2: this wave's tile and contraction steps
+            // the owner's W G for slab s + LA: this wave's tile and contraction steps
             if (o2 == member && dact) {
                 f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < ND; ++u) dacc = TM_MFMA(wdn[U & 1][u], gden[u], dacc);
+                for (int u = 0; u < ND; ++u) dacc = TM_MFMA(wdn[(U + LA) & 1][u], gden[u], dacc);
                 float* dd = dredp + dpl * EL + 4 * q4 * KP + 16 * dtk + i;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dd[r * KP] = dacc[r];
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         // as A operand, the slab piece as B operand), then half of Q, the publication and the request for the next granules, the other half
         float rr[TM_NW], dd[4], wop[KT][4];
         f32x4 bv[4];
-        const float* qsrc = Ab + (U % 3) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
+        const float* qsrc = Ab + (U % NB) * (TM_R * TM_LDA) + q4 * TM_LDA + cw + 4 * i;
         if (cur) {
 #pragma unroll
             for (int tk = 0; tk < KT; ++tk)
@@ -340,32 +355,32 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         };
         if (cur) q_half(0);
         __builtin_amdgcn_sched_barrier(0);
-        // publish slab s + 2: thread e sums the eight waves' values of element e (the owner adds w_old and den)
+        // publish slab s + LA: thread e sums the eight waves' values of element e (the owner adds w_old and den)
         if (pub) {
             float v = rr[0];
 #pragma unroll
             for (int w = 1; w < TM_NW; ++w) v += rr[w];
             const float den = (((dd[0] + dd[1]) + dd[2]) + dd[3]) + a.eps;
-            const float tag = __uint_as_float((unsigned)(s + 3));
-            const int slot = ((s + 2) & (TM_D - 1)) * slotb;
+            const float tag = __uint_as_float((unsigned)(s + LA + 1));
+            const int slot = __builtin_amdgcn_readfirstlane(((s + LA) & (TM_D - 1)) * slotb);
             const int ov = (o2 == member && !(a.xflags & 2)) ? gvoff : BUF_OOB;
             if (plain) {        // the whole team on one XCD: its L2 is the point of coherence, the granules need not leave it
                 buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 0);
-                buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 0);
+                buf_st_f32x2(f32x2{wold[(U + LA) & 1], tag}, rrsrc, ov, slot + T * PLANE, 0);
                 buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 0);
             } else {
                 buf_st_f32x2(f32x2{v, tag}, rrsrc, (a.xflags & 2) ? BUF_OOB : gvoff, slot + member * PLANE, 16);
-                buf_st_f32x2(f32x2{wold[U & 1], tag}, rrsrc, ov, slot + T * PLANE, 16);
+                buf_st_f32x2(f32x2{wold[(U + LA) & 1], tag}, rrsrc, ov, slot + T * PLANE, 16);
                 buf_st_f32x2(f32x2{den, tag}, rrsrc, ov, slot + (T + 1) * PLANE, 16);
             }
         }
-        // the reads of slab s + 1's granules (published a stage ago, used by the next stage)
-        if ((!GD || (s + 1 >= 0 && s + 1 < nsl)) && !(a.xflags & 2)) {
-            const int slot = ((s + 1) & (TM_D - 1)) * slotb;
+        // the reads of slab s + LA - 1's granules (published a stage ago, used LA - 1 stages from now) into the set slab s has just left
+        if ((!GD || (s + LA - 1 >= 0 && s + LA - 1 < nsl)) && !(a.xflags & 2)) {
+            const int slot = __builtin_amdgcn_readfirstlane(((s + LA - 1) & (TM_D - 1)) * slotb);
 #pragma unroll
             for (int j = 0; j < TM_MAXT + 2; ++j) {
                 const int pl = j < TM_MAXT ? (j < T ? j : T - 1) : T + (j - TM_MAXT);
-                gat[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
+                gcur[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -387,20 +402,24 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         o2 = o2 + 1 == T ? 0 : o2 + 1;
         o0 = o0 + 1 == T ? 0 : o0 + 1;
     };
-    auto group = [&](int sb, auto gc) {
+    auto group = [&](int sb, auto gc) __attribute__((always_inline)) {
         stage(sb, std::integral_constant<int, 0>{}, gc);
         stage(sb + 1, std::integral_constant<int, 1>{}, gc);
         stage(sb + 2, std::integral_constant<int, 2>{}, gc);
         stage(sb + 3, std::integral_constant<int, 3>{}, gc);
-        stage(sb + 4, std::integral_constant<int, 4>{}, gc);
-        stage(sb + 5, std::integral_constant<int, 5>{}, gc);
+        if constexpr (PER == 6) {
+            stage(sb + 4, std::integral_constant<int, 4>{}, gc);
+            stage(sb + 5, std::integral_constant<int, 5>{}, gc);
+        }
+        static_assert(PER == 4 || PER == 6, "group");
     };
 
-    int sb = -6;
-    group(sb, std::true_type{});                                           // stages -6 .. -1: the pipeline fills
+    int sb = S0;
+    group(sb, std::true_type{});                                           // the pipeline fills
+    group(sb + PER, std::true_type{});
     sb = 0;
-    for (; sb + 5 + 2 + SD < nfull; sb += 6) group(sb, std::false_type{}); // every slab a stage touches exists and is whole
-    for (; sb < nsl; sb += 6) group(sb, std::true_type{});                 // the pipeline drains
+    for (; sb + PER - 1 + LA + SD < nfull; sb += PER) group(sb, std::false_type{});   // every slab a stage touches exists and is whole
+    for (; sb < nsl; sb += PER) group(sb, std::true_type{});               // the pipeline drains
 
     // the team's partial: accumulator register r of tile (tk, j) is row 16 tk + 4 q4 + r, column cb + 4 i + j
     float* Pt = a.P + (long)team * KP * n + cb + 4 * i;

@@ -29,7 +29,7 @@ int team_cus() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TEAM_MAX_DEVICES) { clear_hip_error(); return 0; }
     if (have[dev]) return cus_of[dev];
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { clear_hip_error(); return 0; }
-    const auto kern = team_fro_kernel<2, 2>;
+    const auto kern = team_fro_kernel<2, 2, 2, 2>;
     allow_lds(kern, TM_LDS_BYTES + 64);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * TM_NW, TM_LDS_BYTES) != hipSuccess || nb < 1) { clear_hip_error(); cus = 0; }
     cus_of[dev] = cus;
@@ -114,10 +114,11 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
 #endif
 #define TEAM_LAUNCH(SD, NT)                                                          \
     do {                                                                             \
+        constexpr int SD16 = (SD) == 3 ? 2 : (SD);       /* the k <= 16 kernel's group is four stages long */ \
         static bool once = false;                                                    \
-        if (!once) { allow_lds(team_fro_kernel<SD, NT, 2>, TM_LDS_BYTES + 64); allow_lds(team_fro_kernel<SD, NT, 1>, tm_lds_bytes(16) + 64); once = true; } \
-        if (p.kp == 16) hipLaunchKernelGGL((team_fro_kernel<SD, NT, 1>), grid, block, tm_lds_bytes(16), st, a); \
-        else hipLaunchKernelGGL((team_fro_kernel<SD, NT, 2>), grid, block, TM_LDS_BYTES, st, a); \
+        if (!once) { allow_lds(team_fro_kernel<SD, NT, 2, 2>, TM_LDS_BYTES + 64); allow_lds(team_fro_kernel<SD16, NT, 1, 3>, tm_lds_bytes(16) + 64); once = true; } \
+        if (p.kp == 16) hipLaunchKernelGGL((team_fro_kernel<SD16, NT, 1, 3>), grid, block, tm_lds_bytes(16), st, a); \
+        else hipLaunchKernelGGL((team_fro_kernel<SD, NT, 2, 2>), grid, block, TM_LDS_BYTES, st, a); \
     } while (0)
 #ifdef DNMF_TUNING
     a.xflags = (int)tune("DNMF_TEAM_X", 0);

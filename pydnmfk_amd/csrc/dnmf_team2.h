@@ -19,6 +19,7 @@
 
 namespace {
 
+constexpr int TM_LDW = tm_ldw(TM_KP);
 constexpr size_t TM2_LDS_BYTES = (size_t)(TM_NBUF * TM_R * TM_LDA + 2 * 4 * TM_R * TM_KP + 2 * 2 * TM_R * TM_KP + 2 * TM_R * TM_LDW + 16) * sizeof(float);
 
 // The LDS words are relaxed atomics between compiler barriers: the ORDER they rely on is the hardware's (the DS operations of a wave
