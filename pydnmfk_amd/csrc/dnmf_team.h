@@ -4,7 +4,7 @@
 // What it computes (dist_nmf.py:716-732 feeding :736-749): for every row r of this rank's block
 //     W[r] <- W[r] * (A[r] H^T) / (W[r] (H H^T) + eps)          and, with the NEW rows,          P += W[r]^T A[r]
 // -- the W update of a row needs that row's WHOLE A[r] H^T before W^T A may touch the row again, so the row block has to stay on
-// chip between its two uses.  A 16-row slab of a 4096-column matrix is 256 KiB: more than one CU's LDS, so a TEAM of T = n / 512
+// chip between its two uses.  A 16-row slab of a 4096-column matrix is 256 KiB: more than one CU's LDS, so a TEAM of T = ceil(n / 512)
 // workgroups (one per CU, all of one XCD where the dispatcher deals blocks round-robin -- speed only) shares it by COLUMNS:
 //
 //   member j keeps its 16 x 512 piece of the slab in LDS (32 KiB, four slabs deep), wave w of its eight waves owning 64 columns for the
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int kk = 16 * tk + i;
-            hreg[tk][g] = kk < k ? *reinterpret_cast<const f32x4*>(a.H + (long)kk * a.ldh + cb + 16 * g + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (columns beyond n -- the last member of a matrix whose width is not a multiple of 512: n % 4 == 0, so a lane's four are in or out -- are zeros)
+            hreg[tk][g] = (kk < k && cb + 16 * g + 4 * q4 < n) ? *reinterpret_cast<const f32x4*>(a.H + (long)kk * a.ldh + cb + 16 * g + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     // this wave's share of the owner's W G (16 x KP, contraction over KP): KT = 2: tile wv & 1, steps 2 (wv >> 1), + 1 -> plane wv >> 1;
     // KT = 1: one tile, step wv of four (waves 0-3) -> plane wv.  The four planes add up to the product either way.
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 
     // MUBUF descriptors at the team's first row / the team's granules: one lane offset per stream, everything else scalar
     const i32x4 arsrc = buf_rsrc((const float*)a.A + row0 * a.lda);
-    const int avoff = (int)(((long)q4 * a.lda + cb + 4 * i) * 4);          // row q4 of a group of four, the lane's four columns
+    const int avoff = cb + 4 * i < n ? (int)(((long)q4 * a.lda + cb + 4 * i) * 4) : BUF_OOB;   // row q4 of a group of four, the lane's four columns (beyond n: zeros)
     const int arow4 = (int)(a.lda * 16);                                   // bytes between groups of four rows
     const i32x4 wrsrc = buf_rsrc(a.W + row0 * a.ldw);
     const bool eon = tid < EL;                                             // thread e = element (er, ekk) of a slab's 16 x KP tile (KT = 1: waves 0-3)
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     for (int tk = 0; tk < KT; ++tk)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4*>(Pt + (long)(16 * tk + 4 * q4 + r) * n) = f32x4{qacc[tk][0][r], qacc[tk][1][r], qacc[tk][2][r], qacc[tk][3][r]};
+            if (cb + 4 * i < n)
+                *reinterpret_cast<f32x4*>(Pt + (long)(16 * tk + 4 * q4 + r) * n) = f32x4{qacc[tk][0][r], qacc[tk][1][r], qacc[tk][2][r], qacc[tk][3][r]};
 
     // the Gram partials: the two contraction halves of a tile meet in LDS, the members' sums in the team's granule planes (once per
     // launch), member 0 adds them in member order and writes the team's 32 x 32 partial for the reduction launch's Gram tail

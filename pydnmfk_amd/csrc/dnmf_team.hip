@@ -52,10 +52,10 @@ bool team_pays(long m, long n, int k) {
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     TeamPlan p{};
     if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
-    if (k < 1 || k > TM_KP || n % TM_C != 0 || n / TM_C > TM_MAXT || m < 4096) return p;
+    if (k < 1 || k > TM_KP || n % 4 != 0 || n < 4 || cdiv(n, TM_C) > TM_MAXT || m < 4096) return p;
     p.kp = k <= 16 ? 16 : 32;
     if (cus <= 0) cus = team_cus();
-    p.T = (int)(n / TM_C);
+    p.T = (int)cdiv(n, TM_C);                                           // the last member's piece may be narrower (its columns beyond n read as zeros)
     p.tpx = (cus / 8) / p.T;
     if (p.tpx < 1) return p;
     p.teams = 8 * p.tpx;

@@ -18,7 +18,9 @@ EPS = float(np.finfo(np.float32).eps)
 # (m, n, k): whole teams, a ragged last slab, rows that leave teams empty, ranks on both sides of the tile sizes, every team size 512 n' allows
 SHAPES = [(4096, 2048, 32), (5000, 2048, 17), (4100, 4096, 24), (8192, 2560, 32), (6007, 3072, 31), (16384, 3584, 20),
           # k <= 16: the 16-wide instantiation (half the threads carry the 16 x 16 tile's elements)
-          (4096, 2048, 16), (5003, 3072, 9), (8192, 4096, 1), (6000, 2560, 13)]
+          (4096, 2048, 16), (5003, 3072, 9), (8192, 4096, 1), (6000, 2560, 13),
+          # n not a multiple of 512: the last member's piece is narrower (down to one lane's four columns)
+          (4096, 2052, 32), (5000, 4000, 24), (4100, 3332, 12), (4096, 2300, 16)]
 
 
 @pytest.fixture(scope="module")
@@ -150,7 +152,8 @@ def test_policy_and_switch(env):
         assert lib.dnmf_mu_fro_onepass(49152, 4096, 32) == 1 and lib.dnmf_mu_fro_onepass(49152, 2048, 32) == 0
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 32) == 0              # parity with two passes: stays on the launch sequence
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 24) == 1
-        assert lib.dnmf_mu_fro_onepass(65536, 4096, 16) == 1 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 0
+        assert lib.dnmf_mu_fro_onepass(65536, 4096, 16) == 1 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 1
+        assert lib.dnmf_mu_fro_onepass(8192, 4002, 32) == 0                # rows of A must be whole 16-byte groups
         assert lib.dnmf_mu_fro_onepass(8192, 8192, 32) == 0               # more than eight 512-column pieces
     finally:
         lib.dnmf_set_onepass(2)
