@@ -91,7 +91,7 @@ int dnmf_aht_update_w(const float* A, long m, long n, long lda, const float* H, 
 
 /* ---- One whole local MU/Frobenius step on one rank (dist_nmf.py:755-771 with p_r = p_c = 1),
  * W first then H with the new W; clamp!=0 applies pyDNMF.py:155-157 after the step. ---- */
-/* k <= 32 on fp32 A with n a multiple of 4 up to 4096 (by default from 2048), m >= 4096, 16-byte aligned rows (and w_update != 0): the step reads A
+/* k <= 32 on fp32 A with n a multiple of 4 up to 4096 (8192 at k <= 16; by default from 2048), m >= 4096, 16-byte aligned rows (and w_update != 0): the step reads A
  * ONCE (csrc/dnmf_team.h): teams of ceil(n / 512) workgroups share 16-row slabs by columns, exchange their 16 x k partials of A H^T inside the
  * kernel, update the slab's W rows and add W_new^T A from the LDS copy of the slab -- dist_nmf.py:729-732 feeding :748-751 without a
  * second pass.  Same update rule; the sums over n run in another association than the two-pass kernels' (results agree to fp32

@@ -91,7 +91,8 @@ struct TeamArgs {
 // team's granules have LA - 1 stages to arrive (requested one stage after their publication).  LA + 1 slabs live in LDS: 2 at k > 16 (the
 // ring fills the LDS), 3 at k <= 16 -- there a stage is short (0.9 us of MFMA) and one stage did not cover the fabric round trip: the
 // exchange cost 0.074 of 0.29 ms (profiles/r06_team_ab.txt)
-template <int SD, int NT, int KT = 2, int LA = 2>
+// MT = members per team the register sets are sized for: 8 (n <= 4096); 16 at k <= 16 only (n <= 8192: the registers allow it there)
+template <int SD, int NT, int KT = 2, int LA = 2, int MT = TM_MAXT>
 __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tm_smem[];
     constexpr int TM_LDW = tm_ldw(16 * KT);
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 
     f32x4 stg[SD][4];
     float wold[2] = {0.f, 0.f}, wdn[2][ND] = {};
-    f32x2 gat[NG][TM_MAXT + 2];                                           // granules of the slabs s + 1 .. s + LA - 1 on their way
+    f32x2 gat[NG][MT + 2];                                           // granules of the slabs s + 1 .. s + LA - 1 on their way
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int j = 0; j < TM_MAXT + 2; ++j) gat[g][j] = f32x2{0.f, 0.f};
+        for (int j = 0; j < MT + 2; ++j) gat[g][j] = f32x2{0.f, 0.f};
 
     // ---- census, second half
     if (tid == 0) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
     const bool gt1 = KT == 2 && ((wv >> 1) & 1), gt2 = KT == 2 && (wv & 1), gkh = (wv >> 2) != 0;
 
     // granules that are not there yet (a late member): read the slab's planes again until they are, bounded by the wall clock
-    auto regather = [&](int t, f32x2 (&gat)[TM_MAXT + 2]) __attribute__((always_inline)) {
+    auto regather = [&](int t, f32x2 (&gat)[MT + 2]) __attribute__((always_inline)) {
         const unsigned want = (unsigned)(t + 1);
         const int slot = __builtin_amdgcn_readfirstlane((t & (TM_D - 1)) * slotb);
         const unsigned long long t0 = wall_clock64();
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int j = 0; j < TM_MAXT + 2; ++j) {
-                const int pl = j < TM_MAXT ? (j < T ? j : T - 1) : T + (j - TM_MAXT);
+            for (int j = 0; j < MT + 2; ++j) {
+                const int pl = j < MT ? (j < T ? j : T - 1) : T + (j - MT);
                 gat[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
             }
 #pragma unroll
-            for (int j = 0; j < TM_MAXT + 2; ++j) ok = ok && __float_as_uint(gat[j][1]) == want;
+            for (int j = 0; j < MT + 2; ++j) ok = ok && __float_as_uint(gat[j][1]) == want;
             if (ok) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 15u) == 15u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
@@ -222,9 +223,9 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         }
     };
 
-    float tmask[TM_MAXT];                                                  // 1 for the planes of real members (uniform values)
+    float tmask[MT];                                                  // 1 for the planes of real members (uniform values)
 #pragma unroll
-    for (int j = 0; j < TM_MAXT; ++j) tmask[j] = j < T ? 1.f : 0.f;
+    for (int j = 0; j < MT; ++j) tmask[j] = j < T ? 1.f : 0.f;
     // owners without a division per stage: o3 / o2 / o0 = (s + LA + 1) / (s + LA) / s modulo T, stepped with s
     constexpr int S0 = -2 * PER;                                           // first stage: the pipeline fills in the two guarded groups
     int o3 = ((S0 + LA + 1) % T + T) % T, o2 = ((S0 + LA) % T + T) % T, o0 = (S0 % T + T) % T;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         float* const dredp = dred + PAR * (4 * EL);
         float* const Wnp = Wn + PAR * (TM_R * TM_LDW);
         const bool pub = !GD || (s + LA >= 0 && s + LA < nsl);
-        f32x2 (&gcur)[TM_MAXT + 2] = gat[U % NG];                           // slab s's granules (requested LA - 1 stages ago); refilled below for slab s + LA - 1
+        f32x2 (&gcur)[MT + 2] = gat[U % NG];                           // slab s's granules (requested LA - 1 stages ago); refilled below for slab s + LA - 1
         const bool cur = !GD || (s >= 0 && s < nsl);
         // S: slab s + LA from the staging registers into its ring slot (the wave's own 64 columns)
         if (pub) {
@@ -292,18 +293,18 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         if (pub) p_half(0);
         __builtin_amdgcn_sched_barrier(0);
         // W update of slab s from the granules read a stage ago -- between the two halves of P, so that neither the wait for the granules nor
-        // the LDS round trip behind it leaves the matrix pipe without queued work.  All tags right <=> their sum is (TM_MAXT + 2) x the tag:
+        // the LDS round trip behind it leaves the matrix pipe without queued work.  All tags right <=> their sum is (MT + 2) x the tag:
         // a slot's earlier contents carry SMALLER tags (zero after the launch's memset, then s + 1 - 8, s + 1 - 16, ...), never larger ones.
         if (cur) {
             const unsigned want = (unsigned)(s + 1);
             unsigned tsum = __float_as_uint(gcur[0][1]);
 #pragma unroll
-            for (int j = 1; j < TM_MAXT + 2; ++j) tsum += __float_as_uint(gcur[j][1]);
-            if (eon && tsum != (TM_MAXT + 2) * want && !(a.xflags & 1)) regather(s, gcur);
+            for (int j = 1; j < MT + 2; ++j) tsum += __float_as_uint(gcur[j][1]);
+            if (eon && tsum != (MT + 2) * want && !(a.xflags & 1)) regather(s, gcur);
             float ah = gcur[0][0];
 #pragma unroll
-            for (int j = 1; j < TM_MAXT; ++j) ah = fmaf(tmask[j], gcur[j][0], ah);     // planes j >= T: x 0 (a re-read of plane T - 1)
-            const float wn = div_pos(gcur[TM_MAXT][0] * ah, gcur[TM_MAXT + 1][0]);
+            for (int j = 1; j < MT; ++j) ah = fmaf(tmask[j], gcur[j][0], ah);     // planes j >= T: x 0 (a re-read of plane T - 1)
+            const float wn = div_pos(gcur[MT][0] * ah, gcur[MT + 1][0]);
             if (eon) Wnp[er * TM_LDW + ekk] = wn;
             const bool st = o0 == member && (!GD || (long)s * TM_R + er < rows);
             buf_st_f32(wn, wrsrc, st ? wevoff : BUF_OOB, __builtin_amdgcn_readfirstlane(s * wslab), 0);
@@ -379,8 +380,8 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         if ((!GD || (s + LA - 1 >= 0 && s + LA - 1 < nsl)) && !(a.xflags & 2)) {
             const int slot = __builtin_amdgcn_readfirstlane(((s + LA - 1) & (TM_D - 1)) * slotb);
 #pragma unroll
-            for (int j = 0; j < TM_MAXT + 2; ++j) {
-                const int pl = j < TM_MAXT ? (j < T ? j : T - 1) : T + (j - TM_MAXT);
+            for (int j = 0; j < MT + 2; ++j) {
+                const int pl = j < MT ? (j < T ? j : T - 1) : T + (j - MT);
                 gcur[j] = buf_ld_f32x2(rrsrc, gvoff, slot + pl * PLANE, 16);
             }
         }
@@ -455,12 +456,12 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
         }
         if (member == 0 && tid < GE) {                       // (GE < 512: whole waves drop out)
             const unsigned long long t0 = wall_clock64();
-            f32x2 g[GH][TM_MAXT];
+            f32x2 g[GH][MT];
             auto fetch = [&]() {                           // all planes of the thread's elements in flight together
 #pragma unroll
                 for (int h = 0; h < GH; ++h)
 #pragma unroll
-                    for (int j = 0; j < TM_MAXT; ++j)
+                    for (int j = 0; j < MT; ++j)
                         g[h][j] = buf_ld_f32x2(grsrc, (tid + 512 * h) * 8, (j < T ? j : T - 1) * (GE * 8), 16);
             };
             unsigned spins = 0;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
 #pragma unroll
                 for (int h = 0; h < GH; ++h)
 #pragma unroll
-                    for (int j = 0; j < TM_MAXT; ++j) ok = ok && __float_as_uint(g[h][j][1]) == 0x7fffffffu;
+                    for (int j = 0; j < MT; ++j) ok = ok && __float_as_uint(g[h][j][1]) == 0x7fffffffu;
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 15u) == 15u && __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64 * TM_NW, 2) void team_fro_kernel(TeamArgs a) {
             for (int h = 0; h < GH; ++h) {
                 float sum = g[h][0][0];
 #pragma unroll
-                for (int j = 1; j < TM_MAXT; ++j) sum = fmaf(tmask[j], g[h][j][0], sum);
+                for (int j = 1; j < MT; ++j) sum = fmaf(tmask[j], g[h][j][0], sum);
                 a.Pg[(long)team * GE + tid + 512 * h] = sum;
             }
         }

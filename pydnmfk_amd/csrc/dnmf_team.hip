@@ -44,7 +44,11 @@ int team_cus() {
 // are within 1 % of each other either way, and the two-pass sequence needs no residency.
 // k <= 16 (round 6, KT = 1): the two-pass kernels are HBM-bound there and the one-pass step won at every shape of the sweep (fourth and fifth
 // block of the file: 2-46 %, 17-22 % at 65536 ... 262144 x 4096).
+// Widths beyond 4096 (teams of 9-16 members, k <= 16 only): the exchange grows with the team (T + 2 planes per slab and member) and ate the
+// gain on tall blocks (65536 / 262144 x 8192: 1-3 %; 32768 x 6144, where 12-member teams leave a quarter of the CUs idle: 27 % SLOWER), so only
+// short blocks take it there (16384 x 8192: 22 %).
 bool team_pays(long m, long n, int k) {
+    if (n > 4096) return m <= 24576;
     return n >= 2048 && (k < 32 || m <= 24576 || (n >= 4096 && m <= 49152) || m >= 196608);
 }
 
@@ -52,7 +56,7 @@ bool team_pays(long m, long n, int k) {
 TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
     TeamPlan p{};
     if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
-    if (k < 1 || k > TM_KP || n % 4 != 0 || n < 4 || cdiv(n, TM_C) > TM_MAXT || m < 4096) return p;
+    if (k < 1 || k > TM_KP || n % 4 != 0 || n < 4 || cdiv(n, TM_C) > (k <= 16 ? 2 * TM_MAXT : TM_MAXT) || m < 4096) return p;
     p.kp = k <= 16 ? 16 : 32;
     if (cus <= 0) cus = team_cus();
     p.T = (int)cdiv(n, TM_C);                                           // the last member's piece may be narrower (its columns beyond n read as zeros)
@@ -116,8 +120,14 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
     do {                                                                             \
         constexpr int SD16 = (SD) == 3 ? 2 : (SD);       /* the k <= 16 kernel's group is four stages long */ \
         static bool once = false;                                                    \
-        if (!once) { allow_lds(team_fro_kernel<SD, NT, 2, 2>, TM_LDS_BYTES + 64); allow_lds(team_fro_kernel<SD16, NT, 1, 3>, tm_lds_bytes(16) + 64); once = true; } \
-        if (p.kp == 16) hipLaunchKernelGGL((team_fro_kernel<SD16, NT, 1, 3>), grid, block, tm_lds_bytes(16), st, a); \
+        if (!once) {                                                                 \
+            allow_lds(team_fro_kernel<SD, NT, 2, 2>, TM_LDS_BYTES + 64);             \
+            allow_lds(team_fro_kernel<SD16, NT, 1, 3>, tm_lds_bytes(16) + 64);       \
+            allow_lds(team_fro_kernel<SD16, NT, 1, 3, 2 * TM_MAXT>, tm_lds_bytes(16) + 64); \
+            once = true;                                                             \
+        }                                                                            \
+        if (p.kp == 16 && p.T > TM_MAXT) hipLaunchKernelGGL((team_fro_kernel<SD16, NT, 1, 3, 2 * TM_MAXT>), grid, block, tm_lds_bytes(16), st, a); \
+        else if (p.kp == 16) hipLaunchKernelGGL((team_fro_kernel<SD16, NT, 1, 3>), grid, block, tm_lds_bytes(16), st, a); \
         else hipLaunchKernelGGL((team_fro_kernel<SD, NT, 2, 2>), grid, block, TM_LDS_BYTES, st, a); \
     } while (0)
 #ifdef DNMF_TUNING

@@ -20,7 +20,9 @@ SHAPES = [(4096, 2048, 32), (5000, 2048, 17), (4100, 4096, 24), (8192, 2560, 32)
           # k <= 16: the 16-wide instantiation (half the threads carry the 16 x 16 tile's elements)
           (4096, 2048, 16), (5003, 3072, 9), (8192, 4096, 1), (6000, 2560, 13),
           # n not a multiple of 512: the last member's piece is narrower (down to one lane's four columns)
-          (4096, 2052, 32), (5000, 4000, 24), (4100, 3332, 12), (4096, 2300, 16)]
+          (4096, 2052, 32), (5000, 4000, 24), (4100, 3332, 12), (4096, 2300, 16),
+          # k <= 16 beyond 4096 columns: teams of up to 16 members
+          (4096, 8192, 16), (5000, 6144, 7), (4100, 5000, 12)]
 
 
 @pytest.fixture(scope="module")
@@ -154,7 +156,8 @@ def test_policy_and_switch(env):
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 24) == 1
         assert lib.dnmf_mu_fro_onepass(65536, 4096, 16) == 1 and lib.dnmf_mu_fro_onepass(8192, 4000, 32) == 1
         assert lib.dnmf_mu_fro_onepass(8192, 4002, 32) == 0                # rows of A must be whole 16-byte groups
-        assert lib.dnmf_mu_fro_onepass(8192, 8192, 32) == 0               # more than eight 512-column pieces
+        assert lib.dnmf_mu_fro_onepass(8192, 8192, 32) == 0               # more than eight 512-column pieces at k > 16
+        assert lib.dnmf_mu_fro_onepass(8192, 8192, 16) == 1 and lib.dnmf_mu_fro_onepass(65536, 8192, 16) == 0
     finally:
         lib.dnmf_set_onepass(2)
     lib.dnmf_set_onepass(0)
