@@ -90,14 +90,18 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
                                                           const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
                                                           const float** P_out, int* nparts, const float** Pg_out, int* kp_out) {
     const TeamPlan p = team_plan(m, n, k);
-    if (!p.ok || dnmf_batch_()->B != 1) return 1;
+    if (!p.ok) return 1;
+    // a batched fit (blockIdx.z = problem in the other kernels): the team kernel takes the whole device, so the problems of a batch run one
+    // after the other -- each exactly as a fit of its own (bit-identical, as the batched entry points promise)
+    const int B = dnmf_batch_()->B;
     if (!(aligned16(A) && lda % 4 == 0 && lda >= n && aligned16(H) && ldh % 4 == 0 && ldh >= n && ldw >= k && aligned16(part))) return 1;
     if ((double)p.rpt * lda * 4.0 >= 2147483648.0 || part_bytes < p.total) return 1;
     hipStream_t st = S(stream);
-    char* base = (char*)part;
+    for (int z = 0; z < B; ++z) {
+    char* base = (char*)batch_ptr(part, z);
     TeamArgs a{};
-    a.A = A; a.lda = lda; a.m = m; a.n = (int)n; a.k = k;
-    a.H = H; a.ldh = ldh; a.G = G; a.W = W; a.ldw = ldw; a.eps = eps;
+    a.A = batch_ptr(A, z); a.lda = lda; a.m = m; a.n = (int)n; a.k = k;
+    a.H = (const float*)batch_ptr(H, z); a.ldh = ldh; a.G = (const float*)batch_ptr(G, z); a.W = (float*)batch_ptr(W, z); a.ldw = ldw; a.eps = eps;
     a.P = (float*)base;
     a.Pg = (float*)(base + p.pg_off);
     a.gx = (unsigned long long*)(base + p.gx_off);
@@ -147,8 +151,9 @@ __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m,
 #undef TEAM_LAUNCH
     (void)sd; (void)nt;
     if (int rc = check_launch("team_fro_kernel")) return rc;
-    *P_out = a.P;
-    *Pg_out = a.Pg;
+    }
+    *P_out = (const float*)part;                                      // problem 0's (the reduction launch moves to its own problem by blockIdx.z)
+    *Pg_out = (const float*)((const char*)part + p.pg_off);
     *kp_out = p.kp;
     *nparts = p.teams_used;
     return DNMF_OK;

@@ -185,3 +185,23 @@ def test_three_hundred_steps_twice_are_bit_identical(env):
     ops.hals_check()
     assert torch.equal(ends[0][0], ends[1][0]) and torch.equal(ends[0][1], ends[1][1])
     assert bool(torch.isfinite(ends[0][0]).all()) and bool(torch.isfinite(ends[0][1]).all())
+
+
+@pytest.mark.parametrize("m,n,k", [(4096, 2048, 12), (5000, 2560, 24)])
+def test_batched_fits_run_the_one_pass_step_per_problem_and_equal_single_fits(env, m, n, k):
+    """A batched whole fit (PyNMF.fit_batch: the perturbations of an NMFk sweep; every other kernel covers the batch with blockIdx.z) runs
+    the team kernel once per problem -- it takes the whole device anyway: the factors equal single fits BIT FOR BIT, and the checker."""
+    from oracle import nmf_oracle as orc
+    from pydnmfk_amd.pyDNMF import PyNMF
+    from tests.test_gpu_parity import _args
+    lib, _ = env
+    assert lib.dnmf_mu_fro_onepass(m, n, k) == 1
+    probs = [_mk(m, n, k, seed=31 + b) for b in range(3)]
+    itr = 12
+    single = [PyNMF(A, factors=[W0, H0], params=_args(k, itr, "fro")).fit() for A, W0, H0 in probs]
+    batch = PyNMF.fit_batch([PyNMF(A, factors=[W0, H0], params=_args(k, itr, "fro")) for A, W0, H0 in probs])
+    for (W1, H1, e1), (W2, H2, e2) in zip(single, batch):
+        assert np.array_equal(W1, W2) and np.array_equal(H1, H2) and abs(e1 - e2) <= 1e-12 * max(1.0, abs(e1))
+    Wr, Hr, _ = orc.fit_single(probs[1][0], probs[1][1], probs[1][2], itr, norm="fro", method="mu")
+    rel = lambda x, r: float(np.linalg.norm(np.asarray(x, dtype=np.float64) - r) / np.linalg.norm(r))
+    assert rel(batch[1][0], Wr) < 1e-4 and rel(batch[1][1], Hr) < 1e-4
