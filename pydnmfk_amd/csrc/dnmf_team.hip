@@ -47,15 +47,19 @@ int team_cus() {
 // Widths beyond 4096 (teams of 9-16 members, k <= 16 only): the exchange grows with the team (T + 2 planes per slab and member) and ate the
 // gain on tall blocks (65536 / 262144 x 8192: 1-3 %; 32768 x 6144, where 12-member teams leave a quarter of the CUs idle: 27 % SLOWER), so only
 // short blocks take it there (16384 x 8192: 22 %).
-bool team_pays(long m, long n, int k) {
+// Inside a BATCHED fit the two-pass kernels cover all problems with every launch (nothing launch-bound is left for the one-pass step to win on
+// short blocks, and it runs the problems one after the other): tools/batchbench.py, 8 x 32768 x 4096, k = 16: +24 % iterations per second;
+// 8 x 16384 x 4096: +18 %; 8 x 32768 x 2048, k = 8: +14 %; 6 x 65536 x 4096, k = 24: +8 %; 20 x 16384 x 2048, k = 10: -2 % -> from 2^26 elements, k < 32.
+bool team_pays(long m, long n, int k, bool batched) {
+    if (batched) return n >= 2048 && n <= 4096 && k < 32 && (double)m * n >= 67108864.0;
     if (n > 4096) return m <= 24576;
     return n >= 2048 && (k < 32 || m <= 24576 || (n >= 4096 && m <= 49152) || m >= 196608);
 }
 
 // shape-only part of the decision (the workspace query has no pointers); `cus` = 0: ask the device
-TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false) {
+TeamPlan team_plan(long m, long n, int k, int cus = 0, bool sizing = false, bool batched = false) {
     TeamPlan p{};
-    if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k))) && !sizing) return p;
+    if ((!g_team_on || !dnmf_persistent_on_() || (g_team_on == 1 && !team_pays(m, n, k, batched))) && !sizing) return p;
     if (k < 1 || k > TM_KP || n % 4 != 0 || n < 4 || cdiv(n, TM_C) > (k <= 16 ? 2 * TM_MAXT : TM_MAXT) || m < 4096) return p;
     p.kp = k <= 16 ? 16 : 32;
     if (cus <= 0) cus = team_cus();
@@ -89,7 +93,7 @@ __attribute__((visibility("hidden"))) size_t dnmf_team_ws_bytes_(long m, long n,
 __attribute__((visibility("hidden"))) int dnmf_team_fro_(const float* A, long m, long n, long lda, float* W, long ldw, const float* H, long ldh,
                                                           const float* G, int k, float eps, void* part, size_t part_bytes, void* stream,
                                                           const float** P_out, int* nparts, const float** Pg_out, int* kp_out) {
-    const TeamPlan p = team_plan(m, n, k);
+    const TeamPlan p = team_plan(m, n, k, 0, false, dnmf_batch_()->B > 1);
     if (!p.ok) return 1;
     // a batched fit (blockIdx.z = problem in the other kernels): the team kernel takes the whole device, so the problems of a batch run one
     // after the other -- each exactly as a fit of its own (bit-identical, as the batched entry points promise)
