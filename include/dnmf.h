@@ -305,9 +305,9 @@ int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, l
  * (v_mfma_f64_16x16x4_f64), one plain tile shape each -- correctness first, the fp32 path is the tuned one.  Everything is `double`
  * in device memory, row-major, leading dimensions in elements; eps = 2.220446049250313e-16; k <= DNMF_TUNED_MAX_K; Gram matrices are
  * plain k x k blocks with their own leading dimension `ldg` (no padding contract).  `ws` >= dnmf_f64_ws_bytes(m, n, k) where an
- * entry point takes one.  The KL products go through the materialised quotient U = A / (W H + eps) (dnmf_f64_kl_quot, an m x n
- * buffer of the caller -- the reference materialises it too, dist_nmf.py:806) followed by dnmf_f64_aht / dnmf_f64_wta on U; the
- * error evaluation through the materialised squared residual (dnmf_f64_sqdiff) and the ordered sums.  Host sequencing of these
+ * entry point takes one.  The KL products (dnmf_f64_kl_uht / dnmf_f64_kl_wtu) keep the quotient U = A / (W H + eps) in registers up to
+ * k = 64 and go through the materialised image beyond (dnmf_f64_kl_quot into an m x n buffer of the caller -- the reference materialises
+ * it too, dist_nmf.py:806 -- followed by dnmf_f64_aht / dnmf_f64_wta on U); the error evaluation through the materialised squared residual (dnmf_f64_sqdiff) and the ordered sums.  Host sequencing of these
  * primitives (1D and 2D grids, exchanges over torch.distributed): pydnmfk_amd/dist_nmf.py with engine.HipOpsF64. ---- */
 size_t dnmf_f64_ws_bytes(long m, long n, int k);
 /* A whole float64 fit on one rank (PyNMF.fit, pyDNMF.py:138-182): `itr` steps of method 0 = MU/FRO (dist_nmf.py:716-751), 1 = MU/KL
@@ -337,6 +337,14 @@ int dnmf_f64_mu_update_h(double* H, int k, long n, long ldh, const double* AtW, 
 /* U[m x n] = A / (W H + eps)   (dist_nmf.py:806) */
 int dnmf_f64_kl_quot(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
                      double* U, long ldu, void* stream);
+/* The two KL products without the image: S[m x k] = (A / (W H + eps)) H^T (dist_nmf.py:806, :810) and S[k x n] = W^T (A / (W H + eps))
+ * (:806, :808).  k <= 64: ONE pass over A each -- a wave forms a 16 x 16 tile of W H on the matrix cores, divides in registers and feeds
+ * the quotient to the second product as an MFMA operand (csrc/dnmf_f64_kl.h); U may be NULL.  k > 64: dnmf_f64_kl_quot into U (m x n,
+ * leading dimension n; DNMF_EINVAL if NULL) followed by dnmf_f64_aht / dnmf_f64_wta.  ws >= dnmf_f64_ws_bytes(m, n, k). */
+int dnmf_f64_kl_uht(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                    double* S, long lds_, double* U, void* ws, size_t ws_bytes, void* stream);
+int dnmf_f64_kl_wtu(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                    double* S, long lds_, double* U, void* ws, size_t ws_bytes, void* stream);
 /* R[m x n] = (A - W H)^2 element-wise   (pyDNMF.py:207, :229) */
 int dnmf_f64_sqdiff(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double* R,
                     long ldr, void* stream);

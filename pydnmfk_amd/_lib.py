@@ -146,6 +146,8 @@ SIGNATURES["dnmf_f64_fit"] = [c_int, c_void_p, c_long, c_long, c_long, c_void_p,
 SIGNATURES["dnmf_f64_mu_update_w"] = [c_void_p, c_long, c_int, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_void_p]
 SIGNATURES["dnmf_f64_mu_update_h"] = [c_void_p, c_int, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_double, c_int, c_void_p]
 SIGNATURES["dnmf_f64_kl_quot"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_double, c_void_p, c_long, c_void_p]
+for _n in ("dnmf_f64_kl_uht", "dnmf_f64_kl_wtu"):      # A m n lda W ldw H ldh k eps S lds U ws ws_bytes stream
+    SIGNATURES[_n] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_double, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_sqdiff"] = [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p]
 SIGNATURES["dnmf_f64_sum"] = [c_void_p, c_long, c_long, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
 SIGNATURES["dnmf_f64_colsum"] = SIGNATURES["dnmf_f64_sum"]

@@ -43,6 +43,40 @@ __device__ __forceinline__ void ldn(double (&d)[N], const double* __restrict__ r
     } else d[0] = (ok && c < cend) ? row[c] : 0.0;
 }
 
+// ---- MUBUF operand loads (dnmf_common.h "buffer addressing").  Round 6: the flat loads above sit behind runtime branches (vector or
+// element-wise, in or out of range), and hipcc answers a load under a branch with s_waitcnt vmcnt(0) at the next use -- the "two
+// register sets" of the NT / TN kernels never overlapped anything (3 waits in f64_nt_kernel<4,4>, all vmcnt(0), behind 335 branches).
+// A buffer load needs no branch: a lane is switched off through its offset, rows beyond the operand fall outside the descriptor's
+// byte count (the hardware returns 0), a 16-byte access only needs 4-byte alignment.
+// descriptor over `bytes` bytes from `base` (both wave-uniform; at most 2 GiB: offsets are 31-bit, BUF_OOB is the off switch)
+__device__ __forceinline__ i32x4 rsrc64(const double* base, long bytes) {
+    i32x4 r = buf_rsrc(base);
+    const long b = bytes < 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffffL : bytes);
+    r[2] = __builtin_amdgcn_readfirstlane((int)b);
+    return r;
+}
+// N consecutive doubles (N = 1, 2, 4) at byte offset vo + soff; `nvalid` of them are in range (the rest: zero).  VEC: nvalid is 0 or N
+// by construction of the caller (column counts divisible by N), so the lane moves as a whole
+template <int N, bool VEC>
+__device__ __forceinline__ void ldq(double (&d)[N], i32x4 rs, int vo, int soff, int nvalid) {
+    if constexpr (VEC) {
+        const int o = nvalid > 0 ? vo : BUF_OOB;
+        if constexpr (N == 4) {
+            const f32x4 a = buf_ld_f32x4(rs, o, soff, 0), b = buf_ld_f32x4(rs, o + 16, soff, 0);
+            const f64x2 x = __builtin_bit_cast(f64x2, a), y = __builtin_bit_cast(f64x2, b);
+            d[0] = x[0]; d[1] = x[1]; d[2] = y[0]; d[3] = y[1];
+        } else if constexpr (N == 2) {
+            const f64x2 x = __builtin_bit_cast(f64x2, buf_ld_f32x4(rs, o, soff, 0));
+            d[0] = x[0]; d[1] = x[1];
+        } else d[0] = __builtin_bit_cast(double, buf_ld_f32x2(rs, o, soff, 0));
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) d[e] = __builtin_bit_cast(double, buf_ld_f32x2(rs, e < nvalid ? vo + 8 * e : BUF_OOB, soff, 0));
+    }
+}
+__device__ __forceinline__ int sgpr(long x) { return __builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int clampi(long x, int hi) { return x < 0 ? 0 : (x > hi ? hi : (int)x); }
+
 // ================================================================================================ NT form
 // out[split][r][j] = sum_{c in split} X[r][c] Y[j][c];  one wave = RT 16-row tiles x NT 16-column tiles of the output.
 // Round 5 (second pass): the first version gave a wave ONE row tile, so every wave read all of Y for 16 rows of X -- four times the
@@ -52,13 +86,14 @@ __device__ __forceinline__ void ldn(double (&d)[N], const double* __restrict__ r
 // CH = 16-column chunks per step: lane group q owns the 4 CH CONSECUTIVE columns c + 4 CH q .. of a step in both operands (the order of
 // the contraction is free), so a row moves in pieces of 128 CH bytes.
 constexpr int nt_ch(int rt, int nt) { return rt * nt <= 8 ? 2 : 1; }      // (two register sets of loads must fit 256 VGPRs)
-template <int RT, int NT>
+// VEC: n % 4 == 0 (a lane's four columns are in range together)
+template <int RT, int NT, bool VEC, int D = 2>      // D = register sets of loads in flight (chunk c + D - 1 is issued before the MFMAs of chunk c)
 __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ X, long ldx, long m, long n, const double* __restrict__ Y,
                                                      long ldy, int kc, double* __restrict__ out, long ldo, long split_stride,
-                                                     long cols_per_split, int vx, int vy) {
+                                                     long cols_per_split) {
     constexpr int CH = nt_ch(RT, NT);
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * RT);
+    const long r0 = ((long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * (16 * RT);
     if (r0 >= m) return;
     const long cb = (long)blockIdx.y * cols_per_split;
     const long ce = cb + cols_per_split < n ? cb + cols_per_split : n;
@@ -67,22 +102,28 @@ __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ 
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const double* xrow[RT]; bool rok[RT];
-    const double* yrow[NT]; bool jok[NT];
+    // the wave's rows of X behind one descriptor (rows beyond m: outside its byte count), one descriptor per 16-row tile of Y
+    const long rows = m - r0 < 16 * RT ? m - r0 : 16 * RT;
+    const i32x4 xd = rsrc64(X + r0 * ldx, ((rows - 1) * ldx + n) * 8);
+    i32x4 yd[NT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { const long r = r0 + 16 * rt + i; rok[rt] = r < m; xrow[rt] = X + (rok[rt] ? r : m - 1) * ldx; }
+    for (int t = 0; t < NT; ++t) yd[t] = rsrc64(Y + (long)16 * t * ldy, ((long)(kc - 16 * t - 1) * ldy + n) * 8);
+    int xvo[RT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { const int j = 16 * t + i; jok[t] = j < kc; yrow[t] = Y + (long)(jok[t] ? j : kc - 1) * ldy; }
-    auto load = [&](double (&a)[RT][CH][4], double (&b)[NT][CH][4], long c) {
+    for (int rt = 0; rt < RT; ++rt) xvo[rt] = (int)(((16 * rt + i) * ldx + 4 * CH * q) * 8);
+    const int yvo = (int)((i * ldy + 4 * CH * q) * 8);
+    auto load = [&](double (&a)[RT][CH][4], double (&b)[NT][CH][4], long c) __attribute__((always_inline)) {
+        const int so = sgpr(c * 8);
 #pragma unroll
         for (int v = 0; v < CH; ++v) {
+            const int nv = clampi(ce - (c + 4 * CH * q + 4 * v), 4);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) ld4(a[rt][v], xrow[rt], c + 4 * CH * q + 4 * v, ce, rok[rt], vx != 0);
+            for (int rt = 0; rt < RT; ++rt) ldq<4, VEC>(a[rt][v], xd, xvo[rt] + 32 * v, so, nv);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ld4(b[t][v], yrow[t], c + 4 * CH * q + 4 * v, ce, jok[t], vy != 0);
+            for (int t = 0; t < NT; ++t) ldq<4, VEC>(b[t][v], yd[t], yvo + 32 * v, so, nv);
         }
     };
-    auto mma = [&](const double (&a)[RT][CH][4], const double (&b)[NT][CH][4]) {
+    auto mma = [&](const double (&a)[RT][CH][4], const double (&b)[NT][CH][4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < CH; ++v)
 #pragma unroll
@@ -93,16 +134,20 @@ __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ 
                     for (int t = 0; t < NT; ++t) acc[rt][t] = MFMA64(a[rt][v][e], b[t][v][e], acc[rt][t]);
     };
     constexpr long STEP = 16 * CH;
-    double a0[RT][CH][4], b0[NT][CH][4], a1[RT][CH][4], b1[NT][CH][4];
-    load(a0, b0, cb);
-    for (long c = cb; c < ce; c += 2 * STEP) {
-        const bool second = c + STEP < ce;
-        if (second) load(a1, b1, c + STEP);
-        mma(a0, b0);
-        if (!second) break;
-        if (c + 2 * STEP < ce) load(a0, b0, c + 2 * STEP);
-        mma(a1, b1);
-    }
+    double a[D][RT][CH][4], b[D][NT][CH][4];
+    const long nch = cdiv(ce - cb, STEP);
+    auto colof = [&](long it) __attribute__((always_inline)) { return cb + it * STEP; };
+    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
+        if (d < nch) load(a[d], b[d], colof(d));
+    });
+    for (long it = 0; it < nch; it += D)
+        static_for<0, D>([&](auto d) __attribute__((always_inline)) {
+            const long ii = it + d;
+            if (ii < nch) {
+                if (ii + (D - 1) < nch) load(a[(d + D - 1) % D], b[(d + D - 1) % D], colof(ii + (D - 1)));
+                mma(a[d], b[d]);
+            }
+        });
     double* o = out + (long)blockIdx.y * split_stride;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -122,14 +167,16 @@ __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ 
 // The MFMA's 16 columns / 16 rows are a free permutation of the output's: column tile cb holds the columns c0 + CT i + cb, so lane i
 // reads CT consecutive doubles of a row of Y with one access (and writes its results the same way); row tile t holds the factor
 // columns (t / VJ) 16 VJ + VJ i + t % VJ (VJ = min(NT, 4) consecutive doubles of a row of X per lane).
+// Operands through per-tile descriptors (16 rows from the tile's first: rows beyond the chunk lie outside the byte count).
+// VEC: n % CT == 0 and kc % VJ == 0.
 constexpr int tn_ct(int nt) { return nt <= 4 ? 4 : 2; }
-template <int NT>
+template <int NT, bool VEC, int D = 2>
 __global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ X, long ldx, int kc, const double* __restrict__ Y, long ldy,
                                                      long n, long m, long rows_per_chunk, int ncolblk, long nwaves,
-                                                     double* __restrict__ P, long chunk_stride, long ldp, int vx, int vy) {
+                                                     double* __restrict__ P, long chunk_stride, long ldp) {
     constexpr int VJ = NT < 4 ? NT : 4, NV = NT / VJ, CT = tn_ct(NT);
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long gw = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (gw >= nwaves) return;
     const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * (16 * CT);
     const long rb = chunk * rows_per_chunk;
@@ -139,18 +186,25 @@ __global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int cb = 0; cb < CT; ++cb) acc[t][cb] = f64x4{0.0, 0.0, 0.0, 0.0};
-    auto load = [&](double (&a)[4][NV][VJ], double (&b)[4][CT], long r) {
+    int yvo[4], xvo[4], nvx[NV];
+    const int nvy = clampi(n - (c0 + CT * i), CT);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        yvo[u] = (int)(((q + 4 * u) * ldy + c0 + CT * i) * 8);
+        xvo[u] = (int)(((q + 4 * u) * ldx + VJ * i) * 8);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) nvx[v] = clampi(kc - (16 * VJ * v + VJ * i), VJ);
+    auto load = [&](double (&a)[4][NV][VJ], double (&b)[4][CT], long r) __attribute__((always_inline)) {
+        const i32x4 yd = rsrc64(Y + r * ldy, ((re - r - 1) * ldy + n) * 8), xd = rsrc64(X + r * ldx, ((re - r - 1) * ldx + kc) * 8);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                              // four steps of 4 rows
-            const long row = r + 4 * u + q;
-            const bool ok = row < re;
-            const long rr = ok ? row : re - 1;
-            ldn<CT>(b[u], Y + rr * ldy, c0 + CT * i, n, ok, vy != 0);
+            ldq<CT, VEC>(b[u], yd, yvo[u], 0, nvy);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) ldn<VJ>(a[u][v], X + rr * ldx, 16 * VJ * v + VJ * i, kc, ok, vx != 0);
+            for (int v = 0; v < NV; ++v) ldq<VJ, VEC>(a[u][v], xd, xvo[u] + 16 * VJ * 8 * v, 0, nvx[v]);
         }
     };
-    auto mma = [&](const double (&a)[4][NV][VJ], const double (&b)[4][CT]) {
+    auto mma = [&](const double (&a)[4][NV][VJ], const double (&b)[4][CT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -158,16 +212,18 @@ __global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ 
 #pragma unroll
                 for (int cb = 0; cb < CT; ++cb) acc[t][cb] = MFMA64(a[u][t / VJ][t % VJ], b[u][cb], acc[t][cb]);
     };
-    double a0[4][NV][VJ], b0[4][CT], a1[4][NV][VJ], b1[4][CT];
-    load(a0, b0, rb);
-    for (long r = rb; r < re; r += 32) {
-        const bool second = r + 16 < re;
-        if (second) load(a1, b1, r + 16);
-        mma(a0, b0);
-        if (!second) break;
-        if (r + 32 < re) load(a0, b0, r + 32);
-        mma(a1, b1);
-    }
+    double a[D][4][NV][VJ], b[D][4][CT];
+    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
+        if (rb + 16 * d < re) load(a[d], b[d], rb + 16 * d);
+    });
+    for (long r = rb; r < re; r += 16 * D)
+        static_for<0, D>([&](auto d) __attribute__((always_inline)) {
+            const long rr = r + 16 * d;
+            if (rr < re) {
+                if (rr + 16 * (D - 1) < re) load(a[(d + D - 1) % D], b[(d + D - 1) % D], rr + 16 * (D - 1));
+                mma(a[d], b[d]);
+            }
+        });
     double* o = P + chunk * chunk_stride;
     const bool vst = (ldp % 2 == 0) && (((uintptr_t)P & 15) == 0) && (chunk_stride % 2 == 0);
 #pragma unroll
@@ -497,6 +553,8 @@ __global__ __launch_bounds__(256) void f64_hals_h_kernel(double* __restrict__ H,
 
 // ------------------------------------------------------------------------------------------------ host side
 bool vec_ok(const double* p, long ld) { return ((uintptr_t)p & 15) == 0 && ld % 2 == 0; }
+// `rows` rows of pitch ld (plus one more row of slack for the lane offsets inside a row) stay inside a descriptor's 31-bit offsets
+bool buf_ok(long ld, long rows) { return (rows + 1) * ld * 8 < 0x7fffffffL; }
 
 struct TnPlan64 { int ncolblk; long nchunks, rows_per_chunk; };
 TnPlan64 plan_tn64(long m, long n, int k) {
@@ -566,6 +624,9 @@ int launch_nn_rows(const double* X, long ldx, long m, int kc, const double* Y, l
     return check_launch("f64 nn");
 }
 
+#include "dnmf_f64_kl.h"
+inline bool kl64_buf_ok(long lda, long ldw, long ldh, int k) { return buf_ok(lda, 16) && buf_ok(ldw, 16) && buf_ok(ldh, k); }
+
 }  // namespace
 
 extern "C" {
@@ -585,6 +646,7 @@ size_t dnmf_f64_ws_bytes(long m, long n, int k) {
     if (nt_splits(m, n) > 1) b = std::max(b, (size_t)nt_splits(m, n) * m * kp * D);    // A H^T of a short A
     b = std::max(b, colsum_slabs(m, n) * D);                                           // column sums of an m x n image
     b = std::max(b, colsum_slabs(m, k) * D);                                           // column sums of W
+    b = std::max(b, kl64_ws_bytes(m, n, k));                                           // the fused KL products (partial slabs)
     return al256(b) + 256;
 }
 
@@ -602,16 +664,20 @@ int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int
         if (!ws || ws_bytes < (size_t)nsplit * m * kp * sizeof(double)) return fail(DNMF_EWS, "f64 aht: workspace too small");
         out = (double*)ws; ldo = kp; sstride = m * kp;
     }
-    const int vx = vec_ok(X, ldx) && cps % 2 == 0, vy = vec_ok(Y, ldy) && cps % 2 == 0;
+    REQ(buf_ok(ldx, 16) && buf_ok(ldy, kc), "f64 aht: a row pitch beyond the 2 GiB window of the float64 operand loads");
+    const bool vec = n % 4 == 0;
     const int nt = tiles16(kc);
     int rt = (m >= 16 * 4 * 256 && nt <= 4) ? 4 : (m >= 16 * 2 * 256 ? 2 : 1);     // row tiles per wave: 16 accumulators at most
     if (tune("DNMF_F64_NT_RT", 0)) rt = (int)tune("DNMF_F64_NT_RT", 0);
-#define NT_CASE(RT_, NT_) hipLaunchKernelGGL((f64_nt_kernel<RT_, NT_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)nsplit), dim3(256), 0, st, \
-                                             X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps, vx, vy)
+    while (rt > 1 && !buf_ok(ldx, 16 * rt)) rt >>= 1;
+#define NT_LAUNCH(RT_, NT_, VEC_) hipLaunchKernelGGL((f64_nt_kernel<RT_, NT_, VEC_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)nsplit), dim3(256), 0, st, \
+                                                     X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps)
+#define NT_CASE(RT_, NT_) do { if (vec) NT_LAUNCH(RT_, NT_, true); else NT_LAUNCH(RT_, NT_, false); } while (0)
 #define NT_ROWS(NT_) do { if (rt == 4) NT_CASE(4, NT_); else if (rt == 2) NT_CASE(2, NT_); else NT_CASE(1, NT_); } while (0)
     if (nt <= 1) NT_ROWS(1); else if (nt <= 2) NT_ROWS(2); else if (nt <= 4) NT_ROWS(4); else if (rt >= 2) NT_CASE(2, 8); else NT_CASE(1, 8);
 #undef NT_ROWS
 #undef NT_CASE
+#undef NT_LAUNCH
     int rc = check_launch("f64 aht");
     if (rc || nsplit == 1) return rc;
     launch_reduce64((const double*)ws, sstride, ldo, (int)nsplit, C, ldc, m, (long)kc, st);
@@ -629,10 +695,14 @@ int dnmf_f64_wta(const double* Y, long m, long n, long ldy, const double* X, int
     if (ws_bytes < (size_t)p.nchunks * kp * ldp * sizeof(double)) return fail(DNMF_EWS, "f64 wta: workspace too small");
     const long nwaves = p.nchunks * p.ncolblk;
     const dim3 grid((unsigned)cdiv(nwaves, 4));
-    const int vx = vec_ok(X, ldx), vy = vec_ok(Y, ldy);
-#define TN_CASE(NT_) hipLaunchKernelGGL((f64_tn_kernel<NT_>), grid, dim3(256), 0, st, X, ldx, kc, Y, ldy, n, m, p.rows_per_chunk, p.ncolblk, nwaves, \
-                                        (double*)ws, (long)kp * ldp, ldp, vx, vy)
+    REQ(buf_ok(ldx, 16) && buf_ok(ldy, 16), "f64 wta: a row pitch beyond the 2 GiB window of the float64 operand loads");
     const int nt = tiles16(kc);
+    const int ntk = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : 8;                    // the instantiation below
+    const bool vec = n % tn_ct(ntk) == 0 && kc % std::min(ntk, 4) == 0;
+#define TN_CASE(NT_) do { if (vec) hipLaunchKernelGGL((f64_tn_kernel<NT_, true>), grid, dim3(256), 0, st, X, ldx, kc, Y, ldy, n, m, p.rows_per_chunk, p.ncolblk, nwaves, \
+                                                      (double*)ws, (long)kp * ldp, ldp); \
+                          else hipLaunchKernelGGL((f64_tn_kernel<NT_, false>), grid, dim3(256), 0, st, X, ldx, kc, Y, ldy, n, m, p.rows_per_chunk, p.ncolblk, nwaves, \
+                                                  (double*)ws, (long)kp * ldp, ldp); } while (0)
     if (nt <= 1) TN_CASE(1); else if (nt <= 2) TN_CASE(2); else if (nt <= 4) TN_CASE(4); else TN_CASE(8);
 #undef TN_CASE
     int rc = check_launch("f64 wta");
@@ -664,6 +734,72 @@ int dnmf_f64_kl_quot(const double* A, long m, long n, long lda, const double* W,
                      double* U, long ldu, void* stream) {
     REQ(A && W && H && U && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && lda >= n && ldw >= k && ldh >= n && ldu >= n, "f64 kl_quot: bad arguments");
     return launch_nn_rows<NN_QUOT>(W, ldw, m, k, H, ldh, n, A, lda, U, ldu, eps, ST(stream));
+}
+
+// S[m x k] = (A / (W H + eps)) H^T  (dist_nmf.py:806, :810) -- k <= 64: one pass over A, the quotient never leaves the registers
+// (csrc/dnmf_f64_kl.h); beyond: through the image U (m x n, the caller's; DNMF_EINVAL without one)
+int dnmf_f64_kl_uht(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                    double* S, long lds_, double* U, void* ws, size_t ws_bytes, void* stream) {
+    REQ(A && W && H && S && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && lda >= n && ldw >= k && ldh >= n && lds_ >= k, "f64 kl_uht: bad arguments");
+    if (k > KL64_MAX_K || tune("DNMF_F64_KL_IMAGE", 0) || !kl64_buf_ok(lda, ldw, ldh, k)) {
+        REQ(U, "f64 kl_uht: k = %d > %d needs the m x n image U", k, KL64_MAX_K);
+        int rc = dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream);
+        return rc ? rc : dnmf_f64_aht(U, m, n, n, H, k, ldh, S, lds_, ws, ws_bytes, stream);
+    }
+    hipStream_t st = ST(stream);
+    KlUhtPlan p = plan_kl_uht(m, n, k);
+    if (tune("DNMF_F64_KL_RT", 0)) { p.rt = (int)tune("DNMF_F64_KL_RT", 0); }
+    const int kp = 16 * tiles16(k);
+    double* out = S; long ldo = lds_, sstride = 0;
+    if (p.nsplit > 1) {
+        if (!ws || ws_bytes < (size_t)p.nsplit * m * kp * sizeof(double)) return fail(DNMF_EWS, "f64 kl_uht: workspace too small");
+        out = (double*)ws; ldo = kp; sstride = m * kp;
+    }
+    const bool vec = n % 4 == 0;
+    while (p.rt > 1 && !(buf_ok(lda, 16 * p.rt) && buf_ok(ldw, 16 * p.rt))) p.rt >>= 1;
+#define UHT_LAUNCH(NT_, RT_, VEC_) hipLaunchKernelGGL((f64_kl_uht_kernel<NT_, RT_, VEC_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)p.nsplit), dim3(256), 0, st, \
+                                                      A, lda, m, n, W, ldw, H, ldh, k, eps, out, ldo, sstride, p.cps)
+#define UHT_CASE(NT_, RT_) do { if (vec) UHT_LAUNCH(NT_, RT_, true); else UHT_LAUNCH(NT_, RT_, false); } while (0)
+    const int nt = tiles16(k);
+    if (nt <= 2 && p.rt >= 4) { if (nt <= 1) UHT_CASE(1, 4); else UHT_CASE(2, 4); }
+    else if (p.rt >= 2) { if (nt <= 1) UHT_CASE(1, 2); else if (nt <= 2) UHT_CASE(2, 2); else UHT_CASE(4, 2); }
+    else { if (nt <= 1) UHT_CASE(1, 1); else if (nt <= 2) UHT_CASE(2, 1); else UHT_CASE(4, 1); }
+#undef UHT_LAUNCH
+#undef UHT_CASE
+    int rc = check_launch("f64 kl_uht");
+    if (rc || p.nsplit == 1) return rc;
+    launch_reduce64((const double*)ws, sstride, ldo, (int)p.nsplit, S, lds_, m, (long)k, st);
+    return check_launch("f64 kl_uht(reduce)");
+}
+
+// S[k x n] = W^T (A / (W H + eps))  (dist_nmf.py:806, :808) -- as dnmf_f64_kl_uht
+int dnmf_f64_kl_wtu(const double* A, long m, long n, long lda, const double* W, long ldw, const double* H, long ldh, int k, double eps,
+                    double* S, long lds_, double* U, void* ws, size_t ws_bytes, void* stream) {
+    REQ(A && W && H && S && ws && m >= 1 && n >= 1 && k >= 1 && k <= DNMF_TUNED_MAX_K && lda >= n && ldw >= k && ldh >= n && lds_ >= n, "f64 kl_wtu: bad arguments");
+    if (k > KL64_MAX_K || tune("DNMF_F64_KL_IMAGE", 0) || !kl64_buf_ok(lda, ldw, ldh, k)) {
+        REQ(U, "f64 kl_wtu: k = %d > %d needs the m x n image U", k, KL64_MAX_K);
+        int rc = dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream);
+        return rc ? rc : dnmf_f64_wta(U, m, n, n, W, k, ldw, S, lds_, ws, ws_bytes, stream);
+    }
+    hipStream_t st = ST(stream);
+    const KlWtuPlan p = plan_kl_wtu(m, n, k);
+    const int kp = 16 * tiles16(k);
+    const long ldp = round_up(n, 16);
+    if (ws_bytes < (size_t)p.nchunks * kp * ldp * sizeof(double)) return fail(DNMF_EWS, "f64 kl_wtu: workspace too small");
+    const long nwaves = p.nchunks * p.ncolblk;
+    const dim3 grid((unsigned)cdiv(nwaves, 4));
+    const int nt = tiles16(k);
+    const bool vec = n % p.ct == 0 && k % 4 == 0;
+#define WTU_CASE(NT_) do { if (vec) hipLaunchKernelGGL((f64_kl_wtu_kernel<NT_, kl_ct(NT_), true>), grid, dim3(256), 0, st, A, lda, m, n, W, ldw, H, ldh, k, eps, \
+                                                       p.rows_per_chunk, p.ncolblk, nwaves, (double*)ws, (long)kp * ldp, ldp); \
+                           else hipLaunchKernelGGL((f64_kl_wtu_kernel<NT_, kl_ct(NT_), false>), grid, dim3(256), 0, st, A, lda, m, n, W, ldw, H, ldh, k, eps, \
+                                                   p.rows_per_chunk, p.ncolblk, nwaves, (double*)ws, (long)kp * ldp, ldp); } while (0)
+    if (nt <= 1) WTU_CASE(1); else if (nt <= 2) WTU_CASE(2); else WTU_CASE(4);
+#undef WTU_CASE
+    int rc = check_launch("f64 kl_wtu");
+    if (rc) return rc;
+    launch_reduce64((const double*)ws, (long)kp * ldp, ldp, (int)p.nchunks, S, lds_, (long)k, n, st);
+    return check_launch("f64 kl_wtu(reduce)");
 }
 
 // R[m x n] = (A - W H)^2 element-wise  (pyDNMF.py:207, :229: the caller sums it -- dnmf_f64_sum / dnmf_f64_colsum)
@@ -782,13 +918,11 @@ int dnmf_f64_fit(int method, const double* A, long m, long n, long lda, double* 
         } else if (method == 1) {                                                     // dist_nmf.py:806-849
             if (w_update) {
                 F64(dnmf_f64_rowsum(H, k, n, ldh, x, stream));
-                F64(dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream));
-                F64(dnmf_f64_aht(U, m, n, n, H, k, ldh, S, k, prim, prim_bytes, stream));
+                F64(dnmf_f64_kl_uht(A, m, n, lda, W, ldw, H, ldh, k, eps, S, k, U, prim, prim_bytes, stream));
                 F64(dnmf_f64_ew(4, W, m, k, ldw, S, k, x, eps, 0, stream));
             }
             F64(dnmf_f64_colsum(W, m, k, ldw, 0, x, prim, prim_bytes, stream));
-            F64(dnmf_f64_kl_quot(A, m, n, lda, W, ldw, H, ldh, k, eps, U, n, stream));
-            F64(dnmf_f64_wta(U, m, n, n, W, k, ldw, S, n, prim, prim_bytes, stream));
+            F64(dnmf_f64_kl_wtu(A, m, n, lda, W, ldw, H, ldh, k, eps, S, n, U, prim, prim_bytes, stream));
             F64(dnmf_f64_ew(3, H, k, n, ldh, S, n, x, eps, clamp, stream));
             if (clamp) F64(dnmf_f64_ew(0, W, m, k, ldw, nullptr, 0, nullptr, eps, 0, stream));
         } else {                                                                      // dist_nmf.py:873-934

@@ -725,11 +725,23 @@ class HipOpsF64:
                                    U.data_ptr(), n, _stream()))
         return U
 
+    def _kl_product(self, fn, A, W, H, eps, out):
+        """one of the two KL products: fused up to k = 64 (the quotient stays in registers, csrc/dnmf_f64_kl.h), through the m x n
+        image beyond"""
+        r = self._r; r(A, "A"); r(W, "W"); r(H, "H"); r(out, "S")
+        m, n = A.shape
+        k = W.shape[1]
+        U = self._image(m, n, A.device) if k > 64 else None
+        ws = self._ws(m, n, k, A.device)
+        check(fn(A.data_ptr(), m, n, _ld(A), W.data_ptr(), _ld(W), H.data_ptr(), _ld(H), k, float(eps), out.data_ptr(), _ld(out),
+                 U.data_ptr() if U is not None else None, ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
     def kl_uht(self, A, W, H, eps, out):
-        return self.aht(self._quot(A, W, H, eps), H, out)          # (A / (W H + eps)) H^T, dist_nmf.py:806,810
+        return self._kl_product(lib.dnmf_f64_kl_uht, A, W, H, eps, out)      # (A / (W H + eps)) H^T, dist_nmf.py:806,810
 
     def kl_wtu(self, A, W, H, eps, out):
-        return self.wta(self._quot(A, W, H, eps), W, out)          # W^T (A / (W H + eps)), dist_nmf.py:806,808
+        return self._kl_product(lib.dnmf_f64_kl_wtu, A, W, H, eps, out)      # W^T (A / (W H + eps)), dist_nmf.py:806,808
 
     def rowsum(self, H, out):
         self._r(H, "H"); self._r(out, "x", 1)

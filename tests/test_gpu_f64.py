@@ -106,6 +106,31 @@ def test_f64_primitives_match_torch(ops, m, n, k):
     assert rel(Hh, Hr) < 1e-11
 
 
+@pytest.mark.parametrize("m,n,k", [(33, 20, 1), (500, 77, 7), (1000, 2048, 16), (700, 1500, 17), (4100, 530, 32), (2500, 1030, 33),
+                                   (9000, 260, 48), (3000, 1200, 64), (70000, 96, 64), (40000, 130, 12), (1500, 300, 65)])
+def test_f64_fused_kl_products(ops, m, n, k):
+    """The KL products that keep the quotient in registers (k <= 64; csrc/dnmf_f64_kl.h) against torch float64 on the same operands:
+    every tile count of k, ragged rows / columns, the column-split form of a short A (partial slabs + ordered reduction), both row-tile
+    counts per wave; k = 65 takes the image path behind the same entry point.  Padded outputs: only the product block is written."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11 * m + 3 * n + k)
+    A = torch.rand(m, n, dtype=torch.float64, device=dev, generator=g)
+    A[A < 0.2] = 0.0                                                  # (sparse-ish counts, as KL data are)
+    W = torch.rand(m, k, dtype=torch.float64, device=dev, generator=g)
+    H = torch.rand(k, n, dtype=torch.float64, device=dev, generator=g)
+    U = A / (W @ H + EPS)
+    S1 = torch.full((m, k + 3), 7.0, dtype=torch.float64, device=dev)
+    ops.kl_uht(A, W, H, EPS, S1[:, :k])
+    assert rel(S1[:, :k], U @ H.t()) < 1e-13 and float(S1[:, k:].min()) == 7.0
+    S2 = torch.full((k + 1, n + 2), 7.0, dtype=torch.float64, device=dev)
+    ops.kl_wtu(A, W, H, EPS, S2[:k, :n])
+    assert rel(S2[:k, :n], W.t() @ U) < 1e-13 and float(S2[k:].min()) == 7.0 and float(S2[:, n:].min()) == 7.0
+    # twice the same bits
+    S3 = torch.empty(m, k, dtype=torch.float64, device=dev)
+    ops.kl_uht(A, W, H, EPS, S3)
+    assert torch.equal(S3, S1[:, :k])
+
+
 @pytest.mark.parametrize("m,n,k", [(200, 150, 6), (2100, 333, 20), (4200, 131, 64), (9000, 70, 100),
                                    (20000, 200, 40), (17000, 130, 100), (16500, 77, 20)])      # (tall shapes: four row tiles per wave)
 def test_f64_products_on_unaligned_views(ops, m, n, k):

@@ -47,6 +47,15 @@ def main():
         ms = timed(fn)
         out["kernels"][name] = {"ms": ms, "tflops": flops / ms / 1e9, "frac_fp64_mfma": flops / ms / 1e9 / PEAK_TF,
                                 "algorithmic_gbs": byts / ms / 1e6, "frac_hbm": byts / ms / 1e6 / PEAK_GBS}
+    # the two KL products (fused up to k = 64: csrc/dnmf_f64_kl.h), checked against torch on the way
+    for name, fn, ref in (("kl_uht ((A / (W H + eps)) H^T)", lambda: ops.kl_uht(A, W, H, eps, AH), lambda: (A / (W @ H + eps)) @ H.t()),
+                          ("kl_wtu (W^T (A / (W H + eps)))", lambda: ops.kl_wtu(A, W, H, eps, AtW), lambda: W.t() @ (A / (W @ H + eps)))):
+        got, want = fn(), ref()
+        err = float((got - want).abs().max() / want.abs().max())
+        ms = timed(fn)
+        out["kernels"][name] = {"ms": ms, "tflops": 2 * fl / ms / 1e9, "frac_fp64_mfma": 2 * fl / ms / 1e9 / PEAK_TF,
+                                "algorithmic_gbs": 8.0 * m * n / ms / 1e6, "rel_err_vs_torch": err}
+        del want
     comms = MPI_comm(None, 1, 1)
     for norm in ("fro", "kl"):
         p = parse()
