@@ -137,16 +137,14 @@ __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ 
     double a[D][RT][CH][4], b[D][NT][CH][4];
     const long nch = cdiv(ce - cb, STEP);
     auto colof = [&](long it) __attribute__((always_inline)) { return cb + it * STEP; };
-    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
-        if (d < nch) load(a[d], b[d], colof(d));
-    });
+    // A load under a condition makes hipcc's wait counts conservative at the join (it then waits for the loads it has just issued:
+    // the same lesson as csrc/dnmf_team.h), so nothing here is conditional: the trip count is rounded up to the ring depth, a chunk
+    // beyond the range loads zeros (all its lanes are switched off) and its MFMAs add nothing.
+    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) { load(a[d], b[d], colof(d)); });
     for (long it = 0; it < nch; it += D)
         static_for<0, D>([&](auto d) __attribute__((always_inline)) {
-            const long ii = it + d;
-            if (ii < nch) {
-                if (ii + (D - 1) < nch) load(a[(d + D - 1) % D], b[(d + D - 1) % D], colof(ii + (D - 1)));
-                mma(a[d], b[d]);
-            }
+            load(a[(d + D - 1) % D], b[(d + D - 1) % D], colof(it + d + (D - 1)));
+            mma(a[d], b[d]);
         });
     double* o = out + (long)blockIdx.y * split_stride;
 #pragma unroll
@@ -213,16 +211,12 @@ __global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ 
                 for (int cb = 0; cb < CT; ++cb) acc[t][cb] = MFMA64(a[u][t / VJ][t % VJ], b[u][cb], acc[t][cb]);
     };
     double a[D][4][NV][VJ], b[D][4][CT];
-    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
-        if (rb + 16 * d < re) load(a[d], b[d], rb + 16 * d);
-    });
+    // (nothing conditional around a load, see f64_nt_kernel: a tile beyond the range has descriptors of zero bytes and reads zeros)
+    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) { load(a[d], b[d], rb + 16 * d); });
     for (long r = rb; r < re; r += 16 * D)
         static_for<0, D>([&](auto d) __attribute__((always_inline)) {
-            const long rr = r + 16 * d;
-            if (rr < re) {
-                if (rr + 16 * (D - 1) < re) load(a[(d + D - 1) % D], b[(d + D - 1) % D], rr + 16 * (D - 1));
-                mma(a[d], b[d]);
-            }
+            load(a[(d + D - 1) % D], b[(d + D - 1) % D], r + 16 * (d + D - 1));
+            mma(a[d], b[d]);
         });
     double* o = P + chunk * chunk_stride;
     const bool vst = (ldp % 2 == 0) && (((uintptr_t)P & 15) == 0) && (chunk_stride % 2 == 0);
@@ -757,9 +751,10 @@ int dnmf_f64_kl_uht(const double* A, long m, long n, long lda, const double* W, 
     }
     const bool vec = n % 4 == 0;
     while (p.rt > 1 && !(buf_ok(lda, 16 * p.rt) && buf_ok(ldw, 16 * p.rt))) p.rt >>= 1;
-#define UHT_LAUNCH(NT_, RT_, VEC_) hipLaunchKernelGGL((f64_kl_uht_kernel<NT_, RT_, VEC_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)p.nsplit), dim3(256), 0, st, \
-                                                      A, lda, m, n, W, ldw, H, ldh, k, eps, out, ldo, sstride, p.cps)
-#define UHT_CASE(NT_, RT_) do { if (vec) UHT_LAUNCH(NT_, RT_, true); else UHT_LAUNCH(NT_, RT_, false); } while (0)
+    const bool full = n % p.cps == 0 && p.cps % 64 == 0;          // every split a whole number of groups of four tiles: the mask-free kernel
+#define UHT_LAUNCH(NT_, RT_, VEC_, FULL_) hipLaunchKernelGGL((f64_kl_uht_kernel<NT_, RT_, VEC_, FULL_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)p.nsplit), dim3(256), 0, st, \
+                                                             A, lda, m, n, W, ldw, H, ldh, k, eps, out, ldo, sstride, p.cps)
+#define UHT_CASE(NT_, RT_) do { if (full) UHT_LAUNCH(NT_, RT_, true, true); else if (vec) UHT_LAUNCH(NT_, RT_, true, false); else UHT_LAUNCH(NT_, RT_, false, false); } while (0)
     const int nt = tiles16(k);
     if (nt <= 2 && p.rt >= 4) { if (nt <= 1) UHT_CASE(1, 4); else UHT_CASE(2, 4); }
     else if (p.rt >= 2) { if (nt <= 1) UHT_CASE(1, 2); else if (nt <= 2) UHT_CASE(2, 2); else UHT_CASE(4, 2); }

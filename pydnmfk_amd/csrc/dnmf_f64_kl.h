@@ -30,9 +30,8 @@ __device__ __forceinline__ double div_pos64(double a, double d) {
 // rho = q + 4 reg is c0 + 4 q + reg (so a lane's four elements of A are consecutive), contraction index of step s in lane group q is
 // j = q KS + s (KS consecutive doubles of a row of W).  Operands through buffer descriptors (dnmf_f64.hip "MUBUF operand loads"): no
 // branch around a load, masks in the lane offsets; the column advance is the wave-uniform SGPR offset.  VEC: n % 4 == 0.
-// Full tiles carry no mask at all (EDGE = false): a row beyond m reads zeros and only feeds its own, never stored, output row; the
-// last tile of a split masks its columns.
-template <int NT, int RT, bool VEC, int D = 2>
+// No row mask anywhere: a row beyond m reads zeros and only feeds its own, never stored, output row.  FULL: no column mask either.
+template <int NT, int RT, bool VEC, bool FULL, int D = 2>
 __global__ __launch_bounds__(256) void f64_kl_uht_kernel(const double* __restrict__ A, long lda, long m, long n, const double* __restrict__ W, long ldw,
                                                          const double* __restrict__ H, long ldh, int kc, double eps, double* __restrict__ out, long ldo,
                                                          long split_stride, long cols_per_split) {
@@ -69,12 +68,17 @@ __global__ __launch_bounds__(256) void f64_kl_uht_kernel(const double* __restric
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
-    auto load = [&](auto edge, double (&a)[RT][4], double (&h1)[KS], double (&h2)[NT][4], long c0) __attribute__((always_inline)) {
+    auto load_a = [&](auto edge, double (&a)[RT][4], long c0) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge)::value;
+        const int so = sgpr(c0 * 8);
+        const int nv = EDGE ? clampi(ce - (c0 + 4 * q), 4) : 4;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ldq<4, VEC || !EDGE>(a[rt], ad, avo[rt], so, nv);
+    };
+    auto load_h = [&](auto edge, double (&h1)[KS], double (&h2)[NT][4], long c0) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge)::value;
         const int so = sgpr(c0 * 8);
         const int nv = EDGE ? clampi(ce - (c0 + 4 * q), 4) : 4, n1 = EDGE ? (c0 + c1 < ce ? 1 : 0) : 1;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) ldq<4, VEC || !EDGE>(a[rt], ad, avo[rt], so, nv);
 #pragma unroll
         for (int s = 0; s < KS; ++s) { double t1[1]; ldq<1, true>(t1, hd, h1vo[s], so, n1); h1[s] = t1[0]; }
 #pragma unroll
@@ -104,22 +108,23 @@ __global__ __launch_bounds__(256) void f64_kl_uht_kernel(const double* __restric
                 for (int t = 0; t < NT; ++t) acc[rt][t] = MFMA64(u[e], h2[t][e], acc[rt][t]);
         }
     };
-    // full tiles [cb, cfull) in the ring, then the last (partial or full, masked) tile on its own
-    const long nfull = (ce - cb) / 16 - ((ce - cb) % 16 == 0 ? 1 : 0);
-    double a[D][RT][4], h1[D][KS], h2[D][NT][4];
-    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
-        if (d < nfull) load(std::false_type{}, a[d], h1[d], h2[d], cb + 16 * d);
-    });
-    for (long it = 0; it < nfull; it += D)
-        static_for<0, D>([&](auto d) __attribute__((always_inline)) {
-            const long ii = it + d;
-            if (ii < nfull) {
-                if (ii + (D - 1) < nfull) load(std::false_type{}, a[(d + D - 1) % D], h1[(d + D - 1) % D], h2[(d + D - 1) % D], cb + 16 * (ii + (D - 1)));
-                tile(std::false_type{}, a[d], h1[d], h2[d], cb + 16 * ii);
-            }
+    // Two rings: the pieces of A come from HBM and are small (RT x 4 doubles a lane) -- DA tiles ahead; the operands from H come from
+    // the L2 and are large -- one tile ahead.  Nothing is conditional around a load (f64_nt_kernel): FULL = every split is a whole number
+    // of groups of U tiles (the host checks), the loads of the last groups that would run past the split re-read its last tile into ring
+    // slots nobody consumes; otherwise every tile carries its column mask and a tile beyond the split is all zeros.
+    constexpr int DA = D + 2, U = DA % 2 == 0 ? DA : 2 * DA;
+    const long ntiles = cdiv(ce - cb, 16);
+    auto tcol = [&](long t) __attribute__((always_inline)) { return cb + 16 * (FULL ? (t < ntiles ? t : ntiles - 1) : t); };
+    using EdgeT = std::integral_constant<bool, !FULL>;
+    double a[DA][RT][4], h1[2][KS], h2[2][NT][4];
+    static_for<0, DA - 1>([&](auto d) __attribute__((always_inline)) { load_a(EdgeT{}, a[d], tcol(d)); });
+    load_h(EdgeT{}, h1[0], h2[0], cb);
+    for (long it = 0; it < ntiles; it += U)
+        static_for<0, U>([&](auto d) __attribute__((always_inline)) {
+            load_a(EdgeT{}, a[(d + DA - 1) % DA], tcol(it + d + (DA - 1)));
+            load_h(EdgeT{}, h1[(d + 1) % 2], h2[(d + 1) % 2], tcol(it + d + 1));
+            tile(EdgeT{}, a[d % DA], h1[d % 2], h2[d % 2], cb + 16 * (it + d));
         });
-    load(std::true_type{}, a[0], h1[0], h2[0], cb + 16 * nfull);
-    tile(std::true_type{}, a[0], h1[0], h2[0], cb + 16 * nfull);
     double* o = out + (long)blockIdx.y * split_stride;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -174,8 +179,13 @@ __global__ __launch_bounds__(256) void f64_kl_wtu_kernel(const double* __restric
     for (int v = 0; v < NT; ++v) nv1[v] = clampi(kc - (q * KS + 4 * v), 4);
 #pragma unroll
     for (int v = 0; v < NV; ++v) nv2[v] = clampi(kc - (16 * VJ * v + VJ * i), VJ);
-    auto load = [&](double (&w1)[KS], double (&w2)[4][NV][VJ], double (&av)[4][CT], long r0) __attribute__((always_inline)) {
-        const i32x4 ad = rsrc64(A + r0 * lda, ((re - r0 - 1) * lda + n) * 8), wd = rsrc64(W + r0 * ldw, ((re - r0 - 1) * ldw + kc) * 8);
+    auto load_a = [&](double (&av)[4][CT], long r0) __attribute__((always_inline)) {
+        const i32x4 ad = rsrc64(A + r0 * lda, ((re - r0 - 1) * lda + n) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ldq<CT, VEC>(av[r], ad, avo[r], 0, nva);
+    };
+    auto load_w = [&](double (&w1)[KS], double (&w2)[4][NV][VJ], long r0) __attribute__((always_inline)) {
+        const i32x4 wd = rsrc64(W + r0 * ldw, ((re - r0 - 1) * ldw + kc) * 8);
 #pragma unroll
         for (int v = 0; v < NT; ++v) {
             double t4[4];
@@ -184,11 +194,9 @@ __global__ __launch_bounds__(256) void f64_kl_wtu_kernel(const double* __restric
             for (int e = 0; e < 4; ++e) w1[4 * v + e] = t4[e];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ldq<CT, VEC>(av[r], ad, avo[r], 0, nva);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int v = 0; v < NV; ++v) ldq<VJ, VEC>(w2[r][v], wd, w2vo[r] + 16 * VJ * 8 * v, 0, nv2[v]);
-        }
     };
     auto tile = [&](auto edge, const double (&w1)[KS], const double (&w2)[4][NV][VJ], const double (&av)[4][CT], long r0) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge)::value;
@@ -213,21 +221,18 @@ __global__ __launch_bounds__(256) void f64_kl_wtu_kernel(const double* __restric
                 for (int cb = 0; cb < CT; ++cb) acc[t][cb] = MFMA64(w2[r][t / VJ][t % VJ], u[cb], acc[t][cb]);
         }
     };
-    const long nfull = (re - rb) / 16 - ((re - rb) % 16 == 0 ? 1 : 0);        // full tiles in the ring, the last one (masked) on its own
-    double w1[D][KS], w2[D][4][NV][VJ], av[D][4][CT];
-    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) {
-        if (d < nfull) load(w1[d], w2[d], av[d], rb + 16 * d);
-    });
-    for (long it = 0; it < nfull; it += D)
-        static_for<0, D>([&](auto d) __attribute__((always_inline)) {
-            const long ii = it + d;
-            if (ii < nfull) {
-                if (ii + (D - 1) < nfull) load(w1[(d + D - 1) % D], w2[(d + D - 1) % D], av[(d + D - 1) % D], rb + 16 * (ii + (D - 1)));
-                tile(std::false_type{}, w1[d], w2[d], av[d], rb + 16 * ii);
-            }
+    // rings: A DA tiles ahead (from HBM), the rows of W one tile ahead (from the L2); nothing conditional around a load (f64_nt_kernel):
+    // the trip count is rounded up, a tile beyond the row range has descriptors of zero bytes, reads zeros and is masked like the last rows
+    constexpr int DA = D + 2, U = DA % 2 == 0 ? DA : 2 * DA;
+    double w1[2][KS], w2[2][4][NV][VJ], av[DA][4][CT];
+    static_for<0, DA - 1>([&](auto d) __attribute__((always_inline)) { load_a(av[d], rb + 16 * d); });
+    load_w(w1[0], w2[0], rb);
+    for (long r = rb; r < re; r += 16 * U)
+        static_for<0, U>([&](auto d) __attribute__((always_inline)) {
+            load_a(av[(d + DA - 1) % DA], r + 16 * (d + DA - 1));
+            load_w(w1[(d + 1) % 2], w2[(d + 1) % 2], r + 16 * (d + 1));
+            tile(std::true_type{}, w1[d % 2], w2[d % 2], av[d % DA], r + 16 * d);
         });
-    load(w1[0], w2[0], av[0], rb + 16 * nfull);
-    tile(std::true_type{}, w1[0], w2[0], av[0], rb + 16 * nfull);
     double* o = P + chunk * chunk_stride;
     const bool vst = (ldp % 2 == 0) && (((uintptr_t)P & 15) == 0) && (chunk_stride % 2 == 0);
 #pragma unroll
@@ -260,7 +265,7 @@ inline KlUhtPlan plan_kl_uht(long m, long n, int k) {
     while (p.rt > 1 && cdiv(m, 16 * p.rt) < 1024) p.rt >>= 1;      // (a wave per SIMD first)
     const long wr = cdiv(m, 16 * p.rt);
     long ns = std::max<long>(1, std::min<long>(2048 / wr, n / 512));
-    p.cps = round_up(cdiv(n, ns), 16);
+    p.cps = round_up(cdiv(n, ns), 64);                             // (whole groups of four tiles where n allows: the mask-free kernel)
     p.nsplit = cdiv(n, p.cps);
     return p;
 }
