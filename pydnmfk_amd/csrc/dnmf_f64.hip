@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void f64_nt_kernel(const double* __restrict__ 
     for (long it = 0; it < nch; it += D)
         static_for<0, D>([&](auto d) __attribute__((always_inline)) {
             load(a[(d + D - 1) % D], b[(d + D - 1) % D], colof(it + d + (D - 1)));
+            __builtin_amdgcn_sched_barrier(0);                    // (the loads of a step go out before its MFMAs: hipcc otherwise spreads them over the block)
             mma(a[d], b[d]);
         });
     double* o = out + (long)blockIdx.y * split_stride;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void f64_tn_kernel(const double* __restrict__ 
     for (long r = rb; r < re; r += 16 * D)
         static_for<0, D>([&](auto d) __attribute__((always_inline)) {
             load(a[(d + D - 1) % D], b[(d + D - 1) % D], r + 16 * (d + D - 1));
+            __builtin_amdgcn_sched_barrier(0);
             mma(a[d], b[d]);
         });
     double* o = P + chunk * chunk_stride;
@@ -664,7 +666,8 @@ int dnmf_f64_aht(const double* X, long m, long n, long ldx, const double* Y, int
     int rt = (m >= 16 * 4 * 256 && nt <= 4) ? 4 : (m >= 16 * 2 * 256 ? 2 : 1);     // row tiles per wave: 16 accumulators at most
     if (tune("DNMF_F64_NT_RT", 0)) rt = (int)tune("DNMF_F64_NT_RT", 0);
     while (rt > 1 && !buf_ok(ldx, 16 * rt)) rt >>= 1;
-#define NT_LAUNCH(RT_, NT_, VEC_) hipLaunchKernelGGL((f64_nt_kernel<RT_, NT_, VEC_>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)nsplit), dim3(256), 0, st, \
+// (three register sets in flight for k <= 16, where the kernel is a stream of A: 0.565 -> 0.509 ms at 65536 x 4096; two beyond)
+#define NT_LAUNCH(RT_, NT_, VEC_) hipLaunchKernelGGL((f64_nt_kernel<RT_, NT_, VEC_, (NT_ == 1 ? 3 : 2)>), dim3((unsigned)cdiv(cdiv(m, 16 * RT_), 4), (unsigned)nsplit), dim3(256), 0, st, \
                                                      X, ldx, m, n, Y, ldy, kc, out, ldo, sstride, cps)
 #define NT_CASE(RT_, NT_) do { if (vec) NT_LAUNCH(RT_, NT_, true); else NT_LAUNCH(RT_, NT_, false); } while (0)
 #define NT_ROWS(NT_) do { if (rt == 4) NT_CASE(4, NT_); else if (rt == 2) NT_CASE(2, NT_); else NT_CASE(1, NT_); } while (0)

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void f64_kl_uht_kernel(const double* __restric
         static_for<0, U>([&](auto d) __attribute__((always_inline)) {
             load_a(EdgeT{}, a[(d + DA - 1) % DA], tcol(it + d + (DA - 1)));
             load_h(EdgeT{}, h1[(d + 1) % 2], h2[(d + 1) % 2], tcol(it + d + 1));
+            __builtin_amdgcn_sched_barrier(0);                    // (loads first, see f64_nt_kernel)
             tile(EdgeT{}, a[d % DA], h1[d % 2], h2[d % 2], cb + 16 * (it + d));
         });
     double* o = out + (long)blockIdx.y * split_stride;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void f64_kl_wtu_kernel(const double* __restric
         static_for<0, U>([&](auto d) __attribute__((always_inline)) {
             load_a(av[(d + DA - 1) % DA], r + 16 * (d + DA - 1));
             load_w(w1[(d + 1) % 2], w2[(d + 1) % 2], r + 16 * (d + 1));
+            __builtin_amdgcn_sched_barrier(0);                    // (loads first, see f64_nt_kernel)
             tile(std::true_type{}, w1[d % 2], w2[d % 2], av[d % DA], r + 16 * d);
         });
     double* o = P + chunk * chunk_stride;
