@@ -326,41 +326,64 @@ __global__ __launch_bounds__(256) void f64_nn_rows_kernel(const double* X, long 
 // CONSECUTIVE doubles of its row of W.  (The first version kept 16 rows of W resident and re-read all of H per row tile -- four
 // times A's bytes through the L2 at k = 64 -- with nothing in flight under its MFMAs: 2.67 ms at 65536 x 4096, k = 64.)
 constexpr int nn_ct(int ks) { return ks <= 16 ? 4 : 2; }
-template <int KS, int MODE>
+// N consecutive doubles to byte offset vo of a descriptor, `nvalid` of them in range (VEC: 0 or N) -- the store twin of ldq: no branch
+// (a store under a branch makes the wait counts of the loads after it conservative, exactly as a load does); never with an SGPR offset
+// (dnmf_common.h RULE)
+template <int N, bool VEC>
+__device__ __forceinline__ void stq(const double (&d)[N], i32x4 rs, int vo, int nvalid) {
+    if constexpr (VEC && N == 4) {
+        const int o = nvalid > 0 ? vo : BUF_OOB;
+        buf_st_f32x4(__builtin_bit_cast(f32x4, f64x2{d[0], d[1]}), rs, o, 0, 0);
+        buf_st_f32x4(__builtin_bit_cast(f32x4, f64x2{d[2], d[3]}), rs, o + 16, 0, 0);
+    } else if constexpr (VEC && N == 2) {
+        buf_st_f32x4(__builtin_bit_cast(f32x4, f64x2{d[0], d[1]}), rs, nvalid > 0 ? vo : BUF_OOB, 0, 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) buf_st_f32x2(__builtin_bit_cast(f32x2, d[e]), rs, e < nvalid ? vo + 8 * e : BUF_OOB, 0, 0);
+    }
+}
+// Round 6: descriptor loads and stores, nothing conditional around a memory instruction (f64_nt_kernel).  VEC: n % CT == 0, kc % 4 == 0.
+template <int KS, int MODE, bool VEC, int D = 2>
 __global__ __launch_bounds__(256) void f64_nn_cols_kernel(const double* __restrict__ X, long ldx, long m, int kc, const double* __restrict__ Y,
                                                           long ldy, long n, const double* __restrict__ A, long lda, double* __restrict__ O,
-                                                          long ldo, double eps, long rows_per_wave, int ncolblk, long nwaves, int vx, int vy,
-                                                          int va, int vo) {
+                                                          long ldo, double eps, long rows_per_wave, int ncolblk, long nwaves) {
     constexpr int CT = nn_ct(KS);
     const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long gw = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (gw >= nwaves) return;
     const long chunk = gw / ncolblk, c0 = (gw % ncolblk) * (16 * CT);
     const long rb = chunk * rows_per_wave;
     const long re = rb + rows_per_wave < m ? rb + rows_per_wave : m;
+    const int nva = clampi(n - (c0 + CT * i), CT);
     double hb[KS][CT];
+    {
+        const i32x4 hd = rsrc64(Y, ((long)(kc - 1) * ldy + n) * 8);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int j = q * KS + s;
-        ldn<CT>(hb[s], Y + (long)(j < kc ? j : kc - 1) * ldy, c0 + CT * i, n, j < kc, vy != 0);
+        for (int s = 0; s < KS; ++s) ldq<CT, VEC>(hb[s], hd, q * KS + s < kc ? (int)(((q * KS + s) * ldy + c0 + CT * i) * 8) : BUF_OOB, 0, nva);
     }
-    auto load = [&](double (&xa)[KS], double (&av)[4][CT], long r0) {
-        const long row = r0 + i;
-        const double* xr = X + (row < re ? row : re - 1) * ldx;
+    const int xvo = (int)((i * ldx + q * KS) * 8);
+    int avo[4], ovo[4], nvx[KS / 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        avo[r] = (int)(((q + 4 * r) * lda + c0 + CT * i) * 8);
+        ovo[r] = (int)(((q + 4 * r) * ldo + c0 + CT * i) * 8);
+    }
+#pragma unroll
+    for (int v = 0; v < KS / 4; ++v) nvx[v] = clampi(kc - (q * KS + 4 * v), 4);
+    auto load = [&](double (&xa)[KS], double (&av)[4][CT], long r0) __attribute__((always_inline)) {
+        const i32x4 xd = rsrc64(X + r0 * ldx, ((re - r0 - 1) * ldx + kc) * 8), ad = rsrc64(A + r0 * lda, ((re - r0 - 1) * lda + n) * 8);
 #pragma unroll
         for (int v = 0; v < KS / 4; ++v) {
             double t4[4];
-            ld4(t4, xr, q * KS + 4 * v, kc, row < re, vx != 0);
+            ldq<4, VEC>(t4, xd, xvo + 32 * v, 0, nvx[v]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xa[4 * v + e] = t4[e];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long row2 = r0 + q + 4 * r;
-            ldn<CT>(av[r], A + (row2 < re ? row2 : re - 1) * lda, c0 + CT * i, n, row2 < re, va != 0);
-        }
+        for (int r = 0; r < 4; ++r) ldq<CT, VEC>(av[r], ad, avo[r], 0, nva);
     };
-    auto tile = [&](const double (&xa)[KS], const double (&av)[4][CT], long r0) {
+    auto tile = [&](const double (&xa)[KS], const double (&av)[4][CT], long r0) __attribute__((always_inline)) {
+        const i32x4 od = rsrc64(O + r0 * ldo, ((re - r0 - 1) * ldo + n) * 8);       // (rows beyond the range: outside the byte count, dropped)
         f64x4 acc[CT];
 #pragma unroll
         for (int cb = 0; cb < CT; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -370,8 +393,6 @@ __global__ __launch_bounds__(256) void f64_nn_cols_kernel(const double* __restri
             for (int cb = 0; cb < CT; ++cb) acc[cb] = MFMA64(xa[s], hb[s][cb], acc[cb]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long row = r0 + q + 4 * r;
-            if (row >= re) continue;
             double o[CT];
 #pragma unroll
             for (int cb = 0; cb < CT; ++cb) {
@@ -379,27 +400,17 @@ __global__ __launch_bounds__(256) void f64_nn_cols_kernel(const double* __restri
                 if constexpr (MODE == NN_QUOT) o[cb] = a / (sum + eps);
                 else { const double d = a - sum; o[cb] = d * d; }
             }
-            double* dst = O + row * ldo + c0 + CT * i;
-            if (vo && c0 + CT * i + CT <= n) {
-#pragma unroll
-                for (int cb = 0; cb < CT; cb += 2) *reinterpret_cast<f64x2*>(dst + cb) = f64x2{o[cb], o[cb + 1]};
-            } else {
-#pragma unroll
-                for (int cb = 0; cb < CT; ++cb)
-                    if (c0 + CT * i + cb < n) dst[cb] = o[cb];
-            }
+            stq<CT, VEC>(o, od, ovo[r], nva);
         }
     };
-    double xa0[KS], av0[4][CT], xa1[KS], av1[4][CT];
-    load(xa0, av0, rb);
-    for (long r = rb; r < re; r += 32) {
-        const bool second = r + 16 < re;
-        if (second) load(xa1, av1, r + 16);
-        tile(xa0, av0, r);
-        if (!second) break;
-        if (r + 32 < re) load(xa0, av0, r + 32);
-        tile(xa1, av1, r + 16);
-    }
+    double xa[D][KS], av[D][4][CT];
+    static_for<0, D - 1>([&](auto d) __attribute__((always_inline)) { load(xa[d], av[d], rb + 16 * d); });
+    for (long r = rb; r < re; r += 16 * D)
+        static_for<0, D>([&](auto d) __attribute__((always_inline)) {
+            load(xa[(d + D - 1) % D], av[(d + D - 1) % D], r + 16 * (d + D - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            tile(xa[d], av[d], r + 16 * d);
+        });
 }
 
 // NN form, column strips: H[j][c] *= S[j][c] / ((G H)[j][c] + eps) for the wave's 16 columns and ALL rows j (dist_nmf.py:750-751);
@@ -599,9 +610,12 @@ int launch_nn_rows(const double* X, long ldx, long m, int kc, const double* Y, l
         nch = std::min<long>(nch, std::max<long>(1, cdiv(m, 64)));
         const long rpw = round_up(cdiv(m, nch), 16);
         const long nwaves = cdiv(m, rpw) * ncolblk;
-        const int vx = vec_ok(X, ldx), vy = vec_ok(Y, ldy), va = vec_ok(A, lda), vo = vec_ok(O, ldo);
-#define NNC_CASE(KS_) hipLaunchKernelGGL((f64_nn_cols_kernel<KS_, MODE>), dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, st, X, ldx, m, kc, Y, ldy, n, \
-                                         A, lda, O, ldo, eps, rpw, ncolblk, nwaves, vx, vy, va, vo)
+        if (!(buf_ok(ldx, 16) && buf_ok(ldy, kc) && buf_ok(lda, 16) && buf_ok(ldo, 16))) return fail(DNMF_EINVAL, "f64 nn(cols): a row pitch beyond the 2 GiB window of the float64 operand loads");
+        const bool vec = n % nn_ct(ks) == 0 && kc % 4 == 0;
+#define NNC_CASE(KS_) do { if (vec) hipLaunchKernelGGL((f64_nn_cols_kernel<KS_, MODE, true>), dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, st, X, ldx, m, kc, Y, ldy, n, \
+                                                       A, lda, O, ldo, eps, rpw, ncolblk, nwaves); \
+                           else hipLaunchKernelGGL((f64_nn_cols_kernel<KS_, MODE, false>), dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, st, X, ldx, m, kc, Y, ldy, n, \
+                                                   A, lda, O, ldo, eps, rpw, ncolblk, nwaves); } while (0)
         if (ks == 4) NNC_CASE(4); else if (ks == 8) NNC_CASE(8); else if (ks == 16) NNC_CASE(16); else NNC_CASE(32);
 #undef NNC_CASE
         return check_launch("f64 nn(cols)");
