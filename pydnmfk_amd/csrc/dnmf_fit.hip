@@ -186,6 +186,9 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
     a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = w_update;
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+#ifdef DNMF_TUNING
+    a.w_update |= (int)tune("DNMF_SMALL_ABL", 0) << 8;
+#endif
     a.patience = g_small_patience;                                     // ticks of the 100 MHz wall clock (2 s unless dnmf_fit_set_timeout)
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
     if (!fro && !w_update) {

@@ -107,6 +107,37 @@ __device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, un
     __syncthreads();
 }
 
+// H (k x n, written by the other workgroups of the problem with write-through stores; read here with sc1 loads) -> rows [0, k) of Hs
+// (the rows [k, KP) are zeroed once, before the first step).  Wave wv takes the rows wv, wv + NW, ..., a lane four consecutive columns;
+// every load of a pass is in flight before the first value is used and no index is divided (round 6: the element-indexed copy, eight
+// loads in flight and a division per element, was 2.4 us of an 18.7 us step at k <= 16 and 5.6 of 29.3 at k = 17, tools/swimbench.py
+// under DNMF_SMALL_ABL).
+template <int NW, int KP>
+__device__ __forceinline__ void hs_fill(const float* H, long ldh, int k, int n, int NS, int LDH, float* Hs, int wv, int lane) {
+    const i32x4 hd = buf_rsrc(H);
+    constexpr int RB = (KP + NW - 1) / NW;                 // a wave's rows in one pass
+    for (int c0 = 0; c0 < NS; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        for (int j0 = wv; j0 < k; j0 += NW * RB) {
+            f32x4 v[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = j0 + u * NW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = buf_ld_f32(hd, (j < k && c + e < n) ? (int)((j * ldh + c + e) * 4) : BUF_OOB, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = j0 + u * NW;
+                if (j < k && c < NS) *reinterpret_cast<f32x4*>(&Hs[j * LDH + c]) = v[u];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void hs_zero_tail(float* Hs, int k, int KP, int LDH, int tid, int T) {
+    for (int idx = k * LDH + tid; idx < KP * LDH; idx += T) Hs[idx] = 0.f;
+}
+
 // ALDS: the slab of A lives in LDS for the whole fit.  !ALDS (k > 16 at the example sizes: slab + H + W do not fit 160 KiB with 128-row
 // slabs, and 64-row slabs of 20 problems do not fit the device in one launch): A streams from the L2 / Infinity Cache -- a problem is
 // ~1 MB -- with the next group's elements requested before this group's MFMAs; LDS then holds H and the slab's W only.
@@ -122,6 +153,12 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
     const int ksteps = (k + 3) >> 2;                      // contraction steps of 4 that hold real columns of W
+#ifdef DNMF_TUNING
+    const int abl = a.w_update >> 8;                       // ablations (WRONG results, timing only): 1 no barrier after the H update, 2 none before it, 4 no reload of H, 8 no H update
+    a.w_update &= 1;
+#else
+    constexpr int abl = 0;
+#endif
     const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + 4, LDH = NS + 4;
     float* pcs = part + (long)P * KP * NS;                 // [P][KP] column sums of W per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -161,19 +198,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
     auto load_h = [&]() {                                  // H -> LDS, then its row sums (every workgroup the same sums)
-        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {          // eight loads in flight per thread
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
-            }
-        }
+        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
         __syncthreads();
         for (int j = wv; j < KP; j += NW) {
             float s = 0.f;
@@ -185,6 +210,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
         }
         __syncthreads();
     };
+    hs_zero_tail(Hs, k, KP, LDH, tid, T);
     load_h();
     // the wave's rows of W as an MFMA operand: lane (row i, q) holds W[16 wv + i][4 s + q]
     float wreg[KS];
@@ -331,30 +357,33 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        if (!(abl & 2)) small_barrier(bar, (unsigned)P * ++gen, a.patience);
         // -------------------------------------------------------------------- H update: this workgroup's share of the elements
-        for (int e = p * T + tid; e < KP * NS; e += P * T) {
+        for (int e = p * T + tid; e < ((abl & 8) ? 0 : k * NS); e += P * T) {      // (the rows [k, KP) of H do not exist)
             const int j = e / NS, c = e - j * NS;
             float sum = 0.f, x = 0.f;                      // W^T U and the column sum of W over all slabs, slab order
-            for (int g0 = 0; g0 < P; g0 += 8) {             // eight partials of each in flight
-                float v[8], y[8];
+            auto add = [&](auto wide, int g0) __attribute__((always_inline)) {      // `wide` partials of each in flight
+                constexpr int WD = decltype(wide)::value;
+                float v[WD], y[WD];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < WD; ++u) {
                     const int g = g0 + u < P ? g0 + u : P - 1;
                     v[u] = ld_dev(&part[((long)g * KP + j) * NS + c]);
                     y[u] = ld_dev(&pcs[g * KP + j]);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { sum += (g0 + u < P) ? v[u] : 0.f; x += (g0 + u < P) ? y[u] : 0.f; }
-            }
+                for (int u = 0; u < WD; ++u) { sum += (g0 + u < P) ? v[u] : 0.f; x += (g0 + u < P) ? y[u] : 0.f; }
+            };
+            if (P <= 8) add(std::integral_constant<int, 8>{}, 0);                      // (one round trip for the slabs of a problem)
+            else for (int g0 = 0; g0 < P; g0 += 12) add(std::integral_constant<int, 12>{}, g0);
             float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(x + eps));
             if (j < k && c < n) {
                 if (clamp) h = fmaxf(h, eps);
                 st_dev(&H[(long)j * a.ldh + c], h);
             }
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience);
-        load_h();
+        if (!(abl & 1)) small_barrier(bar, (unsigned)P * ++gen, a.patience);
+        if (!(abl & 4)) load_h();
         if (clamp) {                                       // W = max(W, eps) after both updates (pyDNMF.py:155)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -447,19 +476,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
     auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
-        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
-            }
-        }
+        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
         __syncthreads();
         if (wv < JT * JT) {
             const int j1 = wv / JT, j2 = wv - j1 * JT;
@@ -475,6 +492,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         }
         __syncthreads();
     };
+    hs_zero_tail(Hs, k, KP, LDH, tid, T);
     load_h();
     float wreg[KS];
 #pragma unroll
@@ -602,16 +620,19 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
             Gs[(e / KP) * LDG + e % KP] = x;
         }
         __syncthreads();
-        for (int e = p * T + tid; e < KP * NS; e += P * T) {
+        for (int e = p * T + tid; e < k * NS; e += P * T) {  // (the rows [k, KP) of H do not exist)
             const int j = e / NS, c = e - j * NS;
             float sum = 0.f;
-            for (int g0 = 0; g0 < P; g0 += 8) {
-                float v[8];
+            auto add = [&](auto wide, int g0) __attribute__((always_inline)) {      // `wide` partials in flight
+                constexpr int WD = decltype(wide)::value;
+                float v[WD];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
+                for (int u = 0; u < WD; ++u) v[u] = ld_dev(&part[((long)(g0 + u < P ? g0 + u : P - 1) * KP + j) * NS + c]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
-            }
+                for (int u = 0; u < WD; ++u) sum += (g0 + u < P) ? v[u] : 0.f;
+            };
+            if (P <= 8) add(std::integral_constant<int, 8>{}, 0);
+            else for (int g0 = 0; g0 < P; g0 += 12) add(std::integral_constant<int, 12>{}, g0);
             float dot = 0.f;
 #pragma unroll
             for (int l = 0; l < KP; ++l) dot = fmaf(Gs[j * LDG + l], Hs[l * LDH + c], dot);
@@ -725,19 +746,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
         }
     }
     auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
-        for (int idx0 = tid; idx0 < KP * NS; idx0 += 8 * T) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                v[u] = (idx < KP * NS && j < k && c < n) ? ld_dev(&H[(long)j * a.ldh + c]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = idx0 + u * T, j = idx / NS, c = idx - j * NS;
-                if (idx < KP * NS) Hs[j * LDH + c] = v[u];
-            }
-        }
+        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
         __syncthreads();
         if (wv < JT * JT) {
             const int j1 = wv / JT, j2 = wv - j1 * JT;
@@ -753,6 +762,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
         }
         __syncthreads();
     };
+    hs_zero_tail(Hs, k, KP, LDH, tid, T);
     load_h();
     float wreg[KS];
 #pragma unroll
