@@ -37,7 +37,8 @@ SmallPlan small_kl_plan(long m, long n, int k) {
     }
     if (!s.nw) return s;
     s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;       // W^T U / W^T A partials + (KL) column sums or (FRO) W^T W per slab
-    s.bytes = ((s.part_floats * sizeof(float) + 255) & ~size_t(255)) + 256;          // ... + the arrival counter
+    s.part_floats = (s.part_floats + 3) & ~size_t(3);                                // ... + the granules {element, step} of H, 16-byte aligned
+    s.bytes = (((s.part_floats + 2 * (size_t)s.kp * s.ns) * sizeof(float) + 255) & ~size_t(255)) + 256;      // ... + the arrival counter
     s.ok = true;
     return s;
 }
@@ -84,7 +85,8 @@ FroBfPlan small_fro_bf16_plan(long m, long n, int k) {
     }
     if (!s.nw) return s;
     s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;
-    s.bytes = ((s.part_floats * sizeof(float) + 255) & ~size_t(255)) + 256;
+    s.part_floats = (s.part_floats + 3) & ~size_t(3);                                  // (the granules of H behind it: 16-byte aligned)
+    s.bytes = (((s.part_floats + 2 * (size_t)s.kp * s.ns) * sizeof(float) + 255) & ~size_t(255)) + 256;
     s.ok = true;
     return s;
 }
@@ -186,6 +188,7 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
     a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = w_update;
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.hg = a.part + sp.part_floats; a.hg_stride = a.part_stride;                       // [kp][ns] granules {H element, step}: zeroed below
 #ifdef DNMF_TUNING
     a.w_update |= (int)tune("DNMF_SMALL_ABL", 0) << 8;
 #endif
@@ -208,6 +211,7 @@ int small_fit(bool fro, const float* A, long m, long n, long lda, float* W, long
         }
     }
     if (hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
+    if (hipMemset2DAsync(a.hg, f.total, 0, 2 * (size_t)sp.kp * sp.ns * sizeof(float), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
 #define SMALL_CASE(KP_, NW_, AL_)                                                                                                 \
     if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
         return fro ? small_kl_launch<KP_, NW_, AL_, true>(sp, a, batch, st, taken) : small_kl_launch<KP_, NW_, AL_, false>(sp, a, batch, st, taken)
@@ -262,9 +266,11 @@ int small_fro_bf16_fit(const void* A, long m, long n, long lda, float* W, long l
     a.m = (int)m; a.n = (int)n; a.k = k; a.eps = eps; a.itr = itr; a.w_update = 1;
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.bar = (unsigned*)(ws + f.small_off + sp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.hg = a.part + sp.part_floats; a.hg_stride = a.part_stride;
     a.patience = g_small_patience;
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
     if (hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
+    if (hipMemset2DAsync(a.hg, f.total, 0, 2 * (size_t)sp.kp * sp.ns * sizeof(float), (size_t)batch, st) != hipSuccess) return fail(DNMF_EHIP, "small fit: memset failed");
 #define FROBF_CASE(KP_, NW_, AL_)                                                                                                 \
     if (sp.kp == KP_ && sp.nw == NW_ && sp.alds == AL_)                                                                           \
         return resident_launch(small_fro_fit_kernel<KP_, NW_, AL_, bf16_t>, 64 * NW_, sp.lds, sp.P, a, batch, st, taken, "small_fro_fit_kernel(bf16)")

@@ -45,6 +45,7 @@ struct SmallKlArgs {
     int z0;                                      // first problem of this launch
     unsigned* slots; long slots_stride;          // HALS: per problem [2][KP][P] column-norm partials (float bits; SLOT_EMPTY = not there yet)
     int cw;                                      // HALS: columns of H a workgroup sweeps (ceil(NS / P))
+    float* hg; long hg_stride;                   // MU fits: per problem [KP][NS] granules {H element, step tag} (zeroed before the launch)
 };
 
 __device__ unsigned int g_small_timeout = 0;     // sticky: a barrier of a persistent fit gave up (dnmf_hals_sweep_status reports it)
@@ -107,15 +108,30 @@ __device__ __forceinline__ void small_barrier(unsigned* bar, unsigned target, un
     __syncthreads();
 }
 
+// the row sums of the rows a wave has just copied (lane partials rs[u] of row wv + u NW) -> xs
+template <int NW, int RB>
+__device__ __forceinline__ void hs_row_sums(const float (&rs)[RB], float* xs, int k, int wv, int lane) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        float t = row16_sum(rs[u]);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane == 0 && wv + u * NW < k) xs[wv + u * NW] = t;
+    }
+}
 // H (k x n, written by the other workgroups of the problem with write-through stores; read here with sc1 loads) -> rows [0, k) of Hs
 // (the rows [k, KP) are zeroed once, before the first step).  Wave wv takes the rows wv, wv + NW, ..., a lane four consecutive columns;
 // every load of a pass is in flight before the first value is used and no index is divided (round 6: the element-indexed copy, eight
 // loads in flight and a division per element, was 2.4 us of an 18.7 us step at k <= 16 and 5.6 of 29.3 at k = 17, tools/swimbench.py
 // under DNMF_SMALL_ABL).
+// xs != nullptr: also the row sums of H (a wave owns whole rows: lane partials, then the wave's reduction) -> xs[j], j < k.
 template <int NW, int KP>
-__device__ __forceinline__ void hs_fill(const float* H, long ldh, int k, int n, int NS, int LDH, float* Hs, int wv, int lane) {
+__device__ __forceinline__ void hs_fill(const float* H, long ldh, int k, int n, int NS, int LDH, float* Hs, int wv, int lane, float* xs = nullptr) {
     const i32x4 hd = buf_rsrc(H);
     constexpr int RB = (KP + NW - 1) / NW;                 // a wave's rows in one pass
+    float rs[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) rs[u] = 0.f;
     for (int c0 = 0; c0 < NS; c0 += 256) {
         const int c = c0 + 4 * lane;
         for (int j0 = wv; j0 < k; j0 += NW * RB) {
@@ -130,9 +146,60 @@ __device__ __forceinline__ void hs_fill(const float* H, long ldh, int k, int n, 
             for (int u = 0; u < RB; ++u) {
                 const int j = j0 + u * NW;
                 if (j < k && c < NS) *reinterpret_cast<f32x4*>(&Hs[j * LDH + c]) = v[u];
+                rs[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
             }
         }
     }
+    if (xs) hs_row_sums<NW, RB>(rs, xs, k, wv, lane);
+}
+// The same copy from the GRANULES of H: the owners of the H update publish every new element as one 8-byte {value, tag = step} store
+// (MI355X_MICROARCH.md "R2 granule": an aligned 8-byte write-through store is observed whole), and a reader takes an element only with the
+// tag of the step it is waiting for -- the data is its own flag, so the device-wide barrier that used to stand between the H update and this
+// copy (1.2-1.5 us of a 19 us step) is gone.  No second buffer is needed: an owner overwrites an element for step t + 1 only after the
+// partials of step t have ALL arrived, and a workgroup writes those after it has read the whole H of step t.  Waits are bounded like
+// small_barrier's (bar[1] = the problem's abort word).
+template <int NW, int KP>
+__device__ __forceinline__ void hs_fill_granules(const float* Hg, int k, int n, int NS, int LDH, float* Hs, int wv, int lane, float want,
+                                                 unsigned* bar, unsigned long long patience, float* xs = nullptr) {
+    const i32x4 gd = buf_rsrc(Hg);
+    constexpr int RB = (KP + NW - 1) / NW;
+    float rs[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) rs[u] = 0.f;
+    for (int c0 = 0; c0 < NS; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        f32x2 g[RB][4];
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int j = wv + u * NW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[u][e] = buf_ld_f32x2(gd, (j < k && c + e < n) ? (j * NS + c + e) * 8 : BUF_OOB, 0, 16);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ok = ok && (!(wv + u * NW < k && c + e < n) || g[u][e][1] == want);
+            if (__all(ok)) break;
+            if ((++spins & 7u) == 7u && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > patience) {
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g_small_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = wv + u * NW;
+            if (j < k && c < NS) *reinterpret_cast<f32x4*>(&Hs[j * LDH + c]) = f32x4{g[u][0][0], g[u][1][0], g[u][2][0], g[u][3][0]};
+            rs[u] += (g[u][0][0] + g[u][1][0]) + (g[u][2][0] + g[u][3][0]);
+        }
+    }
+    if (xs) hs_row_sums<NW, RB>(rs, xs, k, wv, lane);
 }
 __device__ __forceinline__ void hs_zero_tail(float* Hs, int k, int KP, int LDH, int tid, int T) {
     for (int idx = k * LDH + tid; idx < KP * LDH; idx += T) Hs[idx] = 0.f;
@@ -150,11 +217,12 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
     float* H = a.H + (long)z * a.h_stride;
     float* part = a.part + (long)z * a.part_stride;
     unsigned* bar = a.bar + (long)z * a.bar_stride;
+    float* Hg = a.hg + (long)z * a.hg_stride;             // [KP][NS] granules of H (hs_fill_granules)
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
     const int ksteps = (k + 3) >> 2;                      // contraction steps of 4 that hold real columns of W
 #ifdef DNMF_TUNING
-    const int abl = a.w_update >> 8;                       // ablations (WRONG results, timing only): 1 no barrier after the H update, 2 none before it, 4 no reload of H, 8 no H update
+    const int abl = a.w_update >> 8;                       // ablations (WRONG results, timing only): 1 H without waiting for its granules, 2 no barrier before the H update, 4 no reload of H, 8 no H update
     a.w_update &= 1;
 #else
     constexpr int abl = 0;
@@ -197,21 +265,14 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
         const int r = idx / KP, j = idx - r * KP;
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
-    auto load_h = [&]() {                                  // H -> LDS, then its row sums (every workgroup the same sums)
-        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
-        __syncthreads();
-        for (int j = wv; j < KP; j += NW) {
-            float s = 0.f;
-            for (int c = lane; c < NS; c += 64) s += Hs[j * LDH + c];
-            s = row16_sum(s);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (lane == 0) xs[j] = s;
-        }
+    auto load_h = [&](float want) {                        // H -> LDS (want = 0: the caller's H; else the granules of that step), then its row sums
+        if (want == 0.f) hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane, xs);
+        else hs_fill_granules<NW, KP>(Hg, k, n, NS, LDH, Hs, wv, lane, want, bar, a.patience, xs);
         __syncthreads();
     };
     hs_zero_tail(Hs, k, KP, LDH, tid, T);
-    load_h();
+    if (tid >= k && tid < KP) xs[tid] = 0.f;
+    load_h(0.f);
     // the wave's rows of W as an MFMA operand: lane (row i, q) holds W[16 wv + i][4 s + q]
     float wreg[KS];
 #pragma unroll
@@ -355,7 +416,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (16 * jt + 4 * q + r < k) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);   // (only the k real rows are read)
         }
         if (!(abl & 2)) small_barrier(bar, (unsigned)P * ++gen, a.patience);
         // -------------------------------------------------------------------- H update: this workgroup's share of the elements
@@ -379,11 +441,12 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
             float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(x + eps));
             if (j < k && c < n) {
                 if (clamp) h = fmaxf(h, eps);
-                st_dev(&H[(long)j * a.ldh + c], h);
+                H[(long)j * a.ldh + c] = h;                                                    // (read by the host side only, after the launch)
+                buf_st_f32x2(f32x2{h, (float)(it + 1)}, buf_rsrc(Hg), (j * NS + c) * 8, 0, 16);   // published: value and step in one granule
             }
         }
-        if (!(abl & 1)) small_barrier(bar, (unsigned)P * ++gen, a.patience);
-        if (!(abl & 4)) load_h();
+        __syncthreads();                                   // (every thread has read its old elements of Hs)
+        if (!(abl & 4)) load_h((abl & 1) ? 0.f : (float)(it + 1));                              // (no device-wide barrier: the granules carry their step)
         if (clamp) {                                       // W = max(W, eps) after both updates (pyDNMF.py:155)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -419,6 +482,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
     float* H = a.H + (long)z * a.h_stride;
     float* part = a.part + (long)z * a.part_stride;
     unsigned* bar = a.bar + (long)z * a.bar_stride;
+    float* Hg = a.hg + (long)z * a.hg_stride;             // [KP][NS] granules of H (hs_fill_granules)
     const int m = a.m, n = a.n, k = a.k;
     const float eps = a.eps;
     const int NS = (n + 15) & ~15, nct = NS / 16, LDA = NS + (sizeof(TA) == 4 ? 4 : 8), LDH = NS + 4;
@@ -475,8 +539,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         const int r = idx / KP, j = idx - r * KP;
         Ws[r * LDW + j] = (r0 + r < m && j < k) ? W[(r0 + r) * a.ldw + j] : 0.f;
     }
-    auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
-        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
+    auto load_h = [&](float want) {                        // H -> LDS (want = 0: the caller's H; else the granules of that step), then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
+        if (want == 0.f) hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
+        else hs_fill_granules<NW, KP>(Hg, k, n, NS, LDH, Hs, wv, lane, want, bar, a.patience);
         __syncthreads();
         if (wv < JT * JT) {
             const int j1 = wv / JT, j2 = wv - j1 * JT;
@@ -493,7 +558,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
         __syncthreads();
     };
     hs_zero_tail(Hs, k, KP, LDH, tid, T);
-    load_h();
+    load_h(0.f);
     float wreg[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
@@ -594,7 +659,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (16 * jt + 4 * q + r < k) st_dev(&part[((long)p * KP + 16 * jt + 4 * q + r) * NS + c0 + i], acc3[0][jt][r] + acc3[1][jt][r]);   // (only the k real rows are read)
         }
         if (wv < JT * JT) {                                // the slab's W^T W: lane (i, q) reg r = G[16 j1 + 4 q + r][16 j2 + i]
             const int j1 = wv / JT, j2 = wv - j1 * JT;
@@ -639,11 +705,12 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
             float h = Hs[j * LDH + c] * (sum * __builtin_amdgcn_rcpf(dot + eps));
             if (j < k && c < n) {
                 if (clamp) h = fmaxf(h, eps);
-                st_dev(&H[(long)j * a.ldh + c], h);
+                H[(long)j * a.ldh + c] = h;                                                    // (read by the host side only, after the launch)
+                buf_st_f32x2(f32x2{h, (float)(it + 1)}, buf_rsrc(Hg), (j * NS + c) * 8, 0, 16);   // published: value and step in one granule
             }
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience);
-        load_h();
+        __syncthreads();                                   // (every thread has read its old elements of Hs and Gs)
+        load_h((float)(it + 1));                           // (no device-wide barrier: the granules carry their step)
         if (clamp) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
