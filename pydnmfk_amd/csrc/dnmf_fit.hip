@@ -63,8 +63,9 @@ HalsPlan small_hals_plan(long m, long n, int k) {
     }
     if (!s.nw) return s;
     s.part_floats = (size_t)s.P * s.kp * s.ns + (size_t)s.P * s.kp * s.kp;
-    s.slot_words = (size_t)2 * s.kp * s.P;
-    s.bytes = (((s.part_floats + s.slot_words) * 4 + 255) & ~size_t(255)) + 256;
+    s.slot_words = (((size_t)2 * s.kp * s.P) + 3) & ~size_t(3);
+    s.part_floats = (s.part_floats + 3) & ~size_t(3);
+    s.bytes = (((s.part_floats + s.slot_words + 2 * (size_t)s.kp * s.ns) * 4 + 255) & ~size_t(255)) + 256;      // partials | slots | granules of H | counter
     s.ok = true;
     return s;
 }
@@ -240,9 +241,11 @@ int small_hals_fit(bool bf, const void* A, long m, long n, long lda, float* W, l
     a.part = (float*)(ws + f.small_off); a.part_stride = (long)(f.total / sizeof(float));
     a.slots = (unsigned*)(ws + f.small_off) + hp.part_floats; a.slots_stride = (long)(f.total / sizeof(unsigned));
     a.bar = (unsigned*)(ws + f.small_off + hp.bytes - 256); a.bar_stride = (long)(f.total / sizeof(unsigned));
+    a.hg = a.part + hp.part_floats + hp.slot_words; a.hg_stride = a.part_stride;          // [kp][ns] granules {H element, step}
     a.patience = g_small_patience;
     if (batch == 1) { a.a_stride = a.w_stride = a.h_stride = 0; }
-    if (hipMemset2DAsync(a.slots, f.total, 0xff, hp.slot_words * sizeof(unsigned), (size_t)batch, st) != hipSuccess ||
+    if (hipMemset2DAsync(a.hg, f.total, 0, 2 * (size_t)hp.kp * hp.ns * sizeof(float), (size_t)batch, st) != hipSuccess ||
+        hipMemset2DAsync(a.slots, f.total, 0xff, hp.slot_words * sizeof(unsigned), (size_t)batch, st) != hipSuccess ||
         hipMemset2DAsync(a.bar, f.total, 0, 2 * sizeof(unsigned), (size_t)batch, st) != hipSuccess)
         return fail(DNMF_EHIP, "small fit: memset failed");
 #define HALS_CASE(KP_, NW_)                                                                                                       \

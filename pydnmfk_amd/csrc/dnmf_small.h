@@ -736,7 +736,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_fro_fit_kernel(SmallKlArgs a
 //     [parity][kk][slab] -- the value is its own flag -- and every workgroup collects the P slots (the same butterfly sum everywhere);
 //     w = u / norm; T[:, j] -= w G[kk][j] for j > kk.  One exchange per column: the price of the global column norm.
 //   H phase: W^T A + the slab's W^T W as in the Frobenius kernel; barrier; Gram and the workgroup's columns of W^T A summed in slab
-//     order, then a thread per column runs the k rows in sequence (:905-909) on the LDS copy of H; barrier; re-read H.
+//     order, then a thread per column runs the k rows in sequence (:905-909) on the LDS copy of H, published as {value, step} granules;
+//     re-read H from the granules (no second barrier: hs_fill_granules).
 //   The slots of a parity are reset by their owner after the first barrier of the step that used them: every reader is done with them
 //   by then, and they are not written again before the step after next.
 constexpr unsigned SLOT_EMPTY = 0xffffffffu;               // (a NaN pattern: a sum of squares of finite data never has it; NaN data would read as "not there yet" until the wait times out and the fit reports it)
@@ -753,6 +754,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
     float* part = a.part + (long)z * a.part_stride;
     unsigned* bar = a.bar + (long)z * a.bar_stride;
     unsigned* slots = a.slots + (long)z * a.slots_stride;
+    float* Hg = a.hg + (long)z * a.hg_stride;             // [KP][NS] granules of H (hs_fill_granules)
     const int m = a.m, n = a.n, k = a.k, cw = a.cw;
     const float eps = a.eps;
     const int NS = (n + 15) & ~15, nct = NS / 16, LDH = NS + 4;
@@ -812,8 +814,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
             As[r * LDA + c] = (r0 + r < m && c < n) ? A[(r0 + r) * a.lda + c] : TA(0);
         }
     }
-    auto load_h = [&]() {                                  // H -> LDS, then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
-        hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
+    auto load_h = [&](float want) {                        // H -> LDS (want = 0: the caller's H; else the granules of that step), then G = H H^T (wave t = jt1 JT + jt2 owns a 16 x 16 tile)
+        if (want == 0.f) hs_fill<NW, KP>(H, a.ldh, k, n, NS, LDH, Hs, wv, lane);
+        else hs_fill_granules<NW, KP>(Hg, k, n, NS, LDH, Hs, wv, lane, want, bar, a.patience);
         __syncthreads();
         if (wv < JT * JT) {
             const int j1 = wv / JT, j2 = wv - j1 * JT;
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
         __syncthreads();
     };
     hs_zero_tail(Hs, k, KP, LDH, tid, T);
-    load_h();
+    load_h(0.f);
     float wreg[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) wreg[s] = Ws[(16 * wv + i) * LDW + 4 * s + q];
@@ -1028,12 +1031,15 @@ __global__ __launch_bounds__(64 * NW, 1) void small_hals_fit_kernel(SmallKlArgs 
                 if (cok && l < k) {
                     const float v = (c < n) ? h : 0.f;
                     Hs[l * LDH + c] = v;
-                    if (c < n) st_dev(&H[(long)l * a.ldh + c], v);
+                    if (c < n) {
+                        H[(long)l * a.ldh + c] = v;                                               // (read by the host side only, after the launch)
+                        buf_st_f32x2(f32x2{v, (float)(it + 1)}, buf_rsrc(Hg), (l * NS + c) * 8, 0, 16);   // published: value and step in one granule
+                    }
                 }
             }
         }
-        small_barrier(bar, (unsigned)P * ++gen, a.patience);
-        load_h();
+        __syncthreads();                                   // (the sweep of every wave is over: Hs may be overwritten)
+        load_h((float)(it + 1));                           // (no device-wide barrier: the granules carry their step, small_kl_fit_kernel)
         if (clamp) {                                       // W = max(W, eps) (pyDNMF.py:170-172; H is >= eps after its sweep)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
