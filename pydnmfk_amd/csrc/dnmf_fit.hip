@@ -29,7 +29,9 @@ SmallPlan small_kl_plan(long m, long n, int k) {
     // slabs with A in LDS (round 6: at 16 < k <= 32 the 1024 x 256 examples keep A on chip this way, and 20 problems x 11 slabs cover 220
     // of the 256 CUs where 8 slabs covered 160); else 128-row slabs with A streamed from the L2 (H and the slab's W in LDS); else 64-row
     // slabs with A in LDS, or streamed (short, wide problems)
-    const struct { int nw; bool alds; } tries[5] = {{8, true}, {6, true}, {8, false}, {4, true}, {4, false}};
+    struct Try { int nw; bool alds; };
+    Try tries[5] = {{8, true}, {6, true}, {8, false}, {4, true}, {4, false}};
+    if (tune("DNMF_SMALL_NW6", 0)) std::swap(tries[0], tries[1]);      // (tuning build: 96-row slabs first)
     for (const auto& t : tries) {
         const size_t lds = small_kl_lds(s.kp, t.nw, n, t.alds);
         const long P = cdiv(m, 16L * t.nw);

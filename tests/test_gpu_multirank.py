@@ -50,7 +50,9 @@ def test_multirank_library_sequenced_steps_match_reference(name):
 
 @pytest.mark.parametrize("name", ["swim_4x1_fro_float32", "lr200x136k64_2x1_kl_float32", "lr150x140k128_1x2_fro_float32",
                                   "t24x12_2x1_hals_float32", "r25x13_3x1_hals_float32", "swim_4x1_hals_float32",
-                                  "r50x39_4x2_hals_float32"])     # (HALS: the W sweep is ONE persistent launch across the ranks, csrc/dnmf_hals.h HalsPeers)
+                                  # (HALS: the W sweep is ONE persistent launch across the ranks, csrc/dnmf_hals.h HalsPeers.  The 4 x 2 case stacks EIGHT
+                                  # processes with spin-waiting kernels on the one GPU of the test box -- 39 s of time slicing: the long tier)
+                                  long_param("r50x39_4x2_hals_float32")])
 def test_multirank_direct_allreduce_matches_reference(name):
     """Reference golden fits on 1D grids with every step inside the library AND its packed exchange through the direct two-shot
     allreduce over IPC peer buffers (params.direct_allreduce; csrc/dnmf_comm.hip): four / two ranks stacked on the one GPU map
