@@ -51,6 +51,20 @@ struct SmallKlArgs {
 __device__ unsigned int g_small_timeout = 0;     // sticky: a barrier of a persistent fit gave up (dnmf_hals_sweep_status reports it)
 
 // sum over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15), the same value in all of them, fixed association
+// four quotients a / (d + eps) with the additions and products as PACKED fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: two lanes'
+// worth per issue; the fp32 vector instructions of the KL quotient cost about half the time of the step's MFMAs at k <= 16, none of it
+// overlaps them); the same IEEE operations as the scalar form, so the same bits
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 quot4(f32x4 a, f32x4 d, float eps) {
+    const f32x2s e2 = {eps, eps};
+    f32x2s lo = f32x2s{d[0], d[1]} + e2, hi = f32x2s{d[2], d[3]} + e2;
+    lo = f32x2s{__builtin_amdgcn_rcpf(lo[0]), __builtin_amdgcn_rcpf(lo[1])};
+    hi = f32x2s{__builtin_amdgcn_rcpf(hi[0]), __builtin_amdgcn_rcpf(hi[1])};
+    lo = f32x2s{a[0], a[1]} * lo;
+    hi = f32x2s{a[2], a[3]} * hi;
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 __device__ __forceinline__ float row16_sum(float v) {
     auto dpp = [](float x, auto ctrl) {
         const int b = __builtin_bit_cast(int, x);
@@ -296,7 +310,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) apre[t] = a_row4(16 * (t < nct ? t : nct - 1) + 4 * q);
             }
-            for (int ct0 = 0; ct0 < nct; ct0 += 4) {
+            auto wgroup = [&](int ct0, auto tail) __attribute__((always_inline)) {      // TAIL: fewer than four tiles left (a tile beyond the last one repeats it with U = 0)
+                constexpr bool TAIL = decltype(tail)::value;
                 f32x4 acur[4];
                 if constexpr (!ALDS) {
 #pragma unroll
@@ -309,22 +324,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 int c0[4];
                 f32x4 d[4];                                // lane (row i, q) reg r = (W H)[row i][c0 + 4 q + r]
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { c0[t] = 16 * (ct0 + t < nct ? ct0 + t : nct - 1); d[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int t = 0; t < 4; ++t) { c0[t] = 16 * (!TAIL || ct0 + t < nct ? ct0 + t : nct - 1); d[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s >= ksteps) break;                // (the zero-padded steps beyond k: uniform)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Hs[(4 * s + q) * LDH + c0[t] + i], wreg[s], d[t]);
                 }
-                float u[4][4];
+                f32x4 u[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f32x4 av;
                     if constexpr (ALDS) av = *reinterpret_cast<const f32x4*>(&As[(16 * wv + i) * LDA + c0[t] + 4 * q]);
                     else av = acur[t];
-                    const bool live = ct0 + t < nct;       // (a tile beyond the last one repeats it with U = 0)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) u[t][r] = live ? av[r] * __builtin_amdgcn_rcpf(d[t][r] + eps) : 0.f;
+                    u[t] = quot4(av, d[t], eps);
+                    if constexpr (TAIL) { if (!(ct0 + t < nct)) u[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)            // lane (j = i, q) reg r = (U H^T)[row 4 q + r][16 jt + i]
@@ -334,6 +348,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc2[t & 1][jt] = SM_MFMA(u[t][r], hv[r], acc2[t & 1][jt]);
                     }
+            };
+            {
+                int ct0 = 0;
+                for (; ct0 + 4 <= nct; ct0 += 4) wgroup(ct0, std::false_type{});
+                if (ct0 < nct) wgroup(ct0, std::true_type{});
             }
             // U H^T goes through the wave's own rows of Ws into the operand layout (W itself is in wreg)
 #pragma unroll
@@ -399,12 +418,14 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
 #pragma unroll
                     for (int t = 0; t < C; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
                 }
-                float u[4][4];
+                f32x4 u[4];
 #pragma unroll
-                for (int t = 0; t < C; ++t)
+                for (int t = 0; t < C; ++t) {
+                    f32x4 av;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        u[t][r] = (ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r]) * __builtin_amdgcn_rcpf(d[t][r] + eps);
+                    for (int r = 0; r < 4; ++r) av[r] = ALDS ? As[(16 * (rt0 + t) + 4 * q + r) * LDA + c0 + i] : hcur[t][r];
+                    u[t] = quot4(av, d[t], eps);
+                }
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
 #pragma unroll
