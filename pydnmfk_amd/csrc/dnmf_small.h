@@ -1177,9 +1177,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float u[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = acur[t][r] * __builtin_amdgcn_rcpf(d[t][r] + eps);
+                const f32x4 u = quot4(acur[t], d[t], eps);
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)            // lane (col i, q) reg r = (W^T U)[16 jt + 4 q + r][c0 + i]
 #pragma unroll
