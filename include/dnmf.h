@@ -271,7 +271,7 @@ int dnmf_mu_kl_step_bf16x6(const float* A, long m, long n, long lda, float* W, l
  * SMALL MU problems (MU/KL on fp32 A; MU/FRO on fp32 or bf16-stored A; k <= 32, a 128-row slab of A -- in LDS or streamed from the L2 -- or a 64-row slab, all of H
  * and the slab's rows of W in the 160 KiB of LDS of a CU -- n up to ~2400 at k <= 16, ~1200 beyond -- and at most 64 slabs (m <= 8192): the reference's example sizes, swim 1024
  * x 256, wtsi 96 x 21) run the whole loop as ONE persistent kernel per batch (csrc/dnmf_small.h): a workgroup per slab keeps its data in
- * LDS across the steps, the problem's workgroups meet at two barriers per step.  Same update rules, fp32 sums in another association
+ * LDS across the steps, the problem's workgroups meet at ONE barrier per step and pass the new H as {value, step} granules (the waits of both are bounded the same way).  Same update rules, fp32 sums in another association
  * than the step kernels: results agree with dnmf_mu_{kl,fro}_step to fp32 rounding (not bit for bit); a batched fit still equals
  * `batch` single fits bit for bit.  All workgroups of a launch must be resident together (the library splits a batch into as many
  * launches as that takes; do not share the GPU with another stream meanwhile); a barrier that waits longer than 2 s gives up and
