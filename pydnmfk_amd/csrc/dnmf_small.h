@@ -325,11 +325,16 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 f32x4 d[4];                                // lane (row i, q) reg r = (W H)[row i][c0 + 4 q + r]
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { c0[t] = 16 * (!TAIL || ct0 + t < nct ? ct0 + t : nct - 1); d[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                float hop[KS][4];                          // all operands of the group first (one block of LDS reads: a read behind the
+#pragma unroll                                             // uniform `break` below would be waited for right in front of its MFMAs)
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hop[s][t] = Hs[(4 * s + q) * LDH + c0[t] + i];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s >= ksteps) break;                // (the zero-padded steps beyond k: uniform)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Hs[(4 * s + q) * LDH + c0[t] + i], wreg[s], d[t]);
+                    for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(hop[s][t], wreg[s], d[t]);
                 }
                 f32x4 u[4];
 #pragma unroll
@@ -411,12 +416,18 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_fit_kernel(SmallKlArgs a)
                 f32x4 d[4];                                // lane (col i, q) reg r = (W H)[16 rt + 4 q + r][c0 + i]
 #pragma unroll
                 for (int t = 0; t < C; ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float hbv[KS], wop[KS][4];                 // (operands first, as in the W phase)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    hbv[s] = Hs[(4 * s + q) * LDH + c0 + i];
+#pragma unroll
+                    for (int t = 0; t < C; ++t) wop[s][t] = Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q];
+                }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     if (s >= ksteps) break;
-                    const float hb = Hs[(4 * s + q) * LDH + c0 + i];
 #pragma unroll
-                    for (int t = 0; t < C; ++t) d[t] = SM_MFMA(Ws[(16 * (rt0 + t) + i) * LDW + 4 * s + q], hb, d[t]);
+                    for (int t = 0; t < C; ++t) d[t] = SM_MFMA(wop[s][t], hbv[s], d[t]);
                 }
                 f32x4 u[4];
 #pragma unroll
