@@ -1180,11 +1180,16 @@ __global__ __launch_bounds__(64 * NW, 1) void small_kl_hfit_kernel(SmallKlArgs a
                 rt[t] = x < nrt ? x : nrt - 1;             // (a tile beyond the last repeats it; its U is zero: A reads as zero there)
                 d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            float wop[KS][4];                              // (operands first: small_kl_fit_kernel)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wop[s][t] = Wl[(16 * rt[t] + i) * LDW + 4 * s + q];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s >= ksteps) break;                    // (the zero-padded steps beyond k: uniform)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(Wl[(16 * rt[t] + i) * LDW + 4 * s + q], hb[s], d[t]);
+                for (int t = 0; t < 4; ++t) d[t] = SM_MFMA(wop[s][t], hb[s], d[t]);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
