@@ -65,6 +65,14 @@ def main():
         ms = timed(lambda: nmf_algorithms_1D(A, W, H, params=p).update(), reps=5, warm=2)
         flops = (4.0 if norm == "fro" else 8.0) * m * n * k
         out["mu_%s_step" % norm] = {"ms": ms, "tflops": flops / ms / 1e9, "frac_fp64_mfma": flops / ms / 1e9 / PEAK_TF}
+    # the same steps enqueued by ONE library call (dnmf_f64_fit: what PyNMF.fit runs on one rank) -- no Python frame per launch
+    for norm in ("fro", "kl"):
+        Wf, Hf = W.clone(), H.clone()
+        itr = 10
+        ms = timed(lambda: ops.fit("mu", norm, A, Wf, Hf, eps, True, itr), reps=3, warm=1) / itr
+        flops = (4.0 if norm == "fro" else 8.0) * m * n * k
+        out["mu_%s_step_in_fit" % norm] = {"ms": ms, "tflops": flops / ms / 1e9, "frac_fp64_mfma": flops / ms / 1e9 / PEAK_TF,
+                                           "note": "per step of a %d-step dnmf_f64_fit call (incl. normalisation and error evaluation once per call)" % itr}
     print(json.dumps(out))
 
 
