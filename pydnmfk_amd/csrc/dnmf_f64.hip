@@ -1,6 +1,8 @@
 // dnmf_f64.hip -- the update path in float64 (the reference computes in the dtype of A_ij, pyDNMF.py:68, and its own tests feed
-// np.random.rand float64 arrays, tests/test_dist_nmf_1d.py:14-20).  Correctness first: ONE plain tile shape per kernel family on
-// the fp64 matrix cores (v_mfma_f64_16x16x4_f64), no LDS, no tuning -- the fp32 path (csrc/dnmf_nt.h ...) is the tuned one.
+// np.random.rand float64 arrays, tests/test_dist_nmf_1d.py:14-20).  One tile shape per kernel family on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64), operands straight from memory into registers (no LDS); round 6 made the operand streams branch-free
+// (MUBUF descriptor loads, "MUBUF operand loads" below) and fused the KL quotient into its products (dnmf_f64_kl.h):
+// 77-88 % MFMA busy at 65536 x 4096, k = 64 (profiles/r06_f64_*).
 //
 // v_mfma_f64_16x16x4_f64 operand maps (lane l, i = l & 15, q = l >> 4):
 //   A-operand: A[row i][kk = q]   B-operand: B[kk = q][col i]   C/D: col = i, row = q + 4 * reg (reg in [0, 4))
